@@ -1,0 +1,244 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (imported from /root/reference).
+
+Run in the build container only (the reference never travels to the GPU box):
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [case ...]
+
+Each fixture stores: the generating config, the seeds (weights come from
+oracle.ullsam_oracle.fill_param -- regenerable anywhere without the reference), the inputs that are
+not seed-derivable, and the reference's outputs.  Fixtures are data only; no reference source is copied.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from functools import partial
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+from oracle import ullsam_oracle as O  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def fill_module(mod: torch.nn.Module, seed: int, prefix: str = ""):
+    """Overwrite every parameter/persistent buffer of `mod` with fill_param(prefix+name)."""
+    sd = mod.state_dict()
+    new = {k: torch.from_numpy(O.fill_param(prefix + k, tuple(v.shape), seed)).to(v.dtype) for k, v in sd.items()}
+    mod.load_state_dict(new, strict=True)
+    return {prefix + k: tuple(v.shape) for k, v in sd.items()}
+
+
+def rand_image(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).random(shape, dtype=np.float32) * scale).astype(np.float32)
+
+
+def save(name, **kw):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+# ------------------------------------------------------------------------------------------
+def case_vit_tiny():
+    from modeling.image_encoder import ImageEncoderViT
+    cfg = dict(img_size=160, patch_size=16, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4, out_chans=64,
+               qkv_bias=True, use_rel_pos=True, window_size=7, global_attn_indexes=[1])
+    m = ImageEncoderViT(norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), **cfg).eval()
+    fill_module(m, seed=0)
+    x = rand_image((2, 3, 160, 160), seed=1)
+    y = m(torch.from_numpy(x)).numpy()
+    save("vit_tiny", cfg=np.array(repr(cfg)), weight_seed=0, input_seed=1, out=y)
+
+
+def case_vit_b_full():
+    from build_sam import sam_model_registry
+    sam = sam_model_registry["vit_b"]()
+    fill_module(sam.image_encoder, seed=0)
+    x = rand_image((1, 3, 1024, 1024), seed=1)
+    t = time.time()
+    y = sam.image_encoder(torch.from_numpy(x)).numpy()
+    print(f"  reference ViT-B forward {time.time() - t:.1f}s")
+    flat = y.reshape(-1)
+    save("vit_b_full", weight_seed=0, input_seed=1, stride=37, sample=flat[::37].copy(),
+         mean=np.float64(flat.mean()), std=np.float64(flat.std()), absmax=np.float64(np.abs(flat).max()))
+
+
+def _sam_small(depth=2, embed_dim=128, heads=2, glob=(1,)):
+    from modeling import ImageEncoderViT, MaskDecoder, PromptEncoder, Sam, TwoWayTransformer
+    sam = Sam(
+        image_encoder=ImageEncoderViT(depth=depth, embed_dim=embed_dim, img_size=1024, mlp_ratio=4,
+                                      norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=heads, patch_size=16,
+                                      qkv_bias=True, use_rel_pos=True, global_attn_indexes=list(glob), window_size=14,
+                                      out_chans=256),
+        prompt_encoder=PromptEncoder(embed_dim=256, image_embedding_size=(64, 64), input_image_size=(1024, 1024),
+                                     mask_in_chans=16),
+        mask_decoder=MaskDecoder(num_multimask_outputs=3,
+                                 transformer=TwoWayTransformer(depth=2, embedding_dim=256, mlp_dim=2048, num_heads=8),
+                                 transformer_dim=256, iou_head_depth=3, iou_head_hidden_dim=256),
+    ).eval()
+    return sam
+
+
+def case_decoder():
+    """Prompt encoder + mask decoder at full size on a synthetic (LayerNorm-like) image embedding."""
+    sam = _sam_small()
+    fill_module(sam.prompt_encoder, seed=0, prefix="prompt_encoder.")
+    fill_module(sam.mask_decoder, seed=0, prefix="mask_decoder.")
+    rng = np.random.default_rng(2)
+    emb = rng.standard_normal((1, 256, 64, 64), dtype=np.float32)
+    llm = rng.standard_normal((1, 256, 64, 64), dtype=np.float32) * 3.0 + 0.5
+    pts = np.array([[[300.0, 400.0], [700.0, 120.0]], [[512.0, 512.0], [10.0, 1000.0]], [[5.0, 5.0], [900.0, 900.0]]], np.float32)
+    lbl = np.array([[1, 0], [1, 1], [0, -1]], np.int32)
+    boxes = np.array([[100.0, 150.0, 600.0, 700.0], [0.0, 0.0, 1023.0, 1023.0], [400.0, 300.0, 500.0, 350.0]], np.float32)
+    mask_in = rng.standard_normal((3, 1, 256, 256), dtype=np.float32)
+    pe_t = sam.prompt_encoder.get_dense_pe()
+    # emb / llm / mask_in are regenerable: decoder_inputs(seed=2) in tests/util.py draws them in this order
+    out = {"input_seed": 2, "pts": pts, "lbl": lbl, "boxes": boxes, "dense_pe_sample": pe_t.numpy().reshape(-1)[::29].copy()}
+
+    def run(tag, points, bx, msk, llm_h, multi):
+        sp, de = sam.prompt_encoder(points=points, boxes=bx, masks=msk, llm_hidden_states=llm_h)
+        low, iou = sam.mask_decoder(image_embeddings=torch.from_numpy(emb), image_pe=pe_t, sparse_prompt_embeddings=sp,
+                                    dense_prompt_embeddings=de, multimask_output=multi)
+        out[tag + "_sparse"] = sp.numpy()
+        out[tag + "_dense_sample"] = de.numpy().reshape(de.shape[0], -1)[:, ::61].copy()
+        out[tag + "_low"] = low.numpy() if low.shape[1] == 1 else low.numpy()[:, :, ::3, ::3].copy()
+        out[tag + "_iou"] = iou.numpy()
+
+    P = (torch.from_numpy(pts), torch.from_numpy(lbl))
+    llm3 = torch.from_numpy(llm).repeat(3, 1, 1, 1)
+    run("pts_llm_single", P, None, None, llm3, False)          # the uLLSAM metric path (app.py:617-631)
+    run("pts_plain_multi", P, None, None, None, True)          # plain SAM, multimask
+    run("pts_box_plain", P, torch.from_numpy(boxes), None, None, False)
+    run("box_mask", None, torch.from_numpy(boxes), torch.from_numpy(mask_in), None, True)
+    P1 = (torch.from_numpy(pts[:1, :1]), torch.from_numpy(lbl[:1, :1]))
+    run("one_pt_llm", P1, None, None, torch.from_numpy(llm), False)
+    save("decoder", weight_seed=0, **out)
+
+
+LLM_TINY = dict(architectures=["InternLM2ForCausalLM"], vocab_size=92553, hidden_size=256, intermediate_size=512,
+                num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, bias=False,
+                max_position_embeddings=32768, rope_theta=1000000, rms_norm_eps=1e-5, attn_implementation="eager")
+
+
+def _tiny_llm():
+    from modeling.configuration_internlm2 import InternLM2Config
+    from modeling.modeling_internlm2 import InternLM2ForCausalLM
+    cfg = InternLM2Config(**LLM_TINY)
+    cfg.rope_scaling = None  # transformers>=5 aliases it to a dict (SURVEY.md 8(c) workaround 1)
+    m = InternLM2ForCausalLM(cfg).eval()
+    return m
+
+
+def _ref_greedy(lm, emb, mask, max_new, eos=92542):
+    """Manual greedy loop over the reference's own forward + tuple KV cache (SURVEY.md 8(c) workaround 2)."""
+    pos = mask.long().cumsum(-1) - 1
+    pos.masked_fill_(mask == 0, 1)
+    o = lm(inputs_embeds=emb, attention_mask=mask, position_ids=pos, use_cache=True, return_dict=True)
+    past = o.past_key_values
+    toks = []
+    logits0 = o.logits[:, -1].numpy().copy()
+    for _ in range(max_new):
+        t = int(o.logits[0, -1].argmax())
+        toks.append(t)
+        if t == eos:
+            break
+        mask = torch.cat([mask, torch.ones((1, 1), dtype=mask.dtype)], 1)
+        pos = (mask.long().cumsum(-1) - 1)[:, -1:]
+        o = lm(input_ids=torch.tensor([[t]]), attention_mask=mask, position_ids=pos, past_key_values=past,
+               use_cache=True, return_dict=True)
+        past = o.past_key_values
+    return np.asarray(toks, np.int64), logits0
+
+
+def case_llm_tiny():
+    lm = _tiny_llm()
+    fill_module(lm, seed=0, prefix="language_model.")
+    rng = np.random.default_rng(3)
+    B, S = 2, 70
+    emb = (rng.standard_normal((B, S, 256), dtype=np.float32) * 0.5)
+    mask = np.ones((B, S), np.int64)
+    mask[1, :9] = 0  # left padding on sample 1
+    o = lm(inputs_embeds=torch.from_numpy(emb), attention_mask=torch.from_numpy(mask), use_cache=False,
+           output_hidden_states=True, return_dict=True)
+    hidden = o.hidden_states[-1].numpy()
+    logits_last = o.logits[:, -1].numpy()
+    # greedy (B=1, no padding), prompt = first 40 positions of sample 0
+    toks, logits0 = _ref_greedy(lm, torch.from_numpy(emb[:1, :40]), torch.ones((1, 40), dtype=torch.long), 12)
+    save("llm_tiny", weight_seed=0, cfg=np.array(repr(LLM_TINY)), emb=emb, mask=mask, hidden=hidden,
+         logits_last_sample=logits_last[:, ::97].copy(), logits_last_argmax=logits_last.argmax(-1),
+         greedy_tokens=toks, greedy_logits0_sample=logits0[:, ::97].copy())
+
+
+def case_ullsam_tiny():
+    """Composite InternVLSAMModel: shallow ViT (1024^2 in, 256x64x64 out) + tiny LLM + full decoder."""
+    from modeling.configuration_internvl_chat import InternVLChatConfig
+    from modeling.modeling_internvl_sam import InternVLSAMModel
+    sam = _sam_small()
+    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_TINY),
+                             downsample_ratio=0.5, template="internlm2-chat", ps_version="v2", force_image_size=1024)
+    cfg.llm_config.rope_scaling = None
+    m = InternVLSAMModel(cfg, vision_model=sam.image_encoder, prompt_encoder=sam.prompt_encoder,
+                         mask_decoder=sam.mask_decoder).eval()
+    fill_module(m, seed=0)
+    x = rand_image((1, 3, 1024, 1024), seed=1)
+    ids = O.make_input_ids(n_text_pre=20, n_text_post=34, seed=1)  # S = 1+20+1+1024+1+34 = 1081
+    assert ids.shape[1] == 1081
+    tids = torch.from_numpy(ids)
+    out = m(pixel_values=torch.from_numpy(x), input_ids=tids, attention_mask=torch.ones_like(tids),
+            image_flags=(tids == 92546)[..., None].long(), return_dict=True, use_cache=False, output_hidden_states=True)
+    dense_feat = out.hidden_states.numpy()          # [1,256,64,64]
+    img_emb = out.image_embeddings.numpy()
+    pts = np.array([[[512.0, 384.0], [100.0, 900.0]]], np.float32)
+    lbl = np.array([[1, 0]], np.int32)
+    sp, de = m.prompt_encoder(points=(torch.from_numpy(pts), torch.from_numpy(lbl)), boxes=None, masks=None,
+                              llm_hidden_states=out.hidden_states)
+    low, iou = m.mask_decoder(image_embeddings=out.image_embeddings, image_pe=m.prompt_encoder.get_dense_pe(),
+                              sparse_prompt_embeddings=sp, dense_prompt_embeddings=de, multimask_output=False)
+    up = torch.nn.functional.interpolate(low, (1024, 1024), mode="bilinear", align_corners=False)
+    mask = (up[0, 0].sigmoid() > 0.5).numpy()
+    # greedy tokens through the composite's embedding path (generate() :407-431 semantics)
+    vit_embeds, _ = m.extract_feature(torch.from_numpy(x))
+    emb = m.language_model.get_input_embeddings()(tids).clone()
+    emb[tids == 92546] = vit_embeds.reshape(-1, emb.shape[-1])
+    toks, logits0 = _ref_greedy(m.language_model, emb, torch.ones_like(tids), 8)
+    save("ullsam_tiny", weight_seed=0, input_seed=1, ids=ids, pts=pts, lbl=lbl,
+         vit_embeds_sample=vit_embeds.numpy().reshape(-1)[::101].copy(),
+         img_emb_sample=img_emb.reshape(-1)[::37].copy(), dense_feat_sample=dense_feat.reshape(-1)[::37].copy(),
+         logits_last_sample=out.logits[0, -1].numpy()[::97].copy(),
+         low=low.numpy(), iou=iou.numpy(), up_sample=up.numpy().reshape(-1)[::53].copy(),
+         mask_bits=np.packbits(mask), greedy_tokens=toks, greedy_logits0_sample=logits0[:, ::97].copy())
+
+
+def case_sam_forward():
+    """Sam.forward (sam.py:53-131) on a non-square image: preprocess, per-image loop, postprocess."""
+    sam = _sam_small()
+    fill_module(sam, seed=0)
+    img = rand_image((3, 768, 1024), seed=4, scale=255.0)
+    pts = np.array([[[500.0, 375.0]], [[200.0, 600.0]]], np.float32)
+    lbl = np.array([[1], [1]], np.int32)
+    out = sam([{"image": torch.from_numpy(img), "original_size": (600, 800), "point_coords": torch.from_numpy(pts),
+                "point_labels": torch.from_numpy(lbl)}], multimask_output=True)[0]
+    save("sam_forward", weight_seed=0, input_seed=4, pts=pts, lbl=lbl, low=out["low_res_logits"].numpy(),
+         iou=out["iou_predictions"].numpy(), mask_bits=np.packbits(out["masks"].numpy()),
+         mask_shape=np.array(out["masks"].shape))
+
+
+CASES = {"vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
+         "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full}
+
+if __name__ == "__main__":
+    for n in (sys.argv[1:] or list(CASES)):
+        print(f"[gen_golden] {n}")
+        t0 = time.time()
+        CASES[n]()
+        print(f"  done in {time.time() - t0:.1f}s")

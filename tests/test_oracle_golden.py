@@ -1,0 +1,126 @@
+"""Pin the numpy oracle against vectors captured from the reference itself (oracle/gen_golden.py).
+
+The reference ships no tests / golden vectors of its own, so these captured
+outputs are the pin.  fp32 vs fp32: tolerances are accumulation-order noise only.
+"""
+import numpy as np
+import pytest
+
+from oracle import ullsam_oracle as O
+from tests import util as U
+
+
+def _close(a, b, atol, what):
+    err = float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+    assert err <= atol, f"{what}: max abs err {err:.3e} > {atol}"
+
+
+def test_vit_tiny_matches_reference():
+    g = U.gold("vit_tiny")
+    P = U.vit_params(U.VIT_TINY, int(g["weight_seed"]))
+    x = U.rand_image((2, 3, 160, 160), int(g["input_seed"]))
+    y = O.vit_encoder(x, P, **U.vit_run_cfg(U.VIT_TINY))
+    assert y.shape == g["out"].shape == (2, 64, 10, 10)
+    _close(y, g["out"], 2e-4, "vit_tiny output")
+
+
+def test_decoder_matches_reference():
+    g = U.gold("decoder")
+    seed = int(g["weight_seed"])
+    P = {}
+    P.update(O.fill_state(O.prompt_encoder_shapes(prefix="prompt_encoder."), seed))
+    P.update(O.fill_state(O.mask_decoder_shapes(prefix="mask_decoder."), seed))
+    emb, llm, mask_in = U.decoder_inputs(int(g["input_seed"]))
+    pe = O.dense_pe(P, prefix="prompt_encoder.")
+    _close(pe.reshape(-1)[::29], g["dense_pe_sample"], 1e-5, "dense_pe")
+    pts, lbl, boxes = g["pts"], g["lbl"], g["boxes"]
+
+    def run(tag, points, bx, msk, llm_h, multi):
+        sp, de = O.prompt_encoder(P, points, bx, msk, llm_h, prefix="prompt_encoder.")
+        low, iou = O.mask_decoder(P, emb, pe, sp, de, multi, prefix="mask_decoder.")
+        _close(sp, g[tag + "_sparse"], 1e-5, tag + " sparse")
+        _close(de.reshape(de.shape[0], -1)[:, ::61], g[tag + "_dense_sample"], 1e-4, tag + " dense")
+        ref_low = g[tag + "_low"]
+        got = low if low.shape[1] == 1 else low[:, :, ::3, ::3]
+        _close(got, ref_low, 2e-3 * max(1.0, float(np.abs(ref_low).max()) / 10), tag + " low_res")
+        _close(iou, g[tag + "_iou"], 1e-3, tag + " iou")
+
+    run("pts_llm_single", (pts, lbl), None, None, np.repeat(llm, 3, 0), False)
+    run("pts_plain_multi", (pts, lbl), None, None, None, True)
+    run("pts_box_plain", (pts, lbl), boxes, None, None, False)
+    run("box_mask", None, boxes, mask_in, None, True)
+    run("one_pt_llm", (pts[:1, :1], lbl[:1, :1]), None, None, llm, False)
+
+
+def test_llm_tiny_matches_reference():
+    g = U.gold("llm_tiny")
+    P = U.llm_params(U.LLM_TINY, int(g["weight_seed"]))
+    emb, mask = g["emb"], g["mask"]
+    # reference default position_ids = arange (modeling_internlm2.py:893-898) even with left padding
+    hid, _ = O.internlm2_model(P, U.LLM_TINY, emb, mask, prefix="language_model.")
+    valid = mask.astype(bool)
+    _close(hid[valid], g["hidden"][valid], 2e-4, "hidden (non-pad rows)")
+    logits = O.lm_head(P, hid[:, -1], "language_model.")
+    _close(logits[:, ::97], g["logits_last_sample"], 2e-3, "last logits")
+    assert (logits.argmax(-1) == g["logits_last_argmax"]).all()
+    toks = O.greedy_generate(P, U.LLM_TINY, emb[:1, :40], None, 12)
+    assert toks.tolist() == g["greedy_tokens"].tolist(), "greedy token ids must be bit-exact"
+
+
+def test_pixel_shuffle_roundtrip_and_maps():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, 64, 64, 256), dtype=np.float32)
+    y = O.pixel_shuffle_v2(x)
+    assert y.shape == (1, 32, 32, 1024)
+    # closed form used by the HIP gather kernels: out[h2,w2,(h%2)*512+(w%2)*256+c] = x[2h2+h%2, 2w2+w%2, c]
+    for (h, w, c) in [(0, 0, 0), (5, 9, 17), (63, 62, 255), (10, 11, 3)]:
+        assert y[0, h // 2, w // 2, (h % 2) * 512 + (w % 2) * 256 + c] == x[0, h, w, c]
+
+
+@pytest.mark.slow
+def test_ullsam_tiny_matches_reference():
+    g = U.gold("ullsam_tiny")
+    P = U.ullsam_tiny_params(int(g["weight_seed"]))
+    x = U.rand_image((1, 3, 1024, 1024), int(g["input_seed"]))
+    r = O.ullsam_mask_path(P, x, g["ids"], g["pts"], g["lbl"], U.vit_run_cfg(U.VIT_SMALL), U.LLM_TINY)
+    _close(r["vit_embeds"].reshape(-1)[::101], g["vit_embeds_sample"], 1e-3, "vit_embeds")
+    _close(r["image_embeddings"].reshape(-1)[::37], g["img_emb_sample"], 5e-4, "image_embeddings")
+    _close(r["dense_feature"].reshape(-1)[::37], g["dense_feat_sample"], 2e-3, "dense feature")
+    _close(r["low_res_logits"], g["low"], 1e-3 * max(1.0, float(np.abs(g["low"]).max())), "low-res logits")
+    _close(r["iou_predictions"], g["iou"], 1e-3, "iou")
+    ref_mask = np.unpackbits(g["mask_bits"])[:1024 * 1024].reshape(1024, 1024).astype(bool)
+    iou = O.calc_iou(r["masks"][0, 0], ref_mask)
+    assert 1.0 - iou < 1e-4, f"mask IoU vs reference {iou}"
+    # greedy ids through the composite embedding path
+    emb = O.build_inputs_embeds(P, g["ids"], r["vit_embeds"])
+    toks = O.greedy_generate(P, U.LLM_TINY, emb, None, 8)
+    assert toks.tolist() == g["greedy_tokens"].tolist()
+
+
+def test_sam_forward_matches_reference():
+    g = U.gold("sam_forward")
+    seed = int(g["weight_seed"])
+    P = {}
+    P.update(U.vit_params(U.VIT_SMALL, seed, "image_encoder."))
+    P.update(O.fill_state(O.prompt_encoder_shapes(prefix="prompt_encoder."), seed))
+    P.update(O.fill_state(O.mask_decoder_shapes(prefix="mask_decoder."), seed))
+    img = U.rand_image((3, 768, 1024), int(g["input_seed"]), 255.0)
+    r = O.sam_forward_one(P, img, g["pts"], g["lbl"], True, U.vit_run_cfg(U.VIT_SMALL))
+    _close(r["low_res_logits"], g["low"], 1e-3 * max(1.0, float(np.abs(g["low"]).max())), "low_res_logits")
+    _close(r["iou_predictions"], g["iou"], 1e-3, "iou")
+    # second resize to original_size (600, 800), sam.py:161
+    up = O.bilinear_resize(O.bilinear_resize(r["low_res_logits"], (1024, 1024))[..., :768, :1024], (600, 800)) > 0.0
+    shape = tuple(int(v) for v in g["mask_shape"])
+    ref = np.unpackbits(g["mask_bits"])[:int(np.prod(shape))].reshape(shape).astype(bool)
+    assert up.shape == ref.shape
+    assert 1.0 - O.calc_iou(up, ref) < 1e-4
+
+
+@pytest.mark.slow
+def test_vit_b_full_matches_reference():
+    g = U.gold("vit_b_full")
+    P = U.vit_params(U.VIT_B, int(g["weight_seed"]))
+    x = U.rand_image((1, 3, 1024, 1024), int(g["input_seed"]))
+    y = O.vit_encoder(x, P, **U.vit_run_cfg(U.VIT_B))
+    _close(y.reshape(-1)[::int(g["stride"])], g["sample"], 2e-3, "vit_b output sample")
+    assert abs(float(y.mean()) - float(g["mean"])) < 1e-4 and abs(float(y.std()) - float(g["std"])) < 1e-3
