@@ -1,0 +1,105 @@
+/* libullsam_hip.so -- C ABI of the MI355X (gfx950) uLLSAM hot path.
+ *
+ * The reference (ieellee/uLLSAM) has NO native/FFI layer: its hot path is PyTorch ATen calls inside nn.Module.forward
+ * (SURVEY.md section 8(b)).  The drop-in boundary is therefore the Python module surface (ullsam_amd/modeling/*, same
+ * names / signatures / state_dict keys as the reference); this header is the ABI those modules bind with ctypes --
+ * each entry point names the reference call site (file:line under /root/reference) whose ATen ops it replaces.
+ *
+ * Conventions
+ *   - plain pointers are DEVICE pointers (torch tensor.data_ptr()); no torch types cross this boundary
+ *   - dtype: 0 = float32 (parity mode, exact-fp32 MFMA), 1 = bfloat16 (throughput mode, fp32 accumulate)
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); kernels are stream-ordered, never
+ *     allocate, never synchronise, never throw
+ *   - return 0 on success, < 0 on error; ullsam_last_error_string() describes the last error of the calling thread
+ */
+#ifndef ULLSAM_HIP_H
+#define ULLSAM_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ULLSAM_DT_F32 0
+#define ULLSAM_DT_BF16 1
+#define ULLSAM_ACT_NONE 0
+#define ULLSAM_ACT_GELU 1   /* exact erf GELU (nn.GELU default) */
+#define ULLSAM_ACT_RELU 2
+#define ULLSAM_ACT_SWIGLU 3 /* paired 64-column gate/up blocks -> silu(gate)*up */
+
+const char* ullsam_last_error_string(void);
+int ullsam_abi_version(void);
+int ullsam_device_count(void);
+
+/* C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual.  Replaces every nn.Linear / 1x1 conv / stride==kernel conv:
+ * image_encoder.py:227,238,387-395,88-104; common.py:21-26; modeling_internvl_sam.py:88-100;
+ * modeling_internlm2.py:261-264,359,421,1081; transformer.py:220-227 (image side); mask_decoder.py:53-59.
+ * A, W in `dtype`; C float when out_f32 else `dtype`; bias/residual fp32 (nullable); residual row = m %% res_row_mod
+ * when res_row_mod > 0 (pos_embed broadcast, image_encoder.py:107-109).  K %% (128/elem_size) == 0. */
+int ullsam_gemm(int dtype, const void* A, long lda, const void* W, long ldw, void* C, long ldc, int out_f32,
+                const float* bias, const float* residual, long ldr, int res_row_mod, int act, int M, int N, int K,
+                void* stream);
+
+/* Row LayerNorm / RMSNorm, fp32 statistics.  image_encoder.py:151,161; common.py:38-43 (LayerNorm2d on NHWC rows);
+ * modeling_internlm2.py:138-143 (rms=1); prompt_encoder.py:142-149 (no affine + post scale/shift); transformer.py norms. */
+int ullsam_norm(const void* in, int in_dtype, long in_stride, void* out, int out_dtype, long out_stride, const float* w,
+                const float* b, long rows, int D, float eps, int rms, int act, const float* post_scale,
+                const float* post_shift, void* stream);
+
+/* SAM ViT attention on packed qkv [B, gh*gw, 3*heads*hd]; window > 0 fuses window_partition/unpartition and the pad-token
+ * semantics; decomposed rel-pos computed in-kernel.  image_encoder.py:170-177,224-240,243-289,292-361. */
+int ullsam_vit_attention(int dtype, const void* qkv, void* out, const void* rel_h, const void* rel_w, const void* qkv_bias,
+                         int B, int heads, int hd, int grid_h, int grid_w, int window, void* stream);
+
+/* InternLM2 causal GQA attention (prefill), additive masks as modeling_internlm2.py:96-125,830-851; :383-419. */
+int ullsam_causal_attention(int dtype, const void* q, const void* k, const void* v, void* out, const int* key_mask, int B,
+                            int H, int KVH, int hd, int Sq, int Sk, int k_cap, int q_pos0, void* stream);
+
+/* Small-shape attention with explicit strides (decoder token attention transformer.py:220-242; q_len==1 decode). */
+int ullsam_naive_attention(int dtype, const void* q, const void* k, const void* v, void* out, const int* key_mask, int B,
+                           int H, int KVH, int hd, int Sq, int Sk, long q_bs, long q_ts, long q_hs, long k_bs, long k_ts,
+                           long k_hs, long v_bs, long v_ts, long v_hs, long o_bs, long o_ts, long o_hs, float scale,
+                           void* stream);
+
+/* Image -> token cross attention (many queries, few keys), fp32.  transformer.py:178-181. */
+int ullsam_fewkeys_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int hd, int Sq,
+                             int Sk, float scale, void* stream);
+
+/* ViT / projector data movement */
+int ullsam_patch_im2col(int dtype, const float* pixels, void* out, int B, int C, int Hs, int Ws, int S, int patch,
+                        const float* mean, const float* stdv, void* stream);            /* image_encoder.py:391-395, sam.py:164-174 */
+int ullsam_im2col3x3(int dtype, const void* in, void* out, int B, int H, int W, int C, void* stream); /* image_encoder.py:96-102 */
+int ullsam_add_cast(const void* a, int a_dtype, long a_rows, const float* b, long b_rows, void* out, int out_dtype,
+                    long rows, int cols, void* stream);                                  /* transformer.py:165,181; mask_decoder.py:127 */
+int ullsam_transpose_f32(const float* in, float* out, int B, int R, int C, void* stream);  /* image_encoder.py:114 permute */
+int ullsam_pixel_shuffle_ln(int dtype, const float* in_nhwc, void* out, const float* w, const float* b, int B, int H, int W,
+                            int C, float eps, void* stream);                             /* modeling_internvl_sam.py:226-251,89 */
+int ullsam_pixel_unshuffle(const float* in, float* out_nhwc, int B, int H, int W, int C, void* stream); /* :256-268 */
+
+/* LLM data movement */
+int ullsam_scan_image_tokens(const long long* ids, int* rank, int* range, int B, int S, long long img_id, void* stream); /* :135-139,194-199 */
+int ullsam_embed_tokens(int dtype, const void* table, const long long* ids, const int* rank, const float* vit_embeds,
+                        float* out, int B, int S, int D, int n_img, long vocab, void* stream);                          /* :124-158 */
+int ullsam_gather_rows(const void* in, void* out, const int* range, int B, int S, int n, int row_bytes, void* stream);  /* :198-200 */
+int ullsam_rope_split(int dtype, const void* qkv, void* q_out, void* k_cache, void* v_cache, const int* pos,
+                      const float* cos_tab, const float* sin_tab, int B, int S, int KVH, int G, int hd, int cap,
+                      int cache_pos0, void* stream);                                     /* modeling_internlm2.py:361-388,233-247 */
+int ullsam_argmax(const float* logits, long long* out, int rows, long V, long ld, void* stream);
+
+/* Prompt encoder / mask decoder */
+int ullsam_small_linear(const float* x, long ldx, const float* W, const float* b, const float* res, long ldr, float* y,
+                        long ldy, int M, int N, int K, int act, void* stream);           /* transformer.py:220-227; mask_decoder.py:171-176 */
+int ullsam_sparse_embed(const float* coords, const int* labels, const float* boxes, const float* G, const float* emb,
+                        float* out, int P, int Np, int pad, int C, float img_w, float img_h, void* stream); /* prompt_encoder.py:76-103 */
+int ullsam_dense_pe(const float* G, float* out_nhwc, int H, int W, int C, void* stream);  /* prompt_encoder.py:230-241 */
+int ullsam_mask_downscale(const float* masks, float* out_nhwc, int P, int H, int W, int C, int c1, int c2, const float* w0,
+                          const float* b0, const float* g1, const float* be1, const float* w3, const float* b3,
+                          const float* g4, const float* be4, const float* w6, const float* b6, void* stream); /* prompt_encoder.py:54-62 */
+int ullsam_hyper_masks(const float* up2, const float* hyper, float* out, int NB, int NM, int H, int W, int CU, void* stream); /* mask_decoder.py:143-144 */
+int ullsam_resize_bilinear(const float* in, long in_plane_stride, int in_ld, int IH, int IW, float* out, unsigned char* mask,
+                           int N, int OH, int OW, float thr, void* stream);              /* app.py:635-645; sam.py:154-162,123 */
+int ullsam_mask_iou_counts(const unsigned char* a, const unsigned char* b, unsigned long long* counts, int N, long per,
+                           void* stream);                                                /* train_joint_v2.py:683-694 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ULLSAM_HIP_H */

@@ -1,0 +1,211 @@
+"""Kernel-level parity: each HIP kernel (through the C ABI) vs the numpy oracle on seeded inputs.
+
+fp32 mode must match to accumulation-order noise (the f32 MFMA is an exact fma chain); bf16 mode is compared with
+a tolerance that reflects bf16 operand rounding (stated per test).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ullsam_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def T(x, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV).to(dtype).contiguous()
+
+
+def err(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from ullsam_amd import ops as o
+    return o
+
+
+TOL = {torch.float32: 2e-4, torch.bfloat16: 6e-2}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (128, 384, 768), (1, 128, 64), (515, 200, 256)])
+def test_gemm_plain_and_epilogues(ops, dtype, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    a = rng.standard_normal((M, K), dtype=np.float32)
+    w = (rng.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N, dtype=np.float32)
+    res = rng.standard_normal((M, N), dtype=np.float32)
+    ad, wd = T(a, dtype), T(w, dtype)
+    a_r, w_r = ad.float().cpu().numpy(), wd.float().cpu().numpy()  # operands as the kernel sees them
+    ref = a_r @ w_r.T
+    tol = 2e-4 if dtype == torch.float32 else 2e-2  # bf16: only output rounding / accumulation order remains
+    y = ops.gemm(ad, wd, out_f32=True).cpu().numpy()
+    assert err(y, ref) < tol
+    y = ops.gemm(ad, wd, bias=T(bias), act=ops.ACT_GELU, residual=T(res), out_f32=True).cpu().numpy()
+    assert err(y, O.gelu(ref + bias) + res) < tol
+    y = ops.gemm(ad, wd, bias=T(bias), act=ops.ACT_RELU).float().cpu().numpy()
+    assert err(y, np.maximum(ref + bias, 0)) < (tol if dtype == torch.float32 else 5e-2)
+    # row-broadcast residual (pos_embed) + in-place residual update
+    mod = max(1, M // 3)
+    y = ops.gemm(ad, wd, residual=T(res[:mod]), res_row_mod=mod, out_f32=True).cpu().numpy()
+    assert err(y, ref + res[np.arange(M) % mod]) < tol
+    x = T(res)
+    ops.gemm(ad, wd, bias=T(bias), residual=x, out_f32=True, out=x)
+    assert err(x.cpu().numpy(), ref + bias + res) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_swiglu_pair(ops, dtype):
+    rng = np.random.default_rng(5)
+    M, I, K = 200, 256, 128
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w1 = (rng.standard_normal((I, K), dtype=np.float32) / math.sqrt(K)).astype(np.float32)
+    w3 = (rng.standard_normal((I, K), dtype=np.float32) / math.sqrt(K)).astype(np.float32)
+    from ullsam_amd.packing import pack_w13
+    w13 = pack_w13(T(w1, dtype), T(w3, dtype))
+    xd = T(x, dtype)
+    y = ops.gemm(xd, w13, act=ops.ACT_SWIGLU, out_f32=True).cpu().numpy()
+    xr = xd.float().cpu().numpy()
+    ref = O.silu(xr @ T(w1, dtype).float().cpu().numpy().T) * (xr @ T(w3, dtype).float().cpu().numpy().T)
+    assert y.shape == (M, I)
+    assert err(y, ref) < (2e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("D", [64, 256, 768, 1280, 4096])
+def test_norms(ops, D):
+    rng = np.random.default_rng(D)
+    x = rng.standard_normal((37, D), dtype=np.float32) * 2 + 0.3
+    w = rng.standard_normal(D, dtype=np.float32)
+    b = rng.standard_normal(D, dtype=np.float32)
+    y = ops.norm(T(x), T(w), T(b), 1e-6, torch.float32).cpu().numpy()
+    assert err(y, O.layer_norm(x, w, b, 1e-6)) < 2e-5
+    y = ops.norm(T(x), T(w), None, 1e-5, torch.float32, rms=True).cpu().numpy()
+    assert err(y, O.rms_norm(x, w, 1e-5)) < 2e-5
+    y = ops.norm(T(x), None, None, 1e-5, torch.float32, post_scale=T(np.array([0.1], np.float32)),
+                 post_shift=T(np.array([0.05], np.float32))).cpu().numpy()
+    assert err(y, O.layer_norm(x, None, None, 1e-5) * 0.1 + 0.05) < 2e-5
+    yb = ops.norm(T(x, torch.bfloat16), T(w), T(b), 1e-6, torch.bfloat16).float().cpu().numpy()
+    xb = T(x, torch.bfloat16).float().cpu().numpy()
+    assert err(yb, O.layer_norm(xb, w, b, 1e-6)) < 4e-2
+
+
+def _vit_attn_case(ops, dtype, heads, hd, grid, window, B=2, seed=0):
+    D = heads * hd
+    rng = np.random.default_rng(seed)
+    xn = rng.standard_normal((B, grid, grid, D), dtype=np.float32)
+    n = window if window > 0 else grid
+    P = {"qkv.weight": (rng.standard_normal((3 * D, D), dtype=np.float32) / math.sqrt(D)).astype(np.float32),
+         "qkv.bias": rng.standard_normal(3 * D, dtype=np.float32) * 0.3,
+         "rel_pos_h": rng.standard_normal((2 * n - 1, hd), dtype=np.float32) * 0.1,
+         "rel_pos_w": rng.standard_normal((2 * n - 1, hd), dtype=np.float32) * 0.1,
+         "proj.weight": np.eye(D, dtype=np.float32), "proj.bias": np.zeros(D, np.float32)}
+    # oracle: exactly Block.forward's attention branch (window_partition -> Attention -> window_unpartition)
+    if window > 0:
+        xw, pad_hw = O.window_partition(xn, window)
+        ref = O.window_unpartition(O.vit_attention(xw, P, "", heads), window, pad_hw, (grid, grid))
+    else:
+        ref = O.vit_attention(xn, P, "", heads)
+    qkv = O.linear(xn.reshape(-1, D), P["qkv.weight"], P["qkv.bias"])  # UNPADDED tokens
+    out = ops.vit_attention(T(qkv, dtype), T(P["rel_pos_h"], dtype), T(P["rel_pos_w"], dtype), T(P["qkv.bias"], dtype),
+                            B, heads, hd, grid, grid, window)
+    return err(out.float().cpu().numpy().reshape(ref.shape), ref), float(np.abs(ref).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("heads,hd,grid,window", [(2, 64, 10, 7), (2, 64, 10, 0), (2, 80, 16, 14), (1, 80, 12, 0),
+                                                  (2, 64, 64, 14), (1, 64, 64, 0)])
+def test_vit_attention(ops, dtype, heads, hd, grid, window):
+    e, scale = _vit_attn_case(ops, dtype, heads, hd, grid, window)
+    assert e < (1e-4 if dtype == torch.float32 else 3e-2) * max(1.0, scale), (e, scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S,H,KVH,pad", [(2, 70, 2, 1, 9), (1, 200, 4, 2, 0), (1, 1081, 2, 2, 0)])
+def test_rope_and_causal_attention(ops, dtype, B, S, H, KVH, pad):
+    hd, G = 128, H // KVH
+    rng = np.random.default_rng(S)
+    qkv = rng.standard_normal((B, S, KVH, G + 2, hd), dtype=np.float32)
+    mask = np.ones((B, S), np.int64)
+    if pad:
+        mask[-1, :pad] = 0
+    pos = np.arange(S, dtype=np.int64)[None].repeat(B, 0)
+    cos, sin = O.rope_tables(hd, S, 1e6)
+    qd = T(qkv.reshape(B * S, -1), dtype)
+    qr = qd.float().cpu().numpy().reshape(qkv.shape)
+    q = qr[..., :G, :].reshape(B, S, H, hd).transpose(0, 2, 1, 3)
+    k = qr[..., -2, :].transpose(0, 2, 1, 3)
+    v = qr[..., -1, :].transpose(0, 2, 1, 3)
+    c, s = cos[pos][:, None], sin[pos][:, None]
+    q = q * c + O._rotate_half(q) * s
+    k = k * c + O._rotate_half(k) * s
+    a = np.matmul(q, np.repeat(k, G, 1).transpose(0, 1, 3, 2)) / np.float32(math.sqrt(hd)) + O.decoder_mask(mask, S, 0)
+    ref = np.matmul(O.softmax(a.astype(np.float32)), np.repeat(v, G, 1)).transpose(0, 2, 1, 3).reshape(B, S, H * hd)
+    kc = torch.zeros((B, KVH, S + 3, hd), dtype=dtype, device=DEV)
+    vc = torch.zeros_like(kc)
+    qo = ops.rope_split(qd, kc, vc, T(pos.astype(np.int32), torch.int32), T(cos), T(sin), B, S, KVH, G, hd, 0)
+    assert err(kc[:, :, :S].float().cpu().numpy(), k) < (1e-5 if dtype == torch.float32 else 3e-2)
+    out = ops.causal_attention(qo, kc, vc, T(mask.astype(np.int32), torch.int32) if pad else None, B, H, KVH, hd, S, S, 0)
+    got = out.float().cpu().numpy().reshape(B, S, H * hd)
+    valid = mask.astype(bool)
+    assert err(got[valid], ref[valid]) < (2e-4 if dtype == torch.float32 else 4e-2)
+
+
+def test_naive_and_fewkeys_attention(ops):
+    rng = np.random.default_rng(0)
+    B, H, hd, Sq, Sk = 2, 8, 16, 7, 300
+    q = rng.standard_normal((B, Sq, H * hd), dtype=np.float32)
+    k = rng.standard_normal((B, Sk, H * hd), dtype=np.float32)
+    v = rng.standard_normal((B, Sk, H * hd), dtype=np.float32)
+
+    def ref(q, k, v):
+        sp = lambda x: x.reshape(x.shape[0], x.shape[1], H, hd).transpose(0, 2, 1, 3)
+        a = O.softmax(np.matmul(sp(q), sp(k).transpose(0, 1, 3, 2)) / np.float32(math.sqrt(hd)))
+        return np.matmul(a, sp(v)).transpose(0, 2, 1, 3).reshape(q.shape)
+
+    st = lambda S: (S * H * hd, H * hd, hd)
+    out = ops.naive_attention(T(q), T(k), T(v), B, H, H, hd, Sq, Sk, st(Sq), st(Sk), st(Sk), st(Sq), 1 / math.sqrt(hd))
+    assert err(out.cpu().numpy().reshape(q.shape), ref(q, k, v)) < 1e-5
+    out = ops.fewkeys_attention(T(k), T(q), T(q), B, H, hd, Sk, Sq, 1 / math.sqrt(hd))  # image -> tokens
+    assert err(out.cpu().numpy().reshape(k.shape), ref(k, q, q)) < 1e-5
+
+
+def test_data_movement_kernels(ops):
+    rng = np.random.default_rng(1)
+    x = rng.random((2, 3, 32, 48), dtype=np.float32)
+    cols = ops.patch_im2col(T(x), 64, 16, torch.float32).cpu().numpy()
+    xp = np.pad(x, ((0, 0), (0, 0), (0, 32), (0, 16)))
+    ref = xp.reshape(2, 3, 4, 16, 4, 16).transpose(0, 2, 4, 1, 3, 5).reshape(2 * 16, 768)
+    assert err(cols, ref) == 0
+    e = rng.standard_normal((2, 64, 64, 256), dtype=np.float32)
+    w = rng.standard_normal(1024, dtype=np.float32); b = rng.standard_normal(1024, dtype=np.float32)
+    y = ops.pixel_shuffle_ln(T(e), T(w), T(b), 2, 64, 64, 256, 1e-5, torch.float32).cpu().numpy()
+    ref = O.layer_norm(O.pixel_shuffle_v2(e).reshape(2, 1024, 1024), w, b, 1e-5).reshape(2048, 1024)
+    assert err(y, ref) < 2e-5
+    f = rng.standard_normal((2, 1024, 1024), dtype=np.float32)
+    u = ops.pixel_unshuffle(T(f), 2, 64, 64, 256).cpu().numpy()
+    s = f.reshape(2, 32, 32, 1024).transpose(0, 2, 1, 3)
+    s = s.reshape(2, 32, 64, 512).transpose(0, 2, 1, 3).reshape(2, 64, 64, 256)  # [n, Y, X, c]  (NHWC of :268's NCHW)
+    # oracle path: text_aware_dense_feature without the MLP
+    n, h, w_, c = 2, 32, 32, 1024
+    g = f.reshape(n, 32, 32, c).transpose(0, 2, 1, 3)
+    g = g.reshape(n, h, 64, 512).transpose(0, 2, 1, 3).reshape(n, 64, 64, 256).transpose(0, 3, 1, 2)
+    assert err(u.reshape(2, 64, 64, 256).transpose(0, 3, 1, 2), g) == 0
+    t = ops.transpose(T(e.reshape(2, 4096, 256)), 2, 4096, 256).cpu().numpy()
+    assert err(t, e.reshape(2, 4096, 256).transpose(0, 2, 1)) == 0
+    c3 = ops.im2col3x3(T(e[:, :8, :8, :64].copy()), 2, 8, 8, 64).cpu().numpy()
+    ep = np.pad(e[:, :8, :8, :64], ((0, 0), (1, 1), (1, 1), (0, 0)))
+    ref = np.concatenate([ep[:, ky:ky + 8, kx:kx + 8] for ky in range(3) for kx in range(3)], -1).reshape(128, 576)
+    assert err(c3, ref) == 0
+    low = rng.standard_normal((2, 1, 256, 256), dtype=np.float32)
+    up, m = ops.resize_bilinear(T(low), (1024, 1024), threshold=0.0)
+    ref = O.bilinear_resize(low, (1024, 1024))
+    assert err(up.cpu().numpy(), ref) < 1e-5
+    assert (m.cpu().numpy().astype(bool) != (ref > 0)).mean() < 1e-5
+    lg = rng.standard_normal((3, 1000), dtype=np.float32); lg[1, 7] = lg[1, 900] = 50.0
+    assert ops.argmax(T(lg)).cpu().tolist() == lg.argmax(-1).tolist()

@@ -1,0 +1,75 @@
+"""ctypes binding of libullsam_hip.so (declared in include/ullsam_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libullsam_hip.so")
+
+_lib = None
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+# name -> argtypes, exactly mirroring include/ullsam_hip.h
+SIGNATURES = {
+    "ullsam_gemm": [i32, vp, i64, vp, i64, vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, i32, vp],
+    "ullsam_norm": [vp, i32, i64, vp, i32, i64, vp, vp, i64, i32, f32, i32, i32, vp, vp, vp],
+    "ullsam_vit_attention": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "ullsam_causal_attention": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "ullsam_naive_attention": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32] + [i64] * 12 + [f32, vp],
+    "ullsam_fewkeys_attention": [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp],
+    "ullsam_patch_im2col": [i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp],
+    "ullsam_im2col3x3": [i32, vp, vp, i32, i32, i32, i32, vp],
+    "ullsam_add_cast": [vp, i32, i64, vp, i64, vp, i32, i64, i32, vp],
+    "ullsam_transpose_f32": [vp, vp, i32, i32, i32, vp],
+    "ullsam_pixel_shuffle_ln": [i32, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "ullsam_pixel_unshuffle": [vp, vp, i32, i32, i32, i32, vp],
+    "ullsam_scan_image_tokens": [vp, vp, vp, i32, i32, C.c_longlong, vp],
+    "ullsam_embed_tokens": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, vp],
+    "ullsam_gather_rows": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "ullsam_rope_split": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "ullsam_argmax": [vp, vp, i32, i64, i64, vp],
+    "ullsam_small_linear": [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp],
+    "ullsam_sparse_embed": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp],
+    "ullsam_dense_pe": [vp, vp, i32, i32, i32, vp],
+    "ullsam_mask_downscale": [vp, vp, i32, i32, i32, i32, i32, i32] + [vp] * 10 + [vp],
+    "ullsam_hyper_masks": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "ullsam_resize_bilinear": [vp, i64, i32, i32, i32, vp, vp, i32, i32, i32, f32, vp],
+    "ullsam_mask_iou_counts": [vp, vp, vp, i32, i64, vp],
+}
+PLAIN = {"ullsam_last_error_string": ([], C.c_char_p), "ullsam_abi_version": ([], i32), "ullsam_device_count": ([], i32)}
+
+
+class UllsamError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UllsamError(f"{LIB_PATH} not found -- run `python -m ullsam_amd.build` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = i32
+    for name, (args, res) in PLAIN.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.ullsam_last_error_string()
+        raise UllsamError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")

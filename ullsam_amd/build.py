@@ -1,0 +1,65 @@
+"""Build libullsam_hip.so (gfx950) in-tree with hipcc.  hipcc cross-compiles without a GPU.
+
+    python -m ullsam_amd.build [--force]
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libullsam_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-I", os.path.join(os.path.dirname(HERE), "include")]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, "build.sha256")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+
+    def cc(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:
+        objs = list(ex.map(cc, _sources()))
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    with open(stamp, "w") as f:
+        f.write(dig)
+    if verbose:
+        print(f"[ullsam_amd.build] built {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

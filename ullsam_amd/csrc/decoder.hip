@@ -1,0 +1,267 @@
+// Prompt-encoder and mask-decoder kernels (token side is fp32 throughout; the image side uses the MFMA GEMM).
+#include "common.h"
+
+// ---- small dense layer: y[M,N] = act(x[M,K] . W[N,K]^T + b) (+ res) -- one wave per output element ----------------
+// token-side Linear layers of transformer.py:220-227,171-173 and the hypernetwork / IoU MLPs of mask_decoder.py:139-147
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ W,
+                                                           const float* __restrict__ b, const float* __restrict__ res, long ldr,
+                                                           float* __restrict__ y, long ldy, int M, int N, int K, int act) {
+    const int lane = threadIdx.x & 63;
+    const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= (long)M * N) return;
+    const int m = (int)(o / N), n = (int)(o % N);
+    const float* xr = x + (long)m * ldx;
+    const float* wr = W + (long)n * K;
+    float acc = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(xr + k);
+        const float4 w = *reinterpret_cast<const float4*>(wr + k);
+        acc += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        if (b) acc += b[n];
+        if (act == 2) acc = fmaxf(acc, 0.f);
+        else if (act == 1) acc = gelu_erf(acc);
+        if (res) acc += res[(long)m * ldr + n];
+        y[(long)m * ldy + n] = acc;
+    }
+}
+
+extern "C" int ullsam_small_linear(const float* x, long ldx, const float* W, const float* b, const float* res, long ldr, float* y,
+                                   long ldy, int M, int N, int K, int act, void* stream) {
+    ULLSAM_CHECK(K % 4 == 0 && ldx % 4 == 0, "small_linear: K and ldx must be multiples of 4");
+    const long outs = (long)M * N;
+    if (outs == 0) return 0;
+    small_linear_kernel<<<(unsigned)((outs + 3) / 4), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(x, ldx, W, b, res, ldr, y, ldy, M, N, K, act);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- sparse prompt embedding (prompt_encoder.py:76-103,220-250) ---------------------------------------------------
+// coords [P,Np,2] px, labels int32 [P,Np], boxes [P,4] or null.  out f32 [P, n_out, C], n_out = Np + pad + 2*has_box
+// tables: G [2, C/2]; emb rows: 0 not_a_point, 1..4 point_embeddings[0..3]  ([5, C])
+__global__ __launch_bounds__(128) void sparse_embed_kernel(const float* __restrict__ coords, const int* __restrict__ labels,
+                                                           const float* __restrict__ boxes, const float* __restrict__ G,
+                                                           const float* __restrict__ emb, float* __restrict__ out, int P, int Np,
+                                                           int pad, int C, float img_w, float img_h) {
+    const int n_out = Np + pad + (boxes ? 2 : 0);
+    const int p = blockIdx.x / n_out, i = blockIdx.x % n_out;
+    const int half = C / 2;
+    float cx, cy;
+    int label;  // -1 not a point, 0 neg, 1 pos, 2/3 box corners
+    if (i < Np) {
+        cx = coords[((long)p * Np + i) * 2] + 0.5f;
+        cy = coords[((long)p * Np + i) * 2 + 1] + 0.5f;
+        label = labels[(long)p * Np + i];
+    } else if (i < Np + pad) {
+        cx = 0.f; cy = 0.f; label = -1;  // padding point is appended AFTER the +0.5 shift (:81-88)
+    } else {
+        const int corner = i - Np - pad;
+        cx = boxes[(long)p * 4 + 2 * corner] + 0.5f;
+        cy = boxes[(long)p * 4 + 2 * corner + 1] + 0.5f;
+        label = 2 + corner;
+    }
+    const float nx = 2.0f * (cx / img_w) - 1.0f, ny = 2.0f * (cy / img_h) - 1.0f;
+    float* o = out + ((long)p * n_out + i) * C;
+    for (int c = threadIdx.x; c < half; c += blockDim.x) {
+        const float ang = 6.283185307179586f * (nx * G[c] + ny * G[half + c]);
+        float sv = sinf(ang), cv = cosf(ang);
+        if (label == -1) { sv = 0.f; cv = 0.f; }
+        const int row = label + 1;  // -1 -> 0, 0 -> 1, 1 -> 2, 2 -> 3, 3 -> 4
+        if (row >= 0 && row <= 4) { sv += emb[row * C + c]; cv += emb[row * C + half + c]; }
+        o[c] = sv;
+        o[half + c] = cv;
+    }
+}
+
+extern "C" int ullsam_sparse_embed(const float* coords, const int* labels, const float* boxes, const float* G, const float* emb,
+                                   float* out, int P, int Np, int pad, int C, float img_w, float img_h, void* stream) {
+    const int n_out = Np + pad + (boxes ? 2 : 0);
+    if (P * n_out == 0) return 0;
+    sparse_embed_kernel<<<P * n_out, 128, 0, reinterpret_cast<hipStream_t>(stream)>>>(coords, labels, boxes, G, emb, out, P, Np, pad, C, img_w, img_h);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- dense positional encoding grid (prompt_encoder.py:230-241), NHWC f32 [H*W, C] -------------------------------
+__global__ __launch_bounds__(128) void dense_pe_kernel(const float* __restrict__ G, float* __restrict__ out, int H, int W, int C) {
+    const int y = blockIdx.x / W, x = blockIdx.x % W;
+    const int half = C / 2;
+    const float nx = 2.0f * (((float)x + 0.5f) / (float)W) - 1.0f, ny = 2.0f * (((float)y + 0.5f) / (float)H) - 1.0f;
+    float* o = out + (long)blockIdx.x * C;
+    for (int c = threadIdx.x; c < half; c += blockDim.x) {
+        const float ang = 6.283185307179586f * (nx * G[c] + ny * G[half + c]);
+        o[c] = sinf(ang);
+        o[half + c] = cosf(ang);
+    }
+}
+
+extern "C" int ullsam_dense_pe(const float* G, float* out_nhwc, int H, int W, int C, void* stream) {
+    dense_pe_kernel<<<H * W, 128, 0, reinterpret_cast<hipStream_t>(stream)>>>(G, out_nhwc, H, W, C);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- mask-input embedding (mask_downscaling, prompt_encoder.py:54-62), fused per output pixel ----------------------
+// in f32 [P,1,4H,4W] -> out NHWC f32 [P, H*W, C].  conv k2s2 (1->c1) + LN2d + GELU + conv k2s2 (c1->c2) + LN2d + GELU + 1x1 (c2->C)
+__global__ __launch_bounds__(256) void mask_downscale_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C,
+                                                             int c1, int c2, const float* w0, const float* b0, const float* g1,
+                                                             const float* be1, const float* w3, const float* b3, const float* g4,
+                                                             const float* be4, const float* w6, const float* b6) {
+    __shared__ float mid[4][16];  // [2x2 position][c1 <= 16]
+    __shared__ float hid[64];     // c2 <= 64
+    const int pix = blockIdx.x % (H * W), p = blockIdx.x / (H * W);
+    const int y = pix / W, x = pix % W;
+    const int IW = 4 * W;
+    const float* ip = in + (long)p * 16 * H * W;
+    const int t = threadIdx.x;
+    if (t < 4) {  // stage 1 for sub-position t = (sy, sx)
+        const int sy = t >> 1, sx = t & 1;
+        float v[16];
+        float mean = 0.f;
+        for (int c = 0; c < c1; ++c) {
+            float a = b0[c];
+            for (int ky = 0; ky < 2; ++ky)
+                for (int kx = 0; kx < 2; ++kx)
+                    a += w0[c * 4 + ky * 2 + kx] * ip[(long)(4 * y + 2 * sy + ky) * IW + 4 * x + 2 * sx + kx];
+            v[c] = a; mean += a;
+        }
+        mean /= (float)c1;
+        float var = 0.f;
+        for (int c = 0; c < c1; ++c) var += (v[c] - mean) * (v[c] - mean);
+        var /= (float)c1;
+        for (int c = 0; c < c1; ++c) mid[t][c] = gelu_erf((v[c] - mean) / sqrtf(var + 1e-6f) * g1[c] + be1[c]);
+    }
+    __syncthreads();
+    if (t < c2) {  // conv2: weight [c2, c1, 2, 2]
+        float a = b3[t];
+        for (int c = 0; c < c1; ++c)
+            for (int k = 0; k < 4; ++k) a += w3[(t * c1 + c) * 4 + k] * mid[k][c];
+        hid[t] = a;
+    }
+    __syncthreads();
+    if (t == 0) {
+        float mean = 0.f;
+        for (int c = 0; c < c2; ++c) mean += hid[c];
+        mean /= (float)c2;
+        float var = 0.f;
+        for (int c = 0; c < c2; ++c) var += (hid[c] - mean) * (hid[c] - mean);
+        var /= (float)c2;
+        for (int c = 0; c < c2; ++c) hid[c] = gelu_erf((hid[c] - mean) / sqrtf(var + 1e-6f) * g4[c] + be4[c]);
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        float a = b6[c];
+        for (int k = 0; k < c2; ++k) a += w6[c * c2 + k] * hid[k];
+        out[((long)p * H * W + pix) * C + c] = a;
+    }
+}
+
+extern "C" int ullsam_mask_downscale(const float* masks, float* out_nhwc, int P, int H, int W, int C, int c1, int c2, const float* w0,
+                                     const float* b0, const float* g1, const float* be1, const float* w3, const float* b3,
+                                     const float* g4, const float* be4, const float* w6, const float* b6, void* stream) {
+    ULLSAM_CHECK(c1 <= 16 && c2 <= 64, "mask_downscale: c1<=16, c2<=64");
+    if (P == 0) return 0;
+    mask_downscale_kernel<<<P * H * W, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(masks, out_nhwc, H, W, C, c1, c2, w0, b0, g1, be1, w3, b3, g4, be4, w6, b6);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- masks = hyper_in @ upscaled_embedding (mask_decoder.py:143-144) ---------------------------------------------
+// up2 f32 [NB*H*W*4, 4*CU] : row = ((nb*H + y)*W + x)*4 + (ky*2+kx), col = (ky2*2+kx2)*CU + c  (two k2s2 ConvTranspose as GEMMs)
+// hyper f32 [NB, NM, CU];  out f32 [NB, NM, 4H, 4W]
+template <int CU>
+__global__ __launch_bounds__(256) void hyper_masks_kernel(const float* __restrict__ up2, const float* __restrict__ hyper,
+                                                          float* __restrict__ out, int NB, int NM, int H, int W) {
+    __shared__ float hs[8 * CU];
+    const int nb = blockIdx.y;
+    for (int i = threadIdx.x; i < NM * CU; i += 256) hs[i] = hyper[(long)nb * NM * CU + i];
+    __syncthreads();
+    const long per = (long)H * W * 16;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+        const int sub2 = i & 3;
+        const long row = i >> 2;  // ((y*W + x)*4 + sub1)
+        const int sub1 = row & 3;
+        const long pix = row >> 2;
+        const int y = (int)(pix / W), x = (int)(pix % W);
+        const float* src = up2 + (((long)nb * H * W * 4 + row) * 4 + sub2) * CU;
+        float v[CU];
+#pragma unroll
+        for (int c = 0; c < CU; c += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(src + c);
+            v[c] = t.x; v[c + 1] = t.y; v[c + 2] = t.z; v[c + 3] = t.w;
+        }
+        const int Y = 4 * y + 2 * (sub1 >> 1) + (sub2 >> 1), X = 4 * x + 2 * (sub1 & 1) + (sub2 & 1);
+        for (int m = 0; m < NM; ++m) {
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < CU; ++c) a += hs[m * CU + c] * v[c];
+            out[(((long)nb * NM + m) * 4 * H + Y) * 4 * W + X] = a;
+        }
+    }
+}
+
+extern "C" int ullsam_hyper_masks(const float* up2, const float* hyper, float* out, int NB, int NM, int H, int W, int CU, void* stream) {
+    ULLSAM_CHECK(CU == 32 && NM <= 8, "hyper_masks: CU must be 32, NM <= 8");
+    if (NB == 0) return 0;
+    hyper_masks_kernel<32><<<dim3(512, NB), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(up2, hyper, out, NB, NM, H, W);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- bilinear resize (align_corners=False) + optional threshold (app.py:635-645, sam.py:154-162,123) ----------------
+// in f32 [N, IH(valid of in_ld rows), IW] with row stride in_ld and plane stride in_ps; out f32 [N,OH,OW] and/or mask u8
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, long in_ps, int in_ld, int IH, int IW,
+                                                              float* __restrict__ out, unsigned char* __restrict__ mask, int N, int OH,
+                                                              int OW, float thr) {
+    const long total = (long)N * OH * OW;
+    const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+        const long n = i / ((long)OW * OH);
+        float fy = ((float)oy + 0.5f) * sy - 0.5f; if (fy < 0.f) fy = 0.f;
+        float fx = ((float)ox + 0.5f) * sx - 0.5f; if (fx < 0.f) fx = 0.f;
+        const int y0 = min((int)fy, IH - 1), x0 = min((int)fx, IW - 1);
+        const int y1 = min(y0 + 1, IH - 1), x1 = min(x0 + 1, IW - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* p = in + n * in_ps;
+        const float top = p[(long)y0 * in_ld + x0] * (1.f - lx) + p[(long)y0 * in_ld + x1] * lx;
+        const float bot = p[(long)y1 * in_ld + x0] * (1.f - lx) + p[(long)y1 * in_ld + x1] * lx;
+        const float v = top * (1.f - ly) + bot * ly;
+        if (out) out[i] = v;
+        if (mask) mask[i] = v > thr ? 1 : 0;
+    }
+}
+
+extern "C" int ullsam_resize_bilinear(const float* in, long in_plane_stride, int in_ld, int IH, int IW, float* out, unsigned char* mask,
+                                      int N, int OH, int OW, float thr, void* stream) {
+    const long total = (long)N * OH * OW;
+    if (total == 0) return 0;
+    const int grid = (int)min((total + 255) / 256, (long)2048 * 8);
+    resize_bilinear_kernel<<<grid, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(in, in_plane_stride, in_ld, IH, IW, out, mask, N, OH, OW, thr);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- mask IoU (CalcIoU, train_joint_v2.py:683-694): counts[n] = {intersection, union} over u8 masks ------------------
+__global__ __launch_bounds__(256) void mask_iou_kernel(const unsigned char* __restrict__ a, const unsigned char* __restrict__ b,
+                                                       unsigned long long* __restrict__ counts, long per) {
+    const long n = blockIdx.y;
+    unsigned long long inter = 0, uni = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+        const bool x = a[n * per + i] != 0, y = b[n * per + i] != 0;
+        inter += (x && y); uni += (x || y);
+    }
+    for (int o = 32; o > 0; o >>= 1) { inter += __shfl_xor(inter, o, 64); uni += __shfl_xor(uni, o, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&counts[2 * n], inter); atomicAdd(&counts[2 * n + 1], uni); }
+}
+
+extern "C" int ullsam_mask_iou_counts(const unsigned char* a, const unsigned char* b, unsigned long long* counts, int N, long per, void* stream) {
+    if (N == 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(counts, 0, sizeof(unsigned long long) * 2 * N, s) != hipSuccess) { ullsam_set_error("mask_iou: memset failed"); return -2; }
+    mask_iou_kernel<<<dim3(64, N), 256, 0, s>>>(a, b, counts, per);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,272 @@
+// C[M,N] = epilogue(A[M,K] . W[N,K]^T)   -- every nn.Linear / 1x1 conv / im2col conv on the hot path.
+//
+// Reference sites replaced: K1 patch-embed GEMM (image_encoder.py:387-395), K3 qkv
+// (:227), K6 proj (:238), K7 MLP (common.py:21-26), K8 neck convs (image_encoder.py:88-104), K9 mlp1
+// (modeling_internvl_sam.py:88-93), K12 wqkv / K14 wo / K15 SwiGLU (modeling_internlm2.py:359,421,261-264),
+// K16 lm_head (:1081), K17 mlp2 (modeling_internvl_sam.py:95-100), decoder image-side projections
+// (transformer.py:220-227) and the two ConvTranspose2d of mask_decoder.py:53-59 (stride == kernel => GEMM).
+//
+// Layout: A row-major [M, lda], W row-major [N, ldw] (nn.Linear's native [out, in]) so both operands are
+// K-contiguous ("B^T input").  Tile 128x128, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16 tiles.
+// K-tile = 128 bytes per row (64 bf16 / 32 f32).  Global->LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
+// wave instruction = 8 rows), double buffered, one barrier per K-tile.  LDS image: 128-byte rows, 16-byte
+// chunk index XOR (row & 7): the DMA writes lane-linear, so the swizzle is applied to the per-lane SOURCE
+// address and again on the ds_read_b128 (cdna guide 5.4 rule 21) -> conflict-free fragment reads.
+// Epilogue: accumulators -> LDS (fp32) -> coalesced 16/32-byte row stores with bias / GELU(erf) / ReLU /
+// SwiGLU-pair / fp32 residual (optionally row-broadcast, for pos_embed) fused.
+#include "common.h"
+
+struct GemmArgs {
+    const void* A;
+    const void* W;
+    void* C;
+    const float* bias;
+    const float* residual;
+    int M, N, K;
+    long lda, ldw, ldc, ldr;
+    int res_row_mod;
+    int act;      // 0 none, 1 gelu(erf), 2 relu, 3 swiglu pair (tile = [64 gate | 64 up])
+    int out_f32;  // C element type: 1 -> float, 0 -> T
+    int vec_ok;   // stores / residual loads may be 16-byte vectors
+    int tiles_m, tiles_n;
+};
+
+template <typename T>
+__device__ __forceinline__ Frag<T> lds_frag(const char* tile, int row, int ks, int g);
+template <>
+__device__ __forceinline__ Frag<bf16> lds_frag<bf16>(const char* tile, int row, int ks, int g) {
+    const int c = (ks * 4 + g) ^ (row & 7);
+    return load_frag(reinterpret_cast<const bf16*>(tile + row * 128 + (c << 4)));
+}
+template <>
+__device__ __forceinline__ Frag<float> lds_frag<float>(const char* tile, int row, int ks, int g) {
+    (void)ks;
+    const int c0 = (2 * g) ^ (row & 7), c1 = (2 * g + 1) ^ (row & 7);
+    const float4 a = *reinterpret_cast<const float4*>(tile + row * 128 + (c0 << 4));
+    const float4 b = *reinterpret_cast<const float4*>(tile + row * 128 + (c1 << 4));
+    Frag<float> f;
+    f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+    f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+    return f;
+}
+
+template <typename OutT>
+__device__ __forceinline__ void store_row8(OutT* dst, const float* v, int n_valid, bool vec);
+template <>
+__device__ __forceinline__ void store_row8<float>(float* dst, const float* v, int n_valid, bool vec) {
+    if (vec && n_valid == 8) {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        for (int e = 0; e < n_valid; ++e) dst[e] = v[e];
+    }
+}
+template <>
+__device__ __forceinline__ void store_row8<bf16>(bf16* dst, const float* v, int n_valid, bool vec) {
+    if (vec && n_valid == 8) {
+        bf16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        *reinterpret_cast<bf16x8_t*>(dst) = o;
+    } else {
+        for (int e = 0; e < n_valid; ++e) dst[e] = (bf16)v[e];
+    }
+}
+
+template <typename T, typename OutT>
+__device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs, int m0, int n0, int tn, int tid) {
+    OutT* C = reinterpret_cast<OutT*>(p.C);
+    if (p.act == 3) {
+        // SwiGLU pair: tile columns [0,64) = gate rows of w1, [64,128) = up rows of w3 (host prepack);
+        // out[:, tn*64 + j] = silu(gate_j) * up_j      (modeling_internlm2.py:261-264)
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 16 + (tid >> 4);
+            const int j0 = (tid & 15) * 4;
+            const int gm = m0 + row;
+            if (gm >= p.M) continue;
+            const float4 g = *reinterpret_cast<const float4*>(Cs + row * 128 + j0);
+            const float4 u = *reinterpret_cast<const float4*>(Cs + row * 128 + 64 + j0);
+            float4 o = make_float4(silu_f(g.x) * u.x, silu_f(g.y) * u.y, silu_f(g.z) * u.z, silu_f(g.w) * u.w);
+            OutT* dst = C + (size_t)gm * p.ldc + (size_t)tn * 64 + j0;
+            if (p.vec_ok) {
+                store4(dst, o);
+            } else {
+                dst[0] = from_f32<OutT>(o.x); dst[1] = from_f32<OutT>(o.y);
+                dst[2] = from_f32<OutT>(o.z); dst[3] = from_f32<OutT>(o.w);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int row = pass * 16 + (tid >> 4);
+        const int c0 = (tid & 15) * 8;
+        const int gm = m0 + row, gn = n0 + c0;
+        if (gm >= p.M || gn >= p.N) continue;
+        const int n_valid = min(8, p.N - gn);
+        float v[8];
+        const float4 a = *reinterpret_cast<const float4*>(Cs + row * 128 + c0);
+        const float4 b = *reinterpret_cast<const float4*>(Cs + row * 128 + c0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < n_valid) v[e] += p.bias[gn + e];
+        }
+        if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        } else if (p.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.residual) {
+            const int rr = p.res_row_mod > 0 ? (gm % p.res_row_mod) : gm;
+            const float* rp = p.residual + (size_t)rr * p.ldr + gn;
+            if (p.vec_ok && n_valid == 8) {
+                const float4 r0 = *reinterpret_cast<const float4*>(rp);
+                const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            } else {
+                for (int e = 0; e < n_valid; ++e) v[e] += rp[e];
+            }
+        }
+        store_row8<OutT>(C + (size_t)gm * p.ldc + gn, v, n_valid, p.vec_ok != 0);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm128_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int BK = 8 * EPC;
+    constexpr int KSTEPS = BK / 32;
+    char* As = smem;
+    char* Bs = smem + 32768;
+
+    // XCD-aware bijective remap + grouped (8 row-tiles) ordering so neighbouring tiles share an L2
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int GM = 8;
+    const int width = GM * p.tiles_n;
+    const int group = swz / width;
+    const int first_m = group * GM;
+    const int gsize = min(p.tiles_m - first_m, GM);
+    const int tm = first_m + (swz % width) % gsize;
+    const int tn = (swz % width) / gsize;
+    const int m0 = tm * 128, n0 = tn * 128;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const char* a_src[4];
+    const char* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        const int gm = min(m0 + row, p.M - 1);
+        const int gn = min(n0 + row, p.N - 1);
+        a_src[i] = reinterpret_cast<const char*>(p.A) + (size_t)gm * p.lda * sizeof(T) + (c << 4);
+        b_src[i] = reinterpret_cast<const char*>(p.W) + (size_t)gn * p.ldw * sizeof(T) + (c << 4);
+    }
+    const int nk = p.K / BK;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int buf, int kt) {
+        const size_t koff = (size_t)kt * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[i] + koff), LDS_PTR(As + buf * 16384 + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[i] + koff), LDS_PTR(Bs + buf * 16384 + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
+    };
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // tile kt landed (vmcnt(0) + barrier); everyone is done reading buffer (kt+1)&1
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const char* Ab = As + (kt & 1) * 16384;
+        const char* Bb = Bs + (kt & 1) * 16384;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            Frag<T> a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = lds_frag<T>(Ab, wm * 64 + i * 16 + (lane & 15), ks, lane >> 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), ks, lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(a[i], b[j], acc[i][j]);
+        }
+    }
+
+    __syncthreads();
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+                const int col = wn * 64 + j * 16 + (lane & 15);
+                Cs[row * 128 + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    if (p.out_f32)
+        epilogue_rows<T, float>(p, Cs, m0, n0, tn, tid);
+    else
+        epilogue_rows<T, T>(p, Cs, m0, n0, tn, tid);
+}
+
+template <typename T>
+static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr_set = true;
+    }
+    gemm128_kernel<T><<<dim3(a.tiles_m * a.tiles_n), dim3(256), 65536, stream>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, long ldw, void* C, long ldc, int out_f32,
+                           const float* bias, const float* residual, long ldr, int res_row_mod, int act, int M, int N,
+                           int K, void* stream) {
+    ULLSAM_CHECK(dtype == ULLSAM_DT_F32 || dtype == ULLSAM_DT_BF16, "ullsam_gemm: bad dtype %d", dtype);
+    ULLSAM_CHECK(M > 0 && N > 0 && K > 0, "ullsam_gemm: empty problem M=%d N=%d K=%d", M, N, K);
+    const int esz = dtype == ULLSAM_DT_F32 ? 4 : 2;
+    const int bk = 128 / esz;
+    ULLSAM_CHECK(K % bk == 0, "ullsam_gemm: K=%d must be a multiple of %d", K, bk);
+    ULLSAM_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "ullsam_gemm: A/W must be 16-byte aligned");
+    ULLSAM_CHECK((lda * esz) % 16 == 0 && (ldw * esz) % 16 == 0, "ullsam_gemm: lda/ldw rows must be 16-byte multiples");
+    ULLSAM_CHECK(act >= 0 && act <= 3, "ullsam_gemm: bad act %d", act);
+    if (act == 3) ULLSAM_CHECK(N % 128 == 0 && !bias && !residual, "ullsam_gemm: swiglu needs N%%128==0, no bias/residual");
+    GemmArgs a;
+    a.A = A; a.W = W; a.C = C; a.bias = bias; a.residual = residual;
+    a.M = M; a.N = N; a.K = K;
+    a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
+    a.res_row_mod = res_row_mod; a.act = act; a.out_f32 = out_f32;
+    const int osz = out_f32 ? 4 : esz;
+    const int n_out = act == 3 ? N / 2 : N;
+    bool vec = ((uintptr_t)C & 15) == 0 && (ldc * osz) % 16 == 0 && (n_out % 8 == 0);
+    if (residual) vec = vec && ((uintptr_t)residual & 15) == 0 && (ldr % 4 == 0);
+    a.vec_ok = vec ? 1 : 0;
+    a.tiles_m = (M + 127) / 128;
+    a.tiles_n = (N + 127) / 128;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == ULLSAM_DT_F32 ? launch_gemm<float>(a, s) : launch_gemm<bf16>(a, s);
+}

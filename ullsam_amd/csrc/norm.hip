@@ -1,0 +1,110 @@
+// Row-wise LayerNorm / RMSNorm with fp32 statistics.
+//   LayerNorm  : image_encoder.py:151,161 (eps 1e-6 via build_sam.py:72); LayerNorm2d common.py:38-43 (NHWC rows ==
+//                per-pixel channel LN, biased variance); nn.LayerNorm in mlp1/mlp2 (modeling_internvl_sam.py:89,96)
+//                and the decoder (transformer.py, eps 1e-5); F.layer_norm without affine (prompt_encoder.py:142-145).
+//   RMSNorm    : InternLM2RMSNorm.forward modeling_internlm2.py:138-143 (fp32 variance, weight applied last).
+// One wave per row, 16-byte loads, two-pass (mean, then centred variance) entirely in registers: HBM-bound,
+// algorithmic bytes = rows*D*(sizeof(in)+sizeof(out)).
+// Optional fused extras used by the decoder / prompt encoder: post-scale+shift (llm_scale_factor/llm_bias) and
+// an activation (GELU) after the affine.
+#include "common.h"
+
+struct NormArgs {
+    const void* in;
+    void* out;
+    const float* w;
+    const float* b;
+    long rows;
+    int D;
+    long in_stride, out_stride;
+    float eps;
+    int rms;
+    int act;  // 0 none, 1 gelu
+    const float* post_scale;  // device scalar or null
+    const float* post_shift;  // device scalar or null
+};
+
+template <typename TI, typename TO, int MAXV>
+__global__ __launch_bounds__(256) void norm_kernel(NormArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const TI* x = reinterpret_cast<const TI*>(p.in) + row * p.in_stride;
+    TO* y = reinterpret_cast<TO*>(p.out) + row * p.out_stride;
+    const int nv = p.D >> 2;  // float4 groups
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = i * 64 + lane;
+        if (idx < nv) {
+            v[i] = load4(x + idx * 4);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float mean = 0.f;
+    if (!p.rms) mean = wave_sum(s) / (float)p.D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = i * 64 + lane;
+        if (idx < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            ss += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float var = wave_sum(ss) / (float)p.D;
+    const float rstd = p.rms ? rsqrtf(var + p.eps) : 1.0f / sqrtf(var + p.eps);
+    const float ps = p.post_scale ? p.post_scale[0] : 1.f;
+    const float pb = p.post_shift ? p.post_shift[0] : 0.f;
+    const bool post = p.post_scale || p.post_shift;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = i * 64 + lane;
+        if (idx < nv) {
+            float4 o = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd);
+            if (p.w) {
+                const float4 w = *reinterpret_cast<const float4*>(p.w + idx * 4);
+                o.x *= w.x; o.y *= w.y; o.z *= w.z; o.w *= w.w;
+            }
+            if (p.b) {
+                const float4 b = *reinterpret_cast<const float4*>(p.b + idx * 4);
+                o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+            }
+            if (post) { o.x = o.x * ps + pb; o.y = o.y * ps + pb; o.z = o.z * ps + pb; o.w = o.w * ps + pb; }
+            if (p.act == 1) { o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w); }
+            store4(y + idx * 4, o);
+        }
+    }
+}
+
+template <typename TI, typename TO>
+static int launch_norm(const NormArgs& a, hipStream_t s) {
+    const dim3 grid((unsigned)((a.rows + 3) / 4)), block(256);
+    const int nv = a.D / 4;
+    if (nv <= 64) norm_kernel<TI, TO, 1><<<grid, block, 0, s>>>(a);
+    else if (nv <= 256) norm_kernel<TI, TO, 4><<<grid, block, 0, s>>>(a);
+    else if (nv <= 512) norm_kernel<TI, TO, 8><<<grid, block, 0, s>>>(a);
+    else norm_kernel<TI, TO, 16><<<grid, block, 0, s>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// in_dtype/out_dtype: 0 f32, 1 bf16.  w/b may be null.  rms=1 -> RMSNorm (b ignored).
+extern "C" int ullsam_norm(const void* in, int in_dtype, long in_stride, void* out, int out_dtype, long out_stride,
+                           const float* w, const float* b, long rows, int D, float eps, int rms, int act,
+                           const float* post_scale, const float* post_shift, void* stream) {
+    ULLSAM_CHECK(D % 4 == 0 && D > 0 && D <= 4096, "ullsam_norm: D=%d must be a multiple of 4 and <= 4096", D);
+    ULLSAM_CHECK(rows >= 0, "ullsam_norm: bad rows");
+    if (rows == 0) return 0;
+    ULLSAM_CHECK(in_stride % 4 == 0 && out_stride % 4 == 0, "ullsam_norm: strides must be multiples of 4 elements");
+    NormArgs a{in, out, w, rms ? nullptr : b, rows, D, in_stride, out_stride, eps, rms, act, post_scale, post_shift};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (in_dtype == 0 && out_dtype == 0) return launch_norm<float, float>(a, s);
+    if (in_dtype == 0 && out_dtype == 1) return launch_norm<float, bf16>(a, s);
+    if (in_dtype == 1 && out_dtype == 1) return launch_norm<bf16, bf16>(a, s);
+    if (in_dtype == 1 && out_dtype == 0) return launch_norm<bf16, float>(a, s);
+    ULLSAM_CHECK(false, "ullsam_norm: bad dtypes %d %d", in_dtype, out_dtype);
+}

@@ -1,0 +1,155 @@
+"""SAM ViT image encoder on HIP kernels.
+
+API mirror of modeling/image_encoder.py: ImageEncoderViT(...) ctor kwargs (:18-36), `.img_size`,
+forward(x[B,3,S,S]) -> [B,out_chans,S/16,S/16]; identical state_dict keys (pos_embed, patch_embed.proj.*,
+blocks.N.{norm1,attn.{qkv,proj,rel_pos_h,rel_pos_w},norm2,mlp.lin1,mlp.lin2}.*, neck.{0,1,2,3}.*).
+
+Dataflow (per image N = g*g tokens, D = embed_dim), all activations token-major (NHWC), residual stream fp32:
+  patch im2col -> GEMM(+bias +pos_embed) -> L x [ LN -> GEMM qkv -> fused (windowed|global) attention with in-kernel
+  rel-pos and window pad semantics -> GEMM proj (+residual) -> LN -> GEMM lin1+GELU -> GEMM lin2 (+residual) ]
+  -> GEMM 1x1 -> LN -> im2col3x3 -> GEMM -> LN.
+window_partition / window_unpartition / F.pad never materialise (fused into the attention kernel's gather).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple, Type
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..packing import pack_conv3x3
+from .common import LayerNorm, LayerNorm2d, Linear, MLPBlock, Packed
+
+
+class _Conv2dParams(Packed):
+    """Parameter holder with nn.Conv2d's state_dict layout."""
+
+    def __init__(self, cin, cout, k, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        nn.init.normal_(self.weight, std=(cin * k * k) ** -0.5)
+
+
+class PatchEmbed(Packed):
+    """image_encoder.py:364-395."""
+
+    def __init__(self, kernel_size=(16, 16), stride=(16, 16), padding=(0, 0), in_chans=3, embed_dim=768):
+        super().__init__()
+        assert kernel_size == stride and padding == (0, 0), "SAM's PatchEmbed is a non-overlapping conv"
+        self.patch = kernel_size[0]
+        self.proj = _Conv2dParams(in_chans, embed_dim, kernel_size[0])
+
+
+class Attention(Packed):
+    """image_encoder.py:185-222 (parameters only; compute is fused in ImageEncoderViT.forward_tokens)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=True, use_rel_pos=False, rel_pos_zero_init=True, input_size=None):
+        super().__init__()
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = Linear(dim, dim)
+        self.use_rel_pos = use_rel_pos
+        if use_rel_pos:
+            assert input_size is not None, "Input size must be provided if using relative positional encoding."
+            self.rel_pos_h = nn.Parameter(torch.zeros(2 * input_size[0] - 1, self.head_dim))
+            self.rel_pos_w = nn.Parameter(torch.zeros(2 * input_size[1] - 1, self.head_dim))
+
+
+class Block(Packed):
+    """image_encoder.py:119-182."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, norm_layer=LayerNorm, act_layer=nn.GELU,
+                 use_rel_pos=False, rel_pos_zero_init=True, window_size=0, input_size=None):
+        super().__init__()
+        self.norm1 = _make_norm(norm_layer, dim)
+        self.attn = Attention(dim, num_heads, qkv_bias, use_rel_pos, rel_pos_zero_init,
+                              input_size if window_size == 0 else (window_size, window_size))
+        self.norm2 = _make_norm(norm_layer, dim)
+        self.mlp = MLPBlock(embedding_dim=dim, mlp_dim=int(dim * mlp_ratio), act=act_layer)
+        self.window_size = window_size
+
+
+def _make_norm(norm_layer, dim) -> LayerNorm:
+    """Accept the reference's `partial(torch.nn.LayerNorm, eps=1e-6)` (build_sam.py:72) as well as our own class."""
+    probe = norm_layer(dim)
+    eps = getattr(probe, "eps", 1e-5)
+    return LayerNorm(dim, eps=eps)
+
+
+class ImageEncoderViT(Packed):
+    def __init__(self, img_size: int = 1024, patch_size: int = 16, in_chans: int = 3, embed_dim: int = 768, depth: int = 12,
+                 num_heads: int = 12, mlp_ratio: float = 4.0, out_chans: int = 256, qkv_bias: bool = True,
+                 norm_layer: Type[nn.Module] = nn.LayerNorm, act_layer: Type[nn.Module] = nn.GELU, use_abs_pos: bool = True,
+                 use_rel_pos: bool = False, rel_pos_zero_init: bool = True, window_size: int = 0,
+                 global_attn_indexes: Tuple[int, ...] = ()) -> None:
+        super().__init__()
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.embed_dim, self.num_heads, self.out_chans = embed_dim, num_heads, out_chans
+        self.patch_embed = PatchEmbed((patch_size, patch_size), (patch_size, patch_size), in_chans=in_chans, embed_dim=embed_dim)
+        self.pos_embed: Optional[nn.Parameter] = None
+        g = img_size // patch_size
+        if use_abs_pos:
+            self.pos_embed = nn.Parameter(torch.zeros(1, g, g, embed_dim))
+        self.blocks = nn.ModuleList()
+        for i in range(depth):
+            self.blocks.append(Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                                     norm_layer=norm_layer, act_layer=act_layer, use_rel_pos=use_rel_pos,
+                                     rel_pos_zero_init=rel_pos_zero_init,
+                                     window_size=window_size if i not in global_attn_indexes else 0, input_size=(g, g)))
+        self.neck = nn.Sequential(_Conv2dParams(embed_dim, out_chans, 1, bias=False), LayerNorm2d(out_chans),
+                                  _Conv2dParams(out_chans, out_chans, 3, bias=False), LayerNorm2d(out_chans))
+        if not use_rel_pos:
+            raise NotImplementedError("the HIP attention kernel implements SAM's use_rel_pos=True configuration")
+
+    @property
+    def compute_dtype(self) -> torch.dtype:
+        return self.patch_embed.proj.weight.dtype
+
+    # ------------------------------------------------------------------
+    def forward_tokens(self, x: torch.Tensor, pixel_mean: Optional[torch.Tensor] = None,
+                       pixel_std: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x [B,3,Hs<=S,Ws<=S] (any float dtype) -> image embedding, token-major fp32 [B, g*g, out_chans].
+        pixel_mean/std (fp32 [3]) fuse Sam.preprocess (normalise, then zero-pad to S x S; sam.py:164-174)."""
+        dt = self.compute_dtype
+        S, p = self.img_size, self.patch_size
+        g = S // p
+        N = g * g
+        B = x.shape[0]
+        D = self.embed_dim
+        cols = ops.patch_im2col(x.float().contiguous(), S, p, dt, pixel_mean, pixel_std)
+        pe = self.patch_embed.proj
+        wp = self.pk("patch_w", pe.weight, lambda: pe.weight.detach().reshape(D, -1).to(dt).contiguous())
+        pos = None if self.pos_embed is None else self.f32("pos", self.pos_embed).reshape(N, D)
+        xres = ops.gemm(cols, wp, None if pe.bias is None else self.f32("patch_b", pe.bias), residual=pos, res_row_mod=N, out_f32=True)
+        for blk in self.blocks:
+            at = blk.attn
+            xn = ops.norm(xres, *blk.norm1.wb(), blk.norm1.eps, dt)
+            qkv = ops.gemm(xn, at.qkv.w(dt), at.qkv.b())
+            qb = at.qkv.bias if at.qkv.bias is not None else torch.zeros(3 * D, device=x.device)
+            att = ops.vit_attention(qkv, at.cdt("rh", at.rel_pos_h, dt), at.cdt("rw", at.rel_pos_w, dt), at.cdt("qb", qb, dt),
+                                    B, self.num_heads, at.head_dim, g, g, blk.window_size)
+            ops.gemm(att, at.proj.w(dt), at.proj.b(), residual=xres, out_f32=True, out=xres)
+            xn = ops.norm(xres, *blk.norm2.wb(), blk.norm2.eps, dt)
+            h = ops.gemm(xn, blk.mlp.lin1.w(dt), blk.mlp.lin1.b(), act=blk.mlp.act_code)
+            ops.gemm(h, blk.mlp.lin2.w(dt), blk.mlp.lin2.b(), residual=xres, out_f32=True, out=xres)
+        n0, n1, n2, n3 = self.neck[0], self.neck[1], self.neck[2], self.neck[3]
+        C = self.out_chans
+        w0 = self.pk("neck0", n0.weight, lambda: n0.weight.detach().reshape(C, D).to(dt).contiguous())
+        y = ops.gemm(ops.cast(xres, dt), w0, out_f32=True)
+        yn = ops.norm(y, *n1.wb(), n1.eps, dt)
+        w2 = self.pk("neck2", n2.weight, lambda: pack_conv3x3(n2.weight.detach()).to(dt).contiguous())
+        z = ops.gemm(ops.im2col3x3(yn, B, g, g, C), w2, out_f32=True)
+        out = ops.norm(z, *n3.wb(), n3.eps, torch.float32)
+        return out.reshape(B, N, C)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B = x.shape[0]
+        g = self.img_size // self.patch_size
+        tok = self.forward_tokens(x)
+        return ops.transpose(tok, B, g * g, self.out_chans).reshape(B, self.out_chans, g, g).to(self.compute_dtype)

@@ -1,0 +1,119 @@
+"""SAM mask decoder on HIP kernels (API + state_dict mirror of modeling/mask_decoder.py)."""
+from __future__ import annotations
+
+from typing import List, Tuple, Type
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..packing import pack_convT_k2s2
+from .common import LayerNorm2d, Linear, Packed
+
+
+class _Embedding(Packed):
+    def __init__(self, n, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(n, dim))
+
+
+class _ConvT(Packed):
+    """Parameter holder with nn.ConvTranspose2d(k=2, s=2)'s layout: weight [Cin, Cout, 2, 2]."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(cin, cout, 2, 2) * cin ** -0.5)
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+    def packed(self, dt):
+        w = self.pk("w", (self.weight, self.bias), lambda: pack_convT_k2s2(self.weight.detach(), self.bias.detach())[0].to(dt).contiguous())
+        b = self.pk("b", (self.weight, self.bias), lambda: pack_convT_k2s2(self.weight.detach(), self.bias.detach())[1].float().contiguous())
+        return w, b
+
+
+class MLP(Packed):
+    """mask_decoder.py:154-176 (ReLU between layers)."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers, sigmoid_output: bool = False):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+        self.sigmoid_output = sigmoid_output
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = x.float().contiguous()
+        for i, l in enumerate(self.layers):
+            x = ops.small_linear(x, l.f32("w32", l.weight), l.b(), ops.ACT_RELU if i < self.num_layers - 1 else ops.ACT_NONE)
+        if self.sigmoid_output:
+            x = torch.sigmoid(x)
+        return x
+
+
+class MaskDecoder(Packed):
+    def __init__(self, *, transformer_dim: int, transformer: nn.Module, num_multimask_outputs: int = 3,
+                 activation: Type[nn.Module] = nn.GELU, iou_head_depth: int = 3, iou_head_hidden_dim: int = 256) -> None:
+        super().__init__()
+        self.transformer_dim = transformer_dim
+        self.transformer = transformer
+        self.num_multimask_outputs = num_multimask_outputs
+        self.iou_token = _Embedding(1, transformer_dim)
+        self.num_mask_tokens = num_multimask_outputs + 1
+        self.mask_tokens = _Embedding(self.num_mask_tokens, transformer_dim)
+        if activation is not nn.GELU:
+            raise NotImplementedError("output_upscaling is fused with GELU (the only activation SAM builds)")
+        self.output_upscaling = nn.Sequential(_ConvT(transformer_dim, transformer_dim // 4), LayerNorm2d(transformer_dim // 4),
+                                              activation(), _ConvT(transformer_dim // 4, transformer_dim // 8), activation())
+        self.output_hypernetworks_mlps = nn.ModuleList(
+            [MLP(transformer_dim, transformer_dim, transformer_dim // 8, 3) for _ in range(self.num_mask_tokens)])
+        self.iou_prediction_head = MLP(transformer_dim, iou_head_hidden_dim, self.num_mask_tokens, iou_head_depth)
+
+    # -- token-major internals ----------------------------------------------------------------------
+    def predict_masks_tokens(self, image_tokens: torch.Tensor, pe_tokens: torch.Tensor, sparse: torch.Tensor,
+                             dense_tokens: torch.Tensor, hw: Tuple[int, int]):
+        """image_tokens fp32 [1 or P, N, C]; pe_tokens [N, C]; sparse fp32 [P, n, C]; dense_tokens fp32 [P|1, N|1, C].
+        Returns (masks [P, 4, 4h, 4w] fp32, iou [P, 4] fp32) -- predict_masks, mask_decoder.py:112-149."""
+        h, w = hw
+        N, C = h * w, self.transformer_dim
+        P = sparse.shape[0]
+        dt = self.transformer.compute_dtype
+        out_tok = self.pk("out_tokens", (self.iou_token.weight, self.mask_tokens.weight),
+                          lambda: torch.cat([self.iou_token.weight.detach().float(), self.mask_tokens.weight.detach().float()], 0))
+        tokens = torch.cat([out_tok.unsqueeze(0).expand(P, -1, -1), sparse.float()], dim=1).contiguous()
+        # src = repeat_interleave(image_embeddings, P) + dense  (:126-127); row-modular broadcast of both operands
+        keys = ops.add_cast(image_tokens.reshape(-1, C), dense_tokens.reshape(-1, C).contiguous(), torch.float32, rows=P * N)
+        hs, src = self.transformer.forward_tokens(keys.reshape(P, N, C), pe_tokens, tokens)
+        nm = self.num_mask_tokens
+        up0, ln, up1 = self.output_upscaling[0], self.output_upscaling[1], self.output_upscaling[3]
+        w0, b0 = up0.packed(dt)
+        w1, b1 = up1.packed(dt)
+        c4, c8 = C // 4, C // 8
+        u1 = ops.gemm(ops.cast(src.reshape(P * N, C), dt), w0, b0, out_f32=True)           # [P*N, (ky,kx,c4)]
+        u1 = ops.norm(u1.reshape(P * N * 4, c4), *ln.wb(), ln.eps, dt, act=ops.ACT_GELU)   # LayerNorm2d + GELU per output pixel
+        u2 = ops.gemm(u1, w1, b1, act=ops.ACT_GELU, out_f32=True)                          # [P*N*4, (ky2,kx2,c8)]
+        hyper = torch.stack([self.output_hypernetworks_mlps[i](hs[:, 1 + i, :]) for i in range(nm)], dim=1).contiguous()
+        masks = ops.hyper_masks(u2, hyper, P, nm, h, w, c8)
+        iou = self.iou_prediction_head(hs[:, 0, :])
+        return masks, iou
+
+    # -- reference API -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def predict_masks(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings):
+        b, c, h, w = image_embeddings.shape
+        P = sparse_prompt_embeddings.shape[0]
+        tok = lambda x, n: ops.transpose(x.float().contiguous().reshape(n, c, h * w), n, c, h * w)
+        img = tok(image_embeddings, b)
+        pe = tok(image_pe[:1], 1).reshape(h * w, c)
+        d = dense_prompt_embeddings
+        if d.shape[0] != P or d.stride(-1) == 0 or d.stride(-2) == 0:  # broadcast views (no_mask_embed.expand)
+            d = d.expand(P, c, h, w)
+        dense = tok(d, P)
+        if b != 1 and b != P:
+            raise ValueError(f"image_embeddings batch {b} is incompatible with {P} prompts (reference repeat_interleave semantics)")
+        return self.predict_masks_tokens(img, pe, sparse_prompt_embeddings, dense, (h, w))
+
+    @torch.no_grad()
+    def forward(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output: bool):
+        masks, iou_pred = self.predict_masks(image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings)
+        sl = slice(1, None) if multimask_output else slice(0, 1)  # mask_decoder.py:100-105
+        return masks[:, sl, :, :], iou_pred[:, sl]

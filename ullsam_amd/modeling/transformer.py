@@ -1,0 +1,132 @@
+"""Two-way transformer of the SAM mask decoder on HIP kernels (parameters mirror modeling/transformer.py).
+
+Token side (T = 5 + prompts tokens) runs in fp32 with one-wave-per-output kernels; the image side (4096 tokens per
+prompt) uses the MFMA GEMM in the model dtype with an fp32 `keys` stream.
+"""
+from __future__ import annotations
+
+import math
+from typing import Tuple, Type
+
+import torch
+from torch import nn
+
+from .. import ops
+from .common import LayerNorm, Linear, MLPBlock, Packed
+
+
+class Attention(Packed):
+    """transformer.py:187-242 (q/k/v/out projections, optional internal downsampling)."""
+
+    def __init__(self, embedding_dim: int, num_heads: int, downsample_rate: int = 1) -> None:
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.internal_dim = embedding_dim // downsample_rate
+        self.num_heads = num_heads
+        assert self.internal_dim % num_heads == 0, "num_heads must divide embedding_dim."
+        self.q_proj = Linear(embedding_dim, self.internal_dim)
+        self.k_proj = Linear(embedding_dim, self.internal_dim)
+        self.v_proj = Linear(embedding_dim, self.internal_dim)
+        self.out_proj = Linear(self.internal_dim, embedding_dim)
+
+    @property
+    def hd(self):
+        return self.internal_dim // self.num_heads
+
+    def tok(self, lin: Linear, x, act=ops.ACT_NONE, res=None):
+        return ops.small_linear(x, lin.f32("w32", lin.weight), lin.b(), act, res)
+
+    def attend_tokens(self, q, k, v, P, Tq, Tk):
+        """softmax(q k^T / sqrt(hd)) v with the scale applied after QK^T (transformer.py:233-235); fp32 [P*T, internal]."""
+        H, hd, C = self.num_heads, self.hd, self.internal_dim
+        st = lambda T: (T * C, C, hd)
+        return ops.naive_attention(q, k, v, P, H, H, hd, Tq, Tk, st(Tq), st(Tk), st(Tk), st(Tq), 1.0 / math.sqrt(hd))
+
+
+class TwoWayAttentionBlock(Packed):
+    """transformer.py:111-184."""
+
+    def __init__(self, embedding_dim: int, num_heads: int, mlp_dim: int = 2048, activation: Type[nn.Module] = nn.ReLU,
+                 attention_downsample_rate: int = 2, skip_first_layer_pe: bool = False) -> None:
+        super().__init__()
+        self.self_attn = Attention(embedding_dim, num_heads)
+        self.norm1 = LayerNorm(embedding_dim)
+        self.cross_attn_token_to_image = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
+        self.norm2 = LayerNorm(embedding_dim)
+        self.mlp = MLPBlock(embedding_dim, mlp_dim, activation)
+        self.norm3 = LayerNorm(embedding_dim)
+        self.norm4 = LayerNorm(embedding_dim)
+        self.cross_attn_image_to_token = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
+        self.skip_first_layer_pe = skip_first_layer_pe
+
+
+def _token_to_image(at: Attention, queries, qpe, keys_pe_c, keys_c, P, T, N, dt):
+    """queries + attn(q=queries+pe, k=keys+pe, v=keys): token side fp32, image-side K/V projections on MFMA."""
+    q = at.tok(at.q_proj, ops.add_cast(queries, qpe, torch.float32))
+    K = ops.gemm(keys_pe_c, at.k_proj.w(dt), at.k_proj.b(), out_f32=True)
+    V = ops.gemm(keys_c, at.v_proj.w(dt), at.v_proj.b(), out_f32=True)
+    a = at.attend_tokens(q, K, V, P, T, N)
+    return at.tok(at.out_proj, a, res=queries)
+
+
+class TwoWayTransformer(Packed):
+    def __init__(self, depth: int, embedding_dim: int, num_heads: int, mlp_dim: int, activation: Type[nn.Module] = nn.ReLU,
+                 attention_downsample_rate: int = 2) -> None:
+        super().__init__()
+        self.depth, self.embedding_dim, self.num_heads, self.mlp_dim = depth, embedding_dim, num_heads, mlp_dim
+        self.layers = nn.ModuleList([
+            TwoWayAttentionBlock(embedding_dim, num_heads, mlp_dim, activation, attention_downsample_rate, skip_first_layer_pe=(i == 0))
+            for i in range(depth)])
+        self.final_attn_token_to_image = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
+        self.norm_final_attn = LayerNorm(embedding_dim)
+
+    @property
+    def compute_dtype(self):
+        return self.final_attn_token_to_image.k_proj.weight.dtype
+
+    def forward_tokens(self, keys: torch.Tensor, key_pe: torch.Tensor, tokens: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """keys fp32 [P, N, C] (image embedding + dense prompt, token-major), key_pe fp32 [N, C], tokens fp32 [P, T, C].
+        Returns (queries [P,T,C], keys [P,N,C]) as TwoWayTransformer.forward transformer.py:62-108."""
+        dt = self.compute_dtype
+        P, N, C = keys.shape
+        T = tokens.shape[1]
+        keys = keys.reshape(P * N, C)
+        qpe = tokens.reshape(P * T, C).contiguous()
+        queries = qpe
+        f32 = torch.float32
+        for blk in self.layers:
+            sa = blk.self_attn
+            if blk.skip_first_layer_pe:  # no PE and NO residual (:157-158)
+                q_in, res = queries, None
+            else:
+                q_in, res = ops.add_cast(queries, qpe, f32), queries
+            a = sa.attend_tokens(sa.tok(sa.q_proj, q_in), sa.tok(sa.k_proj, q_in), sa.tok(sa.v_proj, queries), P, T, T)
+            queries = ops.norm(sa.tok(sa.out_proj, a, res=res), *blk.norm1.wb(), blk.norm1.eps, f32)
+            keys_pe_c = ops.add_cast(keys, key_pe, dt)   # keys + key_pe, shared by both cross attentions of the block
+            keys_c = ops.cast(keys, dt)
+            queries = ops.norm(_token_to_image(blk.cross_attn_token_to_image, queries, qpe, keys_pe_c, keys_c, P, T, N, dt),
+                               *blk.norm2.wb(), blk.norm2.eps, f32)
+            m = blk.mlp
+            hmid = ops.small_linear(queries, m.lin1.f32("w32", m.lin1.weight), m.lin1.b(), m.act_code)
+            queries = ops.norm(ops.small_linear(hmid, m.lin2.f32("w32", m.lin2.weight), m.lin2.b(), res=queries),
+                               *blk.norm3.wb(), blk.norm3.eps, f32)
+            # image -> token: keys = norm4(keys + attn(q=keys+pe, k=queries+pe, v=queries))   (:176-182)
+            ia = blk.cross_attn_image_to_token
+            q_in = ops.add_cast(queries, qpe, f32)
+            Qi = ops.gemm(keys_pe_c, ia.q_proj.w(dt), ia.q_proj.b(), out_f32=True)
+            a = ops.fewkeys_attention(Qi, ia.tok(ia.k_proj, q_in), ia.tok(ia.v_proj, queries), P, ia.num_heads, ia.hd, N, T,
+                                      1.0 / math.sqrt(ia.hd))
+            upd = ops.gemm(ops.cast(a, dt), ia.out_proj.w(dt), ia.out_proj.b(), residual=keys, out_f32=True)
+            keys = ops.norm(upd, *blk.norm4.wb(), blk.norm4.eps, f32)
+        fa = self.final_attn_token_to_image
+        queries = ops.norm(_token_to_image(fa, queries, qpe, ops.add_cast(keys, key_pe, dt), ops.cast(keys, dt), P, T, N, dt),
+                           *self.norm_final_attn.wb(), self.norm_final_attn.eps, f32)
+        return queries.reshape(P, T, C), keys.reshape(P, N, C)
+
+    @torch.no_grad()
+    def forward(self, image_embedding: torch.Tensor, image_pe: torch.Tensor, point_embedding: torch.Tensor):
+        """Reference signature: image_embedding/image_pe [B,C,h,w], point_embedding [B,T,C] -> (queries, keys[B,hw,C])."""
+        bs, c, h, w = image_embedding.shape
+        keys = ops.transpose(image_embedding.float().contiguous().reshape(bs, c, h * w), bs, c, h * w)
+        pe = ops.transpose(image_pe.float().contiguous().reshape(-1, c, h * w)[:1], 1, c, h * w).reshape(h * w, c)
+        return self.forward_tokens(keys, pe, point_embedding.float().contiguous())

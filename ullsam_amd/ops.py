@@ -1,0 +1,307 @@
+"""Thin torch-tensor wrappers over the C ABI (include/ullsam_hip.h).
+
+torch is plumbing only: device memory, the current HIP stream, dtype bookkeeping.  Every function here launches
+HIP kernels from libullsam_hip.so; none falls back to torch math.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SWIGLU = 0, 1, 2, 3
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"ullsam_amd supports float32 and bfloat16 compute, got {dtype}") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str, dtype=None):
+    if not t.is_cuda:
+        raise _lib.UllsamError(f"{name} must live on the GPU (ullsam_amd has no CPU path)")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         act: int = ACT_NONE, out_f32: bool = False, out: Optional[torch.Tensor] = None, res_row_mod: int = 0) -> torch.Tensor:
+    """out[M, N'] = act(a[M,K] @ w[N,K]^T + bias) + residual   (N' = N/2 for ACT_SWIGLU)."""
+    _chk(a, "a"); _chk(w, "w", a.dtype)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K, (a.shape, w.shape)
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    odt = torch.float32 if out_f32 else a.dtype
+    if out is None:
+        out = torch.empty((M, n_out), dtype=odt, device=a.device)
+    else:
+        _chk(out, "out", odt)
+        assert out.shape == (M, n_out)
+    if bias is not None:
+        _chk(bias, "bias", torch.float32)
+    ldr = 0
+    if residual is not None:
+        _chk(residual, "residual", torch.float32)
+        ldr = residual.shape[-1]
+    _lib.call("ullsam_gemm", dt_code(a.dtype), a.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), n_out, int(out_f32),
+              _p(bias), _p(residual), ldr, res_row_mod, act, M, N, K, _stream())
+    return out
+
+
+def norm(x: torch.Tensor, w: Optional[torch.Tensor], b: Optional[torch.Tensor], eps: float, out_dtype: torch.dtype,
+         rms: bool = False, act: int = ACT_NONE, post_scale: Optional[torch.Tensor] = None,
+         post_shift: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(x, "x")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    if out is None:
+        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    for t in (w, b, post_scale, post_shift):
+        if t is not None:
+            _chk(t, "norm param", torch.float32)
+    _lib.call("ullsam_norm", x.data_ptr(), dt_code(x.dtype), D, out.data_ptr(), dt_code(out.dtype), D, _p(w), _p(b), rows, D,
+              float(eps), int(rms), act, _p(post_scale), _p(post_shift), _stream())
+    return out
+
+
+def vit_attention(qkv: torch.Tensor, rel_h: torch.Tensor, rel_w: torch.Tensor, qkv_bias: torch.Tensor, B: int, heads: int,
+                  hd: int, gh: int, gw: int, window: int) -> torch.Tensor:
+    _chk(qkv, "qkv"); _chk(rel_h, "rel_h", qkv.dtype); _chk(rel_w, "rel_w", qkv.dtype); _chk(qkv_bias, "qkv_bias", qkv.dtype)
+    D = heads * hd
+    assert qkv.numel() == B * gh * gw * 3 * D
+    n = window if window > 0 else gh
+    assert rel_h.shape == (2 * n - 1, hd) and rel_w.shape[1] == hd
+    out = torch.empty((B * gh * gw, D), dtype=qkv.dtype, device=qkv.device)
+    _lib.call("ullsam_vit_attention", dt_code(qkv.dtype), qkv.data_ptr(), out.data_ptr(), rel_h.data_ptr(), rel_w.data_ptr(),
+              qkv_bias.data_ptr(), B, heads, hd, gh, gw, window, _stream())
+    return out
+
+
+def causal_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, key_mask: Optional[torch.Tensor],
+                     B: int, H: int, KVH: int, hd: int, Sq: int, Sk: int, q_pos0: int) -> torch.Tensor:
+    _chk(q, "q"); _chk(k_cache, "k_cache", q.dtype); _chk(v_cache, "v_cache", q.dtype)
+    cap = k_cache.shape[2]
+    if key_mask is not None:
+        _chk(key_mask, "key_mask", torch.int32)
+        assert key_mask.shape == (B, Sk)
+    out = torch.empty((B * Sq, H * hd), dtype=q.dtype, device=q.device)
+    _lib.call("ullsam_causal_attention", dt_code(q.dtype), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(),
+              _p(key_mask), B, H, KVH, hd, Sq, Sk, cap, q_pos0, _stream())
+    return out
+
+
+def naive_attention(q, k, v, B, H, KVH, hd, Sq, Sk, qs, ks, vs, os_, scale, key_mask=None, out=None):
+    """Generic strided attention; qs/ks/vs/os_ = (batch, token, head) element strides."""
+    _chk(q, "q"); _chk(k, "k", q.dtype); _chk(v, "v", q.dtype)
+    if out is None:
+        out = torch.empty((B * Sq, H * hd), dtype=q.dtype, device=q.device)
+    if key_mask is not None:
+        _chk(key_mask, "key_mask", torch.int32)
+    _lib.call("ullsam_naive_attention", dt_code(q.dtype), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _p(key_mask),
+              B, H, KVH, hd, Sq, Sk, *qs, *ks, *vs, *os_, float(scale), _stream())
+    return out
+
+
+def fewkeys_attention(q, k, v, B, H, hd, Sq, Sk, scale):
+    for t in (q, k, v):
+        _chk(t, "qkv", torch.float32)
+    out = torch.empty((B * Sq, H * hd), dtype=torch.float32, device=q.device)
+    _lib.call("ullsam_fewkeys_attention", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, hd, Sq, Sk,
+              float(scale), _stream())
+    return out
+
+
+def patch_im2col(pixels: torch.Tensor, S: int, patch: int, dtype: torch.dtype, mean=None, std=None) -> torch.Tensor:
+    _chk(pixels, "pixels", torch.float32)
+    B, C, Hs, Ws = pixels.shape
+    g = S // patch
+    out = torch.empty((B * g * g, C * patch * patch), dtype=dtype, device=pixels.device)
+    _lib.call("ullsam_patch_im2col", dt_code(dtype), pixels.data_ptr(), out.data_ptr(), B, C, Hs, Ws, S, patch, _p(mean), _p(std),
+              _stream())
+    return out
+
+
+def im2col3x3(x: torch.Tensor, B: int, H: int, W: int, C: int) -> torch.Tensor:
+    _chk(x, "x")
+    out = torch.empty((B * H * W, 9 * C), dtype=x.dtype, device=x.device)
+    _lib.call("ullsam_im2col3x3", dt_code(x.dtype), x.data_ptr(), out.data_ptr(), B, H, W, C, _stream())
+    return out
+
+
+def add_cast(a: torch.Tensor, b: Optional[torch.Tensor], out_dtype: torch.dtype, rows: Optional[int] = None,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[r] = a[r % a_rows] + b[r % b_rows] (b optional, fp32), converted to out_dtype."""
+    _chk(a, "a")
+    cols = a.shape[-1]
+    a_rows = a.numel() // cols
+    b_rows = 0
+    if b is not None:
+        _chk(b, "b", torch.float32)
+        assert b.shape[-1] == cols
+        b_rows = b.numel() // cols
+    if rows is None:
+        rows = max(a_rows, b_rows)
+    if out is None:
+        out = torch.empty((rows, cols), dtype=out_dtype, device=a.device)
+    _lib.call("ullsam_add_cast", a.data_ptr(), dt_code(a.dtype), a_rows, _p(b), b_rows, out.data_ptr(), dt_code(out.dtype), rows,
+              cols, _stream())
+    return out
+
+
+def cast(a: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    if a.dtype == out_dtype:
+        return a
+    return add_cast(a.reshape(-1, a.shape[-1]), None, out_dtype).reshape(a.shape)
+
+
+def transpose(x: torch.Tensor, B: int, R: int, C: int) -> torch.Tensor:
+    """fp32 [B, R, C] -> [B, C, R]."""
+    _chk(x, "x", torch.float32)
+    out = torch.empty((B, C, R), dtype=torch.float32, device=x.device)
+    _lib.call("ullsam_transpose_f32", x.data_ptr(), out.data_ptr(), B, R, C, _stream())
+    return out
+
+
+def pixel_shuffle_ln(x_nhwc: torch.Tensor, w, b, B, H, W, C, eps, dtype) -> torch.Tensor:
+    _chk(x_nhwc, "x", torch.float32)
+    out = torch.empty((B * (H // 2) * (W // 2), 4 * C), dtype=dtype, device=x_nhwc.device)
+    _lib.call("ullsam_pixel_shuffle_ln", dt_code(dtype), x_nhwc.data_ptr(), out.data_ptr(), w.data_ptr(), b.data_ptr(), B, H, W, C,
+              float(eps), _stream())
+    return out
+
+
+def pixel_unshuffle(x: torch.Tensor, B, H, W, C) -> torch.Tensor:
+    _chk(x, "x", torch.float32)
+    out = torch.empty((B, H * W, C), dtype=torch.float32, device=x.device)
+    _lib.call("ullsam_pixel_unshuffle", x.data_ptr(), out.data_ptr(), B, H, W, C, _stream())
+    return out
+
+
+def scan_image_tokens(ids: torch.Tensor, img_id: int):
+    _chk(ids, "input_ids", torch.int64)
+    B, S = ids.shape
+    rank = torch.empty((B, S), dtype=torch.int32, device=ids.device)
+    rng = torch.empty((B, 2), dtype=torch.int32, device=ids.device)
+    _lib.call("ullsam_scan_image_tokens", ids.data_ptr(), rank.data_ptr(), rng.data_ptr(), B, S, int(img_id), _stream())
+    return rank, rng
+
+
+def embed_tokens(table: torch.Tensor, ids: torch.Tensor, rank: Optional[torch.Tensor], vit: Optional[torch.Tensor]) -> torch.Tensor:
+    _chk(table, "tok_embeddings"); _chk(ids, "ids", torch.int64)
+    B, S = ids.shape
+    V, D = table.shape
+    n_img = 0
+    if vit is not None:
+        _chk(vit, "vit_embeds", torch.float32)
+        n_img = vit.numel() // (B * D)
+    out = torch.empty((B * S, D), dtype=torch.float32, device=ids.device)
+    _lib.call("ullsam_embed_tokens", dt_code(table.dtype), table.data_ptr(), ids.data_ptr(), _p(rank), _p(vit), out.data_ptr(), B, S, D,
+              max(n_img, 1), V, _stream())
+    return out
+
+
+def gather_rows(x: torch.Tensor, rng: torch.Tensor, B: int, S: int, n: int) -> torch.Tensor:
+    _chk(x, "x"); _chk(rng, "range", torch.int32)
+    D = x.shape[-1]
+    out = torch.empty((B * n, D), dtype=x.dtype, device=x.device)
+    _lib.call("ullsam_gather_rows", x.data_ptr(), out.data_ptr(), rng.data_ptr(), B, S, n, D * x.element_size(), _stream())
+    return out
+
+
+def rope_split(qkv, k_cache, v_cache, pos, cos_tab, sin_tab, B, S, KVH, G, hd, cache_pos0) -> torch.Tensor:
+    _chk(qkv, "qkv"); _chk(pos, "position_ids", torch.int32); _chk(cos_tab, "cos", torch.float32); _chk(sin_tab, "sin", torch.float32)
+    q = torch.empty((B * S, KVH * G * hd), dtype=qkv.dtype, device=qkv.device)
+    _lib.call("ullsam_rope_split", dt_code(qkv.dtype), qkv.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+              pos.data_ptr(), cos_tab.data_ptr(), sin_tab.data_ptr(), B, S, KVH, G, hd, k_cache.shape[2], cache_pos0, _stream())
+    return q
+
+
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    _chk(logits, "logits", torch.float32)
+    R, V = logits.shape
+    out = torch.empty((R,), dtype=torch.int64, device=logits.device)
+    _lib.call("ullsam_argmax", logits.data_ptr(), out.data_ptr(), R, V, V, _stream())
+    return out
+
+
+def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int = ACT_NONE,
+                 res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(x, "x", torch.float32); _chk(w, "w", torch.float32)
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _lib.call("ullsam_small_linear", x.data_ptr(), K, w.data_ptr(), _p(b), _p(res), N, out.data_ptr(), N, M, N, K, act, _stream())
+    return out
+
+
+def sparse_embed(coords, labels, boxes, G, emb, P, Np, pad, C, img_w, img_h) -> torch.Tensor:
+    n_out = Np + pad + (2 if boxes is not None else 0)
+    out = torch.empty((P, n_out, C), dtype=torch.float32, device=G.device)
+    _lib.call("ullsam_sparse_embed", _p(coords), _p(labels), _p(boxes), G.data_ptr(), emb.data_ptr(), out.data_ptr(), P, Np, pad, C,
+              float(img_w), float(img_h), _stream())
+    return out
+
+
+def dense_pe(G: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    C = G.shape[1] * 2
+    out = torch.empty((H * W, C), dtype=torch.float32, device=G.device)
+    _lib.call("ullsam_dense_pe", G.data_ptr(), out.data_ptr(), H, W, C, _stream())
+    return out
+
+
+def mask_downscale(masks: torch.Tensor, H: int, W: int, C: int, params) -> torch.Tensor:
+    _chk(masks, "masks", torch.float32)
+    P = masks.shape[0]
+    c1, c2 = params[0].shape[0], params[4].shape[0]
+    out = torch.empty((P, H * W, C), dtype=torch.float32, device=masks.device)
+    _lib.call("ullsam_mask_downscale", masks.data_ptr(), out.data_ptr(), P, H, W, C, c1, c2, *[t.data_ptr() for t in params], _stream())
+    return out
+
+
+def hyper_masks(up2: torch.Tensor, hyper: torch.Tensor, NB: int, NM: int, H: int, W: int, CU: int) -> torch.Tensor:
+    out = torch.empty((NB, NM, 4 * H, 4 * W), dtype=torch.float32, device=up2.device)
+    _lib.call("ullsam_hyper_masks", up2.data_ptr(), hyper.data_ptr(), out.data_ptr(), NB, NM, H, W, CU, _stream())
+    return out
+
+
+def resize_bilinear(x: torch.Tensor, out_hw, valid_hw=None, want_float=True, threshold: Optional[float] = None):
+    """x fp32 [..., IH, IW] (optionally only the top-left valid_hw region is the source image)."""
+    _chk(x, "x", torch.float32)
+    IHs, IWs = x.shape[-2:]
+    N = x.numel() // (IHs * IWs)
+    IH, IW = valid_hw if valid_hw is not None else (IHs, IWs)
+    OH, OW = out_hw
+    out = torch.empty(x.shape[:-2] + (OH, OW), dtype=torch.float32, device=x.device) if want_float else None
+    mask = torch.empty(x.shape[:-2] + (OH, OW), dtype=torch.uint8, device=x.device) if threshold is not None else None
+    _lib.call("ullsam_resize_bilinear", x.data_ptr(), IHs * IWs, IWs, IH, IW, _p(out), _p(mask), N, OH, OW,
+              float(threshold if threshold is not None else 0.0), _stream())
+    return out, mask
+
+
+def mask_iou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """CalcIoU (train_joint_v2.py:683-694) over uint8 masks [N, ...] -> fp64 [N]."""
+    _chk(a, "a", torch.uint8); _chk(b, "b", torch.uint8)
+    N = a.shape[0]
+    per = a.numel() // N
+    counts = torch.empty((N, 2), dtype=torch.int64, device=a.device)
+    _lib.call("ullsam_mask_iou_counts", a.data_ptr(), b.data_ptr(), counts.data_ptr(), N, per, _stream())
+    c = counts.double()
+    return (c[:, 0] + 1e-7) / (c[:, 1] + 1e-7)
