@@ -1,0 +1,294 @@
+"""Headline benchmark: images/s end-to-end through the uLLSAM mask path (app.py:580-645 call sequence) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one batch of synthetic 1024x1024 tiles resident in HBM:
+  InternVLSAMModel.forward (SAM ViT encoder -> pixel-shuffle + mlp1 -> InternLM2 prefill -> mlp2 + inverse shuffle)
+  -> PromptEncoder.forward (1 point + LLM dense prompt) -> MaskDecoder.forward -> x4 bilinear upsample -> threshold
+  -> (N > 1) RCCL all-gather of low-res logits + masks.
+Default workload = BASELINE.json configs[2] per GPU (ViT-H + InternLM2-7B-shaped + mask decoder, batch 4, bf16, S = 1081);
+N GPUs process N x 4 images (weak scaling; configs[3] at N = 8).  Weights are random-init (no checkpoints exist offline).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the MFMA GEMM; achieved = algorithmic FLOPs of every GEMM
+launch / their HIP-event durations, measured inside the timed region on the launch stream) and `cpu_baseline` (the numpy
+oracle timed on the host cores on a bounded, depth-reduced sample of the same workload; N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+VIT = {"h": dict(dim=1280, depth=32, heads=16, glob=[7, 15, 23, 31]), "l": dict(dim=1024, depth=24, heads=16, glob=[5, 11, 17, 23]),
+       "b": dict(dim=768, depth=12, heads=12, glob=[2, 5, 8, 11])}
+LLM = {"7b": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8),
+       "2b": dict(hidden_size=2048, intermediate_size=8192, num_hidden_layers=24, num_attention_heads=16, num_key_value_heads=8),
+       "none": None}
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def init_random_(model: torch.nn.Module, seed: int = 0):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    with torch.no_grad():
+        for name, p in list(model.named_parameters()) + list(model.named_buffers()):
+            if not p.is_floating_point():
+                continue
+            leaf = name.split(".")[-1]
+            if "rel_pos" in name:
+                p.normal_(0, 0.1, generator=g)
+            elif "pos_embed" in name:
+                p.normal_(0, 0.05, generator=g)
+            elif "llm_scale_factor" in name:
+                p.fill_(0.1)
+            elif "llm_bias" in name:
+                p.fill_(0.05)
+            elif "gaussian_matrix" in name:
+                p.normal_(0, 1.0, generator=g)
+            elif p.ndim >= 2 and "embed" not in name and "token" not in name:
+                fan_in = p[0].numel() if "output_upscaling" not in name else p.shape[0]
+                p.normal_(0, fan_in ** -0.5, generator=g)
+            elif p.ndim >= 2:
+                p.normal_(0, 0.5, generator=g)
+            elif "norm" in name and leaf == "weight":
+                p.normal_(1.0, 0.05, generator=g)
+            else:
+                p.normal_(0, 0.02, generator=g)
+
+
+def build_model(vit: str, llm: str, dtype: torch.dtype, device: str):
+    from ullsam_amd.build_sam import _build_sam
+    from ullsam_amd.modeling.configuration_internvl_chat import InternVLChatConfig
+    from ullsam_amd.modeling.modeling_internvl_sam import InternVLSAMModel
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        with torch.device(device):
+            v = VIT[vit]
+            sam = _build_sam(v["dim"], v["depth"], v["heads"], v["glob"])
+            if LLM[llm] is None:
+                model = sam
+            else:
+                cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT"]},
+                                         llm_config=dict(architectures=["InternLM2ForCausalLM"], vocab_size=92553, bias=False,
+                                                         max_position_embeddings=32768, rope_theta=1000000, rms_norm_eps=1e-5, **LLM[llm]),
+                                         downsample_ratio=0.5, template="internlm2-chat", ps_version="v2", force_image_size=1024)
+                model = InternVLSAMModel(cfg, vision_model=sam.image_encoder, prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder)
+    finally:
+        torch.set_default_dtype(old)
+    model = model.to(device).to(dtype).eval()
+    init_random_(model)
+    return model
+
+
+class GemmTimer:
+    """HIP-event pairs around every ullsam_gemm launch on the launch stream (torch's current stream)."""
+
+    def __init__(self):
+        from ullsam_amd import ops
+        self.ops, self.orig, self.rec, self.on = ops, ops.gemm, [], False
+
+        def timed(a, w, *args, **kw):
+            if not self.on:
+                return self.orig(a, w, *args, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.orig(a, w, *args, **kw)
+            e1.record()
+            self.rec.append((e0, e1, 2.0 * a.shape[0] * w.shape[0] * a.shape[1]))
+            return out
+
+        ops.gemm = timed
+
+    def summary(self):
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec)
+        fl = sum(f for _, _, f in self.rec)
+        return len(self.rec), ms, fl
+
+
+def make_step(model, B, S, device, dtype, world):
+    from ullsam_amd import ops, parallel
+    from oracle.ullsam_oracle import make_input_ids  # synthetic token ids only (data, not compute)
+    rng = np.random.default_rng(1 + (int(os.environ.get("RANK", "0"))))
+    x = torch.from_numpy(rng.random((B, 3, 1024, 1024), dtype=np.float32)).to(device).to(dtype)
+    pts = torch.from_numpy(rng.uniform(100, 900, (B, 1, 2)).astype(np.float32)).to(device)
+    lbl = torch.ones((B, 1), dtype=torch.int32, device=device)
+    full = hasattr(model, "language_model")
+    if full:
+        ids = torch.from_numpy(make_input_ids(20, S - 1047, seed=1, batch=B)).to(device)
+        assert ids.shape[1] == S
+        am = torch.ones_like(ids)
+        flags = (ids == 92546)[..., None].long()
+
+    def step():
+        if full:
+            out = model(pixel_values=x, input_ids=ids, attention_mask=am, image_flags=flags, return_dict=True, use_cache=False,
+                        output_hidden_states=True)
+            pe, md = model.prompt_encoder, model.mask_decoder
+            image_pe = pe.get_dense_pe()
+            lows, mks = [], []
+            for b in range(B):
+                sp, de = pe(points=(pts[b:b + 1], lbl[b:b + 1]), boxes=None, masks=None, llm_hidden_states=out.hidden_states[b:b + 1])
+                low, iou = md(image_embeddings=out.image_embeddings[b:b + 1], image_pe=image_pe, sparse_prompt_embeddings=sp,
+                              dense_prompt_embeddings=de, multimask_output=False)
+                _, mk = ops.resize_bilinear(low.contiguous(), (1024, 1024), want_float=False, threshold=0.0)
+                lows.append(low); mks.append(mk)
+            low, mk = torch.cat(lows), torch.cat(mks)
+        else:  # configs[1]: Sam.forward, point prompt only
+            recs = [{"image": x[b].float() * 255.0, "original_size": (1024, 1024), "point_coords": pts[b:b + 1], "point_labels": lbl[b:b + 1]}
+                    for b in range(B)]
+            outs = model(recs, multimask_output=False)
+            low = torch.cat([o["low_res_logits"] for o in outs])
+            mk = torch.cat([o["masks"] for o in outs]).to(torch.uint8)
+        if world > 1:
+            low, mk, _ = parallel.gather_mask_results(low, mk, None, counts=[B] * world)
+        return low, mk
+
+    return step
+
+
+def cpu_baseline(vit: str, llm: str, S: int):
+    """Numpy oracle on the host cores, bounded sample: one image, depth-reduced, extrapolated linearly in depth."""
+    from oracle import ullsam_oracle as O
+    v = VIT[vit]
+    D, H = v["dim"], v["heads"]
+    rng = np.random.default_rng(0)
+    t_all = time.time()
+    P = O.fill_state(O.vit_shapes(embed_dim=D, depth=2, num_heads=H, global_attn_indexes=(1,)), 0)
+    xb = rng.standard_normal((1, 64, 64, D), dtype=np.float32)
+
+    def timed(fn, reps=1):
+        fn()  # warm-up (BLAS thread pool, page faults)
+        t = time.time()
+        for _ in range(reps):
+            fn()
+        return (time.time() - t) / reps
+
+    t_w = timed(lambda: O.vit_block(xb, P, "blocks.0.", H, 14, 1e-6))
+    t_g = timed(lambda: O.vit_block(xb, P, "blocks.1.", H, 0, 1e-6))
+    img = rng.random((1, 3, 1024, 1024), dtype=np.float32)
+    t_fix = timed(lambda: O.vit_encoder(img, P, depth=0, num_heads=H, global_attn_indexes=()))
+    n_g = len(v["glob"])
+    t_vit = t_fix + (v["depth"] - n_g) * t_w + n_g * t_g
+    t_llm = t_proj = 0.0
+    if LLM[llm] is not None:
+        c = LLM[llm]
+        cfg = dict(hidden=c["hidden_size"], layers=1, heads=c["num_attention_heads"], kv_heads=c["num_key_value_heads"],
+                   inter=c["intermediate_size"], vocab=8, rope_theta=1e6, eps=1e-5)
+        PL = O.fill_state(O.internlm2_shapes(cfg["hidden"], 1, cfg["heads"], cfg["kv_heads"], cfg["inter"], 8, prefix="lm."), 0)
+        emb = rng.standard_normal((1, S, cfg["hidden"]), dtype=np.float32)
+        t_layer = timed(lambda: O.internlm2_model(PL, cfg, emb, prefix="lm."))
+        t_llm = c["num_hidden_layers"] * t_layer
+        PP = O.fill_state(O.projector_shapes(cfg["hidden"]), 0)
+        feat = rng.standard_normal((1, 256, 64, 64), dtype=np.float32)
+        hid = rng.standard_normal((1, 1024, cfg["hidden"]), dtype=np.float32)
+        t_proj = timed(lambda: (O.extract_feature(PP, feat), O.text_aware_dense_feature(PP, hid)))
+    PD = {}
+    PD.update(O.fill_state(O.prompt_encoder_shapes(prefix="prompt_encoder."), 0))
+    PD.update(O.fill_state(O.mask_decoder_shapes(prefix="mask_decoder."), 0))
+    e = rng.standard_normal((1, 256, 64, 64), dtype=np.float32)
+
+    def dec():
+        sp, de = O.prompt_encoder(PD, (np.array([[[500.0, 500.0]]], np.float32), np.array([[1]])), None, None, e, prefix="prompt_encoder.")
+        low, _ = O.mask_decoder(PD, e, O.dense_pe(PD, prefix="prompt_encoder."), sp, de, False, prefix="mask_decoder.")
+        return O.bilinear_resize(low, (1024, 1024)) > 0
+
+    t_dec = timed(dec)
+    total = t_vit + t_llm + t_proj + t_dec
+    cores = os.cpu_count() or 1
+    return {"value": round(1.0 / total, 6), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": (f"numpy fp32 oracle, 1 image: timed 1 windowed + 1 global ViT-{vit.upper()} block, patch-embed+neck, "
+                       f"1 InternLM2-{llm} layer at S={S}, mlp1+mlp2, prompt-encoder+mask-decoder+upsample; extrapolated linearly "
+                       f"to {v['depth']} blocks / {LLM[llm]['num_hidden_layers'] if LLM[llm] else 0} layers "
+                       f"(vit {t_vit:.1f}s + llm {t_llm:.1f}s + proj {t_proj:.2f}s + dec {t_dec:.2f}s); sampling took {time.time() - t_all:.0f}s")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE configs[2]: 4)")
+    ap.add_argument("--vit", default="h", choices=list(VIT))
+    ap.add_argument("--llm", default="7b", choices=list(LLM))
+    ap.add_argument("--seq", type=int, default=1081)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(device))
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+
+    model = build_model(a.vit, a.llm, dtype, device)
+    timer = GemmTimer()
+    step = make_step(model, a.batch, a.seq, device, dtype, world)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            step()
+        barrier()
+        timer.on = True
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        timer.on = False
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_launch, gemm_ms, gemm_flops = timer.summary()
+    images = a.batch * world * a.steps
+    value = images / dt
+    ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    line = {
+        "metric": "images/s end-to-end (ViT+LLM+mask) 1024^2", "value": round(value, 4), "unit": "images/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (uniform random 1024x1024 tiles, random-init weights, synthetic token ids)",
+        "config": {"workload": (f"uLLSAM mask path (app.py:580-645): SAM ViT-{a.vit.upper()} + "
+                                + (f"InternLM2-{a.llm}-shaped prefill S={a.seq} + " if LLM[a.llm] else "")
+                                + f"prompt encoder + mask decoder + x4 upsample/threshold, 1 point prompt/image, batch {a.batch}/GPU"),
+                   "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": a.seq if LLM[a.llm] else 0,
+                   "parallelism": f"dp{world} (images sharded, weights replicated, RCCL all-gather of masks)"},
+        "roofline": {"bound": "mfma", "kernel": "gemm128_kernel (all nn.Linear / conv-as-GEMM launches)", "achieved": round(ach, 2),
+                     "peak": PEAK_BF16_TFLOPS if a.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
+                     "frac": round(ach / (PEAK_BF16_TFLOPS if a.dtype == "bf16" else 157.3), 4), "traffic": None,
+                     "launches_per_step": n_launch // max(a.steps, 1), "avg_launch_us": round(gemm_ms * 1e3 / max(n_launch, 1), 2),
+                     "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4)},
+    }
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.vit, a.llm, a.seq)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(NWAVES * 64) void flash_attn_kernel(AttnArgs p) {
     char* Ks = smem;
     char* Vs = smem + KT::BYTES;
     // V tile gets 16 extra rows of slack: for HD % 32 != 0 the last d-tile's transposed reads run past HD
-    float* rel_base = reinterpret_cast<float*>(smem + 2 * KT::BYTES + 16 * RS);
+    int* kms = reinterpret_cast<int*>(smem + 2 * KT::BYTES + 16 * RS);  // key-padding mask of the staged tile (64 ints)
+    float* rel_base = reinterpret_cast<float*>(smem + 2 * KT::BYTES + 16 * RS + 256);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,7 +183,13 @@ __global__ __launch_bounds__(NWAVES * 64) void flash_attn_kernel(AttnArgs p) {
         return true;
     };
     uint4 kreg[NCH], vreg[NCH];
+    int km_reg = 1;
+    const int* kmask_g = (MODE == MODE_CAUSAL && p.key_mask) ? p.key_mask + (long)b * Sk : nullptr;
     auto load_tile = [&](int tile) {
+        if (MODE == MODE_CAUSAL && tid < 64) {
+            const int kt = tile * 64 + tid;
+            km_reg = (kmask_g && kt < Sk) ? kmask_g[kt] : 1;
+        }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int idx = c * NT + tid;
@@ -199,6 +206,7 @@ __global__ __launch_bounds__(NWAVES * 64) void flash_attn_kernel(AttnArgs p) {
         }
     };
     auto store_tile = [&]() {
+        if (MODE == MODE_CAUSAL && tid < 64) kms[tid] = km_reg;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int idx = c * NT + tid;
@@ -268,7 +276,6 @@ __global__ __launch_bounds__(NWAVES * 64) void flash_attn_kernel(AttnArgs p) {
         const int last_q = p.q_pos0 + min(p.Sq, (int)(blockIdx.x + 1) * NWAVES * 32) - 1;
         ntiles = min(ntiles, last_q / 64 + 1);
     }
-    const int* kmask = (MODE == MODE_CAUSAL && p.key_mask) ? p.key_mask + (long)b * Sk : nullptr;
     const float FMIN = -3.4028234663852886e38f;  // torch.finfo(float32).min
 
     load_tile(0);
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(NWAVES * 64) void flash_attn_kernel(AttnArgs p) {
                     // additive masks exactly as the reference builds them (fp32): causal min + padding min
                     float add = 0.f;
                     if (kt > q_pos) add += FMIN;
-                    if (kmask && kt < Sk && kmask[kt] == 0) add += FMIN;
+                    if (kms[sub * 32 + crow32(r, h)] == 0) add += FMIN;
                     // = finfo.min (score absorbed) or -inf; deliberately NOT rescaled by log2(e): a row whose
                     // keys are all single-masked must stay uniform over them, as in the reference's eager softmax
                     if (add != 0.f) v = s[r] * p.scale + add;
@@ -373,7 +380,7 @@ static int launch_flash(const AttnArgs& a, hipStream_t s) {
     using KT = KVTile<T, HD>;
     constexpr bool REL = (MODE == MODE_VIT_GLOBAL || MODE == MODE_VIT_WINDOW);
     constexpr int RELROWS = (MODE == MODE_VIT_WINDOW) ? 16 : 64;
-    const size_t lds = 2 * KT::BYTES + 16 * KT::RS + (REL ? (size_t)NWAVES * 2 * RELROWS * 32 * 4 : 0);
+    const size_t lds = 2 * KT::BYTES + 16 * KT::RS + 256 + (REL ? (size_t)NWAVES * 2 * RELROWS * 32 * 4 : 0);
     ULLSAM_CHECK(lds <= 160 * 1024, "flash_attn: LDS %zu exceeds 160 KiB", lds);
     static bool attr = false;
     if (!attr) {
