@@ -1,0 +1,185 @@
+"""CPU-only checks: the C-ABI library loads and exports what include/ullsam_hip.h declares, the host mirror of the
+reference interface (state_dict layouts, configs, packing), no CPU fallback, and the N>1 path under gloo (world_size 2)."""
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ullsam_oracle as O
+from tests import util as U
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ullsam_amd import build, _lib
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "ullsam_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ullsam_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_c_abi_exports_every_declared_symbol(lib):
+    from ullsam_amd import _lib
+    syms = _header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/ullsam_hip.h but not exported"
+    bound = set(_lib.SIGNATURES) | set(_lib.PLAIN)
+    assert bound == set(syms), (bound ^ set(syms))
+    assert lib.ullsam_abi_version() == 1
+    assert lib.ullsam_last_error_string() is not None
+
+
+def test_c_abi_argument_counts_match_header():
+    from ullsam_amd import _lib
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ullsam_hip.h")).read(), flags=re.S)
+    for name, args in _lib.SIGNATURES.items():
+        m = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, src, flags=re.S)
+        assert m, name
+        n = len([a for a in m.group(1).split(",") if a.strip()])
+        assert n == len(args), (name, n, len(args))
+
+
+def test_no_cpu_fallback_and_no_oracle_in_product():
+    from ullsam_amd import _lib, ops
+    with pytest.raises((_lib.UllsamError, TypeError, ValueError)):
+        ops.gemm(torch.zeros(4, 64), torch.zeros(8, 64))  # CPU tensors: must raise, never compute
+    for dp, _, files in os.walk(os.path.join(ROOT, "ullsam_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f"{f} must not use the oracle"
+                assert "/root/reference" not in txt
+
+
+def test_state_dict_layouts_match_reference():
+    from ullsam_amd.build_sam import sam_model_registry
+    sam = sam_model_registry["vit_b"]()
+    exp = {}
+    exp.update(O.vit_shapes(prefix="image_encoder."))
+    exp.update(O.prompt_encoder_shapes(prefix="prompt_encoder."))
+    exp.update(O.mask_decoder_shapes(prefix="mask_decoder."))
+    got = {k: tuple(v.shape) for k, v in sam.state_dict().items()}
+    assert got == {k: tuple(v) for k, v in exp.items()}
+    assert set(sam_model_registry) == {"default", "vit_h", "vit_l", "vit_b"}
+    assert sam.mask_threshold == 0.0 and sam.image_format == "RGB" and sam.image_encoder.img_size == 1024
+    assert not sam.training
+
+
+def test_composite_state_dict_and_attributes():
+    from tests.test_model_gpu import _ullsam_tiny  # noqa: F401  (constructor only; no GPU touched)
+    from ullsam_amd.build_sam import _build_sam
+    from ullsam_amd.modeling.configuration_internvl_chat import InternVLChatConfig
+    from ullsam_amd.modeling.modeling_internvl_sam import InternVLSAMModel
+    c = U.LLM_TINY
+    sam = _build_sam(128, 2, 2, [1])
+    cfg = InternVLChatConfig(llm_config=dict(architectures=["InternLM2ForCausalLM"], vocab_size=c["vocab"], hidden_size=c["hidden"],
+                                             intermediate_size=c["inter"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
+                                             num_key_value_heads=c["kv_heads"], bias=False), ps_version="v2", template="internlm2-chat")
+    m = InternVLSAMModel(cfg, vision_model=sam.image_encoder, prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == {k: tuple(v.shape) for k, v in U.ullsam_tiny_params().items()}
+    assert m.img_context_token_id == 92546 and m.num_image_token == 1024.0 and isinstance(m.num_image_token, float)
+    assert m.template == "internlm2-chat" and m.system_message
+    for a in ("vision_model", "prompt_encoder", "mask_decoder", "language_model", "mlp1", "mlp2"):
+        assert hasattr(m, a)
+
+
+def test_config_defaults_follow_reference():
+    from ullsam_amd.modeling.configuration_internlm2 import InternLM2Config
+    from ullsam_amd.modeling.configuration_internvl_chat import InternVLChatConfig
+    c = InternLM2Config()
+    assert (c.vocab_size, c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.num_attention_heads) == (103168, 4096, 11008, 32, 32)
+    assert c.num_key_value_heads == 32 and c.rms_norm_eps == 1e-6 and c.bias is True and c.rope_theta == 10000
+    with pytest.raises(ValueError):
+        InternLM2Config(rope_scaling={"type": "bogus", "factor": 2.0})
+    v = InternVLChatConfig()
+    assert v.downsample_ratio == 0.5 and v.ps_version == "v1" and v.select_layer == -1
+    with pytest.raises(ValueError):
+        InternVLChatConfig(llm_config={"architectures": ["Nope"]})
+
+
+def test_weight_packing():
+    from ullsam_amd.packing import pack_conv3x3, pack_convT_k2s2, pack_w13
+    rng = np.random.default_rng(0)
+    w1, w3 = rng.standard_normal((128, 16), dtype=np.float32), rng.standard_normal((128, 16), dtype=np.float32)
+    p = pack_w13(torch.from_numpy(w1), torch.from_numpy(w3)).numpy()
+    for t in range(2):
+        assert (p[t * 128:t * 128 + 64] == w1[t * 64:(t + 1) * 64]).all() and (p[t * 128 + 64:(t + 1) * 128] == w3[t * 64:(t + 1) * 64]).all()
+    # conv3x3 pack == the oracle's im2col column order
+    x = rng.standard_normal((1, 5, 6, 8), dtype=np.float32)
+    w = rng.standard_normal((4, 8, 3, 3), dtype=np.float32)
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    cols = np.concatenate([xp[:, ky:ky + 5, kx:kx + 6] for ky in range(3) for kx in range(3)], -1)
+    y = cols @ pack_conv3x3(torch.from_numpy(w)).numpy().T
+    assert np.abs(y - O.conv3x3_nhwc(x, w)).max() < 1e-5
+    # convT pack: GEMM columns (ky, kx, co) reproduce ConvTranspose2d(k=2, s=2)
+    xi = rng.standard_normal((1, 8, 3, 3), dtype=np.float32)
+    wt, bt = rng.standard_normal((8, 4, 2, 2), dtype=np.float32), rng.standard_normal(4, dtype=np.float32)
+    W, Bv = pack_convT_k2s2(torch.from_numpy(wt), torch.from_numpy(bt))
+    g = xi.transpose(0, 2, 3, 1).reshape(9, 8) @ W.numpy().T + Bv.numpy()  # [pix, (ky,kx,co)]
+    ref = O._conv_transpose_k2s2(xi, wt, bt)
+    for pix in range(9):
+        y0, x0 = divmod(pix, 3)
+        for ky in range(2):
+            for kx in range(2):
+                assert np.abs(g[pix, (ky * 2 + kx) * 4:(ky * 2 + kx + 1) * 4] - ref[0, :, 2 * y0 + ky, 2 * x0 + kx]).max() < 1e-5
+
+
+def test_shard_range_partitions():
+    from ullsam_amd.parallel import shard_range
+    for n in (0, 1, 7, 8, 32, 33):
+        for ws in (1, 2, 3, 8):
+            spans = [shard_range(n, r, ws) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from ullsam_amd import parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_total = 5  # ragged: rank 0 gets 3 images, rank 1 gets 2
+        a, b = parallel.shard_range(n_total, rank, world)
+        low = torch.stack([torch.full((1, 4, 4), float(i)) for i in range(a, b)])
+        mk = (low > 1.5).to(torch.uint8)
+        tok = torch.arange(a, b).reshape(-1, 1).repeat(1, 3)
+        glow, gmk, gtok = parallel.gather_mask_results(low, mk, tok)
+        ok = glow.shape[0] == n_total and all(float(glow[i, 0, 0, 0]) == i for i in range(n_total))
+        ok = ok and gmk.sum().item() == 3 * 16 and gtok[:, 0].tolist() == list(range(n_total))
+        eq = parallel.all_gather_rows(torch.full((2, 2), float(rank)), counts=[2, 2])  # equal shards: single collective
+        ok = ok and eq[:, 0].tolist() == [0.0, 0.0, 1.0, 1.0]
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_gather_is_rank_ordered():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
