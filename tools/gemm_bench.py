@@ -1,0 +1,61 @@
+"""A/B the GEMM kernel variants on the workload's shapes in ONE process (interleaved rounds, random data).
+usage: python tools/gemm_bench.py [rounds]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ullsam_amd import ops, _lib
+
+SHAPES = [  # (name, M, N, K, act)
+    ("llm.wqkv", 4324, 6144, 4096, 0), ("llm.wo", 4324, 4096, 4096, 0), ("llm.w13", 4324, 28672, 4096, 3),
+    ("llm.w2", 4324, 4096, 14336, 0), ("vit.qkv", 16384, 3840, 1280, 0), ("vit.proj", 16384, 1280, 1280, 0),
+    ("vit.lin1", 16384, 5120, 1280, 1), ("vit.lin2", 16384, 1280, 5120, 0), ("2b.w13", 4324, 16384, 2048, 3),
+    ("vitb.lin1", 4096, 3072, 768, 1),
+]
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "2"])]
+    lib = _lib.load()
+    dev = "cuda"
+    res = {}
+    for name, M, N, K, act in SHAPES:
+        # cold-operand regime: rotate through > 600 MB of distinct (A, W, C) so nothing is served from L2 / Infinity Cache
+        n_out = N // 2 if act == 3 else N
+        ncopy = max(2, int(6e8 // (2 * (M * K + N * K + M * n_out))) + 1)
+        As = [torch.randn(M, K, device=dev).bfloat16() for _ in range(ncopy)]
+        Ws = [(torch.randn(N, K, device=dev) * K ** -0.5).bfloat16() for _ in range(ncopy)]
+        Cs = [torch.empty(M, n_out, device=dev, dtype=torch.bfloat16) for _ in range(ncopy)]
+        a, w = As[0], Ws[0]
+        bias = torch.randn(N, device=dev) if act == 1 else None
+        ref = None
+        for v in variants:
+            lib.ullsam_set_gemm_variant(v)
+            out = ops.gemm(a, w, bias, act=act)
+            if ref is None:
+                ref = out.float()
+            else:
+                d = (out.float() - ref).abs().max().item()
+                assert d < 0.1, (name, v, d)
+        times = {v: [] for v in variants}
+        for r in range(rounds):
+            for v in variants:
+                lib.ullsam_set_gemm_variant(v)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(ncopy):
+                    ops.gemm(As[i], Ws[i], bias, act=act, out=Cs[i])
+                e1.record()
+                torch.cuda.synchronize()
+                times[v].append(e0.elapsed_time(e1) / ncopy)
+        fl = 2.0 * M * N * K
+        line = f"{name:10s} M={M:6d} N={N:6d} K={K:6d}"
+        for v in variants:
+            t = sorted(times[v])[len(times[v]) // 2]
+            line += f" | v{v}: {t * 1e3:8.1f} us {fl / t / 1e9:7.1f} TF/s"
+        print(line, flush=True)
+    lib.ullsam_set_gemm_variant(0)
+
+
+if __name__ == "__main__":
+    main()

@@ -41,7 +41,8 @@ SIGNATURES = {
     "ullsam_resize_bilinear": [vp, i64, i32, i32, i32, vp, vp, i32, i32, i32, f32, vp],
     "ullsam_mask_iou_counts": [vp, vp, vp, i32, i64, vp],
 }
-PLAIN = {"ullsam_last_error_string": ([], C.c_char_p), "ullsam_abi_version": ([], i32), "ullsam_device_count": ([], i32)}
+PLAIN = {"ullsam_last_error_string": ([], C.c_char_p), "ullsam_abi_version": ([], i32), "ullsam_device_count": ([], i32),
+         "ullsam_set_gemm_variant": ([i32], i32)}
 
 
 class UllsamError(RuntimeError):

@@ -92,8 +92,11 @@ __device__ __forceinline__ Frag<float> pack_p(const f32x16& s, int half, const f
     return f;
 }
 
-template <typename T, int HD, int MODE, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void flash_attn_kernel(AttnArgs p) {
+// FAST64: MODE_VIT_GLOBAL on the 64x64 token grid SAM always uses at 1024^2.  A 32-key block is then half a grid row: its
+// key row is uniform (ONE rel_h LDS read per block) and its key columns are one of two fixed sets, so rel_w lives in 32
+// registers per lane; only rel_h stays in LDS (8 KiB per wave -> two workgroups per CU).
+template <typename T, int HD, int MODE, int NWAVES, bool FAST64>
+__global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) {  // >= 2 waves per SIMD: at most 256 VGPR+AGPR
     using KT = KVTile<T, HD>;
     constexpr int RS = KT::RS;
     constexpr int NT = NWAVES * 64;
@@ -220,13 +223,18 @@ __global__ __launch_bounds__(NWAVES * 64) void flash_attn_kernel(AttnArgs p) {
 
     // ---- rel-pos tables: T^T[e][q] = RelTable[e][:] . q[:]  (unscaled q), scattered to relh[kh][q] / relw[kw][q]
     constexpr int RELROWS = (MODE == MODE_VIT_WINDOW) ? 16 : 64;  // key-grid side: window <= 14, global <= 64
-    float* relh = rel_base + wave * (2 * RELROWS * 32);  // [RELROWS][32] floats each
-    float* relw = relh + RELROWS * 32;
+    constexpr int RELTABS = FAST64 ? 1 : 2;                       // FAST64 keeps rel_w in registers
+    float* relh = rel_base + wave * (RELTABS * RELROWS * 32);     // [RELROWS][32] floats each
+    float* relw = FAST64 ? relh : relh + RELROWS * 32;            // FAST64: the same slab is first used as rel_w scratch
+    float rw[2][16];                                              // FAST64: rel_w * log2(e) for key columns 32*par + crow32(r, h)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) rw[i >> 4][i & 15] = 0.f;
     if (REL) {
         const int NE = 2 * G - 1;  // rows per table (<= 127)
         const T* tabs[2] = {reinterpret_cast<const T*>(p.rel_h), reinterpret_cast<const T*>(p.rel_w)};
 #pragma unroll 1
-        for (int tb = 0; tb < 2; ++tb) {
+        for (int it = 0; it < 2; ++it) {
+            const int tb = FAST64 ? 1 - it : it;  // FAST64: width table first (its slab is then recycled for rel_h)
             __syncthreads();
             // stage table rows 0..127 into the contiguous K|V region (128 rows of RS bytes)
             for (int idx = tid; idx < 128 * CPR; idx += NT) {
@@ -257,6 +265,11 @@ __global__ __launch_bounds__(NWAVES * 64) void flash_attn_kernel(AttnArgs p) {
                     if (e < NE && kk >= 0 && kk < GK) dst[kk * 32 + ql] = acc[r];
                 }
             }
+            if (FAST64 && tb == 1) {
+                __syncthreads();  // both lane halves of every wave have scattered their rel_w entries
+#pragma unroll
+                for (int i = 0; i < 32; ++i) rw[i >> 4][i & 15] = relw[(32 * (i >> 4) + crow32(i & 15, h)) * 32 + ql] * LOG2E;
+            }
         }
         __syncthreads();
     }
@@ -284,6 +297,8 @@ __global__ __launch_bounds__(NWAVES * 64) void flash_attn_kernel(AttnArgs p) {
 #pragma unroll 1
     for (int tile = 0; tile < ntiles; ++tile) {
         if (tile + 1 < ntiles) load_tile(tile + 1);
+        const bool tile_pad = (MODE == MODE_CAUSAL && kmask_g) ? (__any(kms[lane] == 0) != 0) : false;
+        const int wave_first_q = p.q_pos0 + ((int)blockIdx.x * NWAVES + wave) * 32;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int kbase = tile * 64 + sub * 32;
@@ -301,17 +316,22 @@ __global__ __launch_bounds__(NWAVES * 64) void flash_attn_kernel(AttnArgs p) {
                 mma32(a, qf[ks], s);
             }
             float mx = -INFINITY;
+            const float rh64 = FAST64 ? relh[(kbase >> 6) * 32 + ql] * LOG2E : 0.f;  // key row of this 32-key block
+            // causal: blocks entirely in the past of every query of this wave and free of padding need no mask arithmetic
+            const bool interior = (MODE == MODE_CAUSAL) && !tile_pad && (kbase + 31 <= wave_first_q) && (kbase + 31 < Sk);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kt = kbase + crow32(r, h);
                 float v = s[r] * scale2;
-                if (REL) {
+                if (FAST64) {
+                    v += rh64 + rw[sub][r];  // key column = 32*sub + crow32(r, h): compile-time register index
+                } else if (REL) {
                     const int ky = (int)(((float)kt + 0.5f) * invG);
                     const int kx = kt - ky * G;
                     const float bias = (kt < Sk) ? (relh[ky * 32 + ql] + relw[kx * 32 + ql]) : 0.f;
                     v += bias * LOG2E;
                 }
-                if (MODE == MODE_CAUSAL) {
+                if (MODE == MODE_CAUSAL && !interior) {
                     // additive masks exactly as the reference builds them (fp32): causal min + padding min
                     float add = 0.f;
                     if (kt > q_pos) add += FMIN;
@@ -320,7 +340,7 @@ __global__ __launch_bounds__(NWAVES * 64) void flash_attn_kernel(AttnArgs p) {
                     // keys are all single-masked must stay uniform over them, as in the reference's eager softmax
                     if (add != 0.f) v = s[r] * p.scale + add;
                 }
-                if (kt >= Sk) v = -INFINITY;
+                if (!FAST64 && !interior && kt >= Sk) v = -INFINITY;
                 s[r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -337,10 +357,12 @@ __global__ __launch_bounds__(NWAVES * 64) void flash_attn_kernel(AttnArgs p) {
             }
             l_run = l_run * alpha + psum;
             m_run = m_new;
+            if (__any(alpha != 1.0f)) {  // wave-uniform: skip the O rescale when no row maximum moved in this block
 #pragma unroll
-            for (int d = 0; d < DT; ++d)
+                for (int d = 0; d < DT; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
             const Frag<T> p0 = pack_p(s, 0, (const T*)nullptr);
             const Frag<T> p1 = pack_p(s, 1, (const T*)nullptr);
 #pragma unroll
@@ -375,34 +397,41 @@ __global__ __launch_bounds__(NWAVES * 64) void flash_attn_kernel(AttnArgs p) {
     }
 }
 
-template <typename T, int HD, int MODE, int NWAVES>
-static int launch_flash(const AttnArgs& a, hipStream_t s) {
+template <typename T, int HD, int MODE, int NWAVES, bool FAST64>
+static int launch_flash_impl(const AttnArgs& a, hipStream_t s) {
     using KT = KVTile<T, HD>;
     constexpr bool REL = (MODE == MODE_VIT_GLOBAL || MODE == MODE_VIT_WINDOW);
     constexpr int RELROWS = (MODE == MODE_VIT_WINDOW) ? 16 : 64;
-    const size_t lds = 2 * KT::BYTES + 16 * KT::RS + 256 + (REL ? (size_t)NWAVES * 2 * RELROWS * 32 * 4 : 0);
+    const size_t lds = 2 * KT::BYTES + 16 * KT::RS + 256 + (REL ? (size_t)NWAVES * (FAST64 ? 1 : 2) * RELROWS * 32 * 4 : 0);
     ULLSAM_CHECK(lds <= 160 * 1024, "flash_attn: LDS %zu exceeds 160 KiB", lds);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<T, HD, MODE, NWAVES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<T, HD, MODE, NWAVES, FAST64>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     const int qtiles = (a.Sq + NWAVES * 32 - 1) / (NWAVES * 32);
     const int nz = MODE == MODE_VIT_WINDOW ? a.B * a.nwin : a.B;
-    flash_attn_kernel<T, HD, MODE, NWAVES><<<dim3(qtiles, a.H, nz), dim3(NWAVES * 64), lds, s>>>(a);
+    flash_attn_kernel<T, HD, MODE, NWAVES, FAST64><<<dim3(qtiles, a.H, nz), dim3(NWAVES * 64), lds, s>>>(a);
     ULLSAM_LAUNCH_CHECK();
     return 0;
+}
+
+template <typename T, int HD, int MODE, int NWAVES>
+static int launch_flash(const AttnArgs& a, hipStream_t s) {
+    if (MODE == MODE_VIT_GLOBAL && a.grid_h == 64 && a.grid_w == 64) return launch_flash_impl<T, HD, MODE, NWAVES, MODE == MODE_VIT_GLOBAL>(a, s);
+    return launch_flash_impl<T, HD, MODE, NWAVES, false>(a, s);
 }
 
 template <typename T, int MODE, int NWAVES>
 static int dispatch_hd(const AttnArgs& a, int hd, hipStream_t s) {
     switch (hd) {
         case 64: return launch_flash<T, 64, MODE, NWAVES>(a, s);
-        case 80: return launch_flash<T, 80, MODE, NWAVES>(a, s);
-        case 128: return launch_flash<T, 128, MODE, NWAVES>(a, s);
-        default: ULLSAM_CHECK(false, "flash_attn: unsupported head_dim %d (64, 80, 128)", hd);
+        case 80: if (MODE != MODE_CAUSAL) return launch_flash<T, (MODE != MODE_CAUSAL ? 80 : 64), MODE, NWAVES>(a, s); break;
+        case 128: if (MODE == MODE_CAUSAL) return launch_flash<T, (MODE == MODE_CAUSAL ? 128 : 64), MODE, NWAVES>(a, s); break;
+        default: break;
     }
+    ULLSAM_CHECK(false, "flash_attn: unsupported head_dim %d for mode %d (ViT: 64/80, causal: 64/128)", hd, MODE);
 }
 
 // SAM ViT attention on the packed qkv activations [B, grid_h*grid_w, 3*D] (D = heads*hd, per token [3][heads][hd]).

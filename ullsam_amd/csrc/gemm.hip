@@ -73,15 +73,17 @@ __device__ __forceinline__ void store_row8<bf16>(bf16* dst, const float* v, int 
     }
 }
 
-template <typename T, typename OutT>
+template <typename T, typename OutT, int BM, int NTHREADS>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs, int m0, int n0, int tn, int tid) {
+    constexpr int RPP = NTHREADS / 16;      // rows per pass (16 threads x 8 columns cover one 128-wide row)
+    constexpr int PASSES = BM / RPP;
     OutT* C = reinterpret_cast<OutT*>(p.C);
     if (p.act == 3) {
         // SwiGLU pair: tile columns [0,64) = gate rows of w1, [64,128) = up rows of w3 (host prepack);
         // out[:, tn*64 + j] = silu(gate_j) * up_j      (modeling_internlm2.py:261-264)
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int row = pass * 16 + (tid >> 4);
+        for (int pass = 0; pass < PASSES; ++pass) {
+            const int row = pass * RPP + (tid >> 4);
             const int j0 = (tid & 15) * 4;
             const int gm = m0 + row;
             if (gm >= p.M) continue;
@@ -98,21 +100,34 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
         }
         return;
     }
+    // this thread's 8 columns are the same in every pass: fetch their bias once (it was 64 dependent scalar loads per thread)
+    const int c0 = (tid & 15) * 8;
+    const int gn = n0 + c0;
+    if (gn >= p.N) return;
+    const int n_valid = min(8, p.N - gn);
+    float bv[8];
 #pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-        const int row = pass * 16 + (tid >> 4);
-        const int c0 = (tid & 15) * 8;
-        const int gm = m0 + row, gn = n0 + c0;
-        if (gm >= p.M || gn >= p.N) continue;
-        const int n_valid = min(8, p.N - gn);
+    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    if (p.bias) {
+        if (n_valid == 8 && ((reinterpret_cast<uintptr_t>(p.bias + gn) & 15) == 0)) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + gn);
+            const float4 b1 = *reinterpret_cast<const float4*>(p.bias + gn + 4);
+            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        } else {
+            for (int e = 0; e < n_valid; ++e) bv[e] = p.bias[gn + e];
+        }
+    }
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int row = pass * RPP + (tid >> 4);
+        const int gm = m0 + row;
+        if (gm >= p.M) continue;
         float v[8];
         const float4 a = *reinterpret_cast<const float4*>(Cs + row * 128 + c0);
         const float4 b = *reinterpret_cast<const float4*>(Cs + row * 128 + c0 + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        if (p.bias) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) if (e < n_valid) v[e] += p.bias[gn + e];
-        }
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
         if (p.act == 1) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
@@ -226,9 +241,138 @@ __global__ __launch_bounds__(256) void gemm128_kernel(GemmArgs p) {
             }
     __syncthreads();
     if (p.out_f32)
-        epilogue_rows<T, float>(p, Cs, m0, n0, tn, tid);
+        epilogue_rows<T, float, 128, 256>(p, Cs, m0, n0, tn, tid);
     else
-        epilogue_rows<T, T>(p, Cs, m0, n0, tn, tid);
+        epilogue_rows<T, T, 128, 256>(p, Cs, m0, n0, tn, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// v2: 256x128 tile, 8 waves (4 x 2, each 64x64), 3-stage LDS-DMA ring.  One barrier per K-tile; the DMA of tiles kt+1
+// and kt+2 stays in flight across it (counted s_waitcnt vmcnt, raw s_barrier -- a __syncthreads() would drain vmcnt(0),
+// cdna guide section 5 "Pipelining across barriers").  LDS: 3 x (32 KiB A + 16 KiB B) = 144 KiB, one workgroup per CU.
+// RAW: a wave waits for its own DMA pieces of tile kt, then the barrier => every piece of tile kt has landed before any
+// ds_read of it.  WAR: the stage issued after the barrier of iteration kt overwrites the buffer of tile kt-1, whose
+// fragment reads were consumed by MFMAs (data dependence) before their wave reached this barrier.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512) void gemm256x128_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int BK = 8 * EPC;
+    constexpr int KSTEPS = BK / 32;
+    constexpr int STAGE = 49152;  // 32 KiB A + 16 KiB B
+
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int GM = 4;
+    const int width = GM * p.tiles_n;
+    const int group = swz / width;
+    const int first_m = group * GM;
+    const int gsize = min(p.tiles_m - first_m, GM);
+    const int tm = first_m + (swz % width) % gsize;
+    const int tn = (swz % width) / gsize;
+    const int m0 = tm * 256, n0 = tn * 128;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const char* a_src[4];
+    const char* b_src[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        const int gm = min(m0 + row, p.M - 1);
+        a_src[i] = reinterpret_cast<const char*>(p.A) + (size_t)gm * p.lda * sizeof(T) + (c << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        const int gn = min(n0 + row, p.N - 1);
+        b_src[i] = reinterpret_cast<const char*>(p.W) + (size_t)gn * p.ldw * sizeof(T) + (c << 4);
+    }
+    const int nk = p.K / BK;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int buf, int kt) {
+        const size_t koff = (size_t)kt * 128;
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[i] + koff), LDS_PTR(base + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[i] + koff), LDS_PTR(base + 32768 + (wave * 2 + i) * 1024), 16, 0, 0);
+    };
+
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) stage(buf == 0 ? 2 : buf - 1, kt + 2);
+        const char* Ab = smem + buf * STAGE;
+        const char* Bb = Ab + 32768;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            Frag<T> a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = lds_frag<T>(Ab, wm * 64 + i * 16 + (lane & 15), ks, lane >> 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), ks, lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(a[i], b[j], acc[i][j]);
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+
+    __syncthreads();
+    float* Cs = reinterpret_cast<float*>(smem);  // [256][128] fp32 = 128 KiB
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+                const int col = wn * 64 + j * 16 + (lane & 15);
+                Cs[row * 128 + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    if (p.out_f32)
+        epilogue_rows<T, float, 256, 512>(p, Cs, m0, n0, tn, tid);
+    else
+        epilogue_rows<T, T, 256, 512>(p, Cs, m0, n0, tn, tid);
+}
+
+static int g_gemm_variant = 0;  // 0 auto, 1 force v1 (128x128), 2 force v2 (256x128)
+extern "C" int ullsam_set_gemm_variant(int v) { g_gemm_variant = v; return 0; }
+
+template <typename T>
+static int launch_gemm_v2(GemmArgs a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+        attr_set = true;
+    }
+    a.tiles_m = (a.M + 255) / 256;
+    gemm256x128_kernel<T><<<dim3(a.tiles_m * a.tiles_n), dim3(512), 147456, stream>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
 }
 
 template <typename T>
@@ -268,5 +412,7 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     a.tiles_m = (M + 127) / 128;
     a.tiles_n = (N + 127) / 128;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool v2 = g_gemm_variant == 2 || (g_gemm_variant == 0 && M > 512);
+    if (v2) return dtype == ULLSAM_DT_F32 ? launch_gemm_v2<float>(a, s) : launch_gemm_v2<bf16>(a, s);
     return dtype == ULLSAM_DT_F32 ? launch_gemm<float>(a, s) : launch_gemm<bf16>(a, s);
 }
