@@ -19,7 +19,10 @@ def main():
     lib = _lib.load()
     dev = "cuda"
     res = {}
+    only = os.environ.get("GEMM_SHAPES")
     for name, M, N, K, act in SHAPES:
+        if only and name not in only.split(","):
+            continue
         # cold-operand regime: rotate through > 600 MB of distinct (A, W, C) so nothing is served from L2 / Infinity Cache
         n_out = N // 2 if act == 3 else N
         ncopy = max(2, int(6e8 // (2 * (M * K + N * K + M * n_out))) + 1)
