@@ -236,8 +236,29 @@ def main():
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 
     model = build_model(a.vit, a.llm, dtype, device)
+    if os.environ.get("ULLSAM_GEMM_VARIANT"):  # A/B switch for kernel experiments (0 auto, 1 = 128x128, 2 = 256x128)
+        from ullsam_amd import _lib
+        _lib.load().ullsam_set_gemm_variant(int(os.environ["ULLSAM_GEMM_VARIANT"]))
     timer = GemmTimer()
-    step = make_step(model, a.batch, a.seq, device, dtype, world)
+    nstreams = int(os.environ.get("ULLSAM_STREAMS", "1"))
+    if nstreams > 1 and a.batch % nstreams == 0:
+        # the batch's images are independent: run them as `nstreams` sub-batches on separate HIP streams so one sub-batch's
+        # partially filled last wave of workgroups overlaps the other's next kernel
+        subs = [make_step(model, a.batch // nstreams, a.seq, device, dtype, 1) for _ in range(nstreams)]
+        streams = [torch.cuda.Stream() for _ in range(nstreams)]
+
+        def step():
+            cur = torch.cuda.current_stream()
+            outs = []
+            for st, fn in zip(streams, subs):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    outs.append(fn())
+            for st in streams:
+                cur.wait_stream(st)
+            return outs
+    else:
+        step = make_step(model, a.batch, a.seq, device, dtype, world)
 
     def barrier():
         torch.cuda.synchronize()

@@ -209,3 +209,32 @@ def test_data_movement_kernels(ops):
     assert (m.cpu().numpy().astype(bool) != (ref > 0)).mean() < 1e-5
     lg = rng.standard_normal((3, 1000), dtype=np.float32); lg[1, 7] = lg[1, 900] = 50.0
     assert ops.argmax(T(lg)).cpu().tolist() == lg.argmax(-1).tolist()
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_tile_variants_agree_with_oracle(ops, variant, dtype):
+    """All three tile configurations (128x128, 256x128 ring, 256x256) through every epilogue, ragged M and N."""
+    from ullsam_amd import _lib
+    from ullsam_amd.packing import pack_w13
+    lib = _lib.load()
+    rng = np.random.default_rng(variant)
+    M, N, K = 777, 640, 256
+    a = rng.standard_normal((M, K), dtype=np.float32)
+    w = (rng.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N, dtype=np.float32)
+    res = rng.standard_normal((M, N), dtype=np.float32)
+    ad, wd = T(a, dtype), T(w, dtype)
+    ref = ad.float().cpu().numpy() @ wd.float().cpu().numpy().T
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    try:
+        lib.ullsam_set_gemm_variant(variant)
+        y = ops.gemm(ad, wd, bias=T(bias), act=ops.ACT_GELU, residual=T(res), out_f32=True).cpu().numpy()
+        assert err(y, O.gelu(ref + bias) + res) < tol
+        y = ops.gemm(ad, wd[:600].contiguous(), out_f32=False).float().cpu().numpy()  # N = 600: ragged last tile
+        assert err(y, ref[:, :600]) < (tol if dtype == torch.float32 else 6e-2)
+        w1, w3 = wd[:256].contiguous(), wd[256:512].contiguous()
+        y = ops.gemm(ad, pack_w13(w1, w3), act=ops.ACT_SWIGLU, out_f32=True).cpu().numpy()
+        assert err(y, O.silu(ref[:, :256]) * ref[:, 256:512]) < tol
+    finally:
+        lib.ullsam_set_gemm_variant(0)

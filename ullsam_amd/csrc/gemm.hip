@@ -28,6 +28,7 @@ struct GemmArgs {
     int act;      // 0 none, 1 gelu(erf), 2 relu, 3 swiglu pair (tile = [64 gate | 64 up])
     int out_f32;  // C element type: 1 -> float, 0 -> T
     int vec_ok;   // stores / residual loads may be 16-byte vectors
+    int ablate;   // timing-only ablations of the v2 main loop (bit0: no in-loop staging, bit1: no barrier); results are garbage
     int tiles_m, tiles_n;
 };
 
@@ -73,24 +74,26 @@ __device__ __forceinline__ void store_row8<bf16>(bf16* dst, const float* v, int 
     }
 }
 
-template <typename T, typename OutT, int BM, int NTHREADS>
+template <typename T, typename OutT, int BM, int NTHREADS, int BN = 128>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs, int m0, int n0, int tn, int tid) {
-    constexpr int RPP = NTHREADS / 16;      // rows per pass (16 threads x 8 columns cover one 128-wide row)
-    constexpr int PASSES = BM / RPP;
+    constexpr int TPR = BN / 8;             // threads per row (each owns 8 accumulator columns)
+    constexpr int RPP = NTHREADS / TPR;     // rows per pass
+    constexpr int PASSES = BM / RPP;        // BM = rows staged in Cs (row stride BN floats)
     OutT* C = reinterpret_cast<OutT*>(p.C);
     if (p.act == 3) {
         // SwiGLU pair: tile columns [0,64) = gate rows of w1, [64,128) = up rows of w3 (host prepack);
         // out[:, tn*64 + j] = silu(gate_j) * up_j      (modeling_internlm2.py:261-264)
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass) {
-            const int row = pass * RPP + (tid >> 4);
-            const int j0 = (tid & 15) * 4;
+            const int row = pass * RPP + tid / TPR;
+            const int t = tid % TPR;
+            const int grp = t >> 4, j0 = (t & 15) * 4;  // every 128 accumulator columns = [64 gate | 64 up]
             const int gm = m0 + row;
             if (gm >= p.M) continue;
-            const float4 g = *reinterpret_cast<const float4*>(Cs + row * 128 + j0);
-            const float4 u = *reinterpret_cast<const float4*>(Cs + row * 128 + 64 + j0);
+            const float4 g = *reinterpret_cast<const float4*>(Cs + row * BN + grp * 128 + j0);
+            const float4 u = *reinterpret_cast<const float4*>(Cs + row * BN + grp * 128 + 64 + j0);
             float4 o = make_float4(silu_f(g.x) * u.x, silu_f(g.y) * u.y, silu_f(g.z) * u.z, silu_f(g.w) * u.w);
-            OutT* dst = C + (size_t)gm * p.ldc + (size_t)tn * 64 + j0;
+            OutT* dst = C + (size_t)gm * p.ldc + (size_t)tn * (BN / 2) + grp * 64 + j0;
             if (p.vec_ok) {
                 store4(dst, o);
             } else {
@@ -101,7 +104,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
         return;
     }
     // this thread's 8 columns are the same in every pass: fetch their bias once (it was 64 dependent scalar loads per thread)
-    const int c0 = (tid & 15) * 8;
+    const int c0 = (tid % TPR) * 8;
     const int gn = n0 + c0;
     if (gn >= p.N) return;
     const int n_valid = min(8, p.N - gn);
@@ -119,12 +122,12 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
     }
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
-        const int row = pass * RPP + (tid >> 4);
+        const int row = pass * RPP + tid / TPR;
         const int gm = m0 + row;
         if (gm >= p.M) continue;
         float v[8];
-        const float4 a = *reinterpret_cast<const float4*>(Cs + row * 128 + c0);
-        const float4 b = *reinterpret_cast<const float4*>(Cs + row * 128 + c0 + 4);
+        const float4 a = *reinterpret_cast<const float4*>(Cs + row * BN + c0);
+        const float4 b = *reinterpret_cast<const float4*>(Cs + row * BN + c0 + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bv[e];
@@ -319,10 +322,10 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(GemmArgs p) {
     if (nk > 1) stage(1, 1);
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (kt + 1 < nk && !(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) stage(buf == 0 ? 2 : buf - 1, kt + 2);
+        if (!(p.ablate & 2)) __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk && !(p.ablate & 1)) stage(buf == 0 ? 2 : buf - 1, kt + 2);
         const char* Ab = smem + buf * STAGE;
         const char* Bb = Ab + 32768;
 #pragma unroll
@@ -357,6 +360,127 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(GemmArgs p) {
         epilogue_rows<T, float, 256, 512>(p, Cs, m0, n0, tn, tid);
     else
         epilogue_rows<T, T, 256, 512>(p, Cs, m0, n0, tn, tid);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// v3: 256x256 tile, 8 waves (2 x 4), 128x64 per wave (8x4 MFMA 16x16 tiles, 128 accumulator registers), two 64 KiB
+// LDS stages, LDS-DMA double buffer with one barrier per K-tile (the v1 loop).  Versus the 64x64 per-wave tile this
+// issues 12 instead of 16 ds_read_b128 per 32 MFMAs and half the LDS-DMA instructions per MFMA, and halves the
+// L2->LDS bytes per FLOP (ablation + PMC in profiles/).  Used for GEMMs whose 256x256 tile count fills the chip's
+// 256 CUs for several rounds; the epilogue is staged through LDS in two 128-row halves.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int BK = 8 * EPC;
+    constexpr int KSTEPS = BK / 32;
+    constexpr int STAGE = 65536;  // 32 KiB A + 32 KiB B
+
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int GM = 4;
+    const int width = GM * p.tiles_n;
+    const int group = swz / width;
+    const int first_m = group * GM;
+    const int gsize = min(p.tiles_m - first_m, GM);
+    const int tm = first_m + (swz % width) % gsize;
+    const int tn = (swz % width) / gsize;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const char* a_src[4];
+    const char* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        const int gm = min(m0 + row, p.M - 1);
+        const int gn = min(n0 + row, p.N - 1);
+        a_src[i] = reinterpret_cast<const char*>(p.A) + (size_t)gm * p.lda * sizeof(T) + (c << 4);
+        b_src[i] = reinterpret_cast<const char*>(p.W) + (size_t)gn * p.ldw * sizeof(T) + (c << 4);
+    }
+    const int nk = p.K / BK;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int buf, int kt) {
+        const size_t koff = (size_t)kt * 128;
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[i] + koff), LDS_PTR(base + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[i] + koff), LDS_PTR(base + 32768 + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
+    };
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // tile kt landed (vmcnt(0) + barrier); every wave is done reading buffer (kt+1)&1
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const char* Ab = smem + (kt & 1) * STAGE;
+        const char* Bb = Ab + 32768;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            Frag<T> b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), ks, lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const Frag<T> a = lds_frag<T>(Ab, wm * 128 + i * 16 + (lane & 15), ks, lane >> 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(a, b[j], acc[i][j]);
+            }
+        }
+    }
+
+    float* Cs = reinterpret_cast<float*>(smem);  // [128][256] fp32 = 128 KiB, one 128-row half at a time
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = i * 16 + 4 * (lane >> 4) + r;
+                        const int col = wn * 64 + j * 16 + (lane & 15);
+                        Cs[row * 256 + col] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        if (p.out_f32)
+            epilogue_rows<T, float, 128, 512, 256>(p, Cs, m0 + half * 128, n0, tn, tid);
+        else
+            epilogue_rows<T, T, 128, 512, 256>(p, Cs, m0 + half * 128, n0, tn, tid);
+    }
+}
+
+template <typename T>
+static int launch_gemm_v3(GemmArgs a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        attr_set = true;
+    }
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (a.N + 255) / 256;
+    gemm256_kernel<T><<<dim3(a.tiles_m * a.tiles_n), dim3(512), 131072, stream>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
 }
 
 static int g_gemm_variant = 0;  // 0 auto, 1 force v1 (128x128), 2 force v2 (256x128)
@@ -409,10 +533,17 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     bool vec = ((uintptr_t)C & 15) == 0 && (ldc * osz) % 16 == 0 && (n_out % 8 == 0);
     if (residual) vec = vec && ((uintptr_t)residual & 15) == 0 && (ldr % 4 == 0);
     a.vec_ok = vec ? 1 : 0;
+    a.ablate = (g_gemm_variant >> 4) & 3;
     a.tiles_m = (M + 127) / 128;
     a.tiles_n = (N + 127) / 128;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const bool v2 = g_gemm_variant == 2 || (g_gemm_variant == 0 && M > 512);
+    const int variant = g_gemm_variant & 15;
+    // measured end to end (profiles/): the 256x128 3-stage kernel wins on the very wide SwiGLU GEMM, the 128x128 kernel elsewhere
+    const bool v2 = variant == 2 || (variant == 0 && M > 512 && N >= 16384);
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    const bool v3 = variant == 3 || (variant == 0 && t256 >= 768 && (act != 3 || N % 256 == 0));
+    if (act == 3 && (variant == 3) && N % 256 != 0) { ullsam_set_error("ullsam_gemm: v3 swiglu needs N%%256==0"); return -1; }
+    if (v3) return dtype == ULLSAM_DT_F32 ? launch_gemm_v3<float>(a, s) : launch_gemm_v3<bf16>(a, s);
     if (v2) return dtype == ULLSAM_DT_F32 ? launch_gemm_v2<float>(a, s) : launch_gemm_v2<bf16>(a, s);
     return dtype == ULLSAM_DT_F32 ? launch_gemm<float>(a, s) : launch_gemm<bf16>(a, s);
 }
