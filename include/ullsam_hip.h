@@ -28,17 +28,19 @@ extern "C" {
 const char* ullsam_last_error_string(void);
 int ullsam_abi_version(void);
 int ullsam_device_count(void);
-/* GEMM kernel selection for A/B measurements: 0 = auto (by shape), 1 = 128x128 tile, 2 = 256x128 tile / 3-stage ring, 3 = 256x256 tile; +16/+32 = timing-only ablations of variant 2. */
+/* GEMM kernel selection for A/B measurements: 0 = auto (by shape), 1 = 128x128 tile, 2 = 256x128 tile / 3-stage ring, 3 = 256x256 tile; +16/+32 = timing-only ablations of variant 2; +64 = no split-K tail. */
 int ullsam_set_gemm_variant(int variant);
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual.  Replaces every nn.Linear / 1x1 conv / stride==kernel conv:
  * image_encoder.py:227,238,387-395,88-104; common.py:21-26; modeling_internvl_sam.py:88-100;
  * modeling_internlm2.py:261-264,359,421,1081; transformer.py:220-227 (image side); mask_decoder.py:53-59.
  * A, W in `dtype`; C float when out_f32 else `dtype`; bias/residual fp32 (nullable); residual row = m %% res_row_mod
- * when res_row_mod > 0 (pos_embed broadcast, image_encoder.py:107-109).  K %% (128/elem_size) == 0. */
+ * when res_row_mod > 0 (pos_embed broadcast, image_encoder.py:107-109).  K %% (128/elem_size) == 0.
+ * workspace (optional, caller-owned device scratch, >= 32 MiB useful): lets launches whose last wave of tiles is mostly empty
+ * split those tiles along K (fp32 partials in the workspace + a reduce kernel); null disables it. */
 int ullsam_gemm(int dtype, const void* A, long lda, const void* W, long ldw, void* C, long ldc, int out_f32,
                 const float* bias, const float* residual, long ldr, int res_row_mod, int act, int M, int N, int K,
-                void* stream);
+                void* workspace, long ws_bytes, void* stream);
 
 /* Row LayerNorm / RMSNorm, fp32 statistics.  image_encoder.py:151,161; common.py:38-43 (LayerNorm2d on NHWC rows);
  * modeling_internlm2.py:138-143 (rms=1); prompt_encoder.py:142-149 (no affine + post scale/shift); transformer.py norms. */

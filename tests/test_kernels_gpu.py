@@ -238,3 +238,30 @@ def test_gemm_tile_variants_agree_with_oracle(ops, variant, dtype):
         assert err(y, O.silu(ref[:, :256]) * ref[:, 256:512]) < tol
     finally:
         lib.ullsam_set_gemm_variant(0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_split_k_tail_matches_unsplit(ops, dtype):
+    """576 tiles on 512 slots: the 64 tail tiles are cut into 8 K-ranges (fp32 partials + reduce kernel).  Must equal the
+    unsplit launch to accumulation-order noise, through bias + residual + the SwiGLU epilogue."""
+    from ullsam_amd import _lib
+    from ullsam_amd.packing import pack_w13
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    M, N, K = 2300, 4096, 2048
+    a = T(rng.standard_normal((M, K), dtype=np.float32), dtype)
+    w = T((rng.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)).astype(np.float32), dtype)
+    bias, res = T(rng.standard_normal(N, dtype=np.float32)), T(rng.standard_normal((M, N), dtype=np.float32))
+    try:
+        lib.ullsam_set_gemm_variant(1 | 64)
+        y0 = ops.gemm(a, w, bias=bias, residual=res, out_f32=True)
+        s0 = ops.gemm(a, pack_w13(w[:2048].contiguous(), w[2048:].contiguous()), act=ops.ACT_SWIGLU, out_f32=True)
+        lib.ullsam_set_gemm_variant(1)
+        y1 = ops.gemm(a, w, bias=bias, residual=res, out_f32=True)
+        s1 = ops.gemm(a, pack_w13(w[:2048].contiguous(), w[2048:].contiguous()), act=ops.ACT_SWIGLU, out_f32=True)
+    finally:
+        lib.ullsam_set_gemm_variant(0)
+    ref = a.float().cpu().numpy() @ w.float().cpu().numpy().T + bias.cpu().numpy() + res.cpu().numpy()
+    tol = 5e-4 if dtype == torch.float32 else 2e-2
+    assert err(y0.cpu().numpy(), ref) < tol and err(y1.cpu().numpy(), ref) < tol
+    assert err(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-3 and err(s1.cpu().numpy(), s0.cpu().numpy()) < 1e-3

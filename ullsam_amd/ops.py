@@ -40,6 +40,19 @@ def _chk(t: torch.Tensor, name: str, dtype=None):
     return t
 
 
+_WS = {}
+
+
+def _gemm_workspace(device) -> torch.Tensor:
+    """Caller-owned scratch for the GEMM's split-K tail (one 32 MiB buffer per device AND stream: launches on different
+    streams may overlap)."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = _WS[key] = torch.empty(32 << 20, dtype=torch.uint8, device=device)
+    return ws
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          act: int = ACT_NONE, out_f32: bool = False, out: Optional[torch.Tensor] = None, res_row_mod: int = 0) -> torch.Tensor:
     """out[M, N'] = act(a[M,K] @ w[N,K]^T + bias) + residual   (N' = N/2 for ACT_SWIGLU)."""
@@ -60,8 +73,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if residual is not None:
         _chk(residual, "residual", torch.float32)
         ldr = residual.shape[-1]
+    ws = _gemm_workspace(a.device)
     _lib.call("ullsam_gemm", dt_code(a.dtype), a.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), n_out, int(out_f32),
-              _p(bias), _p(residual), ldr, res_row_mod, act, M, N, K, _stream())
+              _p(bias), _p(residual), ldr, res_row_mod, act, M, N, K, ws.data_ptr(), ws.numel(), _stream())
     return out
 
 
