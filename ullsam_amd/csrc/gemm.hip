@@ -30,14 +30,16 @@ struct GemmArgs {
     int vec_ok;   // stores / residual loads may be 16-byte vectors
     int ablate;   // timing-only ablations of the v2 main loop (bit0: no in-loop staging, bit1: no barrier); results are garbage
     int tiles_m, tiles_n;
-    // split-K tail (v1 only): tiles [0, full_tiles) run whole; each of the remaining tiles is cut into ksplit K-ranges whose fp32
-    // partial tiles go to `ws` ([tail][ksplit][128*128]) and are summed + finished by gemm_tail_reduce_kernel
+    // split-K tail (v1 only): tiles [0, full_tiles) run whole; each remaining tile is cut into ksplit K-ranges whose fp32 partial
+    // tiles go to `ws` ([tail][ksplit][128*128]) and are summed + finished by gemm_tail_reduce_kernel
     int full_tiles, ksplit;
     float* ws;
     size_t ws_bytes;
 };
 
-static int g_split_tail = 1;  // ullsam_set_gemm_variant(v | 64) disables the split-K tail (A/B)
+static int g_split_tail = 1;   // ullsam_set_gemm_variant(v | 64) disables the split-K tail (A/B)
+static int g_gemm_variant = 0; // bits 0-3: 0 auto, 1 = 128x128, 2 = 256x128 ring, 3 = 256x256
+static int g_gemm_ablate = 0;  // timing-only ablations / experiments (outputs may be garbage)
 
 template <typename T>
 __device__ __forceinline__ Frag<T> lds_frag(const char* tile, int row, int ks, int g);
@@ -304,6 +306,273 @@ __global__ __launch_bounds__(256) void gemm_tail_reduce_kernel(GemmArgs p) {
         epilogue_rows<T, T, 32, 256>(p, Cs, tm * 128 + slab * 32, tn * 128, tn, tid);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v2: 256x128 tile, 8 waves (4 x 2, each 64x64), 3-stage LDS-DMA ring.  One barrier per K-tile; the DMA of tiles kt+1
+// and kt+2 stays in flight across it (counted s_waitcnt vmcnt, raw s_barrier -- a __syncthreads() would drain vmcnt(0),
+// cdna guide section 5 "Pipelining across barriers").  LDS: 3 x (32 KiB A + 16 KiB B) = 144 KiB, one workgroup per CU.
+// RAW: a wave waits for its own DMA pieces of tile kt, then the barrier => every piece of tile kt has landed before any
+// ds_read of it.  WAR: the stage issued after the barrier of iteration kt overwrites the buffer of tile kt-1, whose
+// fragment reads were consumed by MFMAs (data dependence) before their wave reached this barrier.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512) void gemm256x128_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int BK = 8 * EPC;
+    constexpr int KSTEPS = BK / 32;
+    constexpr int STAGE = 49152;  // 32 KiB A + 16 KiB B
+
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int GM = 4;
+    const int width = GM * p.tiles_n;
+    const int group = swz / width;
+    const int first_m = group * GM;
+    const int gsize = min(p.tiles_m - first_m, GM);
+    const int tm = first_m + (swz % width) % gsize;
+    const int tn = (swz % width) / gsize;
+    const int m0 = tm * 256, n0 = tn * 128;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const char* a_src[4];
+    const char* b_src[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        const int gm = min(m0 + row, p.M - 1);
+        a_src[i] = reinterpret_cast<const char*>(p.A) + (size_t)gm * p.lda * sizeof(T) + (c << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        const int gn = min(n0 + row, p.N - 1);
+        b_src[i] = reinterpret_cast<const char*>(p.W) + (size_t)gn * p.ldw * sizeof(T) + (c << 4);
+    }
+    const int nk = p.K / BK;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int buf, int kt) {
+        const size_t koff = (size_t)kt * 128;
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[i] + koff), LDS_PTR(base + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[i] + koff), LDS_PTR(base + 32768 + (wave * 2 + i) * 1024), 16, 0, 0);
+    };
+
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk && !(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(p.ablate & 2)) __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk && !(p.ablate & 1)) stage(buf == 0 ? 2 : buf - 1, kt + 2);
+        const char* Ab = smem + buf * STAGE;
+        const char* Bb = Ab + 32768;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            Frag<T> a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = lds_frag<T>(Ab, wm * 64 + i * 16 + (lane & 15), ks, lane >> 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), ks, lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(a[i], b[j], acc[i][j]);
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+
+    __syncthreads();
+    float* Cs = reinterpret_cast<float*>(smem);  // [256][128] fp32 = 128 KiB
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+                const int col = wn * 64 + j * 16 + (lane & 15);
+                Cs[row * 128 + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    if (p.out_f32)
+        epilogue_rows<T, float, 256, 512>(p, Cs, m0, n0, tn, tid);
+    else
+        epilogue_rows<T, T, 256, 512>(p, Cs, m0, n0, tn, tid);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// v3: 256x256 tile, 8 waves (2 x 4), 128x64 per wave (8x4 MFMA 16x16 tiles, 128 accumulator registers), two 64 KiB
+// LDS stages, LDS-DMA double buffer with one barrier per K-tile (the v1 loop).  Versus the 64x64 per-wave tile this
+// issues 12 instead of 16 ds_read_b128 per 32 MFMAs and half the LDS-DMA instructions per MFMA, and halves the
+// L2->LDS bytes per FLOP (ablation + PMC in profiles/).  Used for GEMMs whose 256x256 tile count fills the chip's
+// 256 CUs for several rounds; the epilogue is staged through LDS in two 128-row halves.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int EXP>  // EXP: 0 = production; 1 = experiment (A fragments first, one prioritised MFMA cluster)
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int BK = 8 * EPC;
+    constexpr int KSTEPS = BK / 32;
+    constexpr int STAGE = 65536;  // 32 KiB A + 32 KiB B
+
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int GM = 4;
+    const int width = GM * p.tiles_n;
+    const int group = swz / width;
+    const int first_m = group * GM;
+    const int gsize = min(p.tiles_m - first_m, GM);
+    const int tm = first_m + (swz % width) % gsize;
+    const int tn = (swz % width) / gsize;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const char* a_src[4];
+    const char* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        const int gm = min(m0 + row, p.M - 1);
+        const int gn = min(n0 + row, p.N - 1);
+        a_src[i] = reinterpret_cast<const char*>(p.A) + (size_t)gm * p.lda * sizeof(T) + (c << 4);
+        b_src[i] = reinterpret_cast<const char*>(p.W) + (size_t)gn * p.ldw * sizeof(T) + (c << 4);
+    }
+    const int nk = p.K / BK;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int buf, int kt) {
+        const size_t koff = (size_t)kt * 128;
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[i] + koff), LDS_PTR(base + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[i] + koff), LDS_PTR(base + 32768 + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
+    };
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (!(p.ablate & 2)) __syncthreads();  // tile kt landed (vmcnt(0) + barrier); every wave is done reading buffer (kt+1)&1
+        if (kt + 1 < nk && !(p.ablate & 1)) stage((kt + 1) & 1, kt + 1);
+        const char* Ab = smem + (kt & 1) * STAGE;
+        const char* Bb = Ab + 32768;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            Frag<T> b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), ks, lane >> 4);
+            if (EXP == 1) {  // experiment: all 8 A fragments first, then one prioritised MFMA cluster
+                Frag<T> a8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + (lane & 15), ks, lane >> 4);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma16(a8[i], b[j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const Frag<T> a = lds_frag<T>(Ab, wm * 128 + i * 16 + (lane & 15), ks, lane >> 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma16(a, b[j], acc[i][j]);
+                }
+            }
+        }
+    }
+
+    float* Cs = reinterpret_cast<float*>(smem);  // [128][256] fp32 = 128 KiB, one 128-row half at a time
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = i * 16 + 4 * (lane >> 4) + r;
+                        const int col = wn * 64 + j * 16 + (lane & 15);
+                        Cs[row * 256 + col] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        if (p.out_f32)
+            epilogue_rows<T, float, 128, 512, 256>(p, Cs, m0 + half * 128, n0, tn, tid);
+        else
+            epilogue_rows<T, T, 128, 512, 256>(p, Cs, m0 + half * 128, n0, tn, tid);
+    }
+}
+
+template <typename T, int EXP>
+static int launch_gemm_v3_impl(GemmArgs a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<T, EXP>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        attr_set = true;
+    }
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (a.N + 255) / 256;
+    gemm256_kernel<T, EXP><<<dim3(a.tiles_m * a.tiles_n), dim3(512), 131072, stream>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+template <typename T>
+static int launch_gemm_v3(GemmArgs a, hipStream_t stream) {
+    if (a.ablate & 4) return launch_gemm_v3_impl<T, 1>(a, stream);
+    return launch_gemm_v3_impl<T, 0>(a, stream);
+}
+
+// v: bits 0-3 kernel (0 auto), +64 no split-K tail, bits 8-10 timing-only ablations / experiments
+extern "C" int ullsam_set_gemm_variant(int v) { g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_gemm_ablate = (v >> 8) & 7; return 0; }
+
+template <typename T>
+static int launch_gemm_v2(GemmArgs a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+        attr_set = true;
+    }
+    a.tiles_m = (a.M + 255) / 256;
+    gemm256x128_kernel<T><<<dim3(a.tiles_m * a.tiles_n), dim3(512), 147456, stream>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename T>
 static int launch_gemm(GemmArgs a, hipStream_t stream) {
     static bool attr_set = false;
@@ -311,16 +580,16 @@ static int launch_gemm(GemmArgs a, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_set = true;
     }
-    // Split-K tail: with 2 workgroups per CU the chip runs 512 tiles per wave; when the last wave is at most half full, cut
-    // each of its tiles into S K-ranges so the tail costs ~1/S of a wave instead of a whole one (plus a small reduce kernel).
+    // Split-K tail: with 2 workgroups per CU the chip runs 512 tiles per wave; when the last wave is at most half full, cut each
+    // of its tiles into S K-ranges (fp32 partials + a reduce kernel).  Measured (tools/gemm_bench.py, variant 65 vs 1): pays only
+    // when the K loop is long (w2, K=14336: -9 %); at K <= 5120 the reduce pass costs more than the partly empty wave it removes,
+    // because real launches do not run in lock-step waves.
     const int T_ = a.tiles_m * a.tiles_n;
     const int C_ = 512;
     a.full_tiles = T_;
     a.ksplit = 1;
     const int nk = a.K / (128 / (int)sizeof(T));
     const int tail = T_ % C_;
-    // measured (tools/gemm_bench.py, variant 65 vs 1): pays only when the K loop is long (w2: -9 %); at K <= 5120 the reduce
-    // pass costs more than the partly empty wave it removes, because real launches do not run in lock-step waves
     if (g_split_tail && a.ws && T_ > C_ && tail > 0 && tail <= C_ / 2 && nk >= 128) {
         int S = C_ / tail;
         if (S > 16) S = 16;
@@ -362,7 +631,7 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     bool vec = ((uintptr_t)C & 15) == 0 && (ldc * osz) % 16 == 0 && (n_out % 8 == 0);
     if (residual) vec = vec && ((uintptr_t)residual & 15) == 0 && (ldr % 4 == 0);
     a.vec_ok = vec ? 1 : 0;
-    a.ablate = (g_gemm_variant >> 4) & 3;
+    a.ablate = g_gemm_ablate;
     a.ws = reinterpret_cast<float*>(workspace);
     a.ws_bytes = workspace ? (size_t)ws_bytes : 0;
     a.ksplit = 1;
@@ -370,7 +639,7 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     a.tiles_n = (N + 127) / 128;
     a.full_tiles = a.tiles_m * a.tiles_n;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int variant = g_gemm_variant & 15;
+    const int variant = g_gemm_variant;
     // measured end to end (profiles/): the 256x128 3-stage kernel wins on the very wide SwiGLU GEMM, the 128x128 kernel elsewhere
     const bool v2 = variant == 2 || (variant == 0 && M > 512 && N >= 16384);
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
