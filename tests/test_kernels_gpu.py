@@ -265,3 +265,25 @@ def test_gemm_split_k_tail_matches_unsplit(ops, dtype):
     tol = 5e-4 if dtype == torch.float32 else 2e-2
     assert err(y0.cpu().numpy(), ref) < tol and err(y1.cpu().numpy(), ref) < tol
     assert err(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-3 and err(s1.cpu().numpy(), s0.cpu().numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("code", [3 + (1 << 12), 3 + (2 << 12)])
+def test_gemm_v3_schedule_variants(ops, code):
+    """The 256x256 kernel's alternative main-loop schedules (plain interleave; fragments-first with one barrier per K-tile) must
+    give the production (staggered two-group) schedule's result bit for bit; repeated to expose LDS hand-off races."""
+    from ullsam_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    M, N, K = 1500, 1024, 1536
+    a = T(rng.standard_normal((M, K), dtype=np.float32), torch.bfloat16)
+    w = T((rng.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)).astype(np.float32), torch.bfloat16)
+    try:
+        lib.ullsam_set_gemm_variant(3)
+        ref = ops.gemm(a, w, out_f32=True)
+        lib.ullsam_set_gemm_variant(code)
+        for _ in range(20):
+            y = ops.gemm(a, w, out_f32=True)
+            assert torch.equal(y, ref)
+    finally:
+        lib.ullsam_set_gemm_variant(0)
+    assert err(ref.cpu().numpy(), a.float().cpu().numpy() @ w.float().cpu().numpy().T) < 2e-2

@@ -39,7 +39,8 @@ struct GemmArgs {
 
 static int g_split_tail = 1;   // ullsam_set_gemm_variant(v | 64) disables the split-K tail (A/B)
 static int g_gemm_variant = 0; // bits 0-3: 0 auto, 1 = 128x128, 2 = 256x128 ring, 3 = 256x256
-static int g_gemm_ablate = 0;  // timing-only ablations / experiments (outputs may be garbage)
+static int g_gemm_ablate = 0;  // timing-only ablations: bit0 no in-loop staging, bit1 no barrier (outputs are garbage)
+static int g_gemm_sched = 0;   // 256x256 kernel main-loop schedule: 0 production, 1 plain interleave, 2 fragments-first / 1 barrier
 
 template <typename T>
 __device__ __forceinline__ Frag<T> lds_frag(const char* tile, int row, int ks, int g);
@@ -482,36 +483,93 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         }
     };
 
+    if constexpr (EXP == 2 && KSTEPS == 2) {
+        // Staggered two-group schedule.  Per K-tile every wave runs four segments  L0 | C0 | L1 | C1  separated by s_barrier:
+        //   L0: issue the LDS-DMA of tile kt+1 (8 x 1 KiB) + ds_read the k-step-0 fragments     C0: 32 MFMAs
+        //   L1: ds_read the k-step-1 fragments, then wait for this wave's DMA (vmcnt(0))         C1: 32 MFMAs
+        // Waves 4-7 run one segment behind waves 0-3 (one extra barrier up front, balanced at the end), so on every SIMD one wave is
+        // in a load segment while its partner is in a matrix segment.
+        //   RAW: a wave's DMA of tile kt+1 is issued in its L0 and waited for in its L1 (slots 4kt+2 / 4kt+3); the first read of
+        //        tile kt+1 is at slot 4kt+4, behind the barrier that ends slot 4kt+3.
+        //   WAR: buffer (kt+1)&1 was last read (tile kt-1, k-step 1) at slots 4kt-2 / 4kt-1; the DMA into it starts at slot 4kt.
+        const int grp = wave >> 2;
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* Ab = smem + (kt & 1) * STAGE;
+            const char* Bb = Ab + 32768;
+            Frag<T> a8[8], b[4];
+            // ---- L0
+            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), 0, lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + (lane & 15), 0, lane >> 4);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- C0
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(a8[i], b[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- L1
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), 1, lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + (lane & 15), 1, lane >> 4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- C1
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(a8[i], b[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+    } else {
     stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        if (!(p.ablate & 2)) __syncthreads();  // tile kt landed (vmcnt(0) + barrier); every wave is done reading buffer (kt+1)&1
-        if (kt + 1 < nk && !(p.ablate & 1)) stage((kt + 1) & 1, kt + 1);
-        const char* Ab = smem + (kt & 1) * STAGE;
-        const char* Bb = Ab + 32768;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (!(p.ablate & 2)) __syncthreads();  // tile kt landed (vmcnt(0) + barrier); every wave is done reading buffer (kt+1)&1
+            if (kt + 1 < nk && !(p.ablate & 1)) stage((kt + 1) & 1, kt + 1);
+            const char* Ab = smem + (kt & 1) * STAGE;
+            const char* Bb = Ab + 32768;
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            Frag<T> b[4];
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                Frag<T> b[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), ks, lane >> 4);
-            if (EXP == 1) {  // experiment: all 8 A fragments first, then one prioritised MFMA cluster
-                Frag<T> a8[8];
+                for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), ks, lane >> 4);
+                if (EXP == 1) {  // experiment: all 8 A fragments first, then one prioritised MFMA cluster
+                    Frag<T> a8[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + (lane & 15), ks, lane >> 4);
-                __builtin_amdgcn_s_setprio(1);
+                    for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + (lane & 15), ks, lane >> 4);
+                    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                    for (int i = 0; i < 8; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) mma16(a8[i], b[j], acc[i][j]);
-                __builtin_amdgcn_s_setprio(0);
-            } else {
+                        for (int j = 0; j < 4; ++j) mma16(a8[i], b[j], acc[i][j]);
+                    __builtin_amdgcn_s_setprio(0);
+                } else {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const Frag<T> a = lds_frag<T>(Ab, wm * 128 + i * 16 + (lane & 15), ks, lane >> 4);
+                    for (int i = 0; i < 8; ++i) {
+                        const Frag<T> a = lds_frag<T>(Ab, wm * 128 + i * 16 + (lane & 15), ks, lane >> 4);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) mma16(a, b[j], acc[i][j]);
+                        for (int j = 0; j < 4; ++j) mma16(a, b[j], acc[i][j]);
+                    }
                 }
             }
         }
+
     }
 
     float* Cs = reinterpret_cast<float*>(smem);  // [128][256] fp32 = 128 KiB, one 128-row half at a time
@@ -553,12 +611,19 @@ static int launch_gemm_v3_impl(GemmArgs a, hipStream_t stream) {
 }
 template <typename T>
 static int launch_gemm_v3(GemmArgs a, hipStream_t stream) {
-    if (a.ablate & 4) return launch_gemm_v3_impl<T, 1>(a, stream);
-    return launch_gemm_v3_impl<T, 0>(a, stream);
+    // schedules (tools/gemm_bench.py codes 3 / 3+(4<<8) / 3+(6<<8)): the staggered two-group schedule measured +10..15 % on the
+    // K=4096 shapes and neutral at K=1280 against both others, bit-identical results
+    if (g_gemm_sched == 2) return launch_gemm_v3_impl<T, 1>(a, stream);  // fragments first + prioritised MFMA cluster, 1 barrier / K-tile
+    if (g_gemm_sched == 1) return launch_gemm_v3_impl<T, 0>(a, stream);  // plain interleaved loop
+    if (sizeof(T) == 2) return launch_gemm_v3_impl<T, 2>(a, stream);        // production (bf16): staggered two-group schedule
+    return launch_gemm_v3_impl<T, 1>(a, stream);                            // fp32 has one k-step per K-tile: no second segment pair
 }
 
-// v: bits 0-3 kernel (0 auto), +64 no split-K tail, bits 8-10 timing-only ablations / experiments
-extern "C" int ullsam_set_gemm_variant(int v) { g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_gemm_ablate = (v >> 8) & 7; return 0; }
+// v: bits 0-3 kernel (0 auto), +64 no split-K tail, bits 8-9 timing-only ablations, bits 12-13 schedule of the 256x256 kernel
+extern "C" int ullsam_set_gemm_variant(int v) {
+    g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_gemm_ablate = (v >> 8) & 3; g_gemm_sched = (v >> 12) & 3;
+    return 0;
+}
 
 template <typename T>
 static int launch_gemm_v2(GemmArgs a, hipStream_t stream) {
@@ -643,7 +708,10 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     // measured end to end (profiles/): the 256x128 3-stage kernel wins on the very wide SwiGLU GEMM, the 128x128 kernel elsewhere
     const bool v2 = variant == 2 || (variant == 0 && M > 512 && N >= 16384);
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-    const bool v3 = variant == 3 || (variant == 0 && t256 >= 768 && (act != 3 || N % 256 == 0));
+    // 256x256 tiles run one per CU: use them when the last wave of tiles is >= 74 % full (measured crossover, tools/gemm_bench.py:
+    // 408 / 960 / 1280 / 1904 tiles win, 272 / 320 lose to the 128x128 kernel's finer granularity)
+    const double fill = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+    const bool v3 = variant == 3 || (variant == 0 && M >= 1024 && fill >= 0.74 && (act != 3 || N % 256 == 0));
     if (act == 3 && (variant == 3) && N % 256 != 0) { ullsam_set_error("ullsam_gemm: v3 swiglu needs N%%256==0"); return -1; }
     if (v3) return dtype == ULLSAM_DT_F32 ? launch_gemm_v3<float>(a, s) : launch_gemm_v3<bf16>(a, s);
     if (v2) return dtype == ULLSAM_DT_F32 ? launch_gemm_v2<float>(a, s) : launch_gemm_v2<bf16>(a, s);
