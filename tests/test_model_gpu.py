@@ -244,3 +244,46 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libullsam_hip.so")
     with pytest.raises(_lib.UllsamError):
         _lib.load()
+
+
+def test_batched_greedy_generate_matches_single_and_oracle():
+    """generate() at B=2 with left padding == each sample alone (KV cache + cumsum position ids, modeling_internlm2.py:1112-1149);
+    the unpadded sample is also checked against the numpy oracle's greedy loop."""
+    g = U.gold("llm_tiny")
+    lm = _tiny_llm(torch.float32)
+    emb = torch.from_numpy(g["emb"][:, :40].copy()).to(DEV)
+    mask = torch.ones((2, 40), dtype=torch.long, device=DEV)
+    mask[1, :7] = 0
+    both = lm.generate(inputs_embeds=emb, attention_mask=mask, max_new_tokens=6, eos_token_id=-1)
+    for b in range(2):
+        one = lm.generate(inputs_embeds=emb[b:b + 1], attention_mask=mask[b:b + 1], max_new_tokens=6, eos_token_id=-1)
+        assert both[b].tolist() == one[0].tolist()
+    P = U.llm_params(U.LLM_TINY, 0)
+    ref = O.greedy_generate(P, U.LLM_TINY, g["emb"][:1, :40], None, 6, eos_token_id=-1)
+    assert both[0].cpu().tolist() == ref.tolist()
+    # input_ids path returns prompt + new tokens (HF semantics) and stops at eos
+    ids = torch.tensor([[1, 5, 9, 100, 7]], device=DEV)
+    out = lm.generate(input_ids=ids, max_new_tokens=4, eos_token_id=-1)
+    assert out.shape == (1, 9) and out[0, :5].tolist() == ids[0].tolist()
+    first = int(out[0, 5])
+    stop = lm.generate(input_ids=ids, max_new_tokens=4, eos_token_id=first)
+    assert stop.shape == (1, 6)
+
+
+def test_sampling_respects_top_k():
+    lm = _tiny_llm(torch.float32)
+    ids = torch.tensor([[1, 5, 9, 100, 7]], device=DEV)
+    torch.manual_seed(0)
+    greedy = lm.generate(input_ids=ids, max_new_tokens=3, eos_token_id=-1)
+    sampled = lm.generate(input_ids=ids, max_new_tokens=3, eos_token_id=-1, do_sample=True, top_k=1, temperature=0.7, top_p=0.9)
+    assert sampled.tolist() == greedy.tolist()  # top_k=1 sampling degenerates to greedy
+
+
+def test_mask_iou_op_matches_calc_iou():
+    from ullsam_amd import ops
+    rng = np.random.default_rng(0)
+    a = (rng.random((3, 1, 256, 256)) > 0.5)
+    b = (rng.random((3, 1, 256, 256)) > 0.3)
+    got = ops.mask_iou(torch.from_numpy(a.astype(np.uint8)).to(DEV), torch.from_numpy(b.astype(np.uint8)).to(DEV)).cpu().numpy()
+    for i in range(3):
+        assert abs(got[i] - O.calc_iou(a[i], b[i])) < 1e-9
