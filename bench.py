@@ -96,6 +96,7 @@ class GemmTimer:
     def __init__(self):
         from ullsam_amd import ops
         self.ops, self.orig, self.rec, self.on = ops, ops.gemm, [], False
+        self.alg_bytes = 0  # operand + result bytes of every timed launch (each read / written once)
 
         def timed(a, w, *args, **kw):
             if not self.on:
@@ -105,6 +106,7 @@ class GemmTimer:
             out = self.orig(a, w, *args, **kw)
             e1.record()
             self.rec.append((e0, e1, 2.0 * a.shape[0] * w.shape[0] * a.shape[1]))
+            self.alg_bytes += a.numel() * a.element_size() + w.numel() * w.element_size() + out.numel() * out.element_size()
             return out
 
         ops.gemm = timed
@@ -284,6 +286,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_launch, gemm_ms, gemm_flops = timer.summary()
+    traffic = None  # HBM-side bytes per GEMM launch: PMC counters cannot be read in-process; taken from the committed rocprofv3 passes
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_bench_traffic.json")
+    if os.path.exists(tpath) and a.vit == "h" and a.llm == "7b" and a.batch == 4 and a.dtype == "bf16":
+        traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
     images = a.batch * world * a.steps
     value = images / dt
     ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -296,9 +302,11 @@ def main():
                                 + f"prompt encoder + mask decoder + x4 upsample/threshold, 1 point prompt/image, batch {a.batch}/GPU"),
                    "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": a.seq if LLM[a.llm] else 0,
                    "parallelism": f"dp{world} (images sharded, weights replicated, RCCL all-gather of masks)"},
-        "roofline": {"bound": "mfma", "kernel": "gemm128_kernel (all nn.Linear / conv-as-GEMM launches)", "achieved": round(ach, 2),
+        "roofline": {"bound": "mfma", "kernel": "ullsam_gemm: gemm256_kernel / gemm128_kernel (every nn.Linear / conv-as-GEMM launch)", "achieved": round(ach, 2),
                      "peak": PEAK_BF16_TFLOPS if a.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
-                     "frac": round(ach / (PEAK_BF16_TFLOPS if a.dtype == "bf16" else 157.3), 4), "traffic": None,
+                     "frac": round(ach / (PEAK_BF16_TFLOPS if a.dtype == "bf16" else 157.3), 4), "traffic": traffic,
+                     "traffic_unit": "HBM-side bytes per GEMM launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_bench_traffic.json)",
+                     "algorithmic_bytes_per_launch": round(timer.alg_bytes / max(n_launch, 1)),
                      "launches_per_step": n_launch // max(a.steps, 1), "avg_launch_us": round(gemm_ms * 1e3 / max(n_launch, 1), 2),
                      "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4)},
     }

@@ -287,3 +287,31 @@ def test_gemm_v3_schedule_variants(ops, code):
     finally:
         lib.ullsam_set_gemm_variant(0)
     assert err(ref.cpu().numpy(), a.float().cpu().numpy() @ w.float().cpu().numpy().T) < 2e-2
+
+
+def test_gemm256_split_k_tail_matches_unsplit(ops):
+    """272 tiles of 256x256 on 256 CUs: the 16 tail tiles are cut into 8 K-ranges.  Equal to the unsplit launch (accumulation-order
+    noise) with residual and SwiGLU epilogues; sampled rows also against numpy."""
+    from ullsam_amd import _lib
+    from ullsam_amd.packing import pack_w13
+    lib = _lib.load()
+    rng = np.random.default_rng(12)
+    M, N, K = 4324, 4096, 4096
+    a = T(rng.standard_normal((M, K), dtype=np.float32), torch.bfloat16)
+    w = T((rng.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)).astype(np.float32), torch.bfloat16)
+    res = T(rng.standard_normal((M, N), dtype=np.float32))
+    w13 = pack_w13(w[:2048].contiguous(), w[2048:].contiguous())
+    try:
+        lib.ullsam_set_gemm_variant(3 | 64)
+        y0 = ops.gemm(a, w, residual=res, out_f32=True)
+        s0 = ops.gemm(a, w13, act=ops.ACT_SWIGLU, out_f32=True)
+        lib.ullsam_set_gemm_variant(3)
+        for _ in range(5):
+            y1 = ops.gemm(a, w, residual=res, out_f32=True)
+            s1 = ops.gemm(a, w13, act=ops.ACT_SWIGLU, out_f32=True)
+            assert err(y1.cpu().numpy(), y0.cpu().numpy()) < 2e-3 and err(s1.cpu().numpy(), s0.cpu().numpy()) < 2e-3
+    finally:
+        lib.ullsam_set_gemm_variant(0)
+    rows = np.r_[0:32, 4200:4324]
+    ref = a.float().cpu().numpy()[rows] @ w.float().cpu().numpy().T + res.cpu().numpy()[rows]
+    assert err(y1.cpu().numpy()[rows], ref) < 2e-2

@@ -436,10 +436,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     constexpr int KSTEPS = BK / 32;
     constexpr int STAGE = 65536;  // 32 KiB A + 32 KiB B
 
-    const int nblk = p.tiles_m * p.tiles_n;
+    const int nblk = p.full_tiles;  // == tiles_m * tiles_n when the launch has no split-K tail
     const int bid = blockIdx.x;
-    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    int swz, part = -1, tail_idx = 0;
+    if (bid < nblk) {
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+        swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    } else {  // tail tile, one K-range of it (fp32 partial -> workspace, finished by gemm256_tail_reduce_kernel)
+        const int t = bid - nblk;
+        tail_idx = t / p.ksplit;
+        part = t - tail_idx * p.ksplit;
+        swz = nblk + tail_idx;
+    }
     const int GM = 4;
     const int width = GM * p.tiles_n;
     const int group = swz / width;
@@ -465,7 +473,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         a_src[i] = reinterpret_cast<const char*>(p.A) + (size_t)gm * p.lda * sizeof(T) + (c << 4);
         b_src[i] = reinterpret_cast<const char*>(p.W) + (size_t)gn * p.ldw * sizeof(T) + (c << 4);
     }
-    const int nk = p.K / BK;
+    const int nk_all = p.K / BK;
+    const int kt0 = part < 0 ? 0 : (int)((long)part * nk_all / p.ksplit);
+    const int nk = part < 0 ? nk_all : (int)((long)(part + 1) * nk_all / p.ksplit);  // this block's K-tile range is [kt0, nk)
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -493,11 +503,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         //        tile kt+1 is at slot 4kt+4, behind the barrier that ends slot 4kt+3.
         //   WAR: buffer (kt+1)&1 was last read (tile kt-1, k-step 1) at slots 4kt-2 / 4kt-1; the DMA into it starts at slot 4kt.
         const int grp = wave >> 2;
-        stage(0, 0);
+        stage(kt0 & 1, kt0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (grp == 1) __builtin_amdgcn_s_barrier();
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = kt0; kt < nk; ++kt) {
             const char* Ab = smem + (kt & 1) * STAGE;
             const char* Bb = Ab + 32768;
             Frag<T> a8[8], b[4];
@@ -538,8 +548,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();
     } else {
-    stage(0, 0);
-        for (int kt = 0; kt < nk; ++kt) {
+        stage(kt0 & 1, kt0);
+        for (int kt = kt0; kt < nk; ++kt) {
             if (!(p.ablate & 2)) __syncthreads();  // tile kt landed (vmcnt(0) + barrier); every wave is done reading buffer (kt+1)&1
             if (kt + 1 < nk && !(p.ablate & 1)) stage((kt + 1) & 1, kt + 1);
             const char* Ab = smem + (kt & 1) * STAGE;
@@ -589,12 +599,50 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                     }
         }
         __syncthreads();
-        if (p.out_f32)
+        if (part >= 0) {  // raw fp32 partial half-tile -> workspace
+            float4* dst = reinterpret_cast<float4*>(p.ws + ((size_t)tail_idx * p.ksplit + part) * 65536 + half * 32768);
+            const float4* src = reinterpret_cast<const float4*>(Cs);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[i * 512 + tid] = src[i * 512 + tid];
+        } else if (p.out_f32) {
             epilogue_rows<T, float, 128, 512, 256>(p, Cs, m0 + half * 128, n0, tn, tid);
-        else
+        } else {
             epilogue_rows<T, T, 128, 512, 256>(p, Cs, m0 + half * 128, n0, tn, tid);
+        }
     }
 }
+
+// Sum the ksplit fp32 partials of a 16-row slab of one 256x256 tail tile and run the normal epilogue on it.
+template <typename T>
+__global__ __launch_bounds__(256) void gemm256_tail_reduce_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float Cs[16 * 256];
+    const int tid = threadIdx.x;
+    const int tail_idx = blockIdx.x >> 4, slab = blockIdx.x & 15;
+    const int swz = p.full_tiles + tail_idx;
+    const int GM = 4;
+    const int width = GM * p.tiles_n;
+    const int group = swz / width;
+    const int first_m = group * GM;
+    const int gsize = min(p.tiles_m - first_m, GM);
+    const int tm = first_m + (swz % width) % gsize;
+    const int tn = (swz % width) / gsize;
+    const float4* src = reinterpret_cast<const float4*>(p.ws + (size_t)tail_idx * p.ksplit * 65536 + slab * 4096);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float4 a = src[i * 256 + tid];
+        for (int s = 1; s < p.ksplit; ++s) {
+            const float4 b = src[(size_t)s * 16384 + i * 256 + tid];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4*>(Cs)[i * 256 + tid] = a;
+    }
+    __syncthreads();
+    if (p.out_f32)
+        epilogue_rows<T, float, 16, 256, 256>(p, Cs, tm * 256 + slab * 16, tn * 256, tn, tid);
+    else
+        epilogue_rows<T, T, 16, 256, 256>(p, Cs, tm * 256 + slab * 16, tn * 256, tn, tid);
+}
+
 
 template <typename T, int EXP>
 static int launch_gemm_v3_impl(GemmArgs a, hipStream_t stream) {
@@ -605,8 +653,27 @@ static int launch_gemm_v3_impl(GemmArgs a, hipStream_t stream) {
     }
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (a.N + 255) / 256;
-    gemm256_kernel<T, EXP><<<dim3(a.tiles_m * a.tiles_n), dim3(512), 131072, stream>>>(a);
+    // split-K tail (one 256x256 tile per CU => 256 tiles per wave): a sliver of <= 64 tiles behind >= 1 full wave is cut along K
+    const int T_ = a.tiles_m * a.tiles_n;
+    const int nk = a.K / (128 / (int)sizeof(T));
+    const int tail = T_ % 256;
+    a.full_tiles = T_;
+    a.ksplit = 1;
+    if (g_split_tail && a.ws && T_ > 256 && tail > 0 && tail <= 64 && nk >= 64) {
+        int S = 256 / tail;
+        if (S > 8) S = 8;
+        if (S > nk / 8) S = nk / 8;
+        if (S >= 2 && (size_t)tail * S * 262144 <= a.ws_bytes) {
+            a.full_tiles = T_ - tail;
+            a.ksplit = S;
+        }
+    }
+    gemm256_kernel<T, EXP><<<dim3(a.full_tiles + (T_ - a.full_tiles) * a.ksplit), dim3(512), 131072, stream>>>(a);
     ULLSAM_LAUNCH_CHECK();
+    if (a.ksplit > 1) {
+        gemm256_tail_reduce_kernel<T><<<dim3((T_ - a.full_tiles) * 16), dim3(256), 0, stream>>>(a);
+        ULLSAM_LAUNCH_CHECK();
+    }
     return 0;
 }
 template <typename T>
@@ -711,7 +778,9 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     // 256x256 tiles run one per CU: use them when the last wave of tiles is >= 74 % full (measured crossover, tools/gemm_bench.py:
     // 408 / 960 / 1280 / 1904 tiles win, 272 / 320 lose to the 128x128 kernel's finer granularity)
     const double fill = (double)t256 / (double)(((t256 + 255) / 256) * 256);
-    const bool v3 = variant == 3 || (variant == 0 && M >= 1024 && fill >= 0.74 && (act != 3 || N % 256 == 0));
+    const long tail256 = t256 % 256;
+    const bool v3_split = g_split_tail && workspace && t256 > 256 && tail256 > 0 && tail256 <= 64 && K >= 64 * bk;  // see launch_gemm_v3_impl
+    const bool v3 = variant == 3 || (variant == 0 && M >= 1024 && (fill >= 0.74 || v3_split) && (act != 3 || N % 256 == 0));
     if (act == 3 && (variant == 3) && N % 256 != 0) { ullsam_set_error("ullsam_gemm: v3 swiglu needs N%%256==0"); return -1; }
     if (v3) return dtype == ULLSAM_DT_F32 ? launch_gemm_v3<float>(a, s) : launch_gemm_v3<bf16>(a, s);
     if (v2) return dtype == ULLSAM_DT_F32 ? launch_gemm_v2<float>(a, s) : launch_gemm_v2<bf16>(a, s);

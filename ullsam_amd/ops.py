@@ -44,12 +44,12 @@ _WS = {}
 
 
 def _gemm_workspace(device) -> torch.Tensor:
-    """Caller-owned scratch for the GEMM's split-K tail (one 32 MiB buffer per device AND stream: launches on different
+    """Caller-owned scratch for the GEMM's split-K tail (one 64 MiB buffer per device AND stream: launches on different
     streams may overlap)."""
     key = (str(device), torch.cuda.current_stream().cuda_stream)
     ws = _WS.get(key)
     if ws is None:
-        ws = _WS[key] = torch.empty(32 << 20, dtype=torch.uint8, device=device)
+        ws = _WS[key] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
     return ws
 
 
