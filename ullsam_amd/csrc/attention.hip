@@ -42,9 +42,9 @@ struct AttnArgs {
     const void* bias_q; const void* bias_k; const void* bias_v;  // T [H*HD] slices of qkv.bias for pad tokens
 };
 
-template <typename T, int HD> struct KVTile {
+template <typename T, int HD, int TR = 64> struct KVTile {
     static constexpr int RS = HD * (int)sizeof(T) + 16;  // padded row stride in bytes (conflict-free b128 reads)
-    static constexpr int ROWS = 64;
+    static constexpr int ROWS = TR;                      // keys per staged tile: 64, or 128 for the windowed mode (196 keys = 2 tiles)
     static constexpr int BYTES = RS * ROWS;
     static constexpr int CPR = HD * (int)sizeof(T) / 16;  // 16-byte chunks per row
 };
@@ -97,11 +97,12 @@ __device__ __forceinline__ Frag<float> pack_p(const f32x16& s, int half, const f
 // registers per lane; only rel_h stays in LDS (8 KiB per wave -> two workgroups per CU).
 template <typename T, int HD, int MODE, int NWAVES, bool FAST64>
 __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) {  // >= 2 waves per SIMD: at most 256 VGPR+AGPR
-    using KT = KVTile<T, HD>;
+    constexpr int TR = (MODE == MODE_VIT_WINDOW) ? 128 : 64;  // keys per staged K/V tile
+    using KT = KVTile<T, HD, TR>;
     constexpr int RS = KT::RS;
     constexpr int NT = NWAVES * 64;
     constexpr int CPR = KT::CPR;
-    constexpr int NCH = (64 * CPR + NT - 1) / NT;  // 16-byte chunks per thread per K (or V) tile
+    constexpr int NCH = (TR * CPR + NT - 1) / NT;  // 16-byte chunks per thread per K (or V) tile
     constexpr int KSTEPS = HD / 16;
     constexpr int DT = (HD + 31) / 32;
     constexpr bool REL = (MODE == MODE_VIT_GLOBAL || MODE == MODE_VIT_WINDOW);
@@ -199,9 +200,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
             const int row = idx / CPR, ch = idx - row * CPR;
             kreg[c] = make_uint4(0, 0, 0, 0);
             vreg[c] = make_uint4(0, 0, 0, 0);
-            if (row < 64) {
+            if (row < TR) {
                 const T* kp; const T* vp;
-                if (kv_row_src(tile * 64 + row, kp, vp)) {
+                if (kv_row_src(tile * TR + row, kp, vp)) {
                     kreg[c] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(kp) + ch * 16);
                     vreg[c] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(vp) + ch * 16);
                 }
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
         for (int c = 0; c < NCH; ++c) {
             const int idx = c * NT + tid;
             const int row = idx / CPR, ch = idx - row * CPR;
-            if (row < 64) {
+            if (row < TR) {
                 *reinterpret_cast<uint4*>(Ks + row * RS + ch * 16) = kreg[c];
                 *reinterpret_cast<uint4*>(Vs + row * RS + ch * 16) = vreg[c];
             }
@@ -229,7 +230,44 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
     float rw[2][16];                                              // FAST64: rel_w * log2(e) for key columns 32*par + crow32(r, h)
 #pragma unroll
     for (int i = 0; i < 32; ++i) rw[i >> 4][i & 15] = 0.f;
-    if (REL) {
+    load_tile(0);  // K/V tile 0 -> registers now: its global latency hides behind the rel-pos table phase
+    if (MODE == MODE_VIT_WINDOW) {
+        // both tables (2*(2G-1) <= 54 rows) in ONE staging pass: rows [0,NE) = rel_h, [NE,2NE) = rel_w, rest zero
+        const int NE = 2 * G - 1;
+        const T* th = reinterpret_cast<const T*>(p.rel_h);
+        const T* tw = reinterpret_cast<const T*>(p.rel_w);
+        for (int idx = tid; idx < 64 * CPR; idx += NT) {
+            const int row = idx / CPR, ch = idx - row * CPR;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < NE) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(th + (long)row * HD) + ch * 16);
+            else if (row < 2 * NE) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(tw + (long)(row - NE) * HD) + ch * 16);
+            *reinterpret_cast<uint4*>(Ks + row * RS + ch * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const Frag<T> a = load_frag(reinterpret_cast<const T*>(Ks + (32 * t + ql) * RS) + 16 * ks + 8 * h);
+                mma32(a, qf[ks], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int e = 32 * t + crow32(r, h);
+                if (e < NE) {
+                    const int kk = qh + (G - 1) - e;  // rel index e = q - k + (G-1)  (get_rel_pos, image_encoder.py:318-322)
+                    if (kk >= 0 && kk < GHk) relh[kk * 32 + ql] = acc[r];
+                } else if (e < 2 * NE) {
+                    const int kk = qw + (G - 1) - (e - NE);
+                    if (kk >= 0 && kk < G) relw[kk * 32 + ql] = acc[r];
+                }
+            }
+        }
+        __syncthreads();
+    } else     if (REL) {
         const int NE = 2 * G - 1;  // rows per table (<= 127)
         const T* tabs[2] = {reinterpret_cast<const T*>(p.rel_h), reinterpret_cast<const T*>(p.rel_w)};
 #pragma unroll 1
@@ -284,15 +322,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
     const float scale2 = p.scale * LOG2E;
     const int q_pos = p.q_pos0 + qi;
 
-    int ntiles = (Sk + 63) / 64;
+    int ntiles = (Sk + TR - 1) / TR;
     if (MODE == MODE_CAUSAL) {
         const int last_q = p.q_pos0 + min(p.Sq, (int)(blockIdx.x + 1) * NWAVES * 32) - 1;
         ntiles = min(ntiles, last_q / 64 + 1);
     }
     const float FMIN = -3.4028234663852886e38f;  // torch.finfo(float32).min
 
-    load_tile(0);
-    store_tile();
+    store_tile();  // tile 0 was fetched before the table phase
     __syncthreads();
 #pragma unroll 1
     for (int tile = 0; tile < ntiles; ++tile) {
@@ -300,8 +337,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
         const bool tile_pad = (MODE == MODE_CAUSAL && kmask_g) ? (__any(kms[lane] == 0) != 0) : false;
         const int wave_first_q = p.q_pos0 + ((int)blockIdx.x * NWAVES + wave) * 32;
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int kbase = tile * 64 + sub * 32;
+        for (int sub = 0; sub < TR / 32; ++sub) {
+            const int kbase = tile * TR + sub * 32;
             if (kbase >= Sk) continue;
             if (MODE == MODE_CAUSAL) {
                 const int wave_last_q = p.q_pos0 + min(p.Sq, ((int)blockIdx.x * NWAVES + wave + 1) * 32) - 1;
@@ -324,7 +361,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
                 const int kt = kbase + crow32(r, h);
                 float v = s[r] * scale2;
                 if (FAST64) {
-                    v += rh64 + rw[sub][r];  // key column = 32*sub + crow32(r, h): compile-time register index
+                    v += rh64 + rw[sub & 1][r];  // key column = 32*(sub&1) + crow32(r, h): compile-time register index
                 } else if (REL) {
                     const int ky = (int)(((float)kt + 0.5f) * invG);
                     const int kx = kt - ky * G;
@@ -399,7 +436,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
 
 template <typename T, int HD, int MODE, int NWAVES, bool FAST64>
 static int launch_flash_impl(const AttnArgs& a, hipStream_t s) {
-    using KT = KVTile<T, HD>;
+    using KT = KVTile<T, HD, (MODE == MODE_VIT_WINDOW) ? 128 : 64>;
     constexpr bool REL = (MODE == MODE_VIT_GLOBAL || MODE == MODE_VIT_WINDOW);
     constexpr int RELROWS = (MODE == MODE_VIT_WINDOW) ? 16 : 64;
     const size_t lds = 2 * KT::BYTES + 16 * KT::RS + 256 + (REL ? (size_t)NWAVES * (FAST64 ? 1 : 2) * RELROWS * 32 * 4 : 0);
