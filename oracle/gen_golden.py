@@ -233,7 +233,46 @@ def case_sam_forward():
          mask_shape=np.array(out["masks"].shape))
 
 
-CASES = {"vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
+def case_amg():
+    """Helper functions of utils/amg.py run individually on seeded inputs (the reference has no generator class)."""
+    from utils import amg as R
+    rng = np.random.default_rng(6)
+    out = {}
+    # logits with blobs so masks have structure; a few degenerate ones (all below / all above threshold)
+    yy, xx = np.mgrid[0:96, 0:128].astype(np.float32)
+    masks = np.stack([4.0 * np.exp(-(((xx - rng.uniform(0, 128)) / rng.uniform(5, 40)) ** 2 + ((yy - rng.uniform(0, 96)) / rng.uniform(5, 40)) ** 2))
+                      - 1.5 + 0.8 * rng.standard_normal((96, 128)).astype(np.float32) for _ in range(12)]).astype(np.float32)
+    masks[3] = -5.0
+    masks[7] = 5.0
+    out["logits"] = masks
+    t = torch.from_numpy(masks)
+    out["stability"] = R.calculate_stability_score(t, 0.0, 1.0).numpy()
+    out["stability_b"] = R.calculate_stability_score(t.reshape(3, 4, 96, 128), 0.25, 0.5).numpy()
+    binm = t > 0.0
+    out["boxes"] = R.batched_mask_to_box(binm).numpy()
+    out["boxes_4d"] = R.batched_mask_to_box(binm.reshape(3, 4, 96, 128)).numpy()
+    rles = R.mask_to_rle_pytorch(binm)
+    out["rle_lens"] = np.array([len(r["counts"]) for r in rles])
+    out["rle_counts"] = np.concatenate([np.asarray(r["counts"], np.int64) for r in rles])
+    out["rle_area"] = np.array([R.area_from_rle(r) for r in rles])
+    assert all((R.rle_to_mask(r) == binm[i].numpy()).all() for i, r in enumerate(rles))
+    crop, orig = [100, 50, 228, 146], [0, 0, 400, 300]
+    out["near_edge"] = R.is_box_near_crop_edge(torch.from_numpy(out["boxes"]), crop, orig).numpy()
+    out["near_edge_full"] = R.is_box_near_crop_edge(torch.from_numpy(out["boxes"]), [0, 0, 128, 96], [0, 0, 128, 96]).numpy()
+    out["uncrop_boxes"] = R.uncrop_boxes_xyxy(torch.from_numpy(out["boxes"]), crop).numpy()
+    out["uncrop_masks_sum"] = R.uncrop_masks(binm, crop, 300, 400).sum((-1, -2)).numpy()
+    out["grid5"] = R.build_point_grid(5)
+    gl = R.build_all_layer_point_grids(32, 2, 2)
+    out["grid_layers"] = np.array([len(g) for g in gl])
+    out["grid_l2"] = gl[2]
+    cb, li = R.generate_crop_boxes((1500, 2250), 2, 512 / 1500)
+    out["crop_boxes"] = np.asarray(cb)
+    out["crop_layers"] = np.asarray(li)
+    out["xywh"] = np.asarray(R.box_xyxy_to_xywh(torch.tensor([10, 20, 50, 80])))
+    save("amg", input_seed=6, **out)
+
+
+CASES = {"amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
          "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full}
 
 if __name__ == "__main__":

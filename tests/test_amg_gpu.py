@@ -1,0 +1,164 @@
+"""Automatic-mask-generation row: helper kernels bit-exact vs vectors captured from the reference's
+utils/amg.py functions; box NMS vs the oracle's torchvision-semantics restatement; the generator driver vs a numpy re-statement of
+the same flow over the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import amg_oracle as AO
+from oracle import ullsam_oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def test_amg_helpers_bit_exact_vs_reference_vectors():
+    from ullsam_amd.utils import amg as A
+    g = U.gold("amg")
+    logits = T(g["logits"])
+    s = A.calculate_stability_score(logits, 0.0, 1.0).cpu().numpy()
+    assert np.array_equal(s, g["stability"], equal_nan=True)
+    s = A.calculate_stability_score(logits.reshape(3, 4, 96, 128), 0.25, 0.5).cpu().numpy()
+    assert s.shape == (3, 4) and np.array_equal(s, g["stability_b"], equal_nan=True)
+    binm = A.threshold_masks(logits, 0.0)
+    assert np.array_equal(binm.cpu().numpy().astype(bool), g["logits"] > 0)
+    boxes = A.batched_mask_to_box(binm)
+    assert boxes.dtype == torch.int64 and np.array_equal(boxes.cpu().numpy(), g["boxes"])
+    assert np.array_equal(A.batched_mask_to_box(binm.bool().reshape(3, 4, 96, 128)).cpu().numpy(), g["boxes_4d"])
+    rles = A.mask_to_rle_pytorch(binm)
+    assert [len(r["counts"]) for r in rles] == g["rle_lens"].tolist()
+    assert np.concatenate([np.asarray(r["counts"], np.int64) for r in rles]).tolist() == g["rle_counts"].tolist()
+    assert [A.area_from_rle(r) for r in rles] == g["rle_area"].tolist()
+    assert all(r["size"] == [96, 128] for r in rles)
+    for i, r in enumerate(rles):  # encode -> decode round trip
+        assert np.array_equal(A.rle_to_mask(r), g["logits"][i] > 0)
+    crop, orig = [100, 50, 228, 146], [0, 0, 400, 300]
+    assert np.array_equal(A.is_box_near_crop_edge(boxes, crop, orig).cpu().numpy(), g["near_edge"])
+    assert np.array_equal(A.is_box_near_crop_edge(boxes, [0, 0, 128, 96], [0, 0, 128, 96]).cpu().numpy(), g["near_edge_full"])
+    assert np.array_equal(A.uncrop_boxes_xyxy(boxes, crop).cpu().numpy(), g["uncrop_boxes"])
+    assert np.array_equal(A.uncrop_masks(binm, crop, 300, 400).sum((-1, -2)).cpu().numpy(), g["uncrop_masks_sum"])
+    assert A.box_xyxy_to_xywh(torch.tensor([10, 20, 50, 80])).tolist() == g["xywh"].tolist()
+
+
+def test_rle_full_size_and_edge_cases():
+    from ullsam_amd.utils import amg as A
+    rng = np.random.default_rng(0)
+    m = rng.random((5, 1024, 1024)) > 0.5          # worst case: ~half a million runs per mask
+    m[1] = False
+    m[2] = True
+    m[3, :, :512] = True; m[3, :, 512:] = False
+    rles = A.mask_to_rle_pytorch(T(m))
+    ref = AO.mask_to_rle(m)
+    for a, b in zip(rles, ref):
+        assert a["size"] == b["size"] and a["counts"] == b["counts"]
+    assert rles[1]["counts"] == [1024 * 1024] and rles[2]["counts"] == [0, 1024 * 1024]
+    assert A.mask_to_rle_pytorch(T(m[:0])) == []
+    assert np.array_equal(A.batched_mask_to_box(T(m)).cpu().numpy(), AO.batched_mask_to_box(m))
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 700])
+def test_box_nms_matches_oracle(n):
+    from ullsam_amd.utils import amg as A
+    rng = np.random.default_rng(n)
+    xy = rng.uniform(0, 900, (n, 2)).astype(np.float32)
+    wh = rng.uniform(5, 300, (n, 2)).astype(np.float32)
+    boxes = np.concatenate([xy, xy + wh], 1)
+    scores = rng.random(n).astype(np.float32)
+    scores[: n // 3] = scores[0]  # ties: lower index first
+    keep = A.box_nms(T(boxes), T(scores), 0.7).cpu().numpy()
+    ref = AO.box_nms(boxes, scores, 0.7)
+    assert keep.tolist() == ref.tolist()
+    kb = boxes[keep]  # property: survivors do not suppress each other
+    for i in range(len(kb)):
+        iw = np.maximum(np.minimum(kb[i, 2], kb[:, 2]) - np.maximum(kb[i, 0], kb[:, 0]), 0)
+        ih = np.maximum(np.minimum(kb[i, 3], kb[:, 3]) - np.maximum(kb[i, 1], kb[:, 1]), 0)
+        iou = iw * ih / (AO.box_area(kb)[i] + AO.box_area(kb) - iw * ih)
+        iou[i] = 0
+        assert (iou <= 0.7 + 1e-6).all()
+    cat = T((np.arange(n) % 2).astype(np.int64))
+    kc = A.batched_nms(T(boxes), T(scores), cat, 0.7).cpu().numpy()
+    assert set(kc.tolist()) >= set(keep.tolist())  # per-category NMS can only keep more
+
+
+def _small_sam():
+    from ullsam_amd.build_sam import _build_sam
+    from tests.test_model_gpu import load
+    P = {}
+    P.update(U.vit_params(U.VIT_SMALL, 0, "image_encoder."))
+    P.update(O.fill_state(O.prompt_encoder_shapes(prefix="prompt_encoder."), 0))
+    P.update(O.fill_state(O.mask_decoder_shapes(prefix="mask_decoder."), 0))
+    return load(_build_sam(128, 2, 2, [1]), P), P
+
+
+def test_generator_matches_numpy_flow_over_the_oracle():
+    from ullsam_amd.automatic_mask_generator import SamAutomaticMaskGenerator
+    sam, P = _small_sam()
+    img = U.rand_image((3, 384, 512), 21, 255.0)
+    iou_thr, stab_thr, stab_off, nms_thr, side = -1e3, 0.5, 0.05, 1.0, 6  # random-weight masks are full-image blobs: NMS itself is pinned in test_box_nms_matches_oracle
+    gen = SamAutomaticMaskGenerator(sam, points_per_side=side, points_per_batch=20, pred_iou_thresh=iou_thr,
+                                    stability_score_thresh=stab_thr, stability_score_offset=stab_off, box_nms_thresh=nms_thr,
+                                    output_mode="uncompressed_rle")
+    got = gen.generate(torch.from_numpy(img))
+    # ---- the same flow in numpy over the oracle
+    h, w = 384, 512
+    nh, nw = 768, 1024
+    x = O.bilinear_resize(img, (nh, nw))
+    mean = np.asarray([123.675, 116.28, 103.53], np.float32).reshape(3, 1, 1)
+    std = np.asarray([58.395, 57.12, 57.375], np.float32).reshape(3, 1, 1)
+    x = np.pad((x - mean) / std, ((0, 0), (0, 1024 - nh), (0, 0)))
+    emb = O.vit_encoder(x[None], P, prefix="image_encoder.", **U.vit_run_cfg(U.VIT_SMALL))
+    pts = AO.build_point_grid(side) * np.array([[w, h]])
+    coords = (pts * np.array([[nw / w, nh / h]])).astype(np.float32)[:, None, :]
+    sp, de = O.prompt_encoder(P, (coords, np.ones((len(pts), 1), np.int64)), None, None, prefix="prompt_encoder.")
+    low, iou = O.mask_decoder(P, emb, O.dense_pe(P, prefix="prompt_encoder."), sp, de, True, prefix="mask_decoder.")
+    low, iou = low.reshape(-1, 256, 256), iou.reshape(-1)
+    k = iou > iou_thr
+    low, iou_k, pk = low[k], iou[k], np.repeat(pts, 3, 0)[k]
+    masks = O.bilinear_resize(O.bilinear_resize(low, (1024, 1024))[..., :nh, :nw], (h, w))
+    stab = AO.calculate_stability_score(masks, 0.0, stab_off)
+    k2 = stab >= stab_thr
+    masks, iou_k, stab, pk = masks[k2], iou_k[k2], stab[k2], pk[k2]
+    boxes = AO.batched_mask_to_box(masks > 0)
+    keep = AO.box_nms(boxes.astype(np.float32), iou_k, nms_thr)
+    assert len(got) == len(keep) and len(keep) >= 2, (len(got), len(keep))
+    for rec, j in zip(got, keep):
+        assert abs(rec["predicted_iou"] - float(iou_k[j])) < 1e-4 and abs(rec["stability_score"] - float(stab[j])) < 2e-3
+        assert rec["point_coords"][0] == pytest.approx(pk[j].tolist())
+        m_ref = masks[j] > 0
+        m_got = AO.rle_to_mask(rec["segmentation"])
+        assert O.calc_iou(m_got, m_ref) > 0.999, O.calc_iou(m_got, m_ref)
+        assert rec["area"] == int(m_got.sum())
+        bx = AO.batched_mask_to_box(m_got[None])[0]
+        assert rec["bbox"] == [int(bx[0]), int(bx[1]), int(bx[2] - bx[0]), int(bx[3] - bx[1])]
+        assert rec["crop_box"] == [0, 0, w, h]
+
+
+def test_generator_with_crops_invariants():
+    """Two crop layers: records stay consistent (area / bbox / RLE), cross-crop NMS leaves no pair above the threshold."""
+    from ullsam_amd.automatic_mask_generator import SamAutomaticMaskGenerator
+    sam, _ = _small_sam()
+    img = U.rand_image((3, 600, 800), 22, 255.0)
+    gen = SamAutomaticMaskGenerator(sam, points_per_side=4, points_per_batch=64, pred_iou_thresh=-1e3, stability_score_thresh=0.5,
+                                    stability_score_offset=0.05, crop_n_layers=1, crop_n_points_downscale_factor=2)
+    recs = gen.generate(torch.from_numpy(img))
+    assert len(recs) > 0
+    boxes = []
+    for r in recs:
+        seg = r["segmentation"]
+        assert seg.shape == (600, 800) and seg.dtype == bool and r["area"] == int(seg.sum())
+        b = AO.batched_mask_to_box(seg[None])[0]
+        assert r["bbox"] == [int(b[0]), int(b[1]), int(b[2] - b[0]), int(b[3] - b[1])]
+        assert r["stability_score"] >= 0.5
+        boxes.append([b[0], b[1], b[2], b[3]])
+    kb = np.asarray(boxes, np.float32)
+    for i in range(len(kb)):
+        iw = np.maximum(np.minimum(kb[i, 2], kb[:, 2]) - np.maximum(kb[i, 0], kb[:, 0]), 0)
+        ih = np.maximum(np.minimum(kb[i, 3], kb[:, 3]) - np.maximum(kb[i, 1], kb[:, 1]), 0)
+        iou = iw * ih / np.maximum(AO.box_area(kb)[i] + AO.box_area(kb) - iw * ih, 1e-9)
+        iou[i] = 0
+        assert (iou <= 0.7 + 1e-6).all()

@@ -5,6 +5,7 @@ outputs are the pin.  fp32 vs fp32: tolerances are accumulation-order noise only
 """
 import numpy as np
 import pytest
+import torch
 
 from oracle import ullsam_oracle as O
 from tests import util as U
@@ -124,3 +125,32 @@ def test_vit_b_full_matches_reference():
     y = O.vit_encoder(x, P, **U.vit_run_cfg(U.VIT_B))
     _close(y.reshape(-1)[::int(g["stride"])], g["sample"], 2e-3, "vit_b output sample")
     assert abs(float(y.mean()) - float(g["mean"])) < 1e-4 and abs(float(y.std()) - float(g["std"])) < 1e-3
+
+
+def test_amg_oracle_and_host_helpers_match_reference_vectors():
+    """utils/amg.py helpers: the numpy oracle (and the pure-host product helpers) reproduce the reference's outputs bit for bit."""
+    from oracle import amg_oracle as A
+    from ullsam_amd.utils import amg as H
+    g = U.gold("amg")
+    m = g["logits"]
+    assert np.array_equal(A.calculate_stability_score(m, 0.0, 1.0), g["stability"], equal_nan=True)
+    assert np.array_equal(A.calculate_stability_score(m.reshape(3, 4, 96, 128), 0.25, 0.5), g["stability_b"], equal_nan=True)
+    b = m > 0
+    assert np.array_equal(A.batched_mask_to_box(b), g["boxes"]) and np.array_equal(A.batched_mask_to_box(b.reshape(3, 4, 96, 128)), g["boxes_4d"])
+    r = A.mask_to_rle(b)
+    assert [len(x["counts"]) for x in r] == g["rle_lens"].tolist()
+    assert np.concatenate([x["counts"] for x in r]).tolist() == g["rle_counts"].tolist()
+    assert [A.area_from_rle(x) for x in r] == g["rle_area"].tolist() == [H.area_from_rle(x) for x in r]
+    assert all(np.array_equal(A.rle_to_mask(x), b[i]) and np.array_equal(H.rle_to_mask(x), b[i]) for i, x in enumerate(r))
+    assert np.array_equal(A.is_box_near_crop_edge(g["boxes"], [100, 50, 228, 146], [0, 0, 400, 300]), g["near_edge"])
+    assert np.array_equal(A.uncrop_boxes_xyxy(g["boxes"], [100, 50, 228, 146]), g["uncrop_boxes"])
+    for mod in (A, H):
+        assert np.array_equal(mod.build_point_grid(5), g["grid5"])
+        gl = mod.build_all_layer_point_grids(32, 2, 2)
+        assert [len(x) for x in gl] == g["grid_layers"].tolist() and np.array_equal(gl[2], g["grid_l2"])
+        cb, li = mod.generate_crop_boxes((1500, 2250), 2, 512 / 1500)
+        assert np.array_equal(np.asarray(cb), g["crop_boxes"]) and list(li) == g["crop_layers"].tolist()
+    md = H.MaskData(a=[1, 2, 3], b=np.arange(3))
+    md.filter(torch.tensor([True, False, True]))
+    assert md["a"] == [1, 3] and md["b"].tolist() == [0, 2]
+    assert [x for x in H.batch_iterator(2, [1, 2, 3])] == [[[1, 2]], [[3]]]

@@ -40,6 +40,11 @@ SIGNATURES = {
     "ullsam_hyper_masks": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "ullsam_resize_bilinear": [vp, i64, i32, i32, i32, vp, vp, i32, i32, i32, f32, vp],
     "ullsam_mask_iou_counts": [vp, vp, vp, i32, i64, vp],
+    "ullsam_stability_score": [vp, i64, i64, f32, f32, vp, vp, vp],
+    "ullsam_mask_to_box": [vp, i64, i32, i32, vp, vp],
+    "ullsam_rle_changes": [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp],
+    "ullsam_nms_mask": [vp, i32, f32, vp, vp],
+    "ullsam_threshold_u8": [vp, vp, i64, f32, vp],
 }
 PLAIN = {"ullsam_last_error_string": ([], C.c_char_p), "ullsam_abi_version": ([], i32), "ullsam_device_count": ([], i32),
          "ullsam_set_gemm_variant": ([i32], i32)}

@@ -1,0 +1,145 @@
+"""Automatic mask generation on top of the HIP-backed Sam: point grid -> batched prompt encoder + mask decoder ->
+IoU / stability filtering -> boxes -> NMS -> RLE.
+
+The reference ships only the helper functions (utils/amg.py) -- no generator class exists in it (SURVEY.md section 0 / 8(f)
+row 2), so the driver below follows the flow those helpers were written for (Meta's SamAutomaticMaskGenerator: per crop, per
+batch of `points_per_batch` single-point prompts with multimask output; keep masks with predicted IoU > pred_iou_thresh and
+stability >= stability_score_thresh; drop boxes touching an interior crop edge; box NMS per crop, then across crops preferring
+small crops).  Helper parity is pinned (tests/golden/amg.npz); driver parity is checked against a numpy re-statement of the same
+flow over the oracle (tests/test_amg_gpu.py).
+
+Deviations, stated: images are resized with the bilinear kernel (align_corners=False, no antialias) instead of PIL's antialiased
+uint8 resize; `min_mask_region_area` post-processing needs OpenCV and is not available; the predicted-IoU filter is applied before
+the masks are upsampled (it depends only on the IoU head, so the surviving set is identical, and the 3x1024^2-per-prompt logits of
+rejected masks are never materialised).
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .utils import amg as A
+
+
+class SamAutomaticMaskGenerator:
+    def __init__(self, model, points_per_side: Optional[int] = 32, points_per_batch: int = 64, pred_iou_thresh: float = 0.88,
+                 stability_score_thresh: float = 0.95, stability_score_offset: float = 1.0, box_nms_thresh: float = 0.7,
+                 crop_n_layers: int = 0, crop_nms_thresh: float = 0.7, crop_overlap_ratio: float = 512 / 1500,
+                 crop_n_points_downscale_factor: int = 1, point_grids: Optional[List[np.ndarray]] = None,
+                 min_mask_region_area: int = 0, output_mode: str = "binary_mask") -> None:
+        assert (points_per_side is None) != (point_grids is None), "Exactly one of points_per_side or point_grid must be provided."
+        self.point_grids = (A.build_all_layer_point_grids(points_per_side, crop_n_layers, crop_n_points_downscale_factor)
+                            if points_per_side is not None else point_grids)
+        assert output_mode in ("binary_mask", "uncompressed_rle"), f"Unknown or unavailable output_mode {output_mode}."
+        if min_mask_region_area > 0:
+            raise ImportError("min_mask_region_area > 0 needs OpenCV's connected components (remove_small_regions), not installed")
+        self.model = model
+        self.points_per_batch = points_per_batch
+        self.pred_iou_thresh = pred_iou_thresh
+        self.stability_score_thresh = stability_score_thresh
+        self.stability_score_offset = stability_score_offset
+        self.box_nms_thresh = box_nms_thresh
+        self.crop_n_layers = crop_n_layers
+        self.crop_nms_thresh = crop_nms_thresh
+        self.crop_overlap_ratio = crop_overlap_ratio
+        self.output_mode = output_mode
+
+    # -- image side --------------------------------------------------------------------------------------------------
+    def _encode(self, crop: torch.Tensor):
+        """crop fp32 [3,h,w] in 0..255 -> (image tokens [1,N,C], input_size (h', w') in the 1024 frame)."""
+        sam = self.model
+        S = sam.image_encoder.img_size
+        h, w = crop.shape[-2:]
+        scale = S / max(h, w)
+        nh, nw = int(h * scale + 0.5), int(w * scale + 0.5)  # ResizeLongestSide.get_preprocess_shape (utils/transforms.py:93-102)
+        x = crop if (nh, nw) == (h, w) else ops.resize_bilinear(crop.contiguous(), (nh, nw))[0]
+        mean = sam.pixel_mean.reshape(-1).float().contiguous()
+        std = sam.pixel_std.reshape(-1).float().contiguous()
+        return sam.image_encoder.forward_tokens(x[None].contiguous(), mean, std), (nh, nw)
+
+    # -- one batch of point prompts ------------------------------------------------------------------------------------
+    def _process_batch(self, points: np.ndarray, img_tok, input_size, crop_box, orig_size) -> A.MaskData:
+        sam = self.model
+        dev = img_tok.device
+        S = sam.image_encoder.img_size
+        g = S // sam.image_encoder.patch_size
+        ch, cw = crop_box[3] - crop_box[1], crop_box[2] - crop_box[0]
+        pts = torch.from_numpy(points).to(dev).float()
+        scaled = pts * torch.tensor([input_size[1] / cw, input_size[0] / ch], device=dev)  # ResizeLongestSide.apply_coords
+        labels = torch.ones((pts.shape[0], 1), dtype=torch.int32, device=dev)
+        pe = sam.prompt_encoder
+        sparse = pe.sparse_tokens((scaled[:, None, :].contiguous(), labels), None)
+        dense = pe.dense_tokens(pts.shape[0], None, None)
+        low, iou = sam.mask_decoder.predict_masks_tokens(img_tok, pe.dense_pe_tokens(), sparse, dense, (g, g))
+        low, iou = low[:, 1:], iou[:, 1:]                              # multimask_output=True (mask_decoder.py:100-105)
+        n, k = iou.shape
+        flat_iou = iou.reshape(-1)
+        keep = flat_iou > self.pred_iou_thresh
+        idx = torch.nonzero(keep).reshape(-1)
+        data = A.MaskData(iou_preds=flat_iou[idx], points=pts.repeat_interleave(k, dim=0)[idx])
+        if idx.numel() == 0:
+            data["boxes"] = torch.zeros((0, 4), dtype=torch.int64, device=dev)
+            data["rles"] = []
+            data["stability_score"] = flat_iou[idx]
+            return data
+        kept_low = low.reshape(n * k, low.shape[-2], low.shape[-1])[idx].contiguous()
+        masks = sam.postprocess_masks(kept_low[:, None], input_size, (ch, cw))[:, 0]          # logits at crop resolution
+        stab = A.calculate_stability_score(masks, sam.mask_threshold, self.stability_score_offset)
+        data["stability_score"] = stab
+        k2 = stab >= self.stability_score_thresh
+        data.filter(k2)
+        masks = masks[k2]
+        binm = A.threshold_masks(masks, sam.mask_threshold)
+        boxes = A.batched_mask_to_box(binm) if binm.shape[0] else torch.zeros((0, 4), dtype=torch.int64, device=dev)
+        data["boxes"] = boxes
+        orig_h, orig_w = orig_size
+        k3 = ~A.is_box_near_crop_edge(boxes, crop_box, [0, 0, orig_w, orig_h]) if boxes.shape[0] else torch.zeros((0,), dtype=torch.bool, device=dev)
+        if not bool(torch.all(k3)):
+            data.filter(k3)
+            binm = binm[k3]
+        data["rles"] = A.mask_to_rle_pytorch(A.uncrop_masks(binm, crop_box, orig_h, orig_w))
+        return data
+
+    def _process_crop(self, image: torch.Tensor, crop_box, layer_idx: int, orig_size) -> A.MaskData:
+        x0, y0, x1, y1 = crop_box
+        img_tok, input_size = self._encode(image[:, y0:y1, x0:x1])
+        pts = self.point_grids[layer_idx] * np.array([[x1 - x0, y1 - y0]], dtype=np.float64)
+        data = A.MaskData()
+        for (p,) in A.batch_iterator(self.points_per_batch, pts):
+            data.cat(self._process_batch(p, img_tok, input_size, crop_box, orig_size))
+        if len(data["rles"]):
+            keep = A.batched_nms(data["boxes"].float(), data["iou_preds"], torch.zeros_like(data["boxes"][:, 0]), self.box_nms_thresh)
+            data.filter(keep)
+        data["boxes"] = A.uncrop_boxes_xyxy(data["boxes"], crop_box)
+        data["points"] = A.uncrop_points(data["points"], crop_box)
+        data["crop_boxes"] = torch.tensor([crop_box for _ in range(len(data["rles"]))], device=data["boxes"].device).reshape(-1, 4)
+        return data
+
+    @torch.no_grad()
+    def generate(self, image) -> List[Dict[str, Any]]:
+        """image: HxWx3 uint8 / float array (0..255) or a [3,H,W] tensor.  Returns SAM-style records sorted as generated."""
+        dev = self.model.device
+        if isinstance(image, np.ndarray):
+            image = torch.from_numpy(np.ascontiguousarray(image)).permute(2, 0, 1)
+        image = image.to(dev).float().contiguous()
+        orig_size = tuple(int(v) for v in image.shape[-2:])
+        crop_boxes, layer_idxs = A.generate_crop_boxes(orig_size, self.crop_n_layers, self.crop_overlap_ratio)
+        data = A.MaskData()
+        for crop_box, layer_idx in zip(crop_boxes, layer_idxs):
+            data.cat(self._process_crop(image, crop_box, layer_idx, orig_size))
+        if len(crop_boxes) > 1 and len(data["rles"]):
+            cb = data["crop_boxes"].float()
+            scores = 1.0 / ((cb[:, 2] - cb[:, 0]) * (cb[:, 3] - cb[:, 1]))  # prefer masks from smaller crops
+            keep = A.batched_nms(data["boxes"].float(), scores, torch.zeros_like(data["boxes"][:, 0]), self.crop_nms_thresh)
+            data.filter(keep)
+        data.to_numpy()
+        out = []
+        for i, rle in enumerate(data["rles"]):
+            seg = A.rle_to_mask(rle) if self.output_mode == "binary_mask" else rle
+            out.append({"segmentation": seg, "area": A.area_from_rle(rle), "bbox": A.box_xyxy_to_xywh(data["boxes"][i]).tolist(),
+                        "predicted_iou": float(data["iou_preds"][i]), "point_coords": [data["points"][i].tolist()],
+                        "stability_score": float(data["stability_score"][i]), "crop_box": A.box_xyxy_to_xywh(data["crop_boxes"][i]).tolist()})
+        return out

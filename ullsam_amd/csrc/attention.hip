@@ -340,6 +340,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
         for (int sub = 0; sub < TR / 32; ++sub) {
             const int kbase = tile * TR + sub * 32;
             if (kbase >= Sk) continue;
+            if (wave_first_q - p.q_pos0 >= p.Sq) continue;  // wave-uniform: no valid query in this wave
             if (MODE == MODE_CAUSAL) {
                 const int wave_last_q = p.q_pos0 + min(p.Sq, ((int)blockIdx.x * NWAVES + wave + 1) * 32) - 1;
                 if (kbase > wave_last_q) continue;  // wave-uniform: the whole 32-key block is in the future
@@ -519,6 +520,7 @@ extern "C" int ullsam_causal_attention(int dtype, const void* q, const void* k, 
     a.B = B; a.H = H; a.groups = H / KVH; a.Sq = Sq; a.Sk = Sk; a.key_mask = key_mask; a.q_pos0 = q_pos0;
     a.scale = 1.0f / sqrtf((float)hd);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // 4 waves = 128 queries per workgroup (8 waves / 256 queries measured no faster end to end: 94.9 vs 94.5 ms per step)
     return dtype == 0 ? dispatch_hd<float, MODE_CAUSAL, 4>(a, hd, s) : dispatch_hd<bf16, MODE_CAUSAL, 4>(a, hd, s);
 }
 

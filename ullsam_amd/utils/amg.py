@@ -1,0 +1,268 @@
+"""Automatic-mask-generation helpers with the reference's names (utils/amg.py), device work on HIP kernels.
+
+Device-side functions (stability score, mask -> box, RLE encoding, box NMS) take CUDA tensors and launch kernels from
+libullsam_hip.so; they are bit-exact with the reference functions (integer / boolean arithmetic).  Pure bookkeeping
+(point grids, crop boxes, MaskData, uncrop offsets) is host Python, as in the reference.
+"""
+from __future__ import annotations
+
+import math
+from copy import deepcopy
+from typing import Any, Dict, Iterator, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..ops import _chk, _stream
+
+
+class MaskData:
+    """Batched per-mask records: a dict of equal-length lists / arrays / tensors with filter() and cat() (amg.py:16-75)."""
+
+    _OK = (list, np.ndarray, torch.Tensor)
+
+    def __init__(self, **fields) -> None:
+        self._stats: Dict[str, Any] = {}
+        for k, v in fields.items():
+            self[k] = v
+
+    def __setitem__(self, key: str, item: Any) -> None:
+        assert isinstance(item, self._OK), "MaskData only supports list, numpy arrays, and torch tensors."
+        self._stats[key] = item
+
+    def __getitem__(self, key: str) -> Any:
+        return self._stats[key]
+
+    def __delitem__(self, key: str) -> None:
+        del self._stats[key]
+
+    def items(self):
+        return self._stats.items()
+
+    def filter(self, keep: torch.Tensor) -> None:
+        keep_np = keep.detach().cpu().numpy()
+        for k, v in list(self._stats.items()):
+            if v is None:
+                continue
+            if isinstance(v, torch.Tensor):
+                self._stats[k] = v[torch.as_tensor(keep, device=v.device)]
+            elif isinstance(v, np.ndarray):
+                self._stats[k] = v[keep_np]
+            elif isinstance(v, list):
+                idx = np.nonzero(keep_np)[0] if keep.dtype == torch.bool else keep_np
+                self._stats[k] = [v[int(i)] for i in idx]
+            else:
+                raise TypeError(f"MaskData key {k} has an unsupported type {type(v)}.")
+
+    def cat(self, other: "MaskData") -> None:
+        for k, v in other.items():
+            cur = self._stats.get(k)
+            if cur is None:
+                self._stats[k] = deepcopy(v)
+            elif isinstance(v, torch.Tensor):
+                self._stats[k] = torch.cat([cur, v], dim=0)
+            elif isinstance(v, np.ndarray):
+                self._stats[k] = np.concatenate([cur, v], axis=0)
+            elif isinstance(v, list):
+                self._stats[k] = cur + deepcopy(v)
+            else:
+                raise TypeError(f"MaskData key {k} has an unsupported type {type(v)}.")
+
+    def to_numpy(self) -> None:
+        for k, v in self._stats.items():
+            if isinstance(v, torch.Tensor):
+                self._stats[k] = v.detach().cpu().numpy()
+
+
+# ---- host bookkeeping ---------------------------------------------------------------------------------------------
+def build_point_grid(n_per_side: int) -> np.ndarray:
+    """n*n cell-centre points of the unit square, x fastest (amg.py:179-186)."""
+    centres = (np.arange(n_per_side, dtype=np.float64) + 0.5) / n_per_side
+    centres = np.linspace(centres[0], centres[-1], n_per_side)  # same rounding as the reference's linspace
+    gx, gy = np.meshgrid(centres, centres)
+    return np.stack([gx, gy], axis=-1).reshape(-1, 2)
+
+
+def build_all_layer_point_grids(n_per_side: int, n_layers: int, scale_per_layer: int) -> List[np.ndarray]:
+    return [build_point_grid(int(n_per_side / (scale_per_layer ** layer))) for layer in range(n_layers + 1)]
+
+
+def generate_crop_boxes(im_size: Tuple[int, ...], n_layers: int, overlap_ratio: float) -> Tuple[List[List[int]], List[int]]:
+    """Layer i has (2**i)**2 overlapping XYXY crops; layer 0 is the whole image (amg.py:200-234)."""
+    im_h, im_w = im_size
+    short_side = min(im_h, im_w)
+    boxes, layer_of = [[0, 0, im_w, im_h]], [0]
+    for layer in range(1, n_layers + 1):
+        per_side = 2 ** layer
+        overlap = int(overlap_ratio * short_side * (2 / per_side))
+        crop_w = int(math.ceil((overlap * (per_side - 1) + im_w) / per_side))
+        crop_h = int(math.ceil((overlap * (per_side - 1) + im_h) / per_side))
+        for ix in range(per_side):  # x outer, y inner: itertools.product(x0s, y0s) order
+            x0 = int((crop_w - overlap) * ix)
+            for iy in range(per_side):
+                y0 = int((crop_h - overlap) * iy)
+                boxes.append([x0, y0, min(x0 + crop_w, im_w), min(y0 + crop_h, im_h)])
+                layer_of.append(layer)
+    return boxes, layer_of
+
+
+def batch_iterator(batch_size: int, *args) -> Iterator[List[Any]]:
+    n = len(args[0])
+    assert len(args) > 0 and all(len(a) == n for a in args), "Batched iteration must have inputs of all the same size."
+    for start in range(0, n, batch_size):
+        yield [a[start:start + batch_size] for a in args]
+
+
+def box_xyxy_to_xywh(box_xyxy):
+    out = deepcopy(box_xyxy)
+    out[2] = out[2] - out[0]
+    out[3] = out[3] - out[1]
+    return out
+
+
+def _offset(t: torch.Tensor, vals: Sequence[int]) -> torch.Tensor:
+    off = torch.tensor([list(vals)], device=t.device)
+    return off.unsqueeze(1) if t.dim() == 3 else off
+
+
+def uncrop_boxes_xyxy(boxes: torch.Tensor, crop_box: List[int]) -> torch.Tensor:
+    return boxes + _offset(boxes, (crop_box[0], crop_box[1], crop_box[0], crop_box[1]))
+
+
+def uncrop_points(points: torch.Tensor, crop_box: List[int]) -> torch.Tensor:
+    return points + _offset(points, (crop_box[0], crop_box[1]))
+
+
+def uncrop_masks(masks: torch.Tensor, crop_box: List[int], orig_h: int, orig_w: int) -> torch.Tensor:
+    x0, y0, x1, y1 = crop_box
+    if (x0, y0, x1, y1) == (0, 0, orig_w, orig_h):
+        return masks
+    out = torch.zeros(masks.shape[:-2] + (orig_h, orig_w), dtype=masks.dtype, device=masks.device)
+    out[..., y0:y1, x0:x1] = masks
+    return out
+
+
+def is_box_near_crop_edge(boxes: torch.Tensor, crop_box: List[int], orig_box: List[int], atol: float = 20.0) -> torch.Tensor:
+    """Boxes touching a crop edge that is not also an image edge (amg.py:78-88); [N,4] integer boxes -> bool [N]."""
+    b = uncrop_boxes_xyxy(boxes, crop_box).float().cpu().numpy()
+    near_crop = np.abs(b - np.asarray(crop_box, np.float32)[None, :]) <= atol
+    near_image = np.abs(b - np.asarray(orig_box, np.float32)[None, :]) <= atol
+    return torch.from_numpy(np.logical_and(near_crop, ~near_image).any(axis=1)).to(boxes.device)
+
+
+def rle_to_mask(rle: Dict[str, Any]) -> np.ndarray:
+    h, w = rle["size"]
+    counts = np.asarray(rle["counts"], dtype=np.int64)
+    flat = np.repeat(np.arange(len(counts)) % 2 == 1, counts)  # runs alternate 0,1,0,... starting with a 0-run
+    return flat.reshape(w, h).transpose()
+
+
+def area_from_rle(rle: Dict[str, Any]) -> int:
+    return int(sum(rle["counts"][1::2]))
+
+
+def remove_small_regions(mask: np.ndarray, area_thresh: float, mode: str):
+    raise ImportError("remove_small_regions needs OpenCV (cv2.connectedComponentsWithStats), which is not installed; "
+                      "the reference fails the same way (utils/amg.py:274)")
+
+
+def coco_encode_rle(uncompressed_rle: Dict[str, Any]):
+    raise ImportError("coco_encode_rle needs pycocotools, which is not installed (utils/amg.py:295)")
+
+
+# ---- device work ----------------------------------------------------------------------------------------------------
+def calculate_stability_score(masks: torch.Tensor, mask_threshold: float, threshold_offset: float) -> torch.Tensor:
+    """IoU between the mask logits thresholded at +offset and -offset (amg.py:156-176); fp32 [..., H, W] -> fp32 [...]."""
+    m = _chk(masks.float().contiguous(), "masks", torch.float32)
+    lead = m.shape[:-2]
+    per = m.shape[-1] * m.shape[-2]
+    N = m.numel() // per if per else 0
+    counts = torch.empty((max(N, 1), 2), dtype=torch.int32, device=m.device)
+    score = torch.empty((N,), dtype=torch.float32, device=m.device)
+    _lib.call("ullsam_stability_score", m.data_ptr(), N, per, float(mask_threshold), float(threshold_offset), counts.data_ptr(),
+              score.data_ptr(), _stream())
+    return score.reshape(lead)
+
+
+def threshold_masks(masks: torch.Tensor, mask_threshold: float) -> torch.Tensor:
+    """masks > mask_threshold as uint8 (the binarisation step between logits and the integer helpers)."""
+    m = _chk(masks.float().contiguous(), "masks", torch.float32)
+    out = torch.empty(m.shape, dtype=torch.uint8, device=m.device)
+    _lib.call("ullsam_threshold_u8", m.data_ptr(), out.data_ptr(), m.numel(), float(mask_threshold), _stream())
+    return out
+
+
+def _as_u8(masks: torch.Tensor) -> torch.Tensor:
+    if masks.dtype == torch.bool:
+        masks = masks.view(torch.uint8) if masks.is_contiguous() else masks.contiguous().view(torch.uint8)
+    return _chk(masks.contiguous(), "masks", torch.uint8)
+
+
+def batched_mask_to_box(masks: torch.Tensor) -> torch.Tensor:
+    """XYXY boxes around binary masks, [0,0,0,0] for empty ones (amg.py:303-346); [..., H, W] -> int64 [..., 4]."""
+    if masks.numel() == 0:
+        return torch.zeros(*masks.shape[:-2], 4, device=masks.device)
+    m = _as_u8(masks)
+    H, W = m.shape[-2:]
+    N = m.numel() // (H * W)
+    out = torch.empty((N, 4), dtype=torch.int32, device=m.device)
+    _lib.call("ullsam_mask_to_box", m.data_ptr(), N, H, W, out.data_ptr(), _stream())
+    out = out.long()
+    return out.reshape(*masks.shape[:-2], 4) if masks.dim() > 2 else out[0]
+
+
+def mask_to_rle_pytorch(tensor: torch.Tensor) -> List[Dict[str, Any]]:
+    """Uncompressed column-major RLE per mask, pycocotools layout (amg.py:107-135).  Two kernel passes (count, write); the
+    run lengths are differences of the change positions."""
+    m = _as_u8(tensor)
+    b, h, w = m.shape
+    if b == 0:
+        return []
+    counts = torch.empty((b,), dtype=torch.int32, device=m.device)
+    first = torch.empty((b,), dtype=torch.uint8, device=m.device)
+    _lib.call("ullsam_rle_changes", m.data_ptr(), b, h, w, 0, counts.data_ptr(), None, None, first.data_ptr(), _stream())
+    c = counts.cpu().numpy().astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(c)])
+    pos = torch.empty((max(int(offs[-1]), 1),), dtype=torch.int32, device=m.device)
+    offs_d = torch.from_numpy(offs[:-1].copy()).to(m.device)
+    _lib.call("ullsam_rle_changes", m.data_ptr(), b, h, w, 1, counts.data_ptr(), offs_d.data_ptr(), pos.data_ptr(), None, _stream())
+    pos_h, first_h = pos.cpu().numpy().astype(np.int64), first.cpu().numpy()
+    out = []
+    for i in range(b):
+        edges = np.concatenate([[0], pos_h[offs[i]:offs[i + 1]] + 1, [h * w]])
+        runs = (edges[1:] - edges[:-1]).tolist()
+        out.append({"size": [h, w], "counts": ([0] if first_h[i] else []) + runs})
+    return out
+
+
+def box_nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """torchvision.ops.nms semantics (the reference's AMG depends on torchvision, which is absent): kept indices in decreasing
+    score order.  Ordering of the few thousand scores and the greedy scan are host bookkeeping; the N x N IoU suppression
+    matrix is computed on the GPU."""
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    sc = scores.detach().float().cpu().numpy()
+    order = np.lexsort((np.arange(n), -sc.astype(np.float64)))
+    sorted_boxes = _chk(boxes.float()[torch.from_numpy(order).to(boxes.device)].contiguous(), "boxes", torch.float32)
+    nw = (n + 63) // 64
+    mask = torch.empty((n, nw), dtype=torch.int64, device=boxes.device)
+    _lib.call("ullsam_nms_mask", sorted_boxes.data_ptr(), n, float(iou_threshold), mask.data_ptr(), _stream())
+    mh = mask.cpu().numpy().view(np.uint64)
+    removed = np.zeros(nw, dtype=np.uint64)
+    keep = []
+    for i in range(n):
+        if not (removed[i >> 6] >> np.uint64(i & 63)) & np.uint64(1):
+            keep.append(order[i])
+            removed |= mh[i]
+    return torch.from_numpy(np.asarray(keep, dtype=np.int64)).to(boxes.device)
+
+
+def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """torchvision.ops.batched_nms: boxes of different categories never suppress each other (coordinate-offset trick)."""
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    max_coord = boxes.max()
+    offsets = idxs.to(boxes) * (max_coord + 1)
+    return box_nms(boxes + offsets[:, None], scores, iou_threshold)
