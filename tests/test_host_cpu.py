@@ -183,3 +183,39 @@ def test_gloo_world2_gather_is_rank_ordered():
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+def test_checkpoint_loading_conventions(tmp_path):
+    """Reference-layout checkpoints load without key surgery: {"model": sd} torch files, DDP 'module.' prefixes, and
+    InternLM2 safetensors re-prefixed with language_model. (train_joint_v2.py:1466-1555)."""
+    from safetensors.torch import save_file
+    from ullsam_amd import checkpoint
+    from ullsam_amd.build_sam import _build_sam
+    from ullsam_amd.modeling.configuration_internvl_chat import InternVLChatConfig
+    from ullsam_amd.modeling.modeling_internvl_sam import InternVLSAMModel
+    c = U.LLM_TINY
+    llm_cfg = dict(architectures=["InternLM2ForCausalLM"], vocab_size=128, hidden_size=c["hidden"], intermediate_size=c["inter"],
+                   num_hidden_layers=1, num_attention_heads=c["heads"], num_key_value_heads=c["kv_heads"], bias=False)
+
+    def make():
+        sam = _build_sam(128, 1, 2, [0])
+        return InternVLSAMModel(InternVLChatConfig(llm_config=dict(llm_cfg), ps_version="v2"), vision_model=sam.image_encoder,
+                                prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder)
+
+    src, dst = make(), make()
+    with torch.no_grad():
+        for p in src.parameters():
+            p.normal_()
+    sd = src.state_dict()
+    torch.save({"model": {"module." + k: v for k, v in sd.items()}, "epoch": 3}, tmp_path / "final.pt")
+    missing, unexpected = checkpoint.load_ullsam_checkpoint(dst, str(tmp_path / "final.pt"))
+    assert not missing and not unexpected
+    assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
+    # safetensors with bare InternLM2 keys + foreign InternViT keys that must be ignored
+    dst2 = make()
+    llm = {k[len("language_model."):]: v.contiguous() for k, v in sd.items() if k.startswith("language_model.")}
+    llm["vision_model.embeddings.foo"] = torch.zeros(2)
+    save_file(llm, str(tmp_path / "model.safetensors"))
+    missing, unexpected = checkpoint.load_llm_safetensors(dst2, str(tmp_path))
+    assert not unexpected and all(not k.startswith("language_model.") for k in missing)
+    assert torch.equal(dst2.language_model.output.weight, src.language_model.output.weight)

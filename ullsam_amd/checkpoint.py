@@ -1,0 +1,47 @@
+"""Checkpoint loading with the reference's conventions (train_joint_v2.py:1466-1555, app.py:335-341, build_sam.py:103-106).
+
+The state_dict key layout of the HIP-backed modules is identical to the reference's, so its checkpoints load directly:
+  * uLLSAM checkpoints (`final_all_e24.pt`): torch.save'd dict with the weights under "model" -> load_state_dict(strict=False)
+  * SAM checkpoints (`sam_vit_b_01ec64.pth`): plain state_dict for Sam -> sam_model_registry[...](checkpoint=path)
+  * InternVL2_5-2B `model.safetensors`: InternLM2 weights, re-prefixed with `language_model.` (train_joint_v2.py:1515-1548;
+    the checkpoint's own `vision_model.*` / `mlp1.*` tensors belong to InternViT and are skipped, as in the reference)
+No weight files ship with the reference or exist offline, so this path is exercised on synthetic
+files with the real key layout (tests/test_host_cpu.py).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Iterable, Tuple
+
+import torch
+
+
+def _report(model: torch.nn.Module, sd: Dict[str, torch.Tensor]) -> Tuple[list, list]:
+    res = model.load_state_dict(sd, strict=False)
+    return list(res.missing_keys), list(res.unexpected_keys)
+
+
+def load_ullsam_checkpoint(model: torch.nn.Module, path: str) -> Tuple[list, list]:
+    """`checkpoint["model"]` with strict=False (train_joint_v2.py:1472-1479); also accepts a bare state_dict."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt and isinstance(ckpt["model"], dict) else ckpt
+    sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}  # DDP-wrapped saves
+    return _report(model, sd)
+
+
+def load_llm_safetensors(model: torch.nn.Module, path_or_dir: str, prefix: str = "language_model.") -> Tuple[list, list]:
+    """InternLM2 weights from an InternVL-style safetensors file / directory (train_joint_v2.py:1515-1548)."""
+    from safetensors.torch import load_file
+    files: Iterable[str]
+    if os.path.isdir(path_or_dir):
+        files = sorted(os.path.join(path_or_dir, f) for f in os.listdir(path_or_dir) if f.endswith(".safetensors"))
+    else:
+        files = [path_or_dir]
+    sd: Dict[str, torch.Tensor] = {}
+    for f in files:
+        for k, v in load_file(f).items():
+            if k.startswith(prefix):
+                sd[k] = v
+            elif k.startswith(("model.", "output.")):
+                sd[prefix + k] = v
+    return _report(model, sd)
