@@ -28,7 +28,7 @@ extern "C" {
 const char* ullsam_last_error_string(void);
 int ullsam_abi_version(void);
 int ullsam_device_count(void);
-/* GEMM kernel selection for A/B measurements: 0 = auto (by shape), 1 = 128x128 tile, 2 = 256x128 tile / 3-stage ring, 3 = 256x256 tile; +64 = no split-K tail; +256/+512 = timing-only ablations (outputs are garbage); +4096/+8192 = alternative main-loop schedules of the 256x256 kernel. */
+/* GEMM kernel selection for A/B measurements: 0 = auto (by shape), 1 = 128x128 tile, 2 = 256x128 tile / 3-stage ring, 3 = 256x256 tile; +64 = no split-K tail; +256/+512/+1024 = timing-only ablations (outputs are garbage); +4096/+8192 = alternative main-loop schedules of the 256x256 kernel. */
 int ullsam_set_gemm_variant(int variant);
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual.  Replaces every nn.Linear / 1x1 conv / stride==kernel conv:

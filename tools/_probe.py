@@ -18,11 +18,13 @@ def run(M, N, K, act, use_bias, variant, out_f32=False, n=6):
         for i in range(n): ops.gemm(As[i], Ws[i], b, act=act, out_f32=out_f32, out=Cs[i])
         e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / n)
     t = sorted(ts)[2]
-    print(f"v{variant} M={M} N={N} K={K} act={act} bias={use_bias}: {t*1e3:7.1f} us  ({t*1e3/ (((M+255)//256)*((N+255)//256)/256):6.1f} us per 256-tile wave)", flush=True)
-for K in (64, 128, 256, 640, 1280, 2560):
-    run(16384, 5120, K, 1, True, 3)
-run(16384, 5120, 64, 0, False, 3)
-run(16384, 5120, 64, 0, False, 3, out_f32=True)
+    rounds = ((M+255)//256)*((N+255)//256)/256
+    print(f"code {variant:5d} M={M} N={N} K={K} act={act} bias={use_bias}: {t*1e3:7.1f} us  ({t*1e3/rounds:6.1f} us per 256-tile wave, {rounds:.2f} waves)", flush=True)
 for K in (64, 1280):
-    run(16384, 5120, K, 1, True, 1)
+    run(16384, 5120, K, 0, False, 3)
+    run(16384, 5120, K, 0, False, 3 + (4 << 8))
+    run(16384, 5120, K, 1, True, 3)
+run(16384, 1280, 64, 0, False, 3 + 64)          # 320 tiles = 1.25 waves
+run(16384, 256*4, 64, 0, False, 3 + 64)          # exactly 1 wave of 256 tiles
+run(16384, 256*4, 64, 0, False, 3 + 64 + (4 << 8))
 lib.ullsam_set_gemm_variant(0)
