@@ -30,6 +30,8 @@ int ullsam_abi_version(void);
 int ullsam_device_count(void);
 /* GEMM kernel selection for A/B measurements: 0 = auto (by shape), 1 = 128x128 tile, 2 = 256x128 tile / 3-stage ring, 3 = 256x256 tile; +64 = no split-K tail; +256/+512/+1024 = timing-only ablations (outputs are garbage); +4096/+8192 = alternative main-loop schedules of the 256x256 kernel. */
 int ullsam_set_gemm_variant(int variant);
+/* Attention A/B switch: 0 = production, 1 = windowed attention with one 7-wave workgroup per (window, head). */
+int ullsam_set_attn_variant(int variant);
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual.  Replaces every nn.Linear / 1x1 conv / stride==kernel conv:
  * image_encoder.py:227,238,387-395,88-104; common.py:21-26; modeling_internvl_sam.py:88-100;

@@ -97,7 +97,7 @@ __device__ __forceinline__ Frag<float> pack_p(const f32x16& s, int half, const f
 // registers per lane; only rel_h stays in LDS (8 KiB per wave -> two workgroups per CU).
 template <typename T, int HD, int MODE, int NWAVES, bool FAST64>
 __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) {  // >= 2 waves per SIMD: at most 256 VGPR+AGPR
-    constexpr int TR = (MODE == MODE_VIT_WINDOW) ? 128 : 64;  // keys per staged K/V tile
+    constexpr int TR = (MODE == MODE_VIT_WINDOW && NWAVES == 7) ? 128 : 64;  // keys per staged K/V tile
     using KT = KVTile<T, HD, TR>;
     constexpr int RS = KT::RS;
     constexpr int NT = NWAVES * 64;
@@ -331,8 +331,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
 
     store_tile();  // tile 0 was fetched before the table phase
     __syncthreads();
-#pragma unroll 1
-    for (int tile = 0; tile < ntiles; ++tile) {
+    // SAM's windows are always 14x14 (build_sam.py:78): 196 keys = a compile-time tile count, and with the tile loop unrolled
+    // the key -> (row, col) split of every accumulator register is a compile-time constant (two candidates, by lane half).
+    const bool win14 = (MODE == MODE_VIT_WINDOW) && p.win == 14;
+    constexpr int NT14 = (196 + TR - 1) / TR;
+    auto do_tile = [&](const int tile, const bool W14) __attribute__((always_inline)) {
         if (tile + 1 < ntiles) load_tile(tile + 1);
         const bool tile_pad = (MODE == MODE_CAUSAL && kmask_g) ? (__any(kms[lane] == 0) != 0) : false;
         const int wave_first_q = p.q_pos0 + ((int)blockIdx.x * NWAVES + wave) * 32;
@@ -363,6 +366,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
                 float v = s[r] * scale2;
                 if (FAST64) {
                     v += rh64 + rw[sub & 1][r];  // key column = 32*(sub&1) + crow32(r, h): compile-time register index
+                } else if (MODE == MODE_VIT_WINDOW && W14) {
+                    const int k0 = kbase + crow32(r, 0), k1 = k0 + 4;  // the two lane halves' keys; constants after unrolling
+                    const int offh = h ? (k1 / 14) * 32 : (k0 / 14) * 32;
+                    const int offw = h ? (k1 % 14) * 32 : (k0 % 14) * 32;
+                    const bool valid = h ? (k1 < 196) : (k0 < 196);
+                    v = valid ? v + (relh[(offh < 14 * 32 ? offh : 0) + ql] + relw[offw + ql]) * LOG2E : -INFINITY;
                 } else if (REL) {
                     const int ky = (int)(((float)kt + 0.5f) * invG);
                     const int kx = kt - ky * G;
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
                     // keys are all single-masked must stay uniform over them, as in the reference's eager softmax
                     if (add != 0.f) v = s[r] * p.scale + add;
                 }
-                if (!FAST64 && !interior && kt >= Sk) v = -INFINITY;
+                if (!FAST64 && !interior && !(MODE == MODE_VIT_WINDOW && W14) && kt >= Sk) v = -INFINITY;
                 s[r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -414,6 +423,13 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
         __syncthreads();
         if (tile + 1 < ntiles) store_tile();
         __syncthreads();
+    };
+    if (MODE == MODE_VIT_WINDOW && win14) {
+#pragma unroll
+        for (int tile = 0; tile < NT14; ++tile) do_tile(tile, true);
+    } else {
+#pragma unroll 1
+        for (int tile = 0; tile < ntiles; ++tile) do_tile(tile, false);
     }
 
     // ---- normalise and store: lane q holds O^T[d][q], d = 32*dt + crow32(r, h)
@@ -437,7 +453,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
 
 template <typename T, int HD, int MODE, int NWAVES, bool FAST64>
 static int launch_flash_impl(const AttnArgs& a, hipStream_t s) {
-    using KT = KVTile<T, HD, (MODE == MODE_VIT_WINDOW) ? 128 : 64>;
+    using KT = KVTile<T, HD, (MODE == MODE_VIT_WINDOW && NWAVES == 7) ? 128 : 64>;
     constexpr bool REL = (MODE == MODE_VIT_GLOBAL || MODE == MODE_VIT_WINDOW);
     constexpr int RELROWS = (MODE == MODE_VIT_WINDOW) ? 16 : 64;
     const size_t lds = 2 * KT::BYTES + 16 * KT::RS + 256 + (REL ? (size_t)NWAVES * (FAST64 ? 1 : 2) * RELROWS * 32 * 4 : 0);
@@ -472,6 +488,9 @@ static int dispatch_hd(const AttnArgs& a, int hd, hipStream_t s) {
     ULLSAM_CHECK(false, "flash_attn: unsupported head_dim %d for mode %d (ViT: 64/80, causal: 64/128)", hd, MODE);
 }
 
+static int g_attn_variant = 0;
+extern "C" int ullsam_set_attn_variant(int v) { g_attn_variant = v; return 0; }
+
 // SAM ViT attention on the packed qkv activations [B, grid_h*grid_w, 3*D] (D = heads*hd, per token [3][heads][hd]).
 // window == 0 -> global attention.  rel_h/rel_w: [(2S-1), hd] in the activation dtype.  qkv_bias: [3*D] in the
 // activation dtype (only read for window pad tokens).  out: [B, grid_h*grid_w, D].
@@ -500,7 +519,9 @@ extern "C" int ullsam_vit_attention(int dtype, const void* qkv, void* out, const
         a.nwin_w = (grid_w + window - 1) / window;
         a.nwin = a.nwin_w * ((grid_h + window - 1) / window);
         a.Sq = a.Sk = window * window;
-        return dtype == 0 ? dispatch_hd<float, MODE_VIT_WINDOW, 7>(a, hd, s) : dispatch_hd<bf16, MODE_VIT_WINDOW, 7>(a, hd, s);
+        // window = 196 queries: one 7-wave workgroup (128-key tiles) or two 4-wave workgroups (64-key tiles, 3 resident per CU)
+        if (g_attn_variant == 1) return dtype == 0 ? dispatch_hd<float, MODE_VIT_WINDOW, 7>(a, hd, s) : dispatch_hd<bf16, MODE_VIT_WINDOW, 7>(a, hd, s);
+        return dtype == 0 ? dispatch_hd<float, MODE_VIT_WINDOW, 7>(a, hd, s) : dispatch_hd<bf16, MODE_VIT_WINDOW, 4>(a, hd, s);
     }
     a.Sq = a.Sk = (int)N;
     return dtype == 0 ? dispatch_hd<float, MODE_VIT_GLOBAL, 4>(a, hd, s) : dispatch_hd<bf16, MODE_VIT_GLOBAL, 4>(a, hd, s);
