@@ -1,0 +1,29 @@
+"""Throughput of the automatic mask generator (BASELINE.json configs[4] shape: 64x64 point grid on a 2048^2 tile, SAM ViT-H,
+bf16 here -- the fp8 ViT path of that config is not built).  Random-init weights: thresholds are relaxed so masks survive.
+usage: python tools/amg_bench.py [points_per_side] [tile] [vit]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from bench import build_model
+from ullsam_amd.automatic_mask_generator import SamAutomaticMaskGenerator
+
+side = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+tile = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+vit = sys.argv[3] if len(sys.argv) > 3 else "h"
+sam = build_model(vit, "none", torch.bfloat16, "cuda:0")
+gen = SamAutomaticMaskGenerator(sam, points_per_side=side, points_per_batch=64, pred_iou_thresh=-1e9, stability_score_thresh=0.9,
+                                stability_score_offset=0.05, box_nms_thresh=0.7, output_mode="uncompressed_rle")
+img = torch.from_numpy(np.random.default_rng(0).random((3, tile, tile), dtype=np.float32) * 255).cuda()
+t_enc = t_all = 0.0
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    tok, _ = gen._encode(img)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    recs = gen.generate(img)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    if it:
+        t_enc += t1 - t0; t_all += t2 - t1
+print(json.dumps({"workload": f"AMG {side}x{side} points on a {tile}^2 tile, SAM ViT-{vit.upper()}, bf16, 64 prompts/batch, multimask",
+                  "seconds_per_tile": round(t_all / 2, 4), "encoder_seconds": round(t_enc / 2, 4), "prompts_per_s": round(side * side / (t_all / 2), 1),
+                  "masks_kept": len(recs)}))
