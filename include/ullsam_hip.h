@@ -109,8 +109,10 @@ int ullsam_mask_iou_counts(const unsigned char* a, const unsigned char* b, unsig
 int ullsam_stability_score(const float* masks, long N, long per, float mask_threshold, float threshold_offset,
                            unsigned int* counts, float* score, void* stream);                 /* amg.py:156-176 */
 int ullsam_mask_to_box(const unsigned char* masks, long N, int H, int W, int* boxes, void* stream);   /* amg.py:303-346 */
-int ullsam_rle_changes(const unsigned char* masks, long N, int H, int W, int write, int* counts, const long* offsets,
-                       int* out, unsigned char* first, void* stream);                         /* amg.py:107-135 */
+int ullsam_rle_pack(const unsigned char* masks, long N, int H, int W, unsigned long long* words, int* counts,
+                    unsigned char* first, void* stream);                                      /* amg.py:107-135 (transpose + diff) */
+int ullsam_rle_emit(const unsigned long long* words, long N, int H, int W, const long* offsets, int* out,
+                    void* stream);                                                            /* amg.py:119-133 (nonzero -> run edges) */
 int ullsam_nms_mask(const float* boxes, int N, float iou_threshold, unsigned long long* mask, void* stream); /* torchvision.ops.nms (absent dependency) */
 int ullsam_threshold_u8(const float* in, unsigned char* out, long n, float thr, void* stream); /* masks > mask_threshold */
 

@@ -61,6 +61,24 @@ def test_rle_full_size_and_edge_cases():
     assert np.array_equal(A.batched_mask_to_box(T(m)).cpu().numpy(), AO.batched_mask_to_box(m))
 
 
+@pytest.mark.parametrize("shape", [(3, 96, 128), (2, 70, 48), (2, 65, 33), (3, 1, 17), (3, 50, 1), (2, 64, 16), (2, 129, 1040), (1, 1, 1)])
+def test_rle_and_box_ragged_shapes(shape):
+    """Vector path (W % 16 == 0), scalar path, partial 64-row blocks, single rows / columns; bytes other than 0/1 count as set."""
+    from ullsam_amd.utils import amg as A
+    rng = np.random.default_rng(sum(shape))
+    for density in (0.5, 0.03):
+        m = rng.random(shape) < density
+        m[0, -1, -1] = True                          # the last element of the flattening has no successor
+        u8 = (m * rng.integers(1, 256, shape)).astype(np.uint8)
+        for dev_in in (T(m), T(u8)):
+            rles = A.mask_to_rle_pytorch(dev_in)
+            for a, b in zip(rles, AO.mask_to_rle(m)):
+                assert a["size"] == b["size"] and a["counts"] == b["counts"]
+            assert np.array_equal(A.batched_mask_to_box(dev_in).cpu().numpy(), AO.batched_mask_to_box(m))
+        for i, a in enumerate(rles):
+            assert np.array_equal(A.rle_to_mask(a), m[i])
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 700])
 def test_box_nms_matches_oracle(n):
     from ullsam_amd.utils import amg as A

@@ -1,6 +1,6 @@
 """Throughput of the automatic mask generator (BASELINE.json configs[4] shape: 64x64 point grid on a 2048^2 tile, SAM ViT-H,
 bf16 here -- the fp8 ViT path of that config is not built).  Random-init weights: thresholds are relaxed so masks survive.
-usage: python tools/amg_bench.py [points_per_side] [tile] [vit]"""
+usage: python tools/amg_bench.py [points_per_side] [tile] [vit] [stability_thresh] [stability_offset] [iters]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,12 +11,15 @@ from ullsam_amd.automatic_mask_generator import SamAutomaticMaskGenerator
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 tile = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 vit = sys.argv[3] if len(sys.argv) > 3 else "h"
+stab = float(sys.argv[4]) if len(sys.argv) > 4 else 0.9
+off = float(sys.argv[5]) if len(sys.argv) > 5 else 0.05
+iters = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 sam = build_model(vit, "none", torch.bfloat16, "cuda:0")
-gen = SamAutomaticMaskGenerator(sam, points_per_side=side, points_per_batch=64, pred_iou_thresh=-1e9, stability_score_thresh=0.9,
-                                stability_score_offset=0.05, box_nms_thresh=0.7, output_mode="uncompressed_rle")
+gen = SamAutomaticMaskGenerator(sam, points_per_side=side, points_per_batch=64, pred_iou_thresh=-1e9, stability_score_thresh=stab,
+                                stability_score_offset=off, box_nms_thresh=0.7, output_mode="uncompressed_rle")
 img = torch.from_numpy(np.random.default_rng(0).random((3, tile, tile), dtype=np.float32) * 255).cuda()
 t_enc = t_all = 0.0
-for it in range(3):
+for it in range(iters):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     tok, _ = gen._encode(img)
     torch.cuda.synchronize(); t1 = time.perf_counter()
@@ -25,5 +28,5 @@ for it in range(3):
     if it:
         t_enc += t1 - t0; t_all += t2 - t1
 print(json.dumps({"workload": f"AMG {side}x{side} points on a {tile}^2 tile, SAM ViT-{vit.upper()}, bf16, 64 prompts/batch, multimask",
-                  "seconds_per_tile": round(t_all / 2, 4), "encoder_seconds": round(t_enc / 2, 4), "prompts_per_s": round(side * side / (t_all / 2), 1),
+                  "seconds_per_tile": round(t_all / (iters - 1), 4), "encoder_seconds": round(t_enc / (iters - 1), 4), "prompts_per_s": round(side * side / (t_all / (iters - 1)), 1),
                   "masks_kept": len(recs)}))

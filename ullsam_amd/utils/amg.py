@@ -213,20 +213,22 @@ def batched_mask_to_box(masks: torch.Tensor) -> torch.Tensor:
 
 
 def mask_to_rle_pytorch(tensor: torch.Tensor) -> List[Dict[str, Any]]:
-    """Uncompressed column-major RLE per mask, pycocotools layout (amg.py:107-135).  Two kernel passes (count, write); the
-    run lengths are differences of the change positions."""
+    """Uncompressed column-major RLE per mask, pycocotools layout (amg.py:107-135).  One coalesced pass packs the mask into per-column
+    change words, a second emits the ordered change positions; the run lengths are their differences."""
     m = _as_u8(tensor)
     b, h, w = m.shape
     if b == 0:
         return []
+    nyb = (h + 63) // 64
+    words = torch.empty((b, nyb, w), dtype=torch.int64, device=m.device)
     counts = torch.empty((b,), dtype=torch.int32, device=m.device)
     first = torch.empty((b,), dtype=torch.uint8, device=m.device)
-    _lib.call("ullsam_rle_changes", m.data_ptr(), b, h, w, 0, counts.data_ptr(), None, None, first.data_ptr(), _stream())
+    _lib.call("ullsam_rle_pack", m.data_ptr(), b, h, w, words.data_ptr(), counts.data_ptr(), first.data_ptr(), _stream())
     c = counts.cpu().numpy().astype(np.int64)
     offs = np.concatenate([[0], np.cumsum(c)])
     pos = torch.empty((max(int(offs[-1]), 1),), dtype=torch.int32, device=m.device)
     offs_d = torch.from_numpy(offs[:-1].copy()).to(m.device)
-    _lib.call("ullsam_rle_changes", m.data_ptr(), b, h, w, 1, counts.data_ptr(), offs_d.data_ptr(), pos.data_ptr(), None, _stream())
+    _lib.call("ullsam_rle_emit", words.data_ptr(), b, h, w, offs_d.data_ptr(), pos.data_ptr(), _stream())
     pos_h, first_h = pos.cpu().numpy().astype(np.int64), first.cpu().numpy()
     out = []
     for i in range(b):
