@@ -111,8 +111,13 @@ int ullsam_stability_score(const float* masks, long N, long per, float mask_thre
 int ullsam_mask_to_box(const unsigned char* masks, long N, int H, int W, int* boxes, void* stream);   /* amg.py:303-346 */
 int ullsam_rle_pack(const unsigned char* masks, long N, int H, int W, unsigned long long* words, int* counts,
                     unsigned char* first, void* stream);                                      /* amg.py:107-135 (transpose + diff) */
-int ullsam_rle_emit(const unsigned long long* words, long N, int H, int W, const long* offsets, int* out,
+int ullsam_rle_emit(const unsigned long long* words, const int* select, long N, int H, int W, const long* offsets, int* out,
                     void* stream);                                                            /* amg.py:119-133 (nonzero -> run edges) */
+/* generator fast path: postprocess_masks + stability counts + mask->box + RLE change words in one pass, logits never stored */
+int ullsam_amg_postprocess(const float* low, const int* index, long M, int LH, int LW, int S1, int nh, int nw, int CH, int CW,
+                           int FH, int FW, int cx0, int cy0, float mask_threshold, float threshold_offset,
+                           unsigned long long* words, int* rle_counts, unsigned char* first, int* boxes, unsigned int* stab,
+                           void* stream);                      /* sam.py:154-162 + amg.py:156-176, 303-346, 107-135, 251-264 */
 int ullsam_nms_mask(const float* boxes, int N, float iou_threshold, unsigned long long* mask, void* stream); /* torchvision.ops.nms (absent dependency) */
 int ullsam_threshold_u8(const float* in, unsigned char* out, long n, float thr, void* stream); /* masks > mask_threshold */
 

@@ -113,14 +113,63 @@ def _small_sam():
     return load(_build_sam(128, 2, 2, [1]), P), P
 
 
-def test_generator_matches_numpy_flow_over_the_oracle():
+def _smooth_logits(rng, m, h, w, cells=6):
+    """Low-frequency random fields: masks with blobs and long borders instead of salt-and-pepper."""
+    coarse = rng.standard_normal((m, cells, cells)).astype(np.float32) * 3
+    return O.bilinear_resize(coarse, (h, w)) + rng.standard_normal((m, h, w)).astype(np.float32) * 0.05
+
+
+@pytest.mark.parametrize("case", [
+    dict(low=(5, 256, 256), S=1024, inp=(1024, 1024), crop=[0, 0, 2048, 2048], orig=(2048, 2048)),     # BASELINE configs[4] shape
+    dict(low=(4, 256, 256), S=1024, inp=(768, 1024), crop=[0, 0, 512, 384], orig=(384, 512)),           # downscale, padded input
+    dict(low=(4, 64, 64), S=256, inp=(200, 256), crop=[30, 20, 30 + 333, 20 + 260], orig=(300, 400)),   # crop inside a larger frame
+    dict(low=(3, 64, 64), S=256, inp=(256, 190), crop=[0, 7, 95, 7 + 128], orig=(135, 95)),             # crop flush with three frame edges
+    dict(low=(3, 32, 32), S=128, inp=(128, 128), crop=[0, 0, 70, 70], orig=(70, 70)),                   # partial 64-row block
+])
+def test_fused_postprocess_equals_the_helper_chain(case):
+    """postprocess_low_res == postprocess_masks -> calculate_stability_score -> threshold -> batched_mask_to_box -> uncrop_masks ->
+    mask_to_rle_pytorch, the chain the reference's helpers were written for."""
+    from ullsam_amd import ops
+    from ullsam_amd.utils import amg as A
+    rng = np.random.default_rng(7)
+    m, lh, lw = case["low"]
+    low = T(_smooth_logits(rng, m, lh, lw))
+    low[0] = -5.0                                     # empty mask
+    low[1] = 5.0                                      # full mask
+    S, inp, crop, orig = case["S"], case["inp"], case["crop"], case["orig"]
+    ch, cw = crop[3] - crop[1], crop[2] - crop[0]
+    thr, off = 0.0, 0.5
+    up, _ = ops.resize_bilinear(low, (S, S))
+    logits, _ = ops.resize_bilinear(up, (ch, cw), valid_hw=inp)
+    stab = A.calculate_stability_score(logits, thr, off).cpu().numpy()
+    binm = A.threshold_masks(logits, thr)
+    boxes = A.batched_mask_to_box(binm).cpu().numpy()
+    rles = A.mask_to_rle_pytorch(A.uncrop_masks(binm, crop, orig[0], orig[1]))
+    pp = A.postprocess_low_res(low, S, inp, crop, orig, thr, off)
+    assert np.array_equal(pp.boxes, boxes)
+    assert np.array_equal(pp.stability_score, stab, equal_nan=True)
+    got = pp.rles(np.arange(m))
+    for a, b in zip(got, rles):
+        assert a == b
+    sub = pp.rles([m - 1, 1])
+    assert sub[0] == rles[m - 1] and sub[1] == rles[1]
+    # and against the numpy oracle (independent arithmetic: border pixels may flip)
+    ref = O.bilinear_resize(O.bilinear_resize(low.cpu().numpy(), (S, S))[..., :inp[0], :inp[1]], (ch, cw)) > thr
+    for i in range(m):
+        full = np.zeros(orig, bool)
+        full[crop[1]:crop[3], crop[0]:crop[2]] = ref[i]
+        assert (AO.rle_to_mask(got[i]) != full).mean() < 1e-4
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_generator_matches_numpy_flow_over_the_oracle(fused):
     from ullsam_amd.automatic_mask_generator import SamAutomaticMaskGenerator
     sam, P = _small_sam()
     img = U.rand_image((3, 384, 512), 21, 255.0)
     iou_thr, stab_thr, stab_off, nms_thr, side = -1e3, 0.5, 0.05, 1.0, 6  # random-weight masks are full-image blobs: NMS itself is pinned in test_box_nms_matches_oracle
     gen = SamAutomaticMaskGenerator(sam, points_per_side=side, points_per_batch=20, pred_iou_thresh=iou_thr,
                                     stability_score_thresh=stab_thr, stability_score_offset=stab_off, box_nms_thresh=nms_thr,
-                                    output_mode="uncompressed_rle")
+                                    output_mode="uncompressed_rle", fused_postprocess=fused)
     got = gen.generate(torch.from_numpy(img))
     # ---- the same flow in numpy over the oracle
     h, w = 384, 512
@@ -180,3 +229,20 @@ def test_generator_with_crops_invariants():
         iou = iw * ih / np.maximum(AO.box_area(kb)[i] + AO.box_area(kb) - iw * ih, 1e-9)
         iou[i] = 0
         assert (iou <= 0.7 + 1e-6).all()
+
+
+def test_generator_fused_and_helper_chain_agree_with_crops():
+    """crop_n_layers=1 (five crops, masks uncropped into the frame): the fused post-processing path and the helper chain return the
+    same records."""
+    from ullsam_amd.automatic_mask_generator import SamAutomaticMaskGenerator
+    sam, _ = _small_sam()
+    img = torch.from_numpy(U.rand_image((3, 600, 800), 22, 255.0))
+    kw = dict(points_per_side=4, points_per_batch=64, pred_iou_thresh=-1e3, stability_score_thresh=0.5, stability_score_offset=0.05,
+              crop_n_layers=1, crop_n_points_downscale_factor=2, output_mode="uncompressed_rle")
+    a = SamAutomaticMaskGenerator(sam, fused_postprocess=True, **kw).generate(img)
+    b = SamAutomaticMaskGenerator(sam, fused_postprocess=False, **kw).generate(img)
+    assert len(a) == len(b) > 0
+    for ra, rb in zip(a, b):
+        assert ra["segmentation"] == rb["segmentation"] and ra["bbox"] == rb["bbox"] and ra["area"] == rb["area"]
+        assert ra["crop_box"] == rb["crop_box"] and ra["point_coords"] == rb["point_coords"]
+        assert ra["stability_score"] == rb["stability_score"] and ra["predicted_iou"] == rb["predicted_iou"]

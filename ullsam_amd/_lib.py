@@ -43,7 +43,8 @@ SIGNATURES = {
     "ullsam_stability_score": [vp, i64, i64, f32, f32, vp, vp, vp],
     "ullsam_mask_to_box": [vp, i64, i32, i32, vp, vp],
     "ullsam_rle_pack": [vp, i64, i32, i32, vp, vp, vp, vp],
-    "ullsam_rle_emit": [vp, i64, i32, i32, vp, vp, vp],
+    "ullsam_rle_emit": [vp, vp, i64, i32, i32, vp, vp, vp],
+    "ullsam_amg_postprocess": [vp, vp, i64] + [i32] * 11 + [f32, f32, vp, vp, vp, vp, vp, vp],
     "ullsam_nms_mask": [vp, i32, f32, vp, vp],
     "ullsam_threshold_u8": [vp, vp, i64, f32, vp],
 }

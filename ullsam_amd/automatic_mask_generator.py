@@ -11,7 +11,10 @@ flow over the oracle (tests/test_amg_gpu.py).
 Deviations, stated: images are resized with the bilinear kernel (align_corners=False, no antialias) instead of PIL's antialiased
 uint8 resize; `min_mask_region_area` post-processing needs OpenCV and is not available; the predicted-IoU filter is applied before
 the masks are upsampled (it depends only on the IoU head, so the surviving set is identical, and the 3x1024^2-per-prompt logits of
-rejected masks are never materialised).
+rejected masks are never materialised).  With `fused_postprocess=True` (default) the upsample, stability score, mask->box and RLE
+steps of a batch run as one kernel over the low-res logits (`utils.amg.postprocess_low_res`): the full-resolution fp32 logits and
+uint8 masks (16 + 4 MiB per mask on a 2048^2 tile) are never written; `fused_postprocess=False` calls the reference's helpers
+one after the other.  Both produce the same records.
 """
 from __future__ import annotations
 
@@ -29,7 +32,7 @@ class SamAutomaticMaskGenerator:
                  stability_score_thresh: float = 0.95, stability_score_offset: float = 1.0, box_nms_thresh: float = 0.7,
                  crop_n_layers: int = 0, crop_nms_thresh: float = 0.7, crop_overlap_ratio: float = 512 / 1500,
                  crop_n_points_downscale_factor: int = 1, point_grids: Optional[List[np.ndarray]] = None,
-                 min_mask_region_area: int = 0, output_mode: str = "binary_mask") -> None:
+                 min_mask_region_area: int = 0, output_mode: str = "binary_mask", fused_postprocess: bool = True) -> None:
         assert (points_per_side is None) != (point_grids is None), "Exactly one of points_per_side or point_grid must be provided."
         self.point_grids = (A.build_all_layer_point_grids(points_per_side, crop_n_layers, crop_n_points_downscale_factor)
                             if points_per_side is not None else point_grids)
@@ -46,6 +49,7 @@ class SamAutomaticMaskGenerator:
         self.crop_nms_thresh = crop_nms_thresh
         self.crop_overlap_ratio = crop_overlap_ratio
         self.output_mode = output_mode
+        self.fused_postprocess = fused_postprocess
 
     # -- image side --------------------------------------------------------------------------------------------------
     def _encode(self, crop: torch.Tensor):
@@ -77,6 +81,8 @@ class SamAutomaticMaskGenerator:
         low, iou = low[:, 1:], iou[:, 1:]                              # multimask_output=True (mask_decoder.py:100-105)
         n, k = iou.shape
         flat_iou = iou.reshape(-1)
+        if self.fused_postprocess:
+            return self._finish_batch_fused(low.reshape(n * k, low.shape[-2], low.shape[-1]), flat_iou, pts, k, input_size, crop_box, orig_size)
         keep = flat_iou > self.pred_iou_thresh
         idx = torch.nonzero(keep).reshape(-1)
         data = A.MaskData(iou_preds=flat_iou[idx], points=pts.repeat_interleave(k, dim=0)[idx])
@@ -101,6 +107,30 @@ class SamAutomaticMaskGenerator:
             data.filter(k3)
             binm = binm[k3]
         data["rles"] = A.mask_to_rle_pytorch(A.uncrop_masks(binm, crop_box, orig_h, orig_w))
+        return data
+
+    def _finish_batch_fused(self, low, flat_iou, pts, k, input_size, crop_box, orig_size) -> A.MaskData:
+        """The filters of `_process_batch` on host copies of the per-mask scalars, after one fused device pass over all maps."""
+        sam = self.model
+        dev = low.device
+        pp = A.postprocess_low_res(low, sam.image_encoder.img_size, input_size, crop_box, orig_size, sam.mask_threshold,
+                                   self.stability_score_offset)
+        iou_h = flat_iou.float().cpu().numpy()
+        keep = (iou_h > np.float32(self.pred_iou_thresh)) & (pp.stability_score >= np.float32(self.stability_score_thresh))
+        sel = np.nonzero(keep)[0]
+        boxes = pp.boxes[sel]
+        if len(sel):
+            orig_h, orig_w = orig_size
+            b = (boxes + np.asarray([crop_box[0], crop_box[1], crop_box[0], crop_box[1]])).astype(np.float32)
+            near_crop = np.abs(b - np.asarray(crop_box, np.float32)[None, :]) <= 20.0                      # is_box_near_crop_edge
+            near_image = np.abs(b - np.asarray([0, 0, orig_w, orig_h], np.float32)[None, :]) <= 20.0
+            ok = ~np.logical_and(near_crop, ~near_image).any(axis=1)
+            sel, boxes = sel[ok], boxes[ok]
+        sel_d = torch.from_numpy(sel).to(dev)
+        data = A.MaskData(iou_preds=flat_iou[sel_d], points=pts.repeat_interleave(k, dim=0)[sel_d],
+                          stability_score=torch.from_numpy(pp.stability_score[sel]).to(dev),
+                          boxes=torch.from_numpy(boxes.reshape(-1, 4)).to(dev))
+        data["rles"] = pp.rles(sel) if len(sel) else []
         return data
 
     def _process_crop(self, image: torch.Tensor, crop_box, layer_idx: int, orig_size) -> A.MaskData:

@@ -201,11 +201,12 @@ __global__ __launch_bounds__(256) void rle_pack_kernel(const unsigned char* __re
 
 // One workgroup per mask: ordered emission of the change positions from the change words (see rle_pack_kernel).
 __global__ __launch_bounds__(256) void rle_emit_kernel(const unsigned long long* __restrict__ words, int H, int W, int nyb,
-                                                       const long* __restrict__ offsets, int* __restrict__ out) {
+                                                       const int* __restrict__ select, const long* __restrict__ offsets,
+                                                       int* __restrict__ out) {
     __shared__ int wsum[2][4];
-    const long n = blockIdx.x;
+    const long n = select ? select[blockIdx.x] : blockIdx.x;
     const unsigned long long* wp = words + n * (long)nyb * W;
-    int* dst = out + offsets[n];
+    int* dst = out + offsets[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long total = (long)W * nyb;
     int base = 0, par = 0;
@@ -261,10 +262,198 @@ extern "C" int ullsam_rle_pack(const unsigned char* masks, long N, int H, int W,
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
-// offsets i64 [N]: exclusive prefix of counts; out int32 [sum(counts)]: change positions f (t[f] != t[f+1]), ordered per mask.
-extern "C" int ullsam_rle_emit(const unsigned long long* words, long N, int H, int W, const long* offsets, int* out, void* stream) {
+// select int32 [N]: which masks of `words` to emit (NULL = 0..N-1); offsets i64 [N]: exclusive prefix of the selected masks'
+// counts; out int32 [sum(counts)]: change positions f (t[f] != t[f+1]), ordered per mask.
+extern "C" int ullsam_rle_emit(const unsigned long long* words, const int* select, long N, int H, int W, const long* offsets, int* out,
+                               void* stream) {
     if (N == 0) return 0;
-    rle_emit_kernel<<<(unsigned)N, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(words, H, W, (H + 63) / 64, offsets, out);
+    rle_emit_kernel<<<(unsigned)N, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(words, H, W, (H + 63) / 64, select, offsets, out);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- fused mask post-processing for the generator ---------------------------------------------------------------------
+// For every low-res logit map: Sam.postprocess_masks (sam.py:154-162: bilinear to S1 x S1, crop to (nh, nw), bilinear to the crop
+// size (CH, CW)) evaluated on the fly, never written; from the virtual CH x CW logits v the kernel derives, in one pass,
+//   * calculate_stability_score's two counts  #(v > thr+off), #(v > thr-off)                       (amg.py:156-176)
+//   * batched_mask_to_box of (v > thr), in crop coordinates                                         (amg.py:303-346)
+//   * the change words of mask_to_rle_pytorch(uncrop_masks(v > thr, crop_box, FH, FW))              (amg.py:107-135, 251-264)
+// so the 4 B/pixel logits and 1 B/pixel masks of the separate helpers (12288 masks x 16 MiB per 2048^2 tile) are replaced by
+// 1 bit/pixel of change words.  A wave owns 64 frame rows x 64 frame columns (lane = column); the row taps are wave-uniform, so
+// the x-interpolated low-res rows and intermediate rows are memoised in registers (two slots each) while the wave walks down.
+struct Tap { int i0, i1; float l; };
+__device__ inline Tap tap_of(int o, float scale, int n_in) {
+    float f = ((float)o + 0.5f) * scale - 0.5f;
+    if (f < 0.f) f = 0.f;
+    Tap t;
+    t.i0 = min((int)f, n_in - 1);
+    t.i1 = min(t.i0 + 1, n_in - 1);
+    t.l = f - (float)t.i0;
+    return t;
+}
+__device__ inline Tap utap_of(int o, float scale, int n_in) {  // wave-uniform argument -> scalar indices
+    Tap t = tap_of(o, scale, n_in);
+    t.i0 = __builtin_amdgcn_readfirstlane(t.i0);
+    t.i1 = __builtin_amdgcn_readfirstlane(t.i1);
+    return t;
+}
+struct PostGeom { int LH, LW, S1, nh, nw, CH, CW, FH, FW, cx0, cy0; float s1y, s1x, s2y, s2x; };
+
+__device__ inline float post_eval(const float* __restrict__ lowp, const PostGeom& g, int y, int x) {  // one pixel, no memo
+    const Tap ty = tap_of(y, g.s2y, g.nh), tx = tap_of(x, g.s2x, g.nw);
+    float h[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int iy = a ? ty.i1 : ty.i0;
+        const Tap r = tap_of(iy, g.s1y, g.LH);
+        float iv[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const Tap c = tap_of(b ? tx.i1 : tx.i0, g.s1x, g.LW);
+            const float top = lowp[(long)r.i0 * g.LW + c.i0] * (1.f - c.l) + lowp[(long)r.i0 * g.LW + c.i1] * c.l;
+            const float bot = lowp[(long)r.i1 * g.LW + c.i0] * (1.f - c.l) + lowp[(long)r.i1 * g.LW + c.i1] * c.l;
+            iv[b] = top * (1.f - r.l) + bot * r.l;
+        }
+        h[a] = iv[0] * (1.f - tx.l) + iv[1] * tx.l;
+    }
+    return h[0] * (1.f - ty.l) + h[1] * ty.l;
+}
+
+__global__ __launch_bounds__(256) void amg_postprocess_kernel(const float* __restrict__ low, const int* __restrict__ index, PostGeom g,
+                                                              float thr, float off, unsigned long long* __restrict__ words,
+                                                              int* __restrict__ rle_counts, unsigned char* __restrict__ first,
+                                                              int* __restrict__ boxes, unsigned int* __restrict__ stab) {
+    const long n = blockIdx.z;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nyb = (g.FH + 63) >> 6;
+    const int yb = blockIdx.y * 4 + wv;
+    if (yb >= nyb) return;
+    const float* lowp = low + (long)(index ? index[n] : n) * g.LH * g.LW;
+    const int xf = blockIdx.x * 64 + lane;            // frame column
+    const int ys = yb * 64;
+    const int r = min(64, g.FH - ys);                 // frame rows in this block
+    const int x = xf - g.cx0;                         // crop column
+    const bool col_in = xf < g.FW && x >= 0 && x < g.CW;
+    const int xc = min(max(x, 0), g.CW - 1);
+    const Tap tx = tap_of(xc, g.s2x, g.nw);
+    const Tap t0 = tap_of(tx.i0, g.s1x, g.LW), t1 = tap_of(tx.i1, g.s1x, g.LW);
+    const float hi = thr + off, lo = thr - off;
+
+    float ga0 = 0, ga1 = 0, gb0 = 0, gb1 = 0, ha = 0, hb = 0;
+    int gka = -1, gkb = -1, hka = -1, hkb = -1;      // memo keys (wave-uniform): low-res row / intermediate row
+    auto get_g = [&](int lr, float& o0, float& o1) {
+        if (lr == gka) { o0 = ga0; o1 = ga1; return; }
+        if (lr == gkb) { o0 = gb0; o1 = gb1; return; }
+        const float* row = lowp + (long)lr * g.LW;
+        const float a = row[t0.i0] * (1.f - t0.l) + row[t0.i1] * t0.l;
+        const float b = row[t1.i0] * (1.f - t1.l) + row[t1.i1] * t1.l;
+        if (gka <= gkb) { gka = lr; ga0 = a; ga1 = b; } else { gkb = lr; gb0 = a; gb1 = b; }
+        o0 = a; o1 = b;
+    };
+    auto get_h = [&](int iy) -> float {
+        if (iy == hka) return ha;
+        if (iy == hkb) return hb;
+        const Tap rr = utap_of(iy, g.s1y, g.LH);
+        float p0, p1, q0, q1;
+        get_g(rr.i0, p0, p1);
+        get_g(rr.i1, q0, q1);
+        const float i0 = p0 * (1.f - rr.l) + q0 * rr.l, i1 = p1 * (1.f - rr.l) + q1 * rr.l;
+        const float h = i0 * (1.f - tx.l) + i1 * tx.l;
+        if (hka <= hkb) { hka = iy; ha = h; } else { hkb = iy; hb = h; }
+        return h;
+    };
+    auto value = [&](int yc) -> float {               // crop row yc (wave-uniform), this lane's column
+        const Tap ty = utap_of(yc, g.s2y, g.nh);
+        const float h0 = get_h(ty.i0), h1 = get_h(ty.i1);
+        return h0 * (1.f - ty.l) + h1 * ty.l;
+    };
+
+    unsigned long long wm = 0, whi = 0, wlo = 0;
+    for (int half = 0; half < 2; ++half) {
+        unsigned int am = 0, ah = 0, al = 0;
+        for (int i = 0; i < 32; ++i) {
+            const int row = half * 32 + i;
+            if (row >= r) break;
+            const int yc = ys + row - g.cy0;
+            if (yc < 0 || yc >= g.CH) continue;
+            const float v = value(yc);
+            am |= (unsigned int)(v > thr) << i;
+            ah |= (unsigned int)(v > hi) << i;
+            al |= (unsigned int)(v > lo) << i;
+        }
+        wm |= (unsigned long long)am << (32 * half);
+        whi |= (unsigned long long)ah << (32 * half);
+        wlo |= (unsigned long long)al << (32 * half);
+    }
+    if (!col_in) { wm = 0; whi = 0; wlo = 0; }
+    // the element after this word in the frame's Fortran order
+    unsigned int nb = 0;
+    bool has_next = true;
+    if (ys + r < g.FH) {
+        const int yc = ys + r - g.cy0;
+        if (yc >= 0 && yc < g.CH) { const float v = value(yc); nb = col_in && v > thr; }
+    } else if (xf + 1 < g.FW) {
+        const int x2 = xf + 1 - g.cx0;
+        if (g.cy0 == 0 && x2 >= 0 && x2 < g.CW) nb = post_eval(lowp, g, 0, x2) > thr;
+    } else {
+        has_next = false;
+    }
+    const unsigned long long keep = r == 64 ? ~0ull : ((1ull << r) - 1ull);
+    unsigned long long ch = (wm ^ ((wm >> 1) | ((unsigned long long)nb << (r - 1)))) & keep;
+    if (!has_next) ch &= ~(1ull << (r - 1));
+    if (xf < g.FW) words[((long)n * nyb + yb) * g.FW + xf] = ch;
+    if (xf == 0 && yb == 0) first[n] = (unsigned char)(wm & 1ull);
+
+    int cnt = xf < g.FW ? __popcll(ch) : 0;
+    unsigned int ca = __popcll(whi), cb = __popcll(wlo);
+    int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
+    if (wm) {
+        x0 = x1 = x;
+        y0 = ys - g.cy0 + __builtin_ctzll(wm);
+        y1 = ys - g.cy0 + 63 - __builtin_clzll(wm);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_xor(cnt, o, 64); ca += __shfl_xor(ca, o, 64); cb += __shfl_xor(cb, o, 64);
+        x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
+        x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
+    }
+    if (lane == 0) {
+        if (cnt) atomicAdd(&rle_counts[n], cnt);
+        if (ca) atomicAdd(&stab[2 * n], ca);
+        if (cb) atomicAdd(&stab[2 * n + 1], cb);
+        if (x1 >= 0) {
+            atomicMin(&boxes[4 * n + 0], x0); atomicMin(&boxes[4 * n + 1], y0);
+            atomicMax(&boxes[4 * n + 2], x1); atomicMax(&boxes[4 * n + 3], y1);
+        }
+    }
+}
+
+// low f32 [*, LH, LW]; index int32 [M] rows of `low` to process (NULL = 0..M-1); S1 = Sam.image_encoder.img_size; (nh, nw) =
+// input_size; (CH, CW) = crop size; the crop sits at (cx0, cy0) of the FH x FW frame.  Outputs: words u64 [M, ceil(FH/64), FW],
+// rle_counts int [M], first u8 [M], boxes int [M,4] (crop coordinates, zeros when empty), stab u32 [M,2].
+extern "C" int ullsam_amg_postprocess(const float* low, const int* index, long M, int LH, int LW, int S1, int nh, int nw, int CH,
+                                      int CW, int FH, int FW, int cx0, int cy0, float mask_threshold, float threshold_offset,
+                                      unsigned long long* words, int* rle_counts, unsigned char* first, int* boxes,
+                                      unsigned int* stab, void* stream) {
+    if (M == 0) return 0;
+    ULLSAM_CHECK(LH > 0 && LW > 0 && S1 > 0 && nh > 0 && nw > 0 && nh <= S1 && nw <= S1 && CH > 0 && CW > 0, "amg_postprocess: bad sizes");
+    ULLSAM_CHECK(cx0 >= 0 && cy0 >= 0 && cx0 + CW <= FW && cy0 + CH <= FH && (long)FH * FW < (1L << 31), "amg_postprocess: crop outside the frame");
+    ULLSAM_CHECK(((uintptr_t)boxes & 15) == 0, "amg_postprocess: boxes must be 16-byte aligned");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(rle_counts, 0, sizeof(int) * M, s) != hipSuccess || hipMemsetAsync(stab, 0, sizeof(unsigned int) * 2 * M, s) != hipSuccess) {
+        ullsam_set_error("amg_postprocess: memset failed");
+        return -2;
+    }
+    box_init_kernel<<<(unsigned)((M + 255) / 256), 256, 0, s>>>(boxes, M);
+    ULLSAM_LAUNCH_CHECK();
+    PostGeom g;
+    g.LH = LH; g.LW = LW; g.S1 = S1; g.nh = nh; g.nw = nw; g.CH = CH; g.CW = CW; g.FH = FH; g.FW = FW; g.cx0 = cx0; g.cy0 = cy0;
+    g.s1y = (float)LH / (float)S1; g.s1x = (float)LW / (float)S1; g.s2y = (float)nh / (float)CH; g.s2x = (float)nw / (float)CW;
+    const int nyb = (FH + 63) / 64;
+    amg_postprocess_kernel<<<dim3((unsigned)((FW + 63) / 64), (unsigned)((nyb + 3) / 4), (unsigned)M), 256, 0, s>>>(
+        low, index, g, mask_threshold, threshold_offset, words, rle_counts, first, boxes, stab);
+    ULLSAM_LAUNCH_CHECK();
+    box_finish_kernel<<<(unsigned)((M + 255) / 256), 256, 0, s>>>(boxes, M);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }

@@ -212,6 +212,28 @@ def batched_mask_to_box(masks: torch.Tensor) -> torch.Tensor:
     return out.reshape(*masks.shape[:-2], 4) if masks.dim() > 2 else out[0]
 
 
+def _rles_from_words(words: torch.Tensor, select, counts: np.ndarray, first: np.ndarray, h: int, w: int) -> List[Dict[str, Any]]:
+    """Change words [M, ceil(h/64), w] -> RLE dicts of the masks `select` (None = all), given their change counts / first bits."""
+    b = len(counts)
+    if b == 0:
+        return []
+    dev = words.device
+    c = np.asarray(counts, dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(c)])
+    pos = torch.empty((max(int(offs[-1]), 1),), dtype=torch.int32, device=dev)
+    offs_d = torch.from_numpy(offs[:-1].copy()).to(dev)
+    sel_d = None if select is None else torch.as_tensor(np.asarray(select, dtype=np.int32), device=dev)
+    _lib.call("ullsam_rle_emit", words.data_ptr(), None if sel_d is None else sel_d.data_ptr(), b, h, w, offs_d.data_ptr(),
+              pos.data_ptr(), _stream())
+    pos_h = pos.cpu().numpy().astype(np.int64)
+    out = []
+    for i in range(b):
+        edges = np.concatenate([[0], pos_h[offs[i]:offs[i + 1]] + 1, [h * w]])
+        runs = (edges[1:] - edges[:-1]).tolist()
+        out.append({"size": [h, w], "counts": ([0] if first[i] else []) + runs})
+    return out
+
+
 def mask_to_rle_pytorch(tensor: torch.Tensor) -> List[Dict[str, Any]]:
     """Uncompressed column-major RLE per mask, pycocotools layout (amg.py:107-135).  One coalesced pass packs the mask into per-column
     change words, a second emits the ordered change positions; the run lengths are their differences."""
@@ -219,23 +241,49 @@ def mask_to_rle_pytorch(tensor: torch.Tensor) -> List[Dict[str, Any]]:
     b, h, w = m.shape
     if b == 0:
         return []
-    nyb = (h + 63) // 64
-    words = torch.empty((b, nyb, w), dtype=torch.int64, device=m.device)
+    words = torch.empty((b, (h + 63) // 64, w), dtype=torch.int64, device=m.device)
     counts = torch.empty((b,), dtype=torch.int32, device=m.device)
     first = torch.empty((b,), dtype=torch.uint8, device=m.device)
     _lib.call("ullsam_rle_pack", m.data_ptr(), b, h, w, words.data_ptr(), counts.data_ptr(), first.data_ptr(), _stream())
-    c = counts.cpu().numpy().astype(np.int64)
-    offs = np.concatenate([[0], np.cumsum(c)])
-    pos = torch.empty((max(int(offs[-1]), 1),), dtype=torch.int32, device=m.device)
-    offs_d = torch.from_numpy(offs[:-1].copy()).to(m.device)
-    _lib.call("ullsam_rle_emit", words.data_ptr(), b, h, w, offs_d.data_ptr(), pos.data_ptr(), _stream())
-    pos_h, first_h = pos.cpu().numpy().astype(np.int64), first.cpu().numpy()
-    out = []
-    for i in range(b):
-        edges = np.concatenate([[0], pos_h[offs[i]:offs[i + 1]] + 1, [h * w]])
-        runs = (edges[1:] - edges[:-1]).tolist()
-        out.append({"size": [h, w], "counts": ([0] if first_h[i] else []) + runs})
-    return out
+    return _rles_from_words(words, None, counts.cpu().numpy(), first.cpu().numpy(), h, w)
+
+
+class PostprocessedMasks:
+    """Result of `postprocess_low_res`: per low-res map the stability counts, the box (crop coordinates), and the RLE change words
+    of the mask placed in the full frame; `rles(select)` finishes the RLE of the chosen maps."""
+
+    def __init__(self, words, rle_counts, first, boxes, stab, frame):
+        self.words, self.frame = words, frame
+        self.rle_counts, self.first = rle_counts.cpu().numpy(), first.cpu().numpy()
+        self.boxes = boxes.cpu().numpy().astype(np.int64)
+        st = stab.cpu().numpy().view(np.int32)
+        with np.errstate(divide="ignore", invalid="ignore"):  # int32 / int32 true division -> fp32, as calculate_stability_score
+            self.stability_score = st[:, 0].astype(np.float32) / st[:, 1].astype(np.float32)
+
+    def rles(self, select) -> List[Dict[str, Any]]:
+        select = np.asarray(select, dtype=np.int64)
+        return _rles_from_words(self.words, select, self.rle_counts[select], self.first[select], self.frame[0], self.frame[1])
+
+
+def postprocess_low_res(low: torch.Tensor, img_size: int, input_size, crop_box, orig_size, mask_threshold: float,
+                        threshold_offset: float) -> PostprocessedMasks:
+    """Generator fast path over low-res logits [M, h, w]: Sam.postprocess_masks (sam.py:154-162) + calculate_stability_score +
+    batched_mask_to_box + mask_to_rle_pytorch(uncrop_masks(...)) fused in one kernel; the full-resolution logits and masks are never
+    written.  Equivalent to calling those helpers one after the other (same arithmetic per pixel)."""
+    low = _chk(low.float().contiguous(), "low_res_masks", torch.float32)
+    M, lh, lw = low.shape
+    x0, y0, x1, y1 = (int(v) for v in crop_box)
+    fh, fw = int(orig_size[0]), int(orig_size[1])
+    dev = low.device
+    words = torch.empty((M, (fh + 63) // 64, fw), dtype=torch.int64, device=dev)
+    rle_counts = torch.empty((M,), dtype=torch.int32, device=dev)
+    first = torch.empty((M,), dtype=torch.uint8, device=dev)
+    boxes = torch.empty((M, 4), dtype=torch.int32, device=dev)
+    stab = torch.empty((M, 2), dtype=torch.int32, device=dev)
+    _lib.call("ullsam_amg_postprocess", low.data_ptr(), None, M, lh, lw, int(img_size), int(input_size[0]), int(input_size[1]),
+              y1 - y0, x1 - x0, fh, fw, x0, y0, float(mask_threshold), float(threshold_offset), words.data_ptr(),
+              rle_counts.data_ptr(), first.data_ptr(), boxes.data_ptr(), stab.data_ptr(), _stream())
+    return PostprocessedMasks(words, rle_counts, first, boxes, stab, (fh, fw))
 
 
 def box_nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
