@@ -130,7 +130,7 @@ class SamAutomaticMaskGenerator:
         data = A.MaskData(iou_preds=flat_iou[sel_d], points=pts.repeat_interleave(k, dim=0)[sel_d],
                           stability_score=torch.from_numpy(pp.stability_score[sel]).to(dev),
                           boxes=torch.from_numpy(boxes.reshape(-1, 4)).to(dev))
-        data["rles"] = pp.rles(sel) if len(sel) else []
+        data["rles"] = pp.rles(sel, as_list=False) if len(sel) else []
         return data
 
     def _process_crop(self, image: torch.Tensor, crop_box, layer_idx: int, orig_size) -> A.MaskData:
@@ -139,7 +139,7 @@ class SamAutomaticMaskGenerator:
         pts = self.point_grids[layer_idx] * np.array([[x1 - x0, y1 - y0]], dtype=np.float64)
         data = A.MaskData()
         for (p,) in A.batch_iterator(self.points_per_batch, pts):
-            data.cat(self._process_batch(p, img_tok, input_size, crop_box, orig_size))
+            data.cat(self._process_batch(p, img_tok, input_size, crop_box, orig_size), deep=False)
         if len(data["rles"]):
             keep = A.batched_nms(data["boxes"].float(), data["iou_preds"], torch.zeros_like(data["boxes"][:, 0]), self.box_nms_thresh)
             data.filter(keep)
@@ -159,7 +159,7 @@ class SamAutomaticMaskGenerator:
         crop_boxes, layer_idxs = A.generate_crop_boxes(orig_size, self.crop_n_layers, self.crop_overlap_ratio)
         data = A.MaskData()
         for crop_box, layer_idx in zip(crop_boxes, layer_idxs):
-            data.cat(self._process_crop(image, crop_box, layer_idx, orig_size))
+            data.cat(self._process_crop(image, crop_box, layer_idx, orig_size), deep=False)
         if len(crop_boxes) > 1 and len(data["rles"]):
             cb = data["crop_boxes"].float()
             scores = 1.0 / ((cb[:, 2] - cb[:, 0]) * (cb[:, 3] - cb[:, 1]))  # prefer masks from smaller crops
@@ -168,6 +168,8 @@ class SamAutomaticMaskGenerator:
         data.to_numpy()
         out = []
         for i, rle in enumerate(data["rles"]):
+            if not isinstance(rle["counts"], list):
+                rle = {"size": rle["size"], "counts": rle["counts"].tolist()}
             seg = A.rle_to_mask(rle) if self.output_mode == "binary_mask" else rle
             out.append({"segmentation": seg, "area": A.area_from_rle(rle), "bbox": A.box_xyxy_to_xywh(data["boxes"][i]).tolist(),
                         "predicted_iou": float(data["iou_preds"][i]), "point_coords": [data["points"][i].tolist()],

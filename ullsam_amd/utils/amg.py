@@ -55,10 +55,14 @@ class MaskData:
             else:
                 raise TypeError(f"MaskData key {k} has an unsupported type {type(v)}.")
 
-    def cat(self, other: "MaskData") -> None:
+    def cat(self, other: "MaskData", deep: bool = True) -> None:
+        """`deep=False` skips the reference's element-wise deepcopy of list fields (the generator never mutates a batch after
+        concatenating it; deep-copying 12288 RLE records per tile costs more than the GPU work)."""
         for k, v in other.items():
             cur = self._stats.get(k)
-            if cur is None:
+            if isinstance(v, list) and not deep:
+                self._stats[k] = list(v) if cur is None else cur + v
+            elif cur is None:
                 self._stats[k] = deepcopy(v)
             elif isinstance(v, torch.Tensor):
                 self._stats[k] = torch.cat([cur, v], dim=0)
@@ -151,7 +155,7 @@ def is_box_near_crop_edge(boxes: torch.Tensor, crop_box: List[int], orig_box: Li
     return torch.from_numpy(np.logical_and(near_crop, ~near_image).any(axis=1)).to(boxes.device)
 
 
-def rle_to_mask(rle: Dict[str, Any]) -> np.ndarray:
+def rle_to_mask(rle: Dict[str, Any]) -> np.ndarray:  # `counts` may be a list (reference format) or an integer array
     h, w = rle["size"]
     counts = np.asarray(rle["counts"], dtype=np.int64)
     flat = np.repeat(np.arange(len(counts)) % 2 == 1, counts)  # runs alternate 0,1,0,... starting with a 0-run
@@ -159,7 +163,7 @@ def rle_to_mask(rle: Dict[str, Any]) -> np.ndarray:
 
 
 def area_from_rle(rle: Dict[str, Any]) -> int:
-    return int(sum(rle["counts"][1::2]))
+    return int(np.sum(np.asarray(rle["counts"][1::2], dtype=np.int64)))
 
 
 def remove_small_regions(mask: np.ndarray, area_thresh: float, mode: str):
@@ -212,8 +216,10 @@ def batched_mask_to_box(masks: torch.Tensor) -> torch.Tensor:
     return out.reshape(*masks.shape[:-2], 4) if masks.dim() > 2 else out[0]
 
 
-def _rles_from_words(words: torch.Tensor, select, counts: np.ndarray, first: np.ndarray, h: int, w: int) -> List[Dict[str, Any]]:
-    """Change words [M, ceil(h/64), w] -> RLE dicts of the masks `select` (None = all), given their change counts / first bits."""
+def _rles_from_words(words: torch.Tensor, select, counts: np.ndarray, first: np.ndarray, h: int, w: int,
+                     as_list: bool = True) -> List[Dict[str, Any]]:
+    """Change words [M, ceil(h/64), w] -> RLE dicts of the masks `select` (None = all), given their change counts / first bits.
+    `as_list=False` leaves `counts` as int64 arrays (the generator converts only the records that survive NMS)."""
     b = len(counts)
     if b == 0:
         return []
@@ -228,9 +234,9 @@ def _rles_from_words(words: torch.Tensor, select, counts: np.ndarray, first: np.
     pos_h = pos.cpu().numpy().astype(np.int64)
     out = []
     for i in range(b):
-        edges = np.concatenate([[0], pos_h[offs[i]:offs[i + 1]] + 1, [h * w]])
-        runs = (edges[1:] - edges[:-1]).tolist()
-        out.append({"size": [h, w], "counts": ([0] if first[i] else []) + runs})
+        edges = np.concatenate([[0, 0] if first[i] else [0], pos_h[offs[i]:offs[i + 1]] + 1, [h * w]])
+        runs = edges[1:] - edges[:-1]
+        out.append({"size": [h, w], "counts": runs.tolist() if as_list else runs})
     return out
 
 
@@ -260,9 +266,9 @@ class PostprocessedMasks:
         with np.errstate(divide="ignore", invalid="ignore"):  # int32 / int32 true division -> fp32, as calculate_stability_score
             self.stability_score = st[:, 0].astype(np.float32) / st[:, 1].astype(np.float32)
 
-    def rles(self, select) -> List[Dict[str, Any]]:
+    def rles(self, select, as_list: bool = True) -> List[Dict[str, Any]]:
         select = np.asarray(select, dtype=np.int64)
-        return _rles_from_words(self.words, select, self.rle_counts[select], self.first[select], self.frame[0], self.frame[1])
+        return _rles_from_words(self.words, select, self.rle_counts[select], self.first[select], self.frame[0], self.frame[1], as_list)
 
 
 def postprocess_low_res(low: torch.Tensor, img_size: int, input_size, crop_box, orig_size, mask_threshold: float,
