@@ -65,9 +65,16 @@ int ullsam_naive_attention(int dtype, const void* q, const void* k, const void* 
                            long k_hs, long v_bs, long v_ts, long v_hs, long o_bs, long o_ts, long o_hs, float scale,
                            void* stream);
 
-/* Image -> token cross attention (many queries, few keys), fp32.  transformer.py:178-181. */
+/* Image -> token cross attention (many queries, few keys), fp32.  transformer.py:178-181.  q_batch_stride (elements) = 0 when
+   all B batches share one query set (layer 0 of the decoder when B prompts look at one image). */
 int ullsam_fewkeys_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int hd, int Sq,
-                             int Sk, float scale, void* stream);
+                             int Sk, float scale, long q_batch_stride, void* stream);
+
+/* Token -> image cross attention (T <= 8 queries, N image keys, 8 heads x 16), K/V streamed once.  transformer.py:160-166,
+   100-106.  k/v in kv_dtype with element batch strides (0 = shared image); workspace f32 [P*nsplit*T*144]. */
+int ullsam_tok2img_attention(int kv_dtype, const float* q, const void* k, const void* v, float* out, int P, int H, int hd, int T,
+                             int N, long k_batch_stride, long v_batch_stride, float scale, float* workspace, int nsplit,
+                             void* stream);
 
 /* ViT / projector data movement */
 int ullsam_patch_im2col(int dtype, const float* pixels, void* out, int B, int C, int Hs, int Ws, int S, int patch,

@@ -173,6 +173,32 @@ def test_naive_and_fewkeys_attention(ops):
     assert err(out.cpu().numpy().reshape(q.shape), ref(q, k, v)) < 1e-5
     out = ops.fewkeys_attention(T(k), T(q), T(q), B, H, hd, Sk, Sq, 1 / math.sqrt(hd))  # image -> tokens
     assert err(out.cpu().numpy().reshape(k.shape), ref(k, q, q)) < 1e-5
+    out = ops.fewkeys_attention(T(k[:1]), T(q), T(q), B, H, hd, Sk, Sq, 1 / math.sqrt(hd), q_shared=True)
+    assert err(out.cpu().numpy().reshape(k.shape), ref(np.repeat(k[:1], B, 0), q, q)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("P,Tq,N", [(1, 7, 4096), (3, 8, 1000), (70, 6, 4096), (2, 1, 64), (5, 7, 130)])
+def test_tok2img_attention(ops, dtype, P, Tq, N):
+    """Token -> image cross attention streamed over the keys (split-K softmax merge), per-prompt and shared K/V."""
+    rng = np.random.default_rng(P * 1000 + Tq)
+    H, hd = 8, 16
+    q = rng.standard_normal((P, Tq, H * hd), dtype=np.float32) * 2
+    k = rng.standard_normal((P, N, H * hd), dtype=np.float32)
+    v = rng.standard_normal((P, N, H * hd), dtype=np.float32)
+    kd, vd = T(k).to(dtype), T(v).to(dtype)
+    kr, vr = kd.float().cpu().numpy(), vd.float().cpu().numpy()
+
+    def ref(q, k, v):
+        sp = lambda x: x.reshape(x.shape[0], x.shape[1], H, hd).transpose(0, 2, 1, 3)
+        a = O.softmax(np.matmul(sp(q), sp(k).transpose(0, 1, 3, 2)) / np.float32(math.sqrt(hd)))
+        return np.matmul(a, sp(v)).transpose(0, 2, 1, 3).reshape(q.shape)
+
+    out = ops.tok2img_attention(T(q).reshape(P * Tq, -1), kd.reshape(P * N, -1), vd.reshape(P * N, -1), P, H, hd, Tq, N, 1 / math.sqrt(hd))
+    assert err(out.cpu().numpy().reshape(q.shape), ref(q, kr, vr)) < 2e-5
+    out = ops.tok2img_attention(T(q).reshape(P * Tq, -1), kd[:1].reshape(N, -1).contiguous(), vd[:1].reshape(N, -1).contiguous(), P, H, hd, Tq, N,
+                                1 / math.sqrt(hd), kv_shared=True)
+    assert err(out.cpu().numpy().reshape(q.shape), ref(q, np.repeat(kr[:1], P, 0), np.repeat(vr[:1], P, 0))) < 2e-5
 
 
 def test_data_movement_kernels(ops):

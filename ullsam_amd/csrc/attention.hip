@@ -645,11 +645,164 @@ extern "C" int ullsam_naive_attention(int dtype, const void* q, const void* k, c
     return 0;
 }
 
+// ---- token -> image cross attention of the two-way decoder (transformer.py:160-166, 100-106) -------------------------
+// Few queries (T <= 8 tokens) against N = 4096 image keys, P prompts: K and V are streamed once, whole rows, fully coalesced
+// (a lane loads 16 B = EPL channels of one head; LPH lanes share a head and reduce the dot product with two DPP shuffles), all
+// T queries of all heads are scored against each loaded row, online softmax per (query, head) in registers.  Keys are split
+// over `nsplit` workgroups per prompt (flash-decoding): each writes (max, sum, unnormalised o), `tok2img_merge_kernel` combines.
+// C = H*16 = 128 only (SAM's decoder); k/v batch stride 0 = one image shared by every prompt.
+template <typename TK> struct KVRow;
+template <> struct KVRow<float> {
+    static constexpr int EPL = 4;
+    static __device__ __forceinline__ void ld(const void* base, long elem, float (&o)[4]) {
+        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+};
+template <> struct KVRow<bf16> {
+    static constexpr int EPL = 8;
+    static __device__ __forceinline__ void ld(const void* base, long elem, float (&o)[8]) {
+        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(base) + elem);
+        const unsigned int d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[2 * j] = __uint_as_float(d[j] << 16); o[2 * j + 1] = __uint_as_float(d[j] & 0xffff0000u); }
+    }
+};
+
+template <typename TK, int TQ>
+__global__ __launch_bounds__(256) void tok2img_partial_kernel(const float* __restrict__ q, const void* __restrict__ k,
+                                                              const void* __restrict__ v, float* __restrict__ ws, int T, int N,
+                                                              long k_bs, long v_bs, float scale, int nsplit) {
+    constexpr int C = 128, HD = 16, H = 8;
+    constexpr int EPL = KVRow<TK>::EPL, LPH = HD / EPL, LPR = C / EPL, RPW = 64 / LPR;  // lanes per head / per row, rows per wave load
+    __shared__ float so[4][TQ][C];
+    __shared__ float sml[4][TQ][H][2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int split = blockIdx.x, pr = blockIdx.y;
+    const int c = lane % LPR, r = lane / LPR;   // channel chunk, row within the wave load
+    const int ch0 = c * EPL, head = ch0 / HD;
+    const int per = (N + nsplit - 1) / nsplit;
+    const int s0 = split * per, s1 = min(N, s0 + per);
+
+    float qf[TQ][EPL];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) qf[t][e] = t < T ? q[((long)pr * T + t) * C + ch0 + e] : 0.f;
+    float m[TQ], l[TQ], o[TQ][EPL];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) {
+        m[t] = -1e30f; l[t] = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[t][e] = 0.f;
+    }
+    const void* kb = reinterpret_cast<const char*>(k) + (long)pr * k_bs * sizeof(TK);
+    const void* vb = reinterpret_cast<const char*>(v) + (long)pr * v_bs * sizeof(TK);
+    for (int row0 = s0 + wv * RPW; row0 < s1; row0 += 4 * RPW) {
+        const int row = row0 + r;
+        const bool valid = row < s1;
+        const long off = (long)min(row, N - 1) * C + ch0;
+        float kf[EPL], vf[EPL];
+        KVRow<TK>::ld(kb, off, kf);
+        KVRow<TK>::ld(vb, off, vf);
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+            float sc = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) sc += qf[t][e] * kf[e];
+#pragma unroll
+            for (int x = 1; x < LPH; x <<= 1) sc += __shfl_xor(sc, x, 64);
+            sc *= scale;  // after QK^T, as transformer.py:234
+            const float mn = fmaxf(m[t], sc);
+            const float al = __expf(m[t] - mn), pv = valid ? __expf(sc - mn) : 0.f;
+            l[t] = l[t] * al + pv;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[t][e] = o[t][e] * al + pv * vf[e];
+            m[t] = mn;
+        }
+    }
+    // merge the RPW row groups of the wave (lanes c, c + LPR, ...)
+#pragma unroll
+    for (int x = LPR; x < 64; x <<= 1) {
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+            const float m2 = __shfl_xor(m[t], x, 64), l2 = __shfl_xor(l[t], x, 64);
+            const float mn = fmaxf(m[t], m2);
+            const float a1 = __expf(m[t] - mn), a2 = __expf(m2 - mn);
+            l[t] = l[t] * a1 + l2 * a2;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[t][e] = o[t][e] * a1 + __shfl_xor(o[t][e], x, 64) * a2;
+            m[t] = mn;
+        }
+    }
+    if (r == 0) {
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) so[wv][t][ch0 + e] = o[t][e];
+            if ((c % LPH) == 0) { sml[wv][t][head][0] = m[t]; sml[wv][t][head][1] = l[t]; }
+        }
+    }
+    __syncthreads();
+    // merge the 4 waves; partials to ws: o [P][nsplit][T][C], then ml [P][nsplit][T][H][2]
+    float* wo = ws + ((long)pr * nsplit + split) * T * C;
+    float* wml = ws + (long)gridDim.y * nsplit * T * C + ((long)pr * nsplit + split) * T * H * 2;
+    for (int i = tid; i < T * C; i += 256) {
+        const int t = i / C, cc = i % C, hh = cc / HD;
+        float mn = sml[0][t][hh][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) mn = fmaxf(mn, sml[w][t][hh][0]);
+        float acc = 0.f, ll = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a = __expf(sml[w][t][hh][0] - mn);
+            acc += so[w][t][cc] * a;
+            ll += sml[w][t][hh][1] * a;
+        }
+        wo[i] = acc;
+        if ((cc % HD) == 0) { wml[(t * H + hh) * 2] = mn; wml[(t * H + hh) * 2 + 1] = ll; }
+    }
+}
+
+__global__ __launch_bounds__(128) void tok2img_merge_kernel(const float* __restrict__ ws, float* __restrict__ out, int P, int T, int nsplit) {
+    constexpr int C = 128, HD = 16, H = 8;
+    const int pt = blockIdx.x, pr = pt / T, t = pt % T, cc = threadIdx.x, hh = cc / HD;
+    const float* wo = ws + (long)pr * nsplit * T * C;
+    const float* wml = ws + (long)P * nsplit * T * C + (long)pr * nsplit * T * H * 2;
+    float mn = -1e30f;
+    for (int s2 = 0; s2 < nsplit; ++s2) mn = fmaxf(mn, wml[((long)s2 * T + t) * H * 2 + hh * 2]);
+    float acc = 0.f, ll = 0.f;
+    for (int s2 = 0; s2 < nsplit; ++s2) {
+        const float a = __expf(wml[((long)s2 * T + t) * H * 2 + hh * 2] - mn);
+        acc += wo[((long)s2 * T + t) * C + cc] * a;
+        ll += wml[((long)s2 * T + t) * H * 2 + hh * 2 + 1] * a;
+    }
+    out[((long)pr * T + t) * C + cc] = acc / ll;
+}
+
+// q f32 [P,T,128]; k,v [P or 1, N, 128] in kv_dtype with element batch strides (0 = shared); out f32 [P,T,128];
+// workspace f32 [P*nsplit*T*(128+16)].
+extern "C" int ullsam_tok2img_attention(int kv_dtype, const float* q, const void* k, const void* v, float* out, int P, int H, int hd,
+                                        int T, int N, long k_batch_stride, long v_batch_stride, float scale, float* workspace,
+                                        int nsplit, void* stream) {
+    ULLSAM_CHECK(H == 8 && hd == 16, "tok2img_attention: H=%d hd=%d (8 x 16 only)", H, hd);
+    ULLSAM_CHECK(T >= 1 && T <= 8 && N >= 1 && nsplit >= 1 && P >= 1, "tok2img_attention: T=%d (1..8) N=%d nsplit=%d P=%d", T, N, nsplit, P);
+    ULLSAM_CHECK((((uintptr_t)k | (uintptr_t)v) & 15) == 0, "tok2img_attention: k/v must be 16-byte aligned");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(nsplit, P);
+    if (kv_dtype == ULLSAM_DT_F32) tok2img_partial_kernel<float, 8><<<grid, 256, 0, s>>>(q, k, v, workspace, T, N, k_batch_stride, v_batch_stride, scale, nsplit);
+    else tok2img_partial_kernel<bf16, 8><<<grid, 256, 0, s>>>(q, k, v, workspace, T, N, k_batch_stride, v_batch_stride, scale, nsplit);
+    ULLSAM_LAUNCH_CHECK();
+    tok2img_merge_kernel<<<P * T, 128, 0, s>>>(workspace, out, P, T, nsplit);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
 // Many queries x few keys (image -> token cross attention, transformer.py:178-181): one thread per (b, head, query).
 // q:[B,Sq,H*HD] f32, k,v:[B,Sk,H*HD] f32, out:[B,Sq,H*HD] f32.
 template <int HD>
 __global__ __launch_bounds__(256) void fewkeys_attn_kernel(const float* q, const float* k, const float* v, float* out,
-                                                           int B, int H, int Sq, int Sk, float scale) {
+                                                           int B, int H, int Sq, int Sk, float scale, long q_bs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ks = reinterpret_cast<float*>(smem);  // [Sk][HD]
     float* vs = ks + Sk * HD;
@@ -662,7 +815,7 @@ __global__ __launch_bounds__(256) void fewkeys_attn_kernel(const float* q, const
     __syncthreads();
     const int qi = blockIdx.x * 256 + threadIdx.x;
     if (qi >= Sq) return;
-    const float* qp = q + ((long)b * Sq + qi) * H * HD + head * HD;
+    const float* qp = q + (long)b * q_bs + (long)qi * H * HD + head * HD;
     float qr[HD], o[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) { qr[d] = qp[d]; o[d] = 0.f; }
@@ -685,15 +838,16 @@ __global__ __launch_bounds__(256) void fewkeys_attn_kernel(const float* q, const
     for (int d = 0; d < HD; ++d) op[d] = o[d] * inv;
 }
 
+// q_batch_stride in elements: Sq*H*hd for per-batch queries, 0 when every batch shares one query set.
 extern "C" int ullsam_fewkeys_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int hd,
-                                        int Sq, int Sk, float scale, void* stream) {
+                                        int Sq, int Sk, float scale, long q_batch_stride, void* stream) {
     ULLSAM_CHECK(hd == 16 || hd == 32, "fewkeys_attention: hd=%d (16 or 32)", hd);
     ULLSAM_CHECK(Sk > 0 && (size_t)Sk * hd * 8 <= 64 * 1024, "fewkeys_attention: Sk=%d too large", Sk);
     const size_t lds = (size_t)Sk * hd * 8;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((Sq + 255) / 256, H, B);
-    if (hd == 16) fewkeys_attn_kernel<16><<<grid, dim3(256), lds, s>>>(q, k, v, out, B, H, Sq, Sk, scale);
-    else fewkeys_attn_kernel<32><<<grid, dim3(256), lds, s>>>(q, k, v, out, B, H, Sq, Sk, scale);
+    if (hd == 16) fewkeys_attn_kernel<16><<<grid, dim3(256), lds, s>>>(q, k, v, out, B, H, Sq, Sk, scale, q_batch_stride);
+    else fewkeys_attn_kernel<32><<<grid, dim3(256), lds, s>>>(q, k, v, out, B, H, Sq, Sk, scale, q_batch_stride);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }

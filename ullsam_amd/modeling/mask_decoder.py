@@ -81,8 +81,10 @@ class MaskDecoder(Packed):
                           lambda: torch.cat([self.iou_token.weight.detach().float(), self.mask_tokens.weight.detach().float()], 0))
         tokens = torch.cat([out_tok.unsqueeze(0).expand(P, -1, -1), sparse.float()], dim=1).contiguous()
         # src = repeat_interleave(image_embeddings, P) + dense  (:126-127); row-modular broadcast of both operands
-        keys = ops.add_cast(image_tokens.reshape(-1, C), dense_tokens.reshape(-1, C).contiguous(), torch.float32, rows=P * N)
-        hs, src = self.transformer.forward_tokens(keys.reshape(P, N, C), pe_tokens, tokens)
+        dense_rows = dense_tokens.numel() // C
+        Pk = 1 if (image_tokens.shape[0] == 1 and dense_rows in (1, N)) else P   # one image, prompt-independent dense embedding
+        keys = ops.add_cast(image_tokens.reshape(-1, C), dense_tokens.reshape(-1, C).contiguous(), torch.float32, rows=Pk * N)
+        hs, src = self.transformer.forward_tokens(keys.reshape(Pk, N, C), pe_tokens, tokens)
         nm = self.num_mask_tokens
         up0, ln, up1 = self.output_upscaling[0], self.output_upscaling[1], self.output_upscaling[3]
         w0, b0 = up0.packed(dt)

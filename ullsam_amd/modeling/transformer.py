@@ -60,12 +60,18 @@ class TwoWayAttentionBlock(Packed):
         self.skip_first_layer_pe = skip_first_layer_pe
 
 
-def _token_to_image(at: Attention, queries, qpe, keys_pe_c, keys_c, P, T, N, dt):
-    """queries + attn(q=queries+pe, k=keys+pe, v=keys): token side fp32, image-side K/V projections on MFMA."""
+def _token_to_image(at: Attention, queries, qpe, keys_pe_c, keys_c, P, T, N, dt, shared=False):
+    """queries + attn(q=queries+pe, k=keys+pe, v=keys): token side fp32, image-side K/V projections on MFMA (K/V kept in the
+    model dtype), attention streamed over the image keys.  `shared`: one key set [N, C] for all P prompts."""
     q = at.tok(at.q_proj, ops.add_cast(queries, qpe, torch.float32))
-    K = ops.gemm(keys_pe_c, at.k_proj.w(dt), at.k_proj.b(), out_f32=True)
-    V = ops.gemm(keys_c, at.v_proj.w(dt), at.v_proj.b(), out_f32=True)
-    a = at.attend_tokens(q, K, V, P, T, N)
+    K = ops.gemm(keys_pe_c, at.k_proj.w(dt), at.k_proj.b())
+    V = ops.gemm(keys_c, at.v_proj.w(dt), at.v_proj.b())
+    if at.num_heads == 8 and at.hd == 16 and T <= 8:
+        a = ops.tok2img_attention(q, K, V, P, at.num_heads, at.hd, T, N, 1.0 / math.sqrt(at.hd), kv_shared=shared)
+    else:
+        H, hd, C = at.num_heads, at.hd, at.internal_dim
+        kst = (0 if shared else N * C, C, hd)
+        a = ops.naive_attention(q, K.float(), V.float(), P, H, H, hd, T, N, (T * C, C, hd), kst, kst, (T * C, C, hd), 1.0 / math.sqrt(hd))
     return at.tok(at.out_proj, a, res=queries)
 
 
@@ -86,11 +92,16 @@ class TwoWayTransformer(Packed):
 
     def forward_tokens(self, keys: torch.Tensor, key_pe: torch.Tensor, tokens: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """keys fp32 [P, N, C] (image embedding + dense prompt, token-major), key_pe fp32 [N, C], tokens fp32 [P, T, C].
-        Returns (queries [P,T,C], keys [P,N,C]) as TwoWayTransformer.forward transformer.py:62-108."""
+        Returns (queries [P,T,C], keys [P,N,C]) as TwoWayTransformer.forward transformer.py:62-108.
+        keys may be [1, N, C] with P > 1 prompts (one image, many prompts, prompt-independent dense embedding): until the first
+        image -> token attention the image side is identical for every prompt, so its projections of layer 0 are computed once and
+        broadcast (same values as the reference's repeat_interleave, 1/P of the work)."""
         dt = self.compute_dtype
-        P, N, C = keys.shape
-        T = tokens.shape[1]
-        keys = keys.reshape(P * N, C)
+        Pk, N, C = keys.shape
+        P, T = tokens.shape[0], tokens.shape[1]
+        assert Pk in (1, P), (keys.shape, tokens.shape)
+        shared = Pk == 1 and P > 1
+        keys = keys.reshape(Pk * N, C)
         qpe = tokens.reshape(P * T, C).contiguous()
         queries = qpe
         f32 = torch.float32
@@ -104,7 +115,7 @@ class TwoWayTransformer(Packed):
             queries = ops.norm(sa.tok(sa.out_proj, a, res=res), *blk.norm1.wb(), blk.norm1.eps, f32)
             keys_pe_c = ops.add_cast(keys, key_pe, dt)   # keys + key_pe, shared by both cross attentions of the block
             keys_c = ops.cast(keys, dt)
-            queries = ops.norm(_token_to_image(blk.cross_attn_token_to_image, queries, qpe, keys_pe_c, keys_c, P, T, N, dt),
+            queries = ops.norm(_token_to_image(blk.cross_attn_token_to_image, queries, qpe, keys_pe_c, keys_c, P, T, N, dt, shared),
                                *blk.norm2.wb(), blk.norm2.eps, f32)
             m = blk.mlp
             hmid = ops.small_linear(queries, m.lin1.f32("w32", m.lin1.weight), m.lin1.b(), m.act_code)
@@ -115,9 +126,11 @@ class TwoWayTransformer(Packed):
             q_in = ops.add_cast(queries, qpe, f32)
             Qi = ops.gemm(keys_pe_c, ia.q_proj.w(dt), ia.q_proj.b(), out_f32=True)
             a = ops.fewkeys_attention(Qi, ia.tok(ia.k_proj, q_in), ia.tok(ia.v_proj, queries), P, ia.num_heads, ia.hd, N, T,
-                                      1.0 / math.sqrt(ia.hd))
-            upd = ops.gemm(ops.cast(a, dt), ia.out_proj.w(dt), ia.out_proj.b(), residual=keys, out_f32=True)
+                                      1.0 / math.sqrt(ia.hd), q_shared=shared)
+            upd = ops.gemm(ops.cast(a, dt), ia.out_proj.w(dt), ia.out_proj.b(), residual=keys, out_f32=True,
+                           res_row_mod=N if shared else 0)
             keys = ops.norm(upd, *blk.norm4.wb(), blk.norm4.eps, f32)
+            shared = False                               # from here on every prompt has its own image-side stream
         fa = self.final_attn_token_to_image
         queries = ops.norm(_token_to_image(fa, queries, qpe, ops.add_cast(keys, key_pe, dt), ops.cast(keys, dt), P, T, N, dt),
                            *self.norm_final_attn.wb(), self.norm_final_attn.eps, f32)

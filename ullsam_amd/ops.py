@@ -133,12 +133,26 @@ def naive_attention(q, k, v, B, H, KVH, hd, Sq, Sk, qs, ks, vs, os_, scale, key_
     return out
 
 
-def fewkeys_attention(q, k, v, B, H, hd, Sq, Sk, scale):
+def fewkeys_attention(q, k, v, B, H, hd, Sq, Sk, scale, q_shared: bool = False):
+    """q fp32 [B (or 1 when q_shared), Sq, H*hd], k/v fp32 [B, Sk, H*hd] -> fp32 [B*Sq, H*hd]."""
     for t in (q, k, v):
         _chk(t, "qkv", torch.float32)
     out = torch.empty((B * Sq, H * hd), dtype=torch.float32, device=q.device)
     _lib.call("ullsam_fewkeys_attention", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, hd, Sq, Sk,
-              float(scale), _stream())
+              float(scale), 0 if q_shared else Sq * H * hd, _stream())
+    return out
+
+
+def tok2img_attention(q, k, v, P, H, hd, T, N, scale, kv_shared: bool = False):
+    """q fp32 [P*T, H*hd]; k, v [P (or 1 when kv_shared) * N, H*hd] fp32 or bf16 -> fp32 [P*T, H*hd]."""
+    _chk(q, "q", torch.float32); _chk(k, "k"); _chk(v, "v", k.dtype)
+    C = H * hd
+    nsplit = max(1, min(32, -(-512 // P), N // 128))
+    ws = torch.empty((P * nsplit * T * (C + 2 * H),), dtype=torch.float32, device=q.device)
+    out = torch.empty((P * T, C), dtype=torch.float32, device=q.device)
+    bs = 0 if kv_shared else N * C
+    _lib.call("ullsam_tok2img_attention", dt_code(k.dtype), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), P, H, hd, T, N,
+              bs, bs, float(scale), ws.data_ptr(), nsplit, _stream())
     return out
 
 
