@@ -279,8 +279,8 @@ extern "C" int ullsam_rle_emit(const unsigned long long* words, const int* selec
 //   * batched_mask_to_box of (v > thr), in crop coordinates                                         (amg.py:303-346)
 //   * the change words of mask_to_rle_pytorch(uncrop_masks(v > thr, crop_box, FH, FW))              (amg.py:107-135, 251-264)
 // so the 4 B/pixel logits and 1 B/pixel masks of the separate helpers (12288 masks x 16 MiB per 2048^2 tile) are replaced by
-// 1 bit/pixel of change words.  A wave owns 64 frame rows x 64 frame columns (lane = column); the row taps are wave-uniform, so
-// the x-interpolated low-res rows and intermediate rows are memoised in registers (two slots each) while the wave walks down.
+// 1 bit/pixel of change words.  The row taps are wave-uniform, so the x-interpolated low-res rows and intermediate rows are
+// memoised in registers (two slots each) while a wave walks down its 64 rows.
 struct Tap { int i0, i1; float l; };
 __device__ inline Tap tap_of(int o, float scale, int n_in) {
     float f = ((float)o + 0.5f) * scale - 0.5f;
@@ -319,6 +319,17 @@ __device__ inline float post_eval(const float* __restrict__ lowp, const PostGeom
     return h[0] * (1.f - ty.l) + h[1] * ty.l;
 }
 
+// acc = 2*acc + (v > thr): compare + add-with-carry, exact `>` semantics (false for NaN).  Rows are pushed top first, so after
+// 32 pushes the word is bit-reversed (row 0 in bit 31).
+__device__ __forceinline__ void push_gt(unsigned int& acc, float v, float thr) {
+    asm("v_cmp_lt_f32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(v), "v"(thr) : "vcc");
+}
+
+// A wave owns 64 frame rows x 64*NC frame columns; a lane owns NC adjacent columns, so the wave-uniform row bookkeeping (taps,
+// memo lookups) is paid once per 64*NC pixels.  Before walking the rows the wave takes min/max of the low-res footprint of its
+// block: both resizes are convex combinations, so a footprint entirely above (below) every threshold by a rounding margin decides
+// all of the block's bits without evaluating a pixel -- real masks are flat almost everywhere.
+template <int NC>
 __global__ __launch_bounds__(256) void amg_postprocess_kernel(const float* __restrict__ low, const int* __restrict__ index, PostGeom g,
                                                               float thr, float off, unsigned long long* __restrict__ words,
                                                               int* __restrict__ rle_counts, unsigned char* __restrict__ first,
@@ -329,88 +340,198 @@ __global__ __launch_bounds__(256) void amg_postprocess_kernel(const float* __res
     const int yb = blockIdx.y * 4 + wv;
     if (yb >= nyb) return;
     const float* lowp = low + (long)(index ? index[n] : n) * g.LH * g.LW;
-    const int xf = blockIdx.x * 64 + lane;            // frame column
+    const int bx0 = blockIdx.x * 64 * NC;             // first frame column of the wave
+    const int xf0 = bx0 + lane * NC;                  // first frame column of the lane
     const int ys = yb * 64;
     const int r = min(64, g.FH - ys);                 // frame rows in this block
-    const int x = xf - g.cx0;                         // crop column
-    const bool col_in = xf < g.FW && x >= 0 && x < g.CW;
-    const int xc = min(max(x, 0), g.CW - 1);
-    const Tap tx = tap_of(xc, g.s2x, g.nw);
-    const Tap t0 = tap_of(tx.i0, g.s1x, g.LW), t1 = tap_of(tx.i1, g.s1x, g.LW);
     const float hi = thr + off, lo = thr - off;
-
-    float ga0 = 0, ga1 = 0, gb0 = 0, gb1 = 0, ha = 0, hb = 0;
-    int gka = -1, gkb = -1, hka = -1, hkb = -1;      // memo keys (wave-uniform): low-res row / intermediate row
-    auto get_g = [&](int lr, float& o0, float& o1) {
-        if (lr == gka) { o0 = ga0; o1 = ga1; return; }
-        if (lr == gkb) { o0 = gb0; o1 = gb1; return; }
-        const float* row = lowp + (long)lr * g.LW;
-        const float a = row[t0.i0] * (1.f - t0.l) + row[t0.i1] * t0.l;
-        const float b = row[t1.i0] * (1.f - t1.l) + row[t1.i1] * t1.l;
-        if (gka <= gkb) { gka = lr; ga0 = a; ga1 = b; } else { gkb = lr; gb0 = a; gb1 = b; }
-        o0 = a; o1 = b;
-    };
-    auto get_h = [&](int iy) -> float {
-        if (iy == hka) return ha;
-        if (iy == hkb) return hb;
-        const Tap rr = utap_of(iy, g.s1y, g.LH);
-        float p0, p1, q0, q1;
-        get_g(rr.i0, p0, p1);
-        get_g(rr.i1, q0, q1);
-        const float i0 = p0 * (1.f - rr.l) + q0 * rr.l, i1 = p1 * (1.f - rr.l) + q1 * rr.l;
-        const float h = i0 * (1.f - tx.l) + i1 * tx.l;
-        if (hka <= hkb) { hka = iy; ha = h; } else { hkb = iy; hb = h; }
-        return h;
-    };
-    auto value = [&](int yc) -> float {               // crop row yc (wave-uniform), this lane's column
-        const Tap ty = utap_of(yc, g.s2y, g.nh);
-        const float h0 = get_h(ty.i0), h1 = get_h(ty.i1);
-        return h0 * (1.f - ty.l) + h1 * ty.l;
-    };
-
-    unsigned long long wm = 0, whi = 0, wlo = 0;
-    for (int half = 0; half < 2; ++half) {
-        unsigned int am = 0, ah = 0, al = 0;
-        for (int i = 0; i < 32; ++i) {
-            const int row = half * 32 + i;
-            if (row >= r) break;
-            const int yc = ys + row - g.cy0;
-            if (yc < 0 || yc >= g.CH) continue;
-            const float v = value(yc);
-            am |= (unsigned int)(v > thr) << i;
-            ah |= (unsigned int)(v > hi) << i;
-            al |= (unsigned int)(v > lo) << i;
-        }
-        wm |= (unsigned long long)am << (32 * half);
-        whi |= (unsigned long long)ah << (32 * half);
-        wlo |= (unsigned long long)al << (32 * half);
+    Tap tx[NC], t0[NC], t1[NC];
+    bool col_in[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int x = xf0 + j - g.cx0;
+        col_in[j] = xf0 + j < g.FW && x >= 0 && x < g.CW;
+        tx[j] = tap_of(min(max(x, 0), g.CW - 1), g.s2x, g.nw);
+        t0[j] = tap_of(tx[j].i0, g.s1x, g.LW);
+        t1[j] = tap_of(tx[j].i1, g.s1x, g.LW);
     }
-    if (!col_in) { wm = 0; whi = 0; wlo = 0; }
-    // the element after this word in the frame's Fortran order
-    unsigned int nb = 0;
-    bool has_next = true;
-    if (ys + r < g.FH) {
-        const int yc = ys + r - g.cy0;
-        if (yc >= 0 && yc < g.CH) { const float v = value(yc); nb = col_in && v > thr; }
-    } else if (xf + 1 < g.FW) {
-        const int x2 = xf + 1 - g.cx0;
-        if (g.cy0 == 0 && x2 >= 0 && x2 < g.CW) nb = post_eval(lowp, g, 0, x2) > thr;
+    // rows of the block that lie inside the crop: bits [i_lo, i_hi)
+    const int i_lo = max(0, g.cy0 - ys), i_hi = min(r, g.cy0 + g.CH - ys);
+    unsigned long long rowmask = 0;
+    if (i_hi > i_lo) rowmask = ((i_hi - i_lo) == 64 ? ~0ull : ((1ull << (i_hi - i_lo)) - 1ull)) << i_lo;
+
+    // ---- footprint test
+    int decided = 0;  // 1: every pixel of the block is above all thresholds, 2: below all
+    {
+        const int xl = min(max(bx0 - g.cx0, 0), g.CW - 1), xh = min(max(bx0 + 64 * NC - 1 - g.cx0, 0), g.CW - 1);
+        const int yl = min(max(ys - g.cy0, 0), g.CH - 1), yh = min(max(ys + r - g.cy0, 0), g.CH - 1);  // incl. the row after the block
+        const int lc0 = tap_of(tap_of(xl, g.s2x, g.nw).i0, g.s1x, g.LW).i0, lc1 = tap_of(tap_of(xh, g.s2x, g.nw).i1, g.s1x, g.LW).i1;
+        const int lr0 = tap_of(tap_of(yl, g.s2y, g.nh).i0, g.s1y, g.LH).i0, lr1 = tap_of(tap_of(yh, g.s2y, g.nh).i1, g.s1y, g.LH).i1;
+        const int nc = lc1 - lc0 + 1, cells = nc * (lr1 - lr0 + 1);
+        float mn = INFINITY, mx = -INFINITY;
+        int bad = 0;
+        for (int i = lane; i < cells; i += 64) {
+            const int rr = i / nc, cc = i - rr * nc;
+            const float val = lowp[(long)(lr0 + rr) * g.LW + lc0 + cc];
+            mn = fminf(mn, val); mx = fmaxf(mx, val);
+            bad |= !(val == val);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); bad |= __shfl_xor(bad, o, 64);
+        }
+        const float margin = 1e-4f * fmaxf(1.f, fmaxf(fabsf(mn), fabsf(mx)));
+        if (!bad && mn > fmaxf(hi, fmaxf(lo, thr)) + margin) decided = 1;
+        else if (!bad && mx < fminf(hi, fminf(lo, thr)) - margin) decided = 2;
+        decided = __builtin_amdgcn_readfirstlane(decided);
+    }
+
+    unsigned long long wm[NC], whi[NC], wlo[NC];
+    unsigned int nb = 0;                               // bit j: the element after column j's word in the frame's Fortran order
+    if (decided) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) wm[j] = whi[j] = wlo[j] = (decided == 1 && col_in[j]) ? rowmask : 0ull;
+        if (ys + r < g.FH && decided == 1) {
+            const int yc = ys + r - g.cy0;
+            if (yc >= 0 && yc < g.CH)
+#pragma unroll
+                for (int j = 0; j < NC; ++j) nb |= (unsigned int)col_in[j] << j;
+        }
     } else {
-        has_next = false;
+        float ga0[NC], ga1[NC], gb0[NC], gb1[NC], ha[NC], hb[NC];
+        int gka = -1, gkb = -1, hka = -1, hkb = -1;  // memo keys (wave-uniform): low-res row / intermediate row
+        auto get_g = [&](int lr, float (&o0)[NC], float (&o1)[NC]) {
+            if (lr == gka) {
+#pragma unroll
+                for (int j = 0; j < NC; ++j) { o0[j] = ga0[j]; o1[j] = ga1[j]; }
+                return;
+            }
+            if (lr == gkb) {
+#pragma unroll
+                for (int j = 0; j < NC; ++j) { o0[j] = gb0[j]; o1[j] = gb1[j]; }
+                return;
+            }
+            const float* row = lowp + (long)lr * g.LW;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                o0[j] = row[t0[j].i0] * (1.f - t0[j].l) + row[t0[j].i1] * t0[j].l;
+                o1[j] = row[t1[j].i0] * (1.f - t1[j].l) + row[t1[j].i1] * t1[j].l;
+            }
+            if (gka <= gkb) {
+                gka = lr;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) { ga0[j] = o0[j]; ga1[j] = o1[j]; }
+            } else {
+                gkb = lr;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) { gb0[j] = o0[j]; gb1[j] = o1[j]; }
+            }
+        };
+        auto get_h = [&](int iy, float (&h)[NC]) {
+            if (iy == hka) {
+#pragma unroll
+                for (int j = 0; j < NC; ++j) h[j] = ha[j];
+                return;
+            }
+            if (iy == hkb) {
+#pragma unroll
+                for (int j = 0; j < NC; ++j) h[j] = hb[j];
+                return;
+            }
+            const Tap rr = utap_of(iy, g.s1y, g.LH);
+            float p0[NC], p1[NC], q0[NC], q1[NC];
+            get_g(rr.i0, p0, p1);
+            get_g(rr.i1, q0, q1);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const float i0 = p0[j] * (1.f - rr.l) + q0[j] * rr.l, i1 = p1[j] * (1.f - rr.l) + q1[j] * rr.l;
+                h[j] = i0 * (1.f - tx[j].l) + i1 * tx[j].l;
+            }
+            if (hka <= hkb) {
+                hka = iy;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) ha[j] = h[j];
+            } else {
+                hkb = iy;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) hb[j] = h[j];
+            }
+        };
+        auto values = [&](int yc, float (&v)[NC]) {   // crop row yc (wave-uniform), this lane's columns
+            const Tap ty = utap_of(yc, g.s2y, g.nh);
+            float h0[NC], h1[NC];
+            get_h(ty.i0, h0);
+            get_h(ty.i1, h1);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) v[j] = h0[j] * (1.f - ty.l) + h1[j] * ty.l;
+        };
+#pragma unroll
+        for (int j = 0; j < NC; ++j) wm[j] = whi[j] = wlo[j] = 0;
+        for (int half = 0; half < 2; ++half) {
+            unsigned int am[NC], ah[NC], al[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) am[j] = ah[j] = al[j] = 0;
+            for (int i = 0; i < 32; ++i) {
+                const int row = half * 32 + i;
+                if (row >= i_lo && row < i_hi) {
+                    float v[NC];
+                    values(ys + row - g.cy0, v);
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) { push_gt(am[j], v[j], thr); push_gt(ah[j], v[j], hi); push_gt(al[j], v[j], lo); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) { am[j] += am[j]; ah[j] += ah[j]; al[j] += al[j]; }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                wm[j] |= (unsigned long long)__brev(am[j]) << (32 * half);
+                whi[j] |= (unsigned long long)__brev(ah[j]) << (32 * half);
+                wlo[j] |= (unsigned long long)__brev(al[j]) << (32 * half);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            if (!col_in[j]) { wm[j] = 0; whi[j] = 0; wlo[j] = 0; }
+        if (ys + r < g.FH) {
+            const int yc = ys + r - g.cy0;
+            if (yc >= 0 && yc < g.CH) {
+                float v[NC];
+                values(yc, v);
+#pragma unroll
+                for (int j = 0; j < NC; ++j) nb |= (unsigned int)(col_in[j] && v[j] > thr) << j;
+            }
+        }
+    }
+    unsigned int no_next = 0;
+    if (ys + r >= g.FH) {                              // column end: the next element is the top of the next frame column
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int xf = xf0 + j;
+            if (xf + 1 < g.FW) {
+                const int x2 = xf + 1 - g.cx0;
+                if (g.cy0 == 0 && x2 >= 0 && x2 < g.CW) nb |= (unsigned int)(post_eval(lowp, g, 0, x2) > thr) << j;
+            } else {
+                no_next |= 1u << j;
+            }
+        }
     }
     const unsigned long long keep = r == 64 ? ~0ull : ((1ull << r) - 1ull);
-    unsigned long long ch = (wm ^ ((wm >> 1) | ((unsigned long long)nb << (r - 1)))) & keep;
-    if (!has_next) ch &= ~(1ull << (r - 1));
-    if (xf < g.FW) words[((long)n * nyb + yb) * g.FW + xf] = ch;
-    if (xf == 0 && yb == 0) first[n] = (unsigned char)(wm & 1ull);
-
-    int cnt = xf < g.FW ? __popcll(ch) : 0;
-    unsigned int ca = __popcll(whi), cb = __popcll(wlo);
+    int cnt = 0;
+    unsigned int ca = 0, cb = 0;
     int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
-    if (wm) {
-        x0 = x1 = x;
-        y0 = ys - g.cy0 + __builtin_ctzll(wm);
-        y1 = ys - g.cy0 + 63 - __builtin_clzll(wm);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int xf = xf0 + j;
+        unsigned long long ch = (wm[j] ^ ((wm[j] >> 1) | ((unsigned long long)((nb >> j) & 1u) << (r - 1)))) & keep;
+        if ((no_next >> j) & 1u) ch &= ~(1ull << (r - 1));
+        if (xf < g.FW) { words[((long)n * nyb + yb) * g.FW + xf] = ch; cnt += __popcll(ch); }
+        if (xf == 0 && yb == 0) first[n] = (unsigned char)(wm[j] & 1ull);
+        ca += __popcll(whi[j]); cb += __popcll(wlo[j]);
+        if (wm[j]) {
+            x0 = min(x0, xf - g.cx0); x1 = max(x1, xf - g.cx0);
+            y0 = min(y0, ys - g.cy0 + (int)__builtin_ctzll(wm[j]));
+            y1 = max(y1, ys - g.cy0 + 63 - (int)__builtin_clzll(wm[j]));
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         cnt += __shfl_xor(cnt, o, 64); ca += __shfl_xor(ca, o, 64); cb += __shfl_xor(cb, o, 64);
@@ -450,8 +571,12 @@ extern "C" int ullsam_amg_postprocess(const float* low, const int* index, long M
     g.LH = LH; g.LW = LW; g.S1 = S1; g.nh = nh; g.nw = nw; g.CH = CH; g.CW = CW; g.FH = FH; g.FW = FW; g.cx0 = cx0; g.cy0 = cy0;
     g.s1y = (float)LH / (float)S1; g.s1x = (float)LW / (float)S1; g.s2y = (float)nh / (float)CH; g.s2x = (float)nw / (float)CW;
     const int nyb = (FH + 63) / 64;
-    amg_postprocess_kernel<<<dim3((unsigned)((FW + 63) / 64), (unsigned)((nyb + 3) / 4), (unsigned)M), 256, 0, s>>>(
-        low, index, g, mask_threshold, threshold_offset, words, rle_counts, first, boxes, stab);
+    if (FW > 128)
+        amg_postprocess_kernel<4><<<dim3((unsigned)((FW + 255) / 256), (unsigned)((nyb + 3) / 4), (unsigned)M), 256, 0, s>>>(
+            low, index, g, mask_threshold, threshold_offset, words, rle_counts, first, boxes, stab);
+    else
+        amg_postprocess_kernel<1><<<dim3((unsigned)((FW + 63) / 64), (unsigned)((nyb + 3) / 4), (unsigned)M), 256, 0, s>>>(
+            low, index, g, mask_threshold, threshold_offset, words, rle_counts, first, boxes, stab);
     ULLSAM_LAUNCH_CHECK();
     box_finish_kernel<<<(unsigned)((M + 255) / 256), 256, 0, s>>>(boxes, M);
     ULLSAM_LAUNCH_CHECK();
