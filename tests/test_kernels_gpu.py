@@ -95,6 +95,34 @@ def test_norms(ops, D):
     assert err(yb, O.layer_norm(xb, w, b, 1e-6)) < 4e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(448, 256, 256), (64, 32, 256), (17, 4, 256), (100, 2048, 256), (448, 256, 2048), (30, 130, 128)])
+def test_skinny_linear(ops, M, N, K):
+    rng = np.random.default_rng(M + N)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = rng.standard_normal((N, K), dtype=np.float32) / np.float32(math.sqrt(K))
+    b = rng.standard_normal(N, dtype=np.float32)
+    r = rng.standard_normal((M, N), dtype=np.float32)
+    wt = T(np.ascontiguousarray(w.T))
+    assert err(ops.skinny_linear(T(x), wt, T(b)).cpu().numpy(), x @ w.T + b) < 1e-5
+    assert err(ops.skinny_linear(T(x), wt, T(b), ops.ACT_RELU, T(r)).cpu().numpy(), np.maximum(x @ w.T + b, 0) + r) < 1e-5
+    assert err(ops.skinny_linear(T(x), wt, None, ops.ACT_GELU).cpu().numpy(), O.gelu(x @ w.T)) < 1e-5
+    assert err(ops.small_linear(T(x), T(w), T(b)).cpu().numpy(), x @ w.T + b) < 1e-5
+
+
+@pytest.mark.parametrize("D", [32, 64, 48])
+def test_norm_narrow_rows(ops, D):
+    """Many short rows (LayerNorm2d + GELU of the decoder's upscaling path): 16 lanes per row."""
+    rng = np.random.default_rng(D)
+    x = rng.standard_normal((5003, D), dtype=np.float32) * 2 + 0.3
+    w = rng.standard_normal(D, dtype=np.float32)
+    b = rng.standard_normal(D, dtype=np.float32)
+    ref = O.layer_norm(x, w, b, 1e-6)
+    assert err(ops.norm(T(x), T(w), T(b), 1e-6, torch.float32).cpu().numpy(), ref) < 2e-5
+    got = ops.norm(T(x), T(w), T(b), 1e-6, torch.bfloat16, act=ops.ACT_GELU).float().cpu().numpy()
+    assert err(got, O.gelu(ref)) < 4e-2
+    assert err(ops.norm(T(x), T(w), None, 1e-5, torch.float32, rms=True).cpu().numpy(), O.rms_norm(x, w, 1e-5)) < 2e-5
+
+
 def _vit_attn_case(ops, dtype, heads, hd, grid, window, B=2, seed=0):
     D = heads * hd
     rng = np.random.default_rng(seed)

@@ -14,6 +14,9 @@ vit = sys.argv[3] if len(sys.argv) > 3 else "h"
 stab = float(sys.argv[4]) if len(sys.argv) > 4 else 0.9
 off = float(sys.argv[5]) if len(sys.argv) > 5 else 0.05
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+if os.environ.get("ULLSAM_GEMM_VARIANT"):
+    from ullsam_amd import _lib
+    _lib.load().ullsam_set_gemm_variant(int(os.environ["ULLSAM_GEMM_VARIANT"]))
 sam = build_model(vit, "none", torch.bfloat16, "cuda:0")
 gen = SamAutomaticMaskGenerator(sam, points_per_side=side, points_per_batch=64, pred_iou_thresh=-1e9, stability_score_thresh=stab,
                                 stability_score_offset=off, box_nms_thresh=0.7, output_mode="uncompressed_rle")

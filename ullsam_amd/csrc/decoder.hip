@@ -38,6 +38,79 @@ extern "C" int ullsam_small_linear(const float* x, long ldx, const float* W, con
     return 0;
 }
 
+// ---- the same layer for tens to hundreds of rows (many prompts): lanes = 64 outputs, 16 rows per workgroup --------------
+// WT is the transposed weight [K, N], so a wave's weight load is one coalesced row segment; the x values of a row block are
+// wave-uniform (scalar loads) and feed 16 FMAs per loaded weight.  The four waves of a workgroup split K and reduce through LDS.
+template <int KC>
+__global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ WT,
+                                                            const float* __restrict__ b, const float* __restrict__ res, long ldr,
+                                                            float* __restrict__ y, long ldy, int M, int N, int K, int act) {
+    constexpr int RM = 16;
+    __shared__ float red[4][RM][64];
+    __shared__ __attribute__((aligned(16))) float xs[4][RM][KC + 4];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.x * 64 + lane, nc = min(n, N - 1);
+    const int m0 = blockIdx.y * RM;
+    const int kq = K >> 2, k0 = wv * kq;                 // this wave's K range (kq % KC == 0)
+    float acc[RM];
+#pragma unroll
+    for (int i = 0; i < RM; ++i) acc[i] = 0.f;
+    for (int kc = 0; kc < kq; kc += KC) {
+        // stage x[m0 .. m0+15][k0+kc .. +KC) for this wave (coalesced), then every lane reads it back as broadcasts
+        constexpr int C4 = KC / 4;                       // float4 per row
+#pragma unroll
+        for (int j = 0; j < RM * C4 / 64; ++j) {
+            const int idx = j * 64 + lane, row = idx / C4, c4 = idx % C4;
+            const float4 v = *reinterpret_cast<const float4*>(x + (long)min(m0 + row, M - 1) * ldx + k0 + kc + c4 * 4);
+            *reinterpret_cast<float4*>(&xs[wv][row][c4 * 4]) = v;
+        }
+        const float* wp = WT + (long)(k0 + kc) * N + nc;
+#pragma unroll
+        for (int g = 0; g < KC; g += 16) {
+            float w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = wp[(long)(g + u) * N];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+#pragma unroll
+                for (int i = 0; i < RM; ++i) {
+                    const float4 xv = *reinterpret_cast<const float4*>(&xs[wv][i][g + u]);
+                    acc[i] += (xv.x * w[u] + xv.y * w[u + 1]) + (xv.z * w[u + 2] + xv.w * w[u + 3]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RM; ++i) red[wv][i][lane] = acc[i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RM / 4; ++j) {
+        const int i = wv * (RM / 4) + j, m = m0 + i;
+        float v = (red[0][i][lane] + red[1][i][lane]) + (red[2][i][lane] + red[3][i][lane]);
+        if (m < M && n < N) {
+            if (b) v += b[n];
+            if (act == 2) v = fmaxf(v, 0.f);
+            else if (act == 1) v = gelu_erf(v);
+            if (res) v += res[(long)m * ldr + n];
+            y[(long)m * ldy + n] = v;
+        }
+    }
+}
+
+// WT fp32 [K, N] (transposed nn.Linear weight); otherwise as ullsam_small_linear.
+extern "C" int ullsam_skinny_linear(const float* x, long ldx, const float* WT, const float* b, const float* res, long ldr, float* y,
+                                    long ldy, int M, int N, int K, int act, void* stream) {
+    ULLSAM_CHECK(K % 128 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0, "skinny_linear: K %% 128, ldx %% 4, 16-byte aligned x");
+    if ((long)M * N == 0) return 0;
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 15) / 16));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (K % 256 == 0) skinny_linear_kernel<64><<<grid, 256, 0, s>>>(x, ldx, WT, b, res, ldr, y, ldy, M, N, K, act);
+    else skinny_linear_kernel<32><<<grid, 256, 0, s>>>(x, ldx, WT, b, res, ldr, y, ldy, M, N, K, act);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- sparse prompt embedding (prompt_encoder.py:76-103,220-250) ---------------------------------------------------
 // coords [P,Np,2] px, labels int32 [P,Np], boxes [P,4] or null.  out f32 [P, n_out, C], n_out = Np + pad + 2*has_box
 // tables: G [2, C/2]; emb rows: 0 not_a_point, 1..4 point_embeddings[0..3]  ([5, C])

@@ -80,10 +80,58 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs p) {
     }
 }
 
+// D <= 64 (LayerNorm2d over the 64 / 32 channels of the decoder's upscaling path, millions of rows): 16 lanes per row, four rows
+// per wave, so every lane still moves 16 bytes; statistics reduce over the 16-lane group.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void norm_narrow_kernel(NormArgs p) {
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const int nv = p.D >> 2;
+    const bool on = row < p.rows && sub < nv;
+    const TI* x = reinterpret_cast<const TI*>(p.in) + (on ? row : 0) * p.in_stride;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on) v = load4(x + sub * 4);
+    float s = (v.x + v.y) + (v.z + v.w);
+    float mean = 0.f;
+    if (!p.rms) {
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        mean = s / (float)p.D;
+    }
+    float ss = 0.f;
+    if (on) {
+        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        ss = (a * a + b * b) + (c * c + d * d);
+    }
+    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float var = ss / (float)p.D;
+    const float rstd = p.rms ? rsqrtf(var + p.eps) : 1.0f / sqrtf(var + p.eps);
+    if (!on) return;
+    float4 o = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+    if (p.w) {
+        const float4 w = *reinterpret_cast<const float4*>(p.w + sub * 4);
+        o.x *= w.x; o.y *= w.y; o.z *= w.z; o.w *= w.w;
+    }
+    if (p.b) {
+        const float4 b = *reinterpret_cast<const float4*>(p.b + sub * 4);
+        o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+    }
+    if (p.post_scale || p.post_shift) {
+        const float ps = p.post_scale ? p.post_scale[0] : 1.f, pb = p.post_shift ? p.post_shift[0] : 0.f;
+        o.x = o.x * ps + pb; o.y = o.y * ps + pb; o.z = o.z * ps + pb; o.w = o.w * ps + pb;
+    }
+    if (p.act == 1) { o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w); }
+    store4(reinterpret_cast<TO*>(p.out) + row * p.out_stride + sub * 4, o);
+}
+
 template <typename TI, typename TO>
 static int launch_norm(const NormArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)((a.rows + 3) / 4)), block(256);
     const int nv = a.D / 4;
+    if (nv <= 16 && a.rows >= 4096) {
+        norm_narrow_kernel<TI, TO><<<dim3((unsigned)((a.rows + 15) / 16)), block, 0, s>>>(a);
+        ULLSAM_LAUNCH_CHECK();
+        return 0;
+    }
     if (nv <= 64) norm_kernel<TI, TO, 1><<<grid, block, 0, s>>>(a);
     else if (nv <= 256) norm_kernel<TI, TO, 4><<<grid, block, 0, s>>>(a);
     else if (nv <= 512) norm_kernel<TI, TO, 8><<<grid, block, 0, s>>>(a);

@@ -5,7 +5,7 @@ attribute names => same state_dict keys.  Compute goes through ullsam_amd.ops (H
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Tuple, Type
+from typing import Callable, Dict, Optional, Tuple, Type
 
 import torch
 from torch import nn
@@ -71,6 +71,15 @@ class Linear(Packed):
 
     def b(self):
         return None if self.bias is None else self.f32("b", self.bias)
+
+    def tok(self, x: torch.Tensor, act: int = ops.ACT_NONE, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """fp32 token-side application (decoder tokens, hypernetwork / IoU MLPs): one wave per output for a handful of rows,
+        the row-blocked kernel over the transposed weight from 64 rows up (many prompts)."""
+        M = x.numel() // self.in_features
+        if M >= 64 and self.in_features % 128 == 0:
+            wt = self.pk("w32t", self.weight, lambda: self.weight.detach().float().t().contiguous())
+            return ops.skinny_linear(x, wt, self.b(), act, res)
+        return ops.small_linear(x, self.f32("w32", self.weight), self.b(), act, res)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         dt = self.weight.dtype

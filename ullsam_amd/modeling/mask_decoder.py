@@ -44,7 +44,7 @@ class MLP(Packed):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = x.float().contiguous()
         for i, l in enumerate(self.layers):
-            x = ops.small_linear(x, l.f32("w32", l.weight), l.b(), ops.ACT_RELU if i < self.num_layers - 1 else ops.ACT_NONE)
+            x = l.tok(x, ops.ACT_RELU if i < self.num_layers - 1 else ops.ACT_NONE)
         if self.sigmoid_output:
             x = torch.sigmoid(x)
         return x

@@ -34,7 +34,7 @@ class Attention(Packed):
         return self.internal_dim // self.num_heads
 
     def tok(self, lin: Linear, x, act=ops.ACT_NONE, res=None):
-        return ops.small_linear(x, lin.f32("w32", lin.weight), lin.b(), act, res)
+        return lin.tok(x, act, res)
 
     def attend_tokens(self, q, k, v, P, Tq, Tk):
         """softmax(q k^T / sqrt(hd)) v with the scale applied after QK^T (transformer.py:233-235); fp32 [P*T, internal]."""
@@ -118,8 +118,8 @@ class TwoWayTransformer(Packed):
             queries = ops.norm(_token_to_image(blk.cross_attn_token_to_image, queries, qpe, keys_pe_c, keys_c, P, T, N, dt, shared),
                                *blk.norm2.wb(), blk.norm2.eps, f32)
             m = blk.mlp
-            hmid = ops.small_linear(queries, m.lin1.f32("w32", m.lin1.weight), m.lin1.b(), m.act_code)
-            queries = ops.norm(ops.small_linear(hmid, m.lin2.f32("w32", m.lin2.weight), m.lin2.b(), res=queries),
+            hmid = m.lin1.tok(queries, m.act_code)
+            queries = ops.norm(m.lin2.tok(hmid, res=queries),
                                *blk.norm3.wb(), blk.norm3.eps, f32)
             # image -> token: keys = norm4(keys + attn(q=keys+pe, k=queries+pe, v=queries))   (:176-182)
             ia = blk.cross_attn_image_to_token

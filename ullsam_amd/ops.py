@@ -280,6 +280,17 @@ def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], ac
     return out
 
 
+def skinny_linear(x: torch.Tensor, wt: torch.Tensor, b: Optional[torch.Tensor], act: int = ACT_NONE,
+                  res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 Linear for tens..hundreds of rows; wt = weight^T [K, N] fp32."""
+    _chk(x, "x", torch.float32); _chk(wt, "wt", torch.float32)
+    K, N = wt.shape
+    M = x.numel() // K
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _lib.call("ullsam_skinny_linear", x.data_ptr(), K, wt.data_ptr(), _p(b), _p(res), N, out.data_ptr(), N, M, N, K, act, _stream())
+    return out
+
+
 def sparse_embed(coords, labels, boxes, G, emb, P, Np, pad, C, img_w, img_h) -> torch.Tensor:
     n_out = Np + pad + (2 if boxes is not None else 0)
     out = torch.empty((P, n_out, C), dtype=torch.float32, device=G.device)
