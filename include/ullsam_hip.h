@@ -49,6 +49,10 @@ int ullsam_gemm(int dtype, const void* A, long lda, const void* W, long ldw, voi
 int ullsam_norm(const void* in, int in_dtype, long in_stride, void* out, int out_dtype, long out_stride, const float* w,
                 const float* b, long rows, int D, float eps, int rms, int act, const float* post_scale,
                 const float* post_shift, void* stream);
+/* LayerNorm whose result feeds three consumers at once: fp32 stream, compute-dtype copy, compute-dtype (y + pe[row % pe_rows]).
+   transformer.py:182 (norm4) followed by :160-165 / :176-178 of the next block. */
+int ullsam_norm_fanout(const float* in, long rows, int D, const float* w, const float* b, float eps, float* out_f32, void* out_c,
+                       void* out_c_pe, int c_dtype, const float* pe, long pe_rows, void* stream);
 
 /* SAM ViT attention on packed qkv [B, gh*gw, 3*heads*hd]; window > 0 fuses window_partition/unpartition and the pad-token
  * semantics; decomposed rel-pos computed in-kernel.  image_encoder.py:170-177,224-240,243-289,292-361. */
@@ -108,7 +112,7 @@ int ullsam_dense_pe(const float* G, float* out_nhwc, int H, int W, int C, void* 
 int ullsam_mask_downscale(const float* masks, float* out_nhwc, int P, int H, int W, int C, int c1, int c2, const float* w0,
                           const float* b0, const float* g1, const float* be1, const float* w3, const float* b3,
                           const float* g4, const float* be4, const float* w6, const float* b6, void* stream); /* prompt_encoder.py:54-62 */
-int ullsam_hyper_masks(const float* up2, const float* hyper, float* out, int NB, int NM, int H, int W, int CU, void* stream); /* mask_decoder.py:143-144 */
+int ullsam_hyper_masks(int dtype, const void* up2, const float* hyper, float* out, int NB, int NM, int H, int W, int CU, void* stream); /* mask_decoder.py:143-144 */
 int ullsam_resize_bilinear(const float* in, long in_plane_stride, int in_ld, int IH, int IW, float* out, unsigned char* mask,
                            int N, int OH, int OW, float thr, void* stream);              /* app.py:635-645; sam.py:154-162,123 */
 int ullsam_mask_iou_counts(const unsigned char* a, const unsigned char* b, unsigned long long* counts, int N, long per,

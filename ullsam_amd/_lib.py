@@ -18,6 +18,7 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
 SIGNATURES = {
     "ullsam_gemm": [i32, vp, i64, vp, i64, vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, i32, vp, i64, vp],
     "ullsam_norm": [vp, i32, i64, vp, i32, i64, vp, vp, i64, i32, f32, i32, i32, vp, vp, vp],
+    "ullsam_norm_fanout": [vp, i64, i32, vp, vp, f32, vp, vp, vp, i32, vp, i64, vp],
     "ullsam_vit_attention": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "ullsam_causal_attention": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "ullsam_naive_attention": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32] + [i64] * 12 + [f32, vp],
@@ -39,7 +40,7 @@ SIGNATURES = {
     "ullsam_sparse_embed": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp],
     "ullsam_dense_pe": [vp, vp, i32, i32, i32, vp],
     "ullsam_mask_downscale": [vp, vp, i32, i32, i32, i32, i32, i32] + [vp] * 10 + [vp],
-    "ullsam_hyper_masks": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "ullsam_hyper_masks": [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "ullsam_resize_bilinear": [vp, i64, i32, i32, i32, vp, vp, i32, i32, i32, f32, vp],
     "ullsam_mask_iou_counts": [vp, vp, vp, i32, i64, vp],
     "ullsam_stability_score": [vp, i64, i64, f32, f32, vp, vp, vp],

@@ -242,10 +242,10 @@ extern "C" int ullsam_mask_downscale(const float* masks, float* out_nhwc, int P,
 }
 
 // ---- masks = hyper_in @ upscaled_embedding (mask_decoder.py:143-144) ---------------------------------------------
-// up2 f32 [NB*H*W*4, 4*CU] : row = ((nb*H + y)*W + x)*4 + (ky*2+kx), col = (ky2*2+kx2)*CU + c  (two k2s2 ConvTranspose as GEMMs)
+// up2 f32 or bf16 [NB*H*W*4, 4*CU] : row = ((nb*H + y)*W + x)*4 + (ky*2+kx), col = (ky2*2+kx2)*CU + c  (two k2s2 ConvTranspose as GEMMs)
 // hyper f32 [NB, NM, CU];  out f32 [NB, NM, 4H, 4W]
-template <int CU>
-__global__ __launch_bounds__(256) void hyper_masks_kernel(const float* __restrict__ up2, const float* __restrict__ hyper,
+template <typename TU, int CU>
+__global__ __launch_bounds__(256) void hyper_masks_kernel(const TU* __restrict__ up2, const float* __restrict__ hyper,
                                                           float* __restrict__ out, int NB, int NM, int H, int W) {
     __shared__ float hs[8 * CU];
     const int nb = blockIdx.y;
@@ -258,11 +258,11 @@ __global__ __launch_bounds__(256) void hyper_masks_kernel(const float* __restric
         const int sub1 = row & 3;
         const long pix = row >> 2;
         const int y = (int)(pix / W), x = (int)(pix % W);
-        const float* src = up2 + (((long)nb * H * W * 4 + row) * 4 + sub2) * CU;
+        const TU* src = up2 + (((long)nb * H * W * 4 + row) * 4 + sub2) * CU;
         float v[CU];
 #pragma unroll
         for (int c = 0; c < CU; c += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(src + c);
+            const float4 t = load4(src + c);
             v[c] = t.x; v[c + 1] = t.y; v[c + 2] = t.z; v[c + 3] = t.w;
         }
         const int Y = 4 * y + 2 * (sub1 >> 1) + (sub2 >> 1), X = 4 * x + 2 * (sub1 & 1) + (sub2 & 1);
@@ -275,10 +275,13 @@ __global__ __launch_bounds__(256) void hyper_masks_kernel(const float* __restric
     }
 }
 
-extern "C" int ullsam_hyper_masks(const float* up2, const float* hyper, float* out, int NB, int NM, int H, int W, int CU, void* stream) {
+extern "C" int ullsam_hyper_masks(int dtype, const void* up2, const float* hyper, float* out, int NB, int NM, int H, int W, int CU,
+                                  void* stream) {
     ULLSAM_CHECK(CU == 32 && NM <= 8, "hyper_masks: CU must be 32, NM <= 8");
     if (NB == 0) return 0;
-    hyper_masks_kernel<32><<<dim3(512, NB), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(up2, hyper, out, NB, NM, H, W);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == ULLSAM_DT_F32) hyper_masks_kernel<float, 32><<<dim3(512, NB), 256, 0, s>>>((const float*)up2, hyper, out, NB, NM, H, W);
+    else hyper_masks_kernel<bf16, 32><<<dim3(512, NB), 256, 0, s>>>((const bf16*)up2, hyper, out, NB, NM, H, W);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }

@@ -784,7 +784,7 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     const double fill = (double)t256 / (double)(((t256 + 255) / 256) * 256);
     const long tail256 = t256 % 256;
     const bool v3_split = g_split_tail && workspace && t256 > 256 && tail256 > 0 && tail256 <= 64 && K >= 64 * bk;  // see launch_gemm_v3_impl
-    const bool v3 = variant == 3 || (variant == 0 && M >= 1024 && (fill >= 0.74 || v3_split) && (act != 3 || N % 256 == 0));
+    const bool v3 = variant == 3 || (variant == 0 && M >= 1024 && N >= 256 && K >= 8 * bk && (fill >= 0.74 || v3_split) && (act != 3 || N % 256 == 0));  // short K / narrow N: the 256^2 tile's fixed cost or its empty half dominates
     if (act == 3 && (variant == 3) && N % 256 != 0) { ullsam_set_error("ullsam_gemm: v3 swiglu needs N%%256==0"); return -1; }
     if (v3) return dtype == ULLSAM_DT_F32 ? launch_gemm_v3<float>(a, s) : launch_gemm_v3<bf16>(a, s);
     if (v2) return dtype == ULLSAM_DT_F32 ? launch_gemm_v2<float>(a, s) : launch_gemm_v2<bf16>(a, s);

@@ -140,6 +140,54 @@ static int launch_norm(const NormArgs& a, hipStream_t s) {
     return 0;
 }
 
+// ---- LayerNorm with fan-out (norm4 of the two-way block, transformer.py:182, feeding the next block) -----------------
+// y = LN(in) is needed as the fp32 residual stream, in the compute dtype (v projection / upscaling input) and as (y + pe) in the
+// compute dtype (k / q projections): three consumers, one pass -- instead of the norm plus two add_cast passes over [P*N, C].
+template <typename TO>
+__global__ __launch_bounds__(256) void norm_fanout_kernel(const float* __restrict__ in, long rows, int D, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float eps, float* __restrict__ out_f32,
+                                                          TO* __restrict__ out_c, TO* __restrict__ out_c_pe,
+                                                          const float* __restrict__ pe, long pe_rows) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = D >> 2;
+    const bool on = lane < nv;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on) v = *reinterpret_cast<const float4*>(in + row * D + lane * 4);
+    const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) / (float)D;
+    float ss = 0.f;
+    if (on) {
+        const float a = v.x - mean, bb = v.y - mean, c = v.z - mean, d = v.w - mean;
+        ss = (a * a + bb * bb) + (c * c + d * d);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+    if (!on) return;
+    float4 o = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+    if (w) { const float4 t = *reinterpret_cast<const float4*>(w + lane * 4); o.x *= t.x; o.y *= t.y; o.z *= t.z; o.w *= t.w; }
+    if (b) { const float4 t = *reinterpret_cast<const float4*>(b + lane * 4); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+    if (out_f32) *reinterpret_cast<float4*>(out_f32 + row * D + lane * 4) = o;
+    if (out_c) store4(out_c + row * D + lane * 4, o);
+    if (out_c_pe) {
+        const float4 t = *reinterpret_cast<const float4*>(pe + (row % pe_rows) * D + lane * 4);
+        store4(out_c_pe + row * D + lane * 4, make_float4(o.x + t.x, o.y + t.y, o.z + t.z, o.w + t.w));
+    }
+}
+
+// in f32 [rows, D] (D <= 256, D % 4 == 0); out_f32 / out_c / out_c_pe each optional; c_dtype 0 f32, 1 bf16; pe f32 [pe_rows, D].
+extern "C" int ullsam_norm_fanout(const float* in, long rows, int D, const float* w, const float* b, float eps, float* out_f32,
+                                  void* out_c, void* out_c_pe, int c_dtype, const float* pe, long pe_rows, void* stream) {
+    ULLSAM_CHECK(D % 4 == 0 && D > 0 && D <= 256, "norm_fanout: D=%d must be a multiple of 4 and <= 256", D);
+    ULLSAM_CHECK(!out_c_pe || (pe && pe_rows > 0), "norm_fanout: out_c_pe needs pe");
+    if (rows <= 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (c_dtype == 0) norm_fanout_kernel<float><<<grid, 256, 0, s>>>(in, rows, D, w, b, eps, out_f32, (float*)out_c, (float*)out_c_pe, pe, pe_rows);
+    else norm_fanout_kernel<bf16><<<grid, 256, 0, s>>>(in, rows, D, w, b, eps, out_f32, (bf16*)out_c, (bf16*)out_c_pe, pe, pe_rows);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
 // in_dtype/out_dtype: 0 f32, 1 bf16.  w/b may be null.  rms=1 -> RMSNorm (b ignored).
 extern "C" int ullsam_norm(const void* in, int in_dtype, long in_stride, void* out, int out_dtype, long out_stride,
                            const float* w, const float* b, long rows, int D, float eps, int rms, int act,

@@ -84,15 +84,15 @@ class MaskDecoder(Packed):
         dense_rows = dense_tokens.numel() // C
         Pk = 1 if (image_tokens.shape[0] == 1 and dense_rows in (1, N)) else P   # one image, prompt-independent dense embedding
         keys = ops.add_cast(image_tokens.reshape(-1, C), dense_tokens.reshape(-1, C).contiguous(), torch.float32, rows=Pk * N)
-        hs, src = self.transformer.forward_tokens(keys.reshape(Pk, N, C), pe_tokens, tokens)
+        hs, src = self.transformer.forward_tokens(keys.reshape(Pk, N, C), pe_tokens, tokens, keys_in_compute_dtype=True)
         nm = self.num_mask_tokens
         up0, ln, up1 = self.output_upscaling[0], self.output_upscaling[1], self.output_upscaling[3]
         w0, b0 = up0.packed(dt)
         w1, b1 = up1.packed(dt)
         c4, c8 = C // 4, C // 8
-        u1 = ops.gemm(ops.cast(src.reshape(P * N, C), dt), w0, b0, out_f32=True)           # [P*N, (ky,kx,c4)]
+        u1 = ops.gemm(src.reshape(P * N, C), w0, b0, out_f32=True)           # [P*N, (ky,kx,c4)]
         u1 = ops.norm(u1.reshape(P * N * 4, c4), *ln.wb(), ln.eps, dt, act=ops.ACT_GELU)   # LayerNorm2d + GELU per output pixel
-        u2 = ops.gemm(u1, w1, b1, act=ops.ACT_GELU, out_f32=True)                          # [P*N*4, (ky2,kx2,c8)]
+        u2 = ops.gemm(u1, w1, b1, act=ops.ACT_GELU)                          # [P*N*4, (ky2,kx2,c8)]
         hyper = torch.stack([self.output_hypernetworks_mlps[i](hs[:, 1 + i, :]) for i in range(nm)], dim=1).contiguous()
         masks = ops.hyper_masks(u2, hyper, P, nm, h, w, c8)
         iou = self.iou_prediction_head(hs[:, 0, :])

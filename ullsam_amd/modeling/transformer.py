@@ -90,9 +90,11 @@ class TwoWayTransformer(Packed):
     def compute_dtype(self):
         return self.final_attn_token_to_image.k_proj.weight.dtype
 
-    def forward_tokens(self, keys: torch.Tensor, key_pe: torch.Tensor, tokens: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward_tokens(self, keys: torch.Tensor, key_pe: torch.Tensor, tokens: torch.Tensor, keys_in_compute_dtype: bool = False
+                       ) -> Tuple[torch.Tensor, torch.Tensor]:
         """keys fp32 [P, N, C] (image embedding + dense prompt, token-major), key_pe fp32 [N, C], tokens fp32 [P, T, C].
-        Returns (queries [P,T,C], keys [P,N,C]) as TwoWayTransformer.forward transformer.py:62-108.
+        Returns (queries [P,T,C], keys [P,N,C]) as TwoWayTransformer.forward transformer.py:62-108; with `keys_in_compute_dtype`
+        the returned keys are in the model dtype (what the mask decoder's upscaling consumes) and the fp32 copy is never written.
         keys may be [1, N, C] with P > 1 prompts (one image, many prompts, prompt-independent dense embedding): until the first
         image -> token attention the image side is identical for every prompt, so its projections of layer 0 are computed once and
         broadcast (same values as the reference's repeat_interleave, 1/P of the work)."""
@@ -105,7 +107,9 @@ class TwoWayTransformer(Packed):
         qpe = tokens.reshape(P * T, C).contiguous()
         queries = qpe
         f32 = torch.float32
-        for blk in self.layers:
+        keys_pe_c = ops.add_cast(keys, key_pe, dt)       # keys + key_pe: k of token->image, q of image->token
+        keys_c = ops.cast(keys, dt)                      # v of token->image
+        for li, blk in enumerate(self.layers):
             sa = blk.self_attn
             if blk.skip_first_layer_pe:  # no PE and NO residual (:157-158)
                 q_in, res = queries, None
@@ -113,14 +117,11 @@ class TwoWayTransformer(Packed):
                 q_in, res = ops.add_cast(queries, qpe, f32), queries
             a = sa.attend_tokens(sa.tok(sa.q_proj, q_in), sa.tok(sa.k_proj, q_in), sa.tok(sa.v_proj, queries), P, T, T)
             queries = ops.norm(sa.tok(sa.out_proj, a, res=res), *blk.norm1.wb(), blk.norm1.eps, f32)
-            keys_pe_c = ops.add_cast(keys, key_pe, dt)   # keys + key_pe, shared by both cross attentions of the block
-            keys_c = ops.cast(keys, dt)
             queries = ops.norm(_token_to_image(blk.cross_attn_token_to_image, queries, qpe, keys_pe_c, keys_c, P, T, N, dt, shared),
                                *blk.norm2.wb(), blk.norm2.eps, f32)
             m = blk.mlp
             hmid = m.lin1.tok(queries, m.act_code)
-            queries = ops.norm(m.lin2.tok(hmid, res=queries),
-                               *blk.norm3.wb(), blk.norm3.eps, f32)
+            queries = ops.norm(m.lin2.tok(hmid, res=queries), *blk.norm3.wb(), blk.norm3.eps, f32)
             # image -> token: keys = norm4(keys + attn(q=keys+pe, k=queries+pe, v=queries))   (:176-182)
             ia = blk.cross_attn_image_to_token
             q_in = ops.add_cast(queries, qpe, f32)
@@ -129,12 +130,16 @@ class TwoWayTransformer(Packed):
                                       1.0 / math.sqrt(ia.hd), q_shared=shared)
             upd = ops.gemm(ops.cast(a, dt), ia.out_proj.w(dt), ia.out_proj.b(), residual=keys, out_f32=True,
                            res_row_mod=N if shared else 0)
-            keys = ops.norm(upd, *blk.norm4.wb(), blk.norm4.eps, f32)
+            # norm4 feeds the next block's residual (fp32), its v projection (model dtype) and its k / q projections (+pe, model dtype)
+            last = li + 1 == len(self.layers)
+            keys, keys_c, keys_pe_c = ops.norm_fanout(upd, *blk.norm4.wb(), blk.norm4.eps, dt, key_pe,
+                                                      want_f32=not (last and keys_in_compute_dtype))
             shared = False                               # from here on every prompt has its own image-side stream
         fa = self.final_attn_token_to_image
-        queries = ops.norm(_token_to_image(fa, queries, qpe, ops.add_cast(keys, key_pe, dt), ops.cast(keys, dt), P, T, N, dt),
+        queries = ops.norm(_token_to_image(fa, queries, qpe, keys_pe_c, keys_c, P, T, N, dt, shared),
                            *self.norm_final_attn.wb(), self.norm_final_attn.eps, f32)
-        return queries.reshape(P, T, C), keys.reshape(P, N, C)
+        out_keys = keys_c if keys_in_compute_dtype else keys
+        return queries.reshape(P, T, C), out_keys.reshape(-1, N, C)
 
     @torch.no_grad()
     def forward(self, image_embedding: torch.Tensor, image_pe: torch.Tensor, point_embedding: torch.Tensor):

@@ -95,6 +95,24 @@ def norm(x: torch.Tensor, w: Optional[torch.Tensor], b: Optional[torch.Tensor], 
     return out
 
 
+def norm_fanout(x: torch.Tensor, w, b, eps: float, cdt: torch.dtype, pe: Optional[torch.Tensor], want_f32: bool = True,
+                want_c: bool = True):
+    """y = LayerNorm(x fp32 [rows, D]) -> (y fp32 | None, y in cdt | None, (y + pe[row % pe_rows]) in cdt | None) in one pass.
+    With cdt == float32 the compute-dtype copy is the fp32 result itself."""
+    _chk(x, "x", torch.float32)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    f32c = cdt == torch.float32
+    out_f = torch.empty((rows, D), dtype=torch.float32, device=x.device) if (want_f32 or (f32c and want_c)) else None
+    out_c = torch.empty((rows, D), dtype=cdt, device=x.device) if (want_c and not f32c) else None
+    out_pe = torch.empty((rows, D), dtype=cdt, device=x.device) if pe is not None else None
+    if pe is not None:
+        _chk(pe, "pe", torch.float32)
+    _lib.call("ullsam_norm_fanout", x.data_ptr(), rows, D, _p(w), _p(b), float(eps), _p(out_f), _p(out_c), _p(out_pe), dt_code(cdt),
+              _p(pe), pe.numel() // D if pe is not None else 0, _stream())
+    return out_f, (out_f if f32c else out_c), out_pe
+
+
 def vit_attention(qkv: torch.Tensor, rel_h: torch.Tensor, rel_w: torch.Tensor, qkv_bias: torch.Tensor, B: int, heads: int,
                   hd: int, gh: int, gw: int, window: int) -> torch.Tensor:
     _chk(qkv, "qkv"); _chk(rel_h, "rel_h", qkv.dtype); _chk(rel_w, "rel_w", qkv.dtype); _chk(qkv_bias, "qkv_bias", qkv.dtype)
@@ -317,7 +335,7 @@ def mask_downscale(masks: torch.Tensor, H: int, W: int, C: int, params) -> torch
 
 def hyper_masks(up2: torch.Tensor, hyper: torch.Tensor, NB: int, NM: int, H: int, W: int, CU: int) -> torch.Tensor:
     out = torch.empty((NB, NM, 4 * H, 4 * W), dtype=torch.float32, device=up2.device)
-    _lib.call("ullsam_hyper_masks", up2.data_ptr(), hyper.data_ptr(), out.data_ptr(), NB, NM, H, W, CU, _stream())
+    _lib.call("ullsam_hyper_masks", dt_code(up2.dtype), up2.data_ptr(), hyper.data_ptr(), out.data_ptr(), NB, NM, H, W, CU, _stream())
     return out
 
 
