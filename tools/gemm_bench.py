@@ -33,6 +33,8 @@ def main():
         bias = torch.randn(N, device=dev) if act == 1 else None
         ref = None
         for v in variants:
+            if v < 0:
+                continue
             lib.ullsam_set_gemm_variant(v)
             out = ops.gemm(a, w, bias, act=act)
             if ref is None:
@@ -43,11 +45,15 @@ def main():
         times = {v: [] for v in variants}
         for r in range(rounds):
             for v in variants:
-                lib.ullsam_set_gemm_variant(v)
+                if v >= 0:
+                    lib.ullsam_set_gemm_variant(v)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for i in range(ncopy):
-                    ops.gemm(As[i], Ws[i], bias, act=act, out=Cs[i])
+                    if v < 0:   # comparator only: the vendor library's plain GEMM (no epilogue) through torch
+                        torch.nn.functional.linear(As[i], Ws[i])
+                    else:
+                        ops.gemm(As[i], Ws[i], bias, act=act, out=Cs[i])
                 e1.record()
                 torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) / ncopy)
