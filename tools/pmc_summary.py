@@ -23,7 +23,7 @@ def main():
         agg = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int); seen = set()
         for r in csv.DictReader(open(cc)):
             name = short(r["Kernel_Name"])
-            if "gemm" not in name and "flash" not in name and "norm" not in name:
+            if "gemm" not in name and "attn" not in name and "norm" not in name:
                 continue
             key = (name, int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1))
             agg[key][r["Counter_Name"]] += float(r["Counter_Value"])

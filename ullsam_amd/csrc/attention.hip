@@ -47,6 +47,12 @@ template <typename T, int HD, int TR = 64> struct KVTile {
     static constexpr int ROWS = TR;                      // keys per staged tile: 64, or 128 for the windowed mode (196 keys = 2 tiles)
     static constexpr int BYTES = RS * ROWS;
     static constexpr int CPR = HD * (int)sizeof(T) / 16;  // 16-byte chunks per row
+    // V rows are read transposed (ds_read_b64_tr_b16: 32 lanes = 4 rows x 64 contiguous bytes): conflict-free when consecutive
+    // rows start 16 banks apart, i.e. row stride = 64 (mod 256) bytes.  With the K stride (HD*2+16) the four rows overlapped
+    // in 12 of their 16 banks (SQ_LDS_BANK_CONFLICT was 47 % of the LDS cycles of the causal kernel).
+    static constexpr int RSV = sizeof(T) == 2 ? 320 : RS;
+    static constexpr int VBYTES = RSV * ROWS;
+    static_assert(sizeof(T) != 2 || HD * 2 <= 256, "V row does not fit its 320-byte stride");
 };
 
 // ---- V^T fragment: lane (d = d0 + (lane&31), h) element j = V[kv0 + 8*(j>>2) + 4h + (j&3)][d]
@@ -95,11 +101,20 @@ __device__ __forceinline__ Frag<float> pack_p(const f32x16& s, int half, const f
 // FAST64: MODE_VIT_GLOBAL on the 64x64 token grid SAM always uses at 1024^2.  A 32-key block is then half a grid row: its
 // key row is uniform (ONE rel_h LDS read per block) and its key columns are one of two fixed sets, so rel_w lives in 32
 // registers per lane; only rel_h stays in LDS (8 KiB per wave -> two workgroups per CU).
+// Lanes l and l^32 hold the two key halves of one query: combine them with v_permlane32_swap (a VALU op) instead of a
+// ds_bpermute round trip through the LDS.  After the swap every lane holds {lower-half value, upper-half value} in (a, b).
+__device__ __forceinline__ void halves(float x, float& lo, float& hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+
 template <typename T, int HD, int MODE, int NWAVES, bool FAST64>
 __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) {  // >= 2 waves per SIMD: at most 256 VGPR+AGPR
     constexpr int TR = (MODE == MODE_VIT_WINDOW && NWAVES == 7) ? 128 : 64;  // keys per staged K/V tile
     using KT = KVTile<T, HD, TR>;
     constexpr int RS = KT::RS;
+    constexpr int RSV = KT::RSV;
     constexpr int NT = NWAVES * 64;
     constexpr int CPR = KT::CPR;
     constexpr int NCH = (TR * CPR + NT - 1) / NT;  // 16-byte chunks per thread per K (or V) tile
@@ -107,13 +122,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
     constexpr int DT = (HD + 31) / 32;
     constexpr bool REL = (MODE == MODE_VIT_GLOBAL || MODE == MODE_VIT_WINDOW);
     constexpr float LOG2E = 1.4426950408889634f;
+    // bf16 with HD % 32 != 0 (ViT-H: 80): the last 32-wide d-tile of O^T = V^T P^T has unused rows.  A column of ones at V[:, HD]
+    // makes row HD of O^T the softmax denominator (sum of the bf16 p it is normalised with, rescaled by alpha like every other
+    // row), so the 16 adds per lane and block and the running sum disappear from the VALU stream.
+    constexpr bool LSUM_MFMA = sizeof(T) == 2 && (HD % 32) != 0 && (HD % 32) <= 16 && (HD % 8) == 0;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + KT::BYTES;
     // V tile gets 16 extra rows of slack: for HD % 32 != 0 the last d-tile's transposed reads run past HD
-    int* kms = reinterpret_cast<int*>(smem + 2 * KT::BYTES + 16 * RS);  // key-padding mask of the staged tile (64 ints)
-    float* rel_base = reinterpret_cast<float*>(smem + 2 * KT::BYTES + 16 * RS + 256);
+    int* kms = reinterpret_cast<int*>(smem + KT::BYTES + KT::VBYTES + 16 * RSV);  // key-padding mask of the staged tile (64 ints)
+    float* rel_base = reinterpret_cast<float*>(smem + KT::BYTES + KT::VBYTES + 16 * RSV + 256);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,7 +151,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
     const float invG = 1.0f / (float)G;
 
     // ---- this lane's query
-    const int qi = (blockIdx.x * NWAVES + wave) * 32 + ql;  // index within sequence / window
+    // causal: the last query blocks see the most keys -- dispatch them first so the long workgroups do not form the tail
+    const int qblk = (MODE == MODE_CAUSAL) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    const int qi = (qblk * NWAVES + wave) * 32 + ql;  // index within sequence / window
     bool q_valid = qi < p.Sq;
     long q_tok = qi;       // token index in the [B, tokens] tensors (for load and store)
     bool q_store = q_valid;
@@ -217,7 +238,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
             const int row = idx / CPR, ch = idx - row * CPR;
             if (row < TR) {
                 *reinterpret_cast<uint4*>(Ks + row * RS + ch * 16) = kreg[c];
-                *reinterpret_cast<uint4*>(Vs + row * RS + ch * 16) = vreg[c];
+                *reinterpret_cast<uint4*>(Vs + row * RSV + ch * 16) = vreg[c];
             }
         }
     };
@@ -259,10 +280,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
                 const int e = 32 * t + crow32(r, h);
                 if (e < NE) {
                     const int kk = qh + (G - 1) - e;  // rel index e = q - k + (G-1)  (get_rel_pos, image_encoder.py:318-322)
-                    if (kk >= 0 && kk < GHk) relh[kk * 32 + ql] = acc[r];
+                    if (kk >= 0 && kk < GHk) relh[kk * 32 + ql] = acc[r] * LOG2E;  // tables are kept in log2 units
                 } else if (e < 2 * NE) {
                     const int kk = qw + (G - 1) - (e - NE);
-                    if (kk >= 0 && kk < G) relw[kk * 32 + ql] = acc[r];
+                    if (kk >= 0 && kk < G) relw[kk * 32 + ql] = acc[r] * LOG2E;
                 }
             }
         }
@@ -300,13 +321,13 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
                 for (int r = 0; r < 16; ++r) {
                     const int e = 32 * t + crow32(r, h);
                     const int kk = qc + (G - 1) - e;  // rel index e = q - k + (G-1)  (get_rel_pos, image_encoder.py:318-322)
-                    if (e < NE && kk >= 0 && kk < GK) dst[kk * 32 + ql] = acc[r];
+                    if (e < NE && kk >= 0 && kk < GK) dst[kk * 32 + ql] = acc[r] * LOG2E;  // tables are kept in log2 units
                 }
             }
             if (FAST64 && tb == 1) {
                 __syncthreads();  // both lane halves of every wave have scattered their rel_w entries
 #pragma unroll
-                for (int i = 0; i < 32; ++i) rw[i >> 4][i & 15] = relw[(32 * (i >> 4) + crow32(i & 15, h)) * 32 + ql] * LOG2E;
+                for (int i = 0; i < 32; ++i) rw[i >> 4][i & 15] = relw[(32 * (i >> 4) + crow32(i & 15, h)) * 32 + ql];
             }
         }
         __syncthreads();
@@ -324,100 +345,159 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
 
     int ntiles = (Sk + TR - 1) / TR;
     if (MODE == MODE_CAUSAL) {
-        const int last_q = p.q_pos0 + min(p.Sq, (int)(blockIdx.x + 1) * NWAVES * 32) - 1;
+        const int last_q = p.q_pos0 + min(p.Sq, (qblk + 1) * NWAVES * 32) - 1;
         ntiles = min(ntiles, last_q / 64 + 1);
     }
     const float FMIN = -3.4028234663852886e38f;  // torch.finfo(float32).min
 
+    if (LSUM_MFMA) {
+        for (int row = tid; row < TR; row += NT) {
+            *reinterpret_cast<uint4*>(Vs + row * RSV + HD * 2) = make_uint4(0x00003F80u, 0u, 0u, 0u);  // bf16 1.0 at column HD, zeros after
+            *reinterpret_cast<uint4*>(Vs + row * RSV + HD * 2 + 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
     store_tile();  // tile 0 was fetched before the table phase
     __syncthreads();
     // SAM's windows are always 14x14 (build_sam.py:78): 196 keys = a compile-time tile count, and with the tile loop unrolled
     // the key -> (row, col) split of every accumulator register is a compile-time constant (two candidates, by lane half).
     const bool win14 = (MODE == MODE_VIT_WINDOW) && p.win == 14;
     constexpr int NT14 = (196 + TR - 1) / TR;
+    // ---- the three stages of one 32-key block
+    auto qk_block = [&](const int sub, f32x16& s) __attribute__((always_inline)) {  // S^T = K . Q^T
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const Frag<T> a = load_frag(reinterpret_cast<const T*>(Ks + (sub * 32 + ql) * RS) + 16 * ks + 8 * h);
+            mma32(a, qf[ks], s);
+        }
+    };
+    // scores -> unnormalised probabilities in place (online softmax); returns the factor the running O must be scaled by
+    auto soft_block = [&](const int tile, const int sub, const bool W14, const bool tile_pad, const int wave_first_q, f32x16& s)
+                          __attribute__((always_inline)) -> float {
+        const int kbase = tile * TR + sub * 32;
+        float mx = -INFINITY;
+        // FAST64: the key row of this 32-key block is the same for all 16 scores of a lane, so its rel_h term is added to the
+        // block maximum and folded into the exponent offset instead of into every score
+        const float rh64 = FAST64 ? relh[(kbase >> 6) * 32 + ql] : 0.f;
+        // causal: blocks entirely in the past of every query of this wave and free of padding need no mask arithmetic
+        const bool interior = (MODE == MODE_CAUSAL) && !tile_pad && (kbase + 31 <= wave_first_q) && (kbase + 31 < Sk);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kt = kbase + crow32(r, h);
+            float v;
+            if (FAST64) {
+                v = s[r] * scale2 + rw[sub & 1][r];  // key column = 32*(sub&1) + crow32(r, h): compile-time register index
+            } else if (MODE == MODE_VIT_WINDOW && W14) {
+                const int k0 = kbase + crow32(r, 0), k1 = k0 + 4;  // the two lane halves' keys; constants after unrolling
+                const int offh = h ? (k1 / 14) * 32 : (k0 / 14) * 32;
+                const int offw = h ? (k1 % 14) * 32 : (k0 % 14) * 32;
+                const bool valid = h ? (k1 < 196) : (k0 < 196);
+                v = valid ? s[r] * scale2 + (relh[(offh < 14 * 32 ? offh : 0) + ql] + relw[offw + ql]) : -INFINITY;
+            } else if (REL) {
+                const int ky = (int)(((float)kt + 0.5f) * invG);
+                const int kx = kt - ky * G;
+                const float bias = (kt < Sk) ? (relh[ky * 32 + ql] + relw[kx * 32 + ql]) : 0.f;
+                v = s[r] * scale2 + bias;
+            } else {
+                v = s[r] * scale2;
+            }
+            if (MODE == MODE_CAUSAL && !interior) {
+                // additive masks exactly as the reference builds them (fp32): causal min + padding min
+                float add = 0.f;
+                if (kt > q_pos) add += FMIN;
+                if (kms[sub * 32 + crow32(r, h)] == 0) add += FMIN;
+                // = finfo.min (score absorbed) or -inf; deliberately NOT rescaled by log2(e): a row whose
+                // keys are all single-masked must stay uniform over them, as in the reference's eager softmax
+                if (add != 0.f) v = s[r] * p.scale + add;
+            }
+            if (!FAST64 && !interior && !(MODE == MODE_VIT_WINDOW && W14) && kt >= Sk) v = -INFINITY;
+            s[r] = v;
+            mx = fmaxf(mx, v);
+        }
+        {
+            float lo, hi;
+            halves(mx, lo, hi);
+            mx = fmaxf(lo, hi) + rh64;
+        }
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
+        const float m_off = m_use - rh64;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(s[r] - m_off);  // raw v_exp_f32: arguments are <= 0, underflow to 0 is the intent
+            s[r] = pv;
+            if (!LSUM_MFMA) psum += pv;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        return alpha;
+    };
+    auto pv_block = [&](const int sub, const Frag<T>& p0, const Frag<T>& p1) __attribute__((always_inline)) {  // O^T += V^T . P^T
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            const Frag<T> v0 = load_vt_frag<RSV>(Vs, sub * 32, d * 32, lane, (const T*)nullptr);
+            mma32(v0, p0, o[d]);
+            const Frag<T> v1 = load_vt_frag<RSV>(Vs, sub * 32 + 16, d * 32, lane, (const T*)nullptr);
+            mma32(v1, p1, o[d]);
+        }
+    };
+    auto scale_o = [&](const float alpha) __attribute__((always_inline)) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    };
+
+    // The ViT kernels (bf16) are VALU-bound: per 32-key block a lane spends ~140 issue slots on the softmax against 11 MFMAs, and a
+    // wave that runs QK -> softmax -> PV in sequence leaves the matrix pipe idle during its own softmax.  PIPE software-pipelines
+    // the blocks of a staged tile inside the wave: while block j's softmax runs on the VALU, the matrix pipe computes the scores of
+    // block j+1 and the PV product of block j-1 (independent registers, one basic block: the O rescale is unconditional there).
+    constexpr bool PIPE_OK = sizeof(T) == 2 && REL;
     auto do_tile = [&](const int tile, const bool W14) __attribute__((always_inline)) {
         if (tile + 1 < ntiles) load_tile(tile + 1);
         const bool tile_pad = (MODE == MODE_CAUSAL && kmask_g) ? (__any(kms[lane] == 0) != 0) : false;
-        const int wave_first_q = p.q_pos0 + ((int)blockIdx.x * NWAVES + wave) * 32;
+        const int wave_first_q = p.q_pos0 + (qblk * NWAVES + wave) * 32;
+        constexpr int NSUB = TR / 32;
+        if (PIPE_OK && (FAST64 || W14)) {
+            // block validity is a compile-time fact here: FAST64 has Sk = 4096 (every block full); W14 has Sk = 196 with the tile
+            // index a constant of the unrolled tile loop
+            auto valid = [&](const int sub) { return FAST64 || (tile * TR + sub * 32 < 196); };
+            if (wave_first_q - p.q_pos0 < p.Sq && valid(0)) {  // wave-uniform: this wave has queries
+                f32x16 sc[2];
+                Frag<T> p0, p1;
+                qk_block(0, sc[0]);
 #pragma unroll
-        for (int sub = 0; sub < TR / 32; ++sub) {
-            const int kbase = tile * TR + sub * 32;
-            if (kbase >= Sk) continue;
-            if (wave_first_q - p.q_pos0 >= p.Sq) continue;  // wave-uniform: no valid query in this wave
-            if (MODE == MODE_CAUSAL) {
-                const int wave_last_q = p.q_pos0 + min(p.Sq, ((int)blockIdx.x * NWAVES + wave + 1) * 32) - 1;
-                if (kbase > wave_last_q) continue;  // wave-uniform: the whole 32-key block is in the future
-            }
-            f32x16 s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const Frag<T> a = load_frag(reinterpret_cast<const T*>(Ks + (sub * 32 + ql) * RS) + 16 * ks + 8 * h);
-                mma32(a, qf[ks], s);
-            }
-            float mx = -INFINITY;
-            const float rh64 = FAST64 ? relh[(kbase >> 6) * 32 + ql] * LOG2E : 0.f;  // key row of this 32-key block
-            // causal: blocks entirely in the past of every query of this wave and free of padding need no mask arithmetic
-            const bool interior = (MODE == MODE_CAUSAL) && !tile_pad && (kbase + 31 <= wave_first_q) && (kbase + 31 < Sk);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kt = kbase + crow32(r, h);
-                float v = s[r] * scale2;
-                if (FAST64) {
-                    v += rh64 + rw[sub & 1][r];  // key column = 32*(sub&1) + crow32(r, h): compile-time register index
-                } else if (MODE == MODE_VIT_WINDOW && W14) {
-                    const int k0 = kbase + crow32(r, 0), k1 = k0 + 4;  // the two lane halves' keys; constants after unrolling
-                    const int offh = h ? (k1 / 14) * 32 : (k0 / 14) * 32;
-                    const int offw = h ? (k1 % 14) * 32 : (k0 % 14) * 32;
-                    const bool valid = h ? (k1 < 196) : (k0 < 196);
-                    v = valid ? v + (relh[(offh < 14 * 32 ? offh : 0) + ql] + relw[offw + ql]) * LOG2E : -INFINITY;
-                } else if (REL) {
-                    const int ky = (int)(((float)kt + 0.5f) * invG);
-                    const int kx = kt - ky * G;
-                    const float bias = (kt < Sk) ? (relh[ky * 32 + ql] + relw[kx * 32 + ql]) : 0.f;
-                    v += bias * LOG2E;
+                for (int sub = 0; sub < NSUB; ++sub) {
+                    if (!valid(sub)) break;
+                    if (sub + 1 < NSUB && valid(sub + 1)) qk_block(sub + 1, sc[(sub + 1) & 1]);
+                    if (sub > 0) pv_block(sub - 1, p0, p1);
+                    const float alpha = soft_block(tile, sub, W14, false, wave_first_q, sc[sub & 1]);
+                    scale_o(alpha);
+                    p0 = pack_p(sc[sub & 1], 0, (const T*)nullptr);
+                    p1 = pack_p(sc[sub & 1], 1, (const T*)nullptr);
+                    if (sub + 1 == NSUB || !valid(sub + 1)) pv_block(sub, p0, p1);  // drain before the tile buffer is recycled
                 }
-                if (MODE == MODE_CAUSAL && !interior) {
-                    // additive masks exactly as the reference builds them (fp32): causal min + padding min
-                    float add = 0.f;
-                    if (kt > q_pos) add += FMIN;
-                    if (kms[sub * 32 + crow32(r, h)] == 0) add += FMIN;
-                    // = finfo.min (score absorbed) or -inf; deliberately NOT rescaled by log2(e): a row whose
-                    // keys are all single-masked must stay uniform over them, as in the reference's eager softmax
-                    if (add != 0.f) v = s[r] * p.scale + add;
+            }
+        } else {
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const int kbase = tile * TR + sub * 32;
+                if (kbase >= Sk) continue;
+                if (wave_first_q - p.q_pos0 >= p.Sq) continue;  // wave-uniform: no valid query in this wave
+                if (MODE == MODE_CAUSAL) {
+                    const int wave_last_q = p.q_pos0 + min(p.Sq, (qblk * NWAVES + wave + 1) * 32) - 1;
+                    if (kbase > wave_last_q) continue;  // wave-uniform: the whole 32-key block is in the future
                 }
-                if (!FAST64 && !interior && !(MODE == MODE_VIT_WINDOW && W14) && kt >= Sk) v = -INFINITY;
-                s[r] = v;
-                mx = fmaxf(mx, v);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
-            float psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(s[r] - m_use);
-                s[r] = pv;
-                psum += pv;
-            }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-            if (__any(alpha != 1.0f)) {  // wave-uniform: skip the O rescale when no row maximum moved in this block
-#pragma unroll
-                for (int d = 0; d < DT; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            }
-            const Frag<T> p0 = pack_p(s, 0, (const T*)nullptr);
-            const Frag<T> p1 = pack_p(s, 1, (const T*)nullptr);
-#pragma unroll
-            for (int d = 0; d < DT; ++d) {
-                const Frag<T> v0 = load_vt_frag<RS>(Vs, sub * 32, d * 32, lane, (const T*)nullptr);
-                mma32(v0, p0, o[d]);
-                const Frag<T> v1 = load_vt_frag<RS>(Vs, sub * 32 + 16, d * 32, lane, (const T*)nullptr);
-                mma32(v1, p1, o[d]);
+                f32x16 sc;
+                qk_block(sub, sc);
+                const float alpha = soft_block(tile, sub, W14, tile_pad, wave_first_q, sc);
+                if (__any(alpha != 1.0f)) scale_o(alpha);  // wave-uniform: skip the O rescale when no row maximum moved in this block
+                const Frag<T> p0 = pack_p(sc, 0, (const T*)nullptr);
+                const Frag<T> p1 = pack_p(sc, 1, (const T*)nullptr);
+                pv_block(sub, p0, p1);
             }
         }
         __syncthreads();
@@ -433,7 +513,18 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
     }
 
     // ---- normalise and store: lane q holds O^T[d][q], d = 32*dt + crow32(r, h)
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    {
+        float lo, hi;
+        if (LSUM_MFMA) {  // row HD of O^T: d-tile DT-1, crow32(r, h) == HD % 32 at h = 0
+            constexpr int RL = ((HD % 32) & 3) + 4 * ((HD % 32) >> 3);
+            halves(o[DT - 1][RL], lo, hi);
+            l_tot = lo;
+        } else {
+            halves(l_run, lo, hi);
+            l_tot = lo + hi;
+        }
+    }
     const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (q_store) {
         T* op = reinterpret_cast<T*>(p.out) + (long)b * p.o_bs + q_tok * p.o_ts + (long)head * p.o_hs;
@@ -456,7 +547,7 @@ static int launch_flash_impl(const AttnArgs& a, hipStream_t s) {
     using KT = KVTile<T, HD, (MODE == MODE_VIT_WINDOW && NWAVES == 7) ? 128 : 64>;
     constexpr bool REL = (MODE == MODE_VIT_GLOBAL || MODE == MODE_VIT_WINDOW);
     constexpr int RELROWS = (MODE == MODE_VIT_WINDOW) ? 16 : 64;
-    const size_t lds = 2 * KT::BYTES + 16 * KT::RS + 256 + (REL ? (size_t)NWAVES * (FAST64 ? 1 : 2) * RELROWS * 32 * 4 : 0);
+    const size_t lds = KT::BYTES + KT::VBYTES + 16 * KT::RSV + 256 + (REL ? (size_t)NWAVES * (FAST64 ? 1 : 2) * RELROWS * 32 * 4 : 0);
     ULLSAM_CHECK(lds <= 160 * 1024, "flash_attn: LDS %zu exceeds 160 KiB", lds);
     static bool attr = false;
     if (!attr) {
@@ -486,6 +577,295 @@ static int dispatch_hd(const AttnArgs& a, int hd, hipStream_t s) {
         default: break;
     }
     ULLSAM_CHECK(false, "flash_attn: unsupported head_dim %d for mode %d (ViT: 64/80, causal: 64/128)", hd, MODE);
+}
+
+// ------------------------------------------------------------------------------------------------------
+//  win14_attn_kernel: SAM's 14x14 windowed attention (build_sam.py:78), bf16, ONE 4-wave workgroup per (image, window, head).
+//  The tiled kernel spends two thirds of its time before the first score: every (window, head) was staged by two workgroups
+//  (two query tiles), each fetching the 196 K and V slices (160 B out of every 7680-byte token), the rel-pos tables and running
+//  the table products.  Here the whole window is fetched and staged in LDS once; each wave handles two 32-query groups
+//  (196 = 7 groups over 4 waves) against it; both rel-pos tables live in 28 registers per lane and group (the query's 14 row and
+//  14 column terms; the column table is pre-rotated for the upper lane half, whose keys sit 4 further), so LDS holds only K and
+//  V: 77.5 KB, two workgroups per CU.  Workgroups are renumbered so that an XCD walks the heads of one window back to back
+//  (neighbouring heads share 128-byte lines of the packed qkv row).  The seven 32-key blocks of a group are unrolled and
+//  software-pipelined (scores of block j+1 and the PV product of block j-1 on the matrix pipe under block j's softmax); the
+//  softmax denominator comes out of the PV product through a column of ones at V[:, HD].
+//  Same arithmetic as flash_attn_kernel<.., MODE_VIT_WINDOW, ..>.
+// ------------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256, 2) void win14_attn_kernel(AttnArgs p) {
+    typedef bf16 T;
+    constexpr int G = 14, NK = 196, NB = 7, NT = 256, NGRP = 2;
+    constexpr int KSTEPS = HD / 16, DT = (HD + 31) / 32;
+    constexpr int RS = HD * 2 + 16;         // K row stride: conflict-free ds_read_b128 of 32 rows
+    constexpr int RSV = 192;                // V row stride = -64 (mod 256): conflict-free ds_read_b64_tr_b16 of 4 rows x 64 B
+    constexpr int CPR = HD * 2 / 16;        // 16-byte chunks per row
+    constexpr int KBYTES = NK * RS, VROWS = 224;
+    constexpr int NCH = (NK * CPR + NT - 1) / NT;
+    constexpr float LOG2E = 1.4426950408889634f;
+    static_assert(HD == 80, "win14_attn_kernel is laid out for head_dim 80 (ones column at V[:, 80..95], 192-byte V rows)");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + KBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, ql = lane & 31;
+    // problem index: workgroup ids go round robin over the 8 XCDs; give every XCD a contiguous range of (window, head) problems
+    const int nprob = gridDim.x;
+    int prob;
+    {
+        const int bid = blockIdx.x, q8 = nprob >> 3, r8 = nprob & 7, xcd = bid & 7;
+        prob = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    }
+    // The two workgroups resident on a CU start together and would run their fetch phase (80 KB each, a 41 MB burst chip-wide) and
+    // their matrix phase in lockstep, round after round (identical durations).  The second resident workgroup of the first round
+    // waits a fraction of a workgroup's duration once, so that from then on one fetches while the other computes (measured on the
+    // ViT-H shape: 102 us without, 85 us with 6.8 us of stagger, 87 / 92 us with 10 / 14 us).
+    if (p.q_pos0 > 0 && (int)blockIdx.x < 512 && (((int)blockIdx.x >> 3) & 32))
+        for (int i = 0; i < p.q_pos0; ++i) __builtin_amdgcn_s_sleep(127);
+    const int head = prob % p.H;
+    int wz = (prob / p.H) % p.nwin, b = prob / (p.H * p.nwin);
+    const int wy = wz / p.nwin_w, wx = wz % p.nwin_w;
+    const T* Q = reinterpret_cast<const T*>(p.q);
+    const T* K = reinterpret_cast<const T*>(p.k);
+    const T* V = reinterpret_cast<const T*>(p.v);
+
+    // ---- K / V of the whole window -> registers (their latency hides behind the table phase)
+    uint4 kreg[NCH], vreg[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int idx = c * NT + tid;
+        const int row = idx / CPR, ch = idx - row * CPR;
+        kreg[c] = make_uint4(0, 0, 0, 0);
+        vreg[c] = make_uint4(0, 0, 0, 0);
+        if (row < NK) {
+            const int ky = row / G, kx = row - ky * G;
+            const int gy = wy * G + ky, gx = wx * G + kx;
+            const T* kp; const T* vp;
+            if (gy < p.grid_h && gx < p.grid_w) {
+                const long tok = (long)gy * p.grid_w + gx;
+                kp = K + (long)b * p.k_bs + tok * p.k_ts + (long)head * p.k_hs;
+                vp = V + (long)b * p.v_bs + tok * p.v_ts + (long)head * p.v_hs;
+            } else {  // window pad token: LN output padded with zeros => k = bias_k, v = bias_v (live key)
+                kp = reinterpret_cast<const T*>(p.bias_k) + (long)head * HD;
+                vp = reinterpret_cast<const T*>(p.bias_v) + (long)head * HD;
+            }
+            kreg[c] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(kp) + ch * 16);
+            vreg[c] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(vp) + ch * 16);
+        }
+    }
+    // ---- rel-pos tables: rows [0,27) = rel_h, [27,54) = rel_w, staged in the (still free) V region with the K row stride
+    constexpr int NE = 2 * G - 1;
+    {
+        const T* th = reinterpret_cast<const T*>(p.rel_h);
+        const T* tw = reinterpret_cast<const T*>(p.rel_w);
+        for (int idx = tid; idx < 64 * CPR; idx += NT) {
+            const int row = idx / CPR, ch = idx - row * CPR;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < NE) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(th + (long)row * HD) + ch * 16);
+            else if (row < 2 * NE) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(tw + (long)(row - NE) * HD) + ch * 16);
+            *reinterpret_cast<uint4*>(Vs + row * RS + ch * 16) = v;
+        }
+    }
+    // ---- per query group: the lane's query fragments and its rel-pos terms
+    Frag<T> qf[NGRP][KSTEPS];
+    float relh_r[NGRP][G], relw_r[NGRP][G];  // relw_r is rotated by 4 for the upper lane half: its keys are k0 + 4
+    bool q_store[NGRP];
+    long q_tok[NGRP];
+#pragma unroll
+    for (int g = 0; g < NGRP; ++g) {
+        const int qi = (g * 4 + wave) * 32 + ql;
+        const bool q_valid = qi < NK;
+        const int qh = qi / G, qw = qi - qh * G;
+        const int qgy = wy * G + qh, qgx = wx * G + qw;
+        q_store[g] = q_valid && qgy < p.grid_h && qgx < p.grid_w;
+        q_tok[g] = (long)qgy * p.grid_w + qgx;
+        const T* qp = Q + (long)b * p.q_bs + q_tok[g] * p.q_ts + (long)head * p.q_hs;
+        const T* bq = reinterpret_cast<const T*>(p.bias_q) + (long)head * HD;  // window pad token: q = qkv.bias
+#pragma unroll
+        for (int t = 0; t < KSTEPS; ++t) {
+            if (q_store[g]) qf[g][t] = load_frag(qp + 16 * t + 8 * h);
+            else if (q_valid) qf[g][t] = load_frag(bq + 16 * t + 8 * h);
+            else qf[g][t] = zero_frag<T>();
+        }
+    }
+    __syncthreads();  // table rows staged
+    // T^T[e][q] = Table[e][:] . q[:] (unscaled q, image_encoder.py:231-234), scattered per query to a wave-private scratch
+    // [28][32] (rows 0..13: rel_h by key row, 14..27: rel_w by key column), in log2 units
+    float* scratch = reinterpret_cast<float*>(Vs + 64 * RS) + wave * (2 * G * 32);
+    auto rel_group = [&](const int g) __attribute__((always_inline)) {
+        const int qi = (g * 4 + wave) * 32 + ql;
+        const int qh = qi / G, qw = qi - qh * G;
+        if ((g * 4 + wave) * 32 < NK) {  // wave-uniform: the eighth group does not exist
+#pragma unroll 1
+            for (int t = 0; t < 2; ++t) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    const Frag<T> a = load_frag(reinterpret_cast<const T*>(Vs + (32 * t + ql) * RS) + 16 * ks + 8 * h);
+                    mma32(a, qf[g][ks], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int e = 32 * t + crow32(r, h);
+                    if (e < NE) {
+                        const int kk = qh + (G - 1) - e;  // rel index e = q - k + (G-1)  (get_rel_pos, image_encoder.py:318-322)
+                        if (kk >= 0 && kk < G) scratch[kk * 32 + ql] = acc[r] * LOG2E;
+                    } else if (e < 2 * NE) {
+                        const int kk = qw + (G - 1) - (e - NE);
+                        if (kk >= 0 && kk < G) scratch[(G + kk) * 32 + ql] = acc[r] * LOG2E;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            relh_r[g][j] = scratch[j * 32 + ql];
+            const int jw = h ? (j + 4 < G ? j + 4 : j + 4 - G) : j;
+            relw_r[g][j] = scratch[(G + jw) * 32 + ql];
+        }
+    };
+    rel_group(0);
+    rel_group(1);
+    __syncthreads();  // every wave is done with the table rows and its scratch: the region becomes V
+    // ---- stage K and V (+ the ones column, zero pad rows)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int idx = c * NT + tid;
+        const int row = idx / CPR, ch = idx - row * CPR;
+        if (row < NK) {
+            *reinterpret_cast<uint4*>(Ks + row * RS + ch * 16) = kreg[c];
+            *reinterpret_cast<uint4*>(Vs + row * RSV + ch * 16) = vreg[c];
+        }
+    }
+    for (int row = tid; row < VROWS; row += NT) {
+        *reinterpret_cast<uint4*>(Vs + row * RSV + HD * 2) = make_uint4(0x00003F80u, 0u, 0u, 0u);  // bf16 1.0 at column HD
+        *reinterpret_cast<uint4*>(Vs + row * RSV + HD * 2 + 16) = make_uint4(0u, 0u, 0u, 0u);
+        if (row >= NK) {
+#pragma unroll
+            for (int ch = 0; ch < CPR; ++ch) *reinterpret_cast<uint4*>(Vs + row * RSV + ch * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    __syncthreads();
+
+    const float scale2 = p.scale * LOG2E;
+    auto run_group = [&](const int g) __attribute__((always_inline)) {  // g is a literal at both call sites: register arrays stay static
+        if ((g * 4 + wave) * 32 >= NK) return;  // wave-uniform
+        // ---- seven 32-key blocks, software-pipelined
+        f32x16 o[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+        float m_run = -INFINITY;
+        auto qk_block = [&](const int blk, f32x16& sc) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {  // rows >= 196 of the last block read into the V region: finite, masked below
+                const Frag<T> a = load_frag(reinterpret_cast<const T*>(Ks + (blk * 32 + ql) * RS) + 16 * ks + 8 * h);
+                mma32(a, qf[g][ks], sc);
+            }
+        };
+        auto pv_block = [&](const int blk, const Frag<T>& p0, const Frag<T>& p1) __attribute__((always_inline)) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const Frag<T> v0 = load_vt_frag<RSV>(Vs, blk * 32, d * 32, lane, (const T*)nullptr);
+                mma32(v0, p0, o[d]);
+                const Frag<T> v1 = load_vt_frag<RSV>(Vs, blk * 32 + 16, d * 32, lane, (const T*)nullptr);
+                mma32(v1, p1, o[d]);
+            }
+        };
+        auto soft_block = [&](const int blk, f32x16& sc) __attribute__((always_inline)) -> float {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k0 = blk * 32 + crow32(r, 0), k1 = k0 + 4;  // keys of the lower / upper lane half: compile-time constants
+                const int y0 = k0 / G, y1 = k1 / G, x0 = k0 - y0 * G;
+                const bool ok0 = k0 < NK, ok1 = k1 < NK;
+                float v;
+                if (!ok0 && !ok1) {
+                    v = -INFINITY;
+                } else {
+                    const float bh = (y0 == y1 || !ok1) ? relh_r[g][y0 < G ? y0 : 0] : (h ? relh_r[g][y1 < G ? y1 : 0] : relh_r[g][y0]);
+                    v = sc[r] * scale2 + (bh + relw_r[g][x0]);
+                    if (!ok1) v = h ? -INFINITY : v;
+                }
+                sc[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            {
+                float lo, hi;
+                halves(mx, lo, hi);
+                mx = fmaxf(lo, hi);
+            }
+            const float m_new = fmaxf(m_run, mx);  // every block has at least one live key for every query: m_new is finite
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_new);
+            m_run = m_new;
+            return alpha;
+        };
+        {
+            f32x16 sc[2];
+            Frag<T> p0, p1;
+            qk_block(0, sc[0]);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                if (blk + 1 < NB) qk_block(blk + 1, sc[(blk + 1) & 1]);
+                if (blk > 0) pv_block(blk - 1, p0, p1);
+                const float alpha = soft_block(blk, sc[blk & 1]);
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                p0 = pack_p(sc[blk & 1], 0, (const T*)nullptr);
+                p1 = pack_p(sc[blk & 1], 1, (const T*)nullptr);
+            }
+            pv_block(NB - 1, p0, p1);
+        }
+        // ---- normalise (row HD of O^T is the denominator: d-tile DT-1, register crow32^-1(HD % 32) of the lower half) and store
+        float l_tot;
+        {
+            constexpr int RL = ((HD % 32) & 3) + 4 * ((HD % 32) >> 3);
+            float lo, hi;
+            halves(o[DT - 1][RL], lo, hi);
+            l_tot = lo;
+        }
+        const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        if (q_store[g]) {
+            T* op = reinterpret_cast<T*>(p.out) + (long)b * p.o_bs + q_tok[g] * p.o_ts + (long)head * p.o_hs;
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int dd = 32 * d + 8 * rq + 4 * h;
+                    if (dd < HD) {
+                        const float4 v = make_float4(o[d][4 * rq] * inv_l, o[d][4 * rq + 1] * inv_l, o[d][4 * rq + 2] * inv_l,
+                                                     o[d][4 * rq + 3] * inv_l);
+                        store4(op + dd, v);
+                    }
+                }
+        }
+    };
+    run_group(0);
+    run_group(1);
+}
+
+static int launch_win14(const AttnArgs& a, hipStream_t s) {
+    constexpr int HD = 80;
+    const size_t lds = 196 * (HD * 2 + 16) + 224 * 192;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(win14_attn_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    win14_attn_kernel<HD><<<dim3(a.H * a.B * a.nwin), dim3(256), lds, s>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
 }
 
 static int g_attn_variant = 0;
@@ -519,6 +899,9 @@ extern "C" int ullsam_vit_attention(int dtype, const void* qkv, void* out, const
         a.nwin_w = (grid_w + window - 1) / window;
         a.nwin = a.nwin_w * ((grid_h + window - 1) / window);
         a.Sq = a.Sk = window * window;
+        // SAM's own shape (14x14 windows, head_dim 80, bf16): the whole-window kernel; variant 2 forces the tiled kernel for A/B
+        a.q_pos0 = g_attn_variant >= 3 ? g_attn_variant - 3 : 2;  // stagger of the second resident workgroup, units of s_sleep(127) = 3.4 us (A/B: variant 3 + n)
+        if (dtype == 1 && window == 14 && hd == 80 && g_attn_variant != 1 && g_attn_variant != 2) return launch_win14(a, s);
         // window = 196 queries: one 7-wave workgroup (128-key tiles) or two 4-wave workgroups (64-key tiles, 3 resident per CU)
         if (g_attn_variant == 1) return dtype == 0 ? dispatch_hd<float, MODE_VIT_WINDOW, 7>(a, hd, s) : dispatch_hd<bf16, MODE_VIT_WINDOW, 7>(a, hd, s);
         return dtype == 0 ? dispatch_hd<float, MODE_VIT_WINDOW, 7>(a, hd, s) : dispatch_hd<bf16, MODE_VIT_WINDOW, 4>(a, hd, s);
