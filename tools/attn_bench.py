@@ -18,14 +18,14 @@ def t(fn, n=4, reps=5):
     return sorted(ts)[reps // 2] * 1e3
 rh14, rw14 = (torch.randn(27, hd, device=dev) * 0.1).bfloat16(), (torch.randn(27, hd, device=dev) * 0.1).bfloat16()
 rh64, rw64 = (torch.randn(127, hd, device=dev) * 0.1).bfloat16(), (torch.randn(127, hd, device=dev) * 0.1).bfloat16()
+H, KVH, S = 32, 8, 1081
+q = torch.randn(B * S, H * 128, device=dev).bfloat16()
+kc = torch.randn(B, KVH, S, 128, device=dev).bfloat16(); vc = torch.randn(B, KVH, S, 128, device=dev).bfloat16()
 for v in (int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "1"])):
     lib.ullsam_set_attn_variant(v)
     w = t(lambda i: ops.vit_attention(qkv[i], rh14, rw14, bias, B, heads, hd, 64, 64, 14))
     g = t(lambda i: ops.vit_attention(qkv[i], rh64, rw64, bias, B, heads, hd, 64, 64, 0))
     print(f"variant {v}: window {w:7.1f} us ({19.67e3 / w:6.1f} TF/s)   global {g:7.1f} us ({343.6e3 / g:6.1f} TF/s)", flush=True)
-H, KVH, S = 32, 8, 1081
-q = torch.randn(B * S, H * 128, device=dev).bfloat16()
-kc = torch.randn(B, KVH, S, 128, device=dev).bfloat16(); vc = torch.randn(B, KVH, S, 128, device=dev).bfloat16()
-c = t(lambda i: ops.causal_attention(q, kc, vc, None, B, H, KVH, 128, S, S, 0))
-print(f"causal {c:7.1f} us ({B * H * S * S * 128 * 2 / c / 1e6:6.1f} TF/s causal-halved)")
+    c = t(lambda i: ops.causal_attention(q, kc, vc, None, B, H, KVH, 128, S, S, 0))
+    print(f"variant {v}: causal {c:7.1f} us ({B * H * S * S * 128 * 2 / c / 1e6:6.1f} TF/s causal-halved)", flush=True)
 lib.ullsam_set_attn_variant(0)

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libullsam_hip.so")
+LIB_PATH = os.environ.get("ULLSAM_HIP_LIB") or os.path.join(_HERE, "lib", "libullsam_hip.so")  # env: A/B a side build (developer switch)
 
 _lib = None
 

@@ -110,8 +110,8 @@ __device__ __forceinline__ void halves(float x, float& lo, float& hi) {
 }
 
 template <typename T, int HD, int MODE, int NWAVES, bool FAST64>
-__global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) {  // >= 2 waves per SIMD: at most 256 VGPR+AGPR
-    constexpr int TR = (MODE == MODE_VIT_WINDOW && NWAVES == 7) ? 128 : 64;  // keys per staged K/V tile
+__global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 1 : 2) void flash_attn_kernel(AttnArgs p) {  // 8 waves per CU = 2 per SIMD: at most 256 VGPR+AGPR
+    constexpr int TR = ((MODE == MODE_VIT_WINDOW && NWAVES == 7) || NWAVES == 8) ? 128 : 64;  // keys per staged K/V tile
     using KT = KVTile<T, HD, TR>;
     constexpr int RS = KT::RS;
     constexpr int RSV = KT::RSV;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
     char* Vs = smem + KT::BYTES;
     // V tile gets 16 extra rows of slack: for HD % 32 != 0 the last d-tile's transposed reads run past HD
     int* kms = reinterpret_cast<int*>(smem + KT::BYTES + KT::VBYTES + 16 * RSV);  // key-padding mask of the staged tile (64 ints)
-    float* rel_base = reinterpret_cast<float*>(smem + KT::BYTES + KT::VBYTES + 16 * RSV + 256);
+    float* rel_base = reinterpret_cast<float*>(smem + KT::BYTES + KT::VBYTES + 16 * RSV + 512);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
     int km_reg = 1;
     const int* kmask_g = (MODE == MODE_CAUSAL && p.key_mask) ? p.key_mask + (long)b * Sk : nullptr;
     auto load_tile = [&](int tile) {
-        if (MODE == MODE_CAUSAL && tid < 64) {
-            const int kt = tile * 64 + tid;
+        if (MODE == MODE_CAUSAL && tid < TR) {
+            const int kt = tile * TR + tid;
             km_reg = (kmask_g && kt < Sk) ? kmask_g[kt] : 1;
         }
 #pragma unroll
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
         }
     };
     auto store_tile = [&]() {
-        if (MODE == MODE_CAUSAL && tid < 64) kms[tid] = km_reg;
+        if (MODE == MODE_CAUSAL && tid < TR) kms[tid] = km_reg;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int idx = c * NT + tid;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
     int ntiles = (Sk + TR - 1) / TR;
     if (MODE == MODE_CAUSAL) {
         const int last_q = p.q_pos0 + min(p.Sq, (qblk + 1) * NWAVES * 32) - 1;
-        ntiles = min(ntiles, last_q / 64 + 1);
+        ntiles = min(ntiles, last_q / TR + 1);
     }
     const float FMIN = -3.4028234663852886e38f;  // torch.finfo(float32).min
 
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
     constexpr bool PIPE_OK = sizeof(T) == 2 && REL;
     auto do_tile = [&](const int tile, const bool W14) __attribute__((always_inline)) {
         if (tile + 1 < ntiles) load_tile(tile + 1);
-        const bool tile_pad = (MODE == MODE_CAUSAL && kmask_g) ? (__any(kms[lane] == 0) != 0) : false;
+        const bool tile_pad = (MODE == MODE_CAUSAL && kmask_g) ? (__any(kms[lane] == 0 || (TR > 64 && kms[lane + 64] == 0)) != 0) : false;
         const int wave_first_q = p.q_pos0 + (qblk * NWAVES + wave) * 32;
         constexpr int NSUB = TR / 32;
         if (PIPE_OK && (FAST64 || W14)) {
@@ -544,10 +544,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_kernel(AttnArgs p) 
 
 template <typename T, int HD, int MODE, int NWAVES, bool FAST64>
 static int launch_flash_impl(const AttnArgs& a, hipStream_t s) {
-    using KT = KVTile<T, HD, (MODE == MODE_VIT_WINDOW && NWAVES == 7) ? 128 : 64>;
+    using KT = KVTile<T, HD, ((MODE == MODE_VIT_WINDOW && NWAVES == 7) || NWAVES == 8) ? 128 : 64>;
     constexpr bool REL = (MODE == MODE_VIT_GLOBAL || MODE == MODE_VIT_WINDOW);
     constexpr int RELROWS = (MODE == MODE_VIT_WINDOW) ? 16 : 64;
-    const size_t lds = KT::BYTES + KT::VBYTES + 16 * KT::RSV + 256 + (REL ? (size_t)NWAVES * (FAST64 ? 1 : 2) * RELROWS * 32 * 4 : 0);
+    const size_t lds = KT::BYTES + KT::VBYTES + 16 * KT::RSV + 512 + (REL ? (size_t)NWAVES * (FAST64 ? 1 : 2) * RELROWS * 32 * 4 : 0);
     ULLSAM_CHECK(lds <= 160 * 1024, "flash_attn: LDS %zu exceeds 160 KiB", lds);
     static bool attr = false;
     if (!attr) {
@@ -925,6 +925,8 @@ extern "C" int ullsam_causal_attention(int dtype, const void* q, const void* k, 
     a.scale = 1.0f / sqrtf((float)hd);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // 4 waves = 128 queries per workgroup (8 waves / 256 queries measured no faster end to end: 94.9 vs 94.5 ms per step)
+    // variant 1: 8-wave workgroups (256 queries) over 128-key tiles, one per CU -- twice the matrix work per staged tile
+    if (g_attn_variant == 1 && dtype == 1) return dispatch_hd<bf16, MODE_CAUSAL, 8>(a, hd, s);
     return dtype == 0 ? dispatch_hd<float, MODE_CAUSAL, 4>(a, hd, s) : dispatch_hd<bf16, MODE_CAUSAL, 4>(a, hd, s);
 }
 
