@@ -382,6 +382,28 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 1 : 2) void flash_attn_k
         const float rh64 = FAST64 ? relh[(kbase >> 6) * 32 + ql] : 0.f;
         // causal: blocks entirely in the past of every query of this wave and free of padding need no mask arithmetic
         const bool interior = (MODE == MODE_CAUSAL) && !tile_pad && (kbase + 31 <= wave_first_q) && (kbase + 31 < Sk);
+        if (MODE == MODE_CAUSAL && interior) {
+            // no mask, no bias: the maximum is taken on the raw scores and the scale rides in the exponent's FMA
+            // (16 FMA + 8 max3 instead of 16 mul + 16 sub + the select chains of the masked path)
+            float mr = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mr = fmaxf(mr, s[r]);
+            float lo, hi;
+            halves(mr, lo, hi);
+            const float mx = fmaxf(lo, hi) * scale2;
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(s[r] * scale2 - m_new);
+                s[r] = pv;
+                psum += pv;
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+            return alpha;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kt = kbase + crow32(r, h);
