@@ -10,6 +10,8 @@ SHAPES = [  # (name, M, N, K, act)
     ("llm.w2", 4324, 4096, 14336, 0), ("vit.qkv", 16384, 3840, 1280, 0), ("vit.proj", 16384, 1280, 1280, 0),
     ("vit.lin1", 16384, 5120, 1280, 1), ("vit.lin2", 16384, 1280, 5120, 0), ("2b.w13", 4324, 16384, 2048, 3),
     ("vitb.lin1", 4096, 3072, 768, 1),
+    # act code + 16: fp32 output with an fp32 residual updated in place (the residual-stream GEMMs of both transformers)
+    ("vit.proj+r", 16384, 1280, 1280, 16), ("vit.lin2+r", 16384, 1280, 5120, 16), ("llm.wo+r", 4324, 4096, 4096, 16), ("llm.w2+r", 4324, 4096, 14336, 16),
 ]
 
 
@@ -23,12 +25,14 @@ def main():
     for name, M, N, K, act in SHAPES:
         if only and name not in only.split(","):
             continue
+        res = act >= 16
+        act &= 15
         # cold-operand regime: rotate through > 600 MB of distinct (A, W, C) so nothing is served from L2 / Infinity Cache
         n_out = N // 2 if act == 3 else N
         ncopy = max(2, int(6e8 // (2 * (M * K + N * K + M * n_out))) + 1)
         As = [torch.randn(M, K, device=dev).bfloat16() for _ in range(ncopy)]
         Ws = [(torch.randn(N, K, device=dev) * K ** -0.5).bfloat16() for _ in range(ncopy)]
-        Cs = [torch.empty(M, n_out, device=dev, dtype=torch.bfloat16) for _ in range(ncopy)]
+        Cs = [torch.zeros(M, n_out, device=dev, dtype=torch.float32 if res else torch.bfloat16) for _ in range(ncopy)]
         a, w = As[0], Ws[0]
         bias = torch.randn(N, device=dev) if act == 1 else None
         ref = None
@@ -36,7 +40,7 @@ def main():
             if v < 0:
                 continue
             lib.ullsam_set_gemm_variant(v)
-            out = ops.gemm(a, w, bias, act=act)
+            out = ops.gemm(a, w, bias, act=act, out_f32=res)
             if ref is None:
                 ref = out.float()
             else:
@@ -53,7 +57,7 @@ def main():
                     if v < 0:   # comparator only: the vendor library's plain GEMM (no epilogue) through torch
                         torch.nn.functional.linear(As[i], Ws[i])
                     else:
-                        ops.gemm(As[i], Ws[i], bias, act=act, out=Cs[i])
+                        ops.gemm(As[i], Ws[i], bias, act=act, out=Cs[i], out_f32=res, residual=Cs[i] if res else None)
                 e1.record()
                 torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) / ncopy)
