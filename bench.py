@@ -217,8 +217,8 @@ def cpu_baseline(vit: str, llm: str, S: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE configs[2]: 4)")
     ap.add_argument("--vit", default="h", choices=list(VIT))
     ap.add_argument("--llm", default="7b", choices=list(LLM))
