@@ -11,6 +11,7 @@ SHAPES = [  # (name, M, N, K, act)
     ("vit.lin1", 16384, 5120, 1280, 1), ("vit.lin2", 16384, 1280, 5120, 0), ("2b.w13", 4324, 16384, 2048, 3),
     ("vitb.lin1", 4096, 3072, 768, 1),
     # act code + 16: fp32 output with an fp32 residual updated in place (the residual-stream GEMMs of both transformers)
+    ("dec.kproj", 262144, 128, 256, 0), ("dec.up1", 262144, 256, 256, 0),
     ("vit.proj+r", 16384, 1280, 1280, 16), ("vit.lin2+r", 16384, 1280, 5120, 16), ("llm.wo+r", 4324, 4096, 4096, 16), ("llm.w2+r", 4324, 4096, 14336, 16),
 ]
 
