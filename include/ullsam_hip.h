@@ -49,6 +49,8 @@ int ullsam_gemm(int dtype, const void* A, long lda, const void* W, long ldw, voi
 int ullsam_norm(const void* in, int in_dtype, long in_stride, void* out, int out_dtype, long out_stride, const float* w,
                 const float* b, long rows, int D, float eps, int rms, int act, const float* post_scale,
                 const float* post_shift, void* stream);
+int ullsam_set_norm_variant(int v);   /* developer switch: non-zero = wave-per-row kernel for every shape (A/B) */
+
 /* LayerNorm whose result feeds three consumers at once: fp32 stream, compute-dtype copy, compute-dtype (y + pe[row % pe_rows]).
    transformer.py:182 (norm4) followed by :160-165 / :176-178 of the next block. */
 int ullsam_norm_fanout(const float* in, long rows, int D, const float* w, const float* b, float eps, float* out_f32, void* out_c,

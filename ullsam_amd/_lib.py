@@ -52,7 +52,8 @@ SIGNATURES = {
     "ullsam_threshold_u8": [vp, vp, i64, f32, vp],
 }
 PLAIN = {"ullsam_last_error_string": ([], C.c_char_p), "ullsam_abi_version": ([], i32), "ullsam_device_count": ([], i32),
-         "ullsam_set_gemm_variant": ([i32], i32), "ullsam_set_attn_variant": ([i32], i32)}
+         "ullsam_set_gemm_variant": ([i32], i32), "ullsam_set_attn_variant": ([i32], i32),
+         "ullsam_set_norm_variant": ([i32], i32)}
 
 
 class UllsamError(RuntimeError):
