@@ -83,53 +83,58 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs p) {
 // One workgroup per row (rows of >= 1024 elements): a lane holds D/1024 float4 instead of D/256, four times as many rows are in
 // flight per CU and no wave waits on sixteen of its own loads before it can start reducing.  The statistics cross the four waves
 // through LDS.  Same arithmetic as norm_kernel (the partial sums are combined in wave order).
-template <typename TI, typename TO, int MAXV>
+template <typename TI, typename TO, int MAXV, int WPR = 4>  // WPR waves share a row; a workgroup holds 4 / WPR rows
 __global__ __launch_bounds__(256) void norm_block_kernel(NormArgs p) {
     __shared__ float red[2][4];
+    constexpr int TPR = WPR * 64;                 // threads per row
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long row = blockIdx.x;
-    const TI* x = reinterpret_cast<const TI*>(p.in) + row * p.in_stride;
-    TO* y = reinterpret_cast<TO*>(p.out) + row * p.out_stride;
+    const int sub = wv / WPR, t = tid - sub * TPR;  // row slot inside the workgroup, thread index inside the row
+    const long row = (long)blockIdx.x * (4 / WPR) + sub;
+    const bool live = row < p.rows;
+    const TI* x = reinterpret_cast<const TI*>(p.in) + (live ? row : 0) * p.in_stride;
+    TO* y = reinterpret_cast<TO*>(p.out) + (live ? row : 0) * p.out_stride;
     const int nv = p.D >> 2;
     float4 v[MAXV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int idx = i * 256 + tid;
-        if (idx < nv) {
+        const int idx = i * TPR + t;
+        if (idx < nv && live) {
             v[i] = load4(x + idx * 4);
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         } else {
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    float mean = 0.f;
-    if (!p.rms) {
-        s = wave_sum(s);
-        if (lane == 0) red[0][wv] = s;
+    auto row_sum = [&](float part, int slot) -> float {  // sum over the WPR waves of this row
+        part = wave_sum(part);
+        if (lane == 0) red[slot][wv] = part;
         __syncthreads();
-        mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)p.D;
-    }
+        float tot = red[slot][sub * WPR];
+#pragma unroll
+        for (int k = 1; k < WPR; ++k) tot += red[slot][sub * WPR + k];
+        return tot;
+    };
+    float mean = 0.f;
+    if (!p.rms) mean = row_sum(s, 0) / (float)p.D;
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int idx = i * 256 + tid;
-        if (idx < nv) {
+        const int idx = i * TPR + t;
+        if (idx < nv && live) {
             const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
             ss += (a * a + b * b) + (c * c + d * d);
         }
     }
-    ss = wave_sum(ss);
-    if (lane == 0) red[1][wv] = ss;
-    __syncthreads();
-    const float var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)p.D;
+    const float var = row_sum(ss, 1) / (float)p.D;
     const float rstd = p.rms ? rsqrtf(var + p.eps) : 1.0f / sqrtf(var + p.eps);
     const float ps = p.post_scale ? p.post_scale[0] : 1.f;
     const float pb = p.post_shift ? p.post_shift[0] : 0.f;
     const bool post = p.post_scale || p.post_shift;
+    if (!live) return;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int idx = i * 256 + tid;
+        const int idx = i * TPR + t;
         if (idx < nv) {
             float4 o = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd);
             if (p.w) {
