@@ -622,11 +622,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 }
 
 // Sum the ksplit fp32 partials of a 16-row slab of one 256x256 tail tile and run the normal epilogue on it.
-template <typename T>
-__global__ __launch_bounds__(256) void gemm256_tail_reduce_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float Cs[16 * 256];
+// ROWS x 256 slab per workgroup of NT threads.  <16, 256>: few, fat workgroups -- right when the partials are tens of MB and the
+// pass is bandwidth-bound (ViT lin2: 64 tail tiles x 4 splits).  <4, 128>: 64 workgroups per tail tile for the LLM's 16-tile tails
+// (wo / w2, 8 splits), where the launch is latency-bound: 12.8 -> 8.9 us.  The ksplit loads of a thread are independent and
+// unrolled, so they are in flight together.
+template <typename T, int ROWS, int NT>
+__global__ __launch_bounds__(NT) void gemm256_tail_reduce_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float Cs[ROWS * 256];
+    constexpr int SPT = 256 / ROWS;              // slabs per tile
+    constexpr int VPT = ROWS * 64 / NT;          // float4 per thread and partial
     const int tid = threadIdx.x;
-    const int tail_idx = blockIdx.x >> 4, slab = blockIdx.x & 15;
+    const int tail_idx = blockIdx.x / SPT, slab = blockIdx.x % SPT;
     const int swz = p.full_tiles + tail_idx;
     const int GM = 4;
     const int width = GM * p.tiles_n;
@@ -635,23 +641,26 @@ __global__ __launch_bounds__(256) void gemm256_tail_reduce_kernel(GemmArgs p) {
     const int gsize = min(p.tiles_m - first_m, GM);
     const int tm = first_m + (swz % width) % gsize;
     const int tn = (swz % width) / gsize;
-    const float4* src = reinterpret_cast<const float4*>(p.ws + (size_t)tail_idx * p.ksplit * 65536 + slab * 4096);
+    const float4* src = reinterpret_cast<const float4*>(p.ws + (size_t)tail_idx * p.ksplit * 65536 + slab * (ROWS * 256));
+    float4 acc[VPT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float4 a = src[i * 256 + tid];
-        for (int s = 1; s < p.ksplit; ++s) {
-            const float4 b = src[(size_t)s * 16384 + i * 256 + tid];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    for (int i = 0; i < VPT; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int s = 0; s < p.ksplit; ++s) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const float4 b = src[(size_t)s * 16384 + i * NT + tid];
+            acc[i].x += b.x; acc[i].y += b.y; acc[i].z += b.z; acc[i].w += b.w;
         }
-        reinterpret_cast<float4*>(Cs)[i * 256 + tid] = a;
     }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) reinterpret_cast<float4*>(Cs)[i * NT + tid] = acc[i];
     __syncthreads();
     if (p.out_f32)
-        epilogue_rows<T, float, 16, 256, 256>(p, Cs, tm * 256 + slab * 16, tn * 256, tn, tid);
+        epilogue_rows<T, float, ROWS, NT, 256>(p, Cs, tm * 256 + slab * ROWS, tn * 256, tn, tid);
     else
-        epilogue_rows<T, T, 16, 256, 256>(p, Cs, tm * 256 + slab * 16, tn * 256, tn, tid);
+        epilogue_rows<T, T, ROWS, NT, 256>(p, Cs, tm * 256 + slab * ROWS, tn * 256, tn, tid);
 }
-
 
 template <typename T, int EXP>
 static int launch_gemm_v3_impl(GemmArgs a, hipStream_t stream) {
@@ -680,7 +689,9 @@ static int launch_gemm_v3_impl(GemmArgs a, hipStream_t stream) {
     gemm256_kernel<T, EXP><<<dim3(a.full_tiles + (T_ - a.full_tiles) * a.ksplit), dim3(512), 131072, stream>>>(a);
     ULLSAM_LAUNCH_CHECK();
     if (a.ksplit > 1) {
-        gemm256_tail_reduce_kernel<T><<<dim3((T_ - a.full_tiles) * 16), dim3(256), 0, stream>>>(a);
+        const int tail_tiles = T_ - a.full_tiles;
+        if (tail_tiles * a.ksplit <= 128) gemm256_tail_reduce_kernel<T, 4, 128><<<dim3(tail_tiles * 64), dim3(128), 0, stream>>>(a);
+        else gemm256_tail_reduce_kernel<T, 16, 256><<<dim3(tail_tiles * 16), dim3(256), 0, stream>>>(a);
         ULLSAM_LAUNCH_CHECK();
     }
     return 0;
