@@ -109,6 +109,27 @@ def test_skinny_linear(ops, M, N, K):
     assert err(ops.small_linear(T(x), T(w), T(b)).cpu().numpy(), x @ w.T + b) < 1e-5
 
 
+@pytest.mark.parametrize("D", [2048, 4096, 3072])
+def test_norm_long_rows_workgroup_per_row(ops, D):
+    """Rows of >= 2048 elements, >= 1024 of them (the LLM's RMSNorm): one workgroup per row, statistics across waves through LDS."""
+    rng = np.random.default_rng(D)
+    x = rng.standard_normal((1500, D), dtype=np.float32) * 2 + 0.3
+    w = rng.standard_normal(D, dtype=np.float32)
+    b = rng.standard_normal(D, dtype=np.float32)
+    assert err(ops.norm(T(x), T(w), None, 1e-5, torch.float32, rms=True).cpu().numpy(), O.rms_norm(x, w, 1e-5)) < 2e-5
+    assert err(ops.norm(T(x), T(w), T(b), 1e-6, torch.float32).cpu().numpy(), O.layer_norm(x, w, b, 1e-6)) < 2e-5
+    got = ops.norm(T(x), T(w), None, 1e-5, torch.bfloat16, rms=True).float().cpu().numpy()
+    assert err(got, O.rms_norm(x, w, 1e-5)) < 4e-2
+    from ullsam_amd import _lib
+    lib = _lib.load()
+    try:  # the wave-per-row kernel gives the same numbers up to summation order
+        lib.ullsam_set_norm_variant(1)
+        alt = ops.norm(T(x), T(w), None, 1e-5, torch.float32, rms=True).cpu().numpy()
+    finally:
+        lib.ullsam_set_norm_variant(0)
+    assert err(alt, O.rms_norm(x, w, 1e-5)) < 2e-5
+
+
 @pytest.mark.parametrize("D", [32, 64, 48])
 def test_norm_narrow_rows(ops, D):
     """Many short rows (LayerNorm2d + GELU of the decoder's upscaling path): 16 lanes per row."""
@@ -319,6 +340,31 @@ def test_gemm_split_k_tail_matches_unsplit(ops, dtype):
     tol = 5e-4 if dtype == torch.float32 else 2e-2
     assert err(y0.cpu().numpy(), ref) < tol and err(y1.cpu().numpy(), ref) < tol
     assert err(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-3 and err(s1.cpu().numpy(), s0.cpu().numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(4324, 4096, 4096), (16384, 1280, 5120)])
+def test_gemm_256_split_k_tail_matches_unsplit(ops, M, N, K):
+    """256x256 kernel: 272 tiles (16-tile tail cut 8 ways, 4-row reduce slabs) and 320 tiles (64-tile tail cut 4 ways, 16-row slabs):
+    the split launch + reduce kernel must equal the unsplit launch to accumulation-order noise, through bias + fp32 residual."""
+    from ullsam_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(M)
+    a = T(rng.standard_normal((M, K), dtype=np.float32), torch.bfloat16)
+    w = T((rng.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)).astype(np.float32), torch.bfloat16)
+    bias, res = T(rng.standard_normal(N, dtype=np.float32)), T(rng.standard_normal((M, N), dtype=np.float32))
+    try:
+        lib.ullsam_set_gemm_variant(3 | 64)
+        y0 = ops.gemm(a, w, bias=bias, residual=res, out_f32=True)
+        b0 = ops.gemm(a, w, bias=bias, act=ops.ACT_GELU)
+        lib.ullsam_set_gemm_variant(3)
+        y1 = ops.gemm(a, w, bias=bias, residual=res, out_f32=True)
+        b1 = ops.gemm(a, w, bias=bias, act=ops.ACT_GELU)
+    finally:
+        lib.ullsam_set_gemm_variant(0)
+    assert err(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-3 and err(b1.float().cpu().numpy(), b0.float().cpu().numpy()) < 2e-2
+    rows = rng.choice(M, 64, replace=False)
+    ref = a[rows].float().cpu().numpy() @ w.float().cpu().numpy().T + bias.cpu().numpy() + res[rows].cpu().numpy()
+    assert err(y1[rows].cpu().numpy(), ref) < 2e-2
 
 
 @pytest.mark.parametrize("code", [3 + (1 << 12), 3 + (2 << 12)])
