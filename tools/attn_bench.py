@@ -21,6 +21,9 @@ rh64, rw64 = (torch.randn(127, hd, device=dev) * 0.1).bfloat16(), (torch.randn(1
 H, KVH, S = 32, 8, 1081
 q = torch.randn(B * S, H * 128, device=dev).bfloat16()
 kc = torch.randn(B, KVH, S, 128, device=dev).bfloat16(); vc = torch.randn(B, KVH, S, 128, device=dev).bfloat16()
+ops.vit_attention(qkv[0], rh64, rw64, bias, B, heads, hd, 64, 64, 0); torch.cuda.synchronize()  # clocks / caches warm
+for _ in range(3): ops.vit_attention(qkv[0], rh64, rw64, bias, B, heads, hd, 64, 64, 0)
+torch.cuda.synchronize()
 for v in (int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "1"])):
     lib.ullsam_set_attn_variant(v)
     w = t(lambda i: ops.vit_attention(qkv[i], rh14, rw14, bias, B, heads, hd, 64, 64, 14))

@@ -134,12 +134,6 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 1 : 2) void flash_attn_k
     int* kms = reinterpret_cast<int*>(smem + KT::BYTES + KT::VBYTES + 16 * RSV);  // key-padding mask of the staged tile (64 ints)
     float* rel_base = reinterpret_cast<float*>(smem + KT::BYTES + KT::VBYTES + 16 * RSV + 512);
 
-    if (FAST64 && p.win > 0) {
-        // the two workgroups resident on a CU are identical (64 tiles each) and would stage and compute in lockstep for the whole
-        // launch; the second one of the first round waits p.win x 3.4 us once (measured: 632 us without, 567 us with 6.8 us)
-        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if (lin < 512 && ((lin >> 3) & 32)) for (int i = 0; i < p.win; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, ql = lane & 31;
@@ -935,7 +929,6 @@ extern "C" int ullsam_vit_attention(int dtype, const void* qkv, void* out, const
         return dtype == 0 ? dispatch_hd<float, MODE_VIT_WINDOW, 7>(a, hd, s) : dispatch_hd<bf16, MODE_VIT_WINDOW, 4>(a, hd, s);
     }
     a.Sq = a.Sk = (int)N;
-    a.win = g_attn_variant >= 3 ? g_attn_variant - 3 : 2;  // global mode: stagger of co-resident workgroups (A/B: variant 3 + n)
     return dtype == 0 ? dispatch_hd<float, MODE_VIT_GLOBAL, 4>(a, hd, s) : dispatch_hd<bf16, MODE_VIT_GLOBAL, 4>(a, hd, s);
 }
 
