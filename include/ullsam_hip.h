@@ -71,6 +71,11 @@ int ullsam_naive_attention(int dtype, const void* q, const void* k, const void* 
                            long k_hs, long v_bs, long v_ts, long v_hs, long o_bs, long o_ts, long o_hs, float scale,
                            void* stream);
 
+/* Decode step (q_len == 1): one bf16 query per head against the bf16 KV cache [B, KVH, cap, 128], the heads of a GQA group
+   together, keys split over nsplit workgroups.  modeling_internlm2.py:383-419, mask :834.  workspace f32 [B*KVH*nsplit*(H/KVH)*130]. */
+int ullsam_decode_attention(const void* q, const void* kc, const void* vc, const int* key_mask, void* out, int B, int H, int KVH,
+                            int hd, int Sk, int cap, float scale, float* workspace, int nsplit, void* stream);
+
 /* Image -> token cross attention (many queries, few keys), fp32.  transformer.py:178-181.  q_batch_stride (elements) = 0 when
    all B batches share one query set (layer 0 of the decoder when B prompts look at one image). */
 int ullsam_fewkeys_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int hd, int Sq,

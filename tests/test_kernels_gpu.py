@@ -226,6 +226,34 @@ def test_naive_and_fewkeys_attention(ops):
     assert err(out.cpu().numpy().reshape(k.shape), ref(np.repeat(k[:1], B, 0), q, q)) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,KVH,Sk", [(4, 32, 8, 1100), (1, 16, 8, 70), (3, 8, 1, 513), (2, 32, 8, 5)])
+def test_decode_attention(ops, B, H, KVH, Sk):
+    """q_len == 1 against the bf16 KV cache: GQA groups together, split-K softmax merge, left-padding mask (finfo.min additive)."""
+    rng = np.random.default_rng(Sk)
+    hd, cap = 128, Sk + 7
+    q = T(rng.standard_normal((B, H * hd), dtype=np.float32), torch.bfloat16)
+    kc = T(rng.standard_normal((B, KVH, cap, hd), dtype=np.float32), torch.bfloat16)
+    vc = T(rng.standard_normal((B, KVH, cap, hd), dtype=np.float32), torch.bfloat16)
+    mask = np.ones((B, Sk), np.int32)
+    if Sk > 8:
+        mask[0, :3] = 0                                  # left padding on the first sequence
+    qf = q.float().cpu().numpy().reshape(B, H, hd)
+    kf = kc.float().cpu().numpy()[:, :, :Sk]
+    vf = vc.float().cpu().numpy()[:, :, :Sk]
+    G = H // KVH
+    sc = np.einsum("bhd,bhkd->bhk", qf, np.repeat(kf, G, 1)) / np.float32(math.sqrt(hd))
+    sc = sc + np.where(mask[:, None, :] == 0, np.finfo(np.float32).min, 0).astype(np.float32)
+    ref = np.einsum("bhk,bhkd->bhd", O.softmax(sc), np.repeat(vf, G, 1)).reshape(B, H * hd)
+    for km in (T(mask, torch.int32), None):
+        out = ops.decode_attention(q, kc, vc, km, B, H, KVH, hd, Sk).float().cpu().numpy()
+        if km is None:
+            sc2 = np.einsum("bhd,bhkd->bhk", qf, np.repeat(kf, G, 1)) / np.float32(math.sqrt(hd))
+            ref2 = np.einsum("bhk,bhkd->bhd", O.softmax(sc2), np.repeat(vf, G, 1)).reshape(B, H * hd)
+            assert err(out, ref2) < 2e-2
+        else:
+            assert err(out, ref) < 2e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("P,Tq,N", [(1, 7, 4096), (3, 8, 1000), (70, 6, 4096), (2, 1, 64), (5, 7, 130)])
 def test_tok2img_attention(ops, dtype, P, Tq, N):
@@ -340,6 +368,29 @@ def test_gemm_split_k_tail_matches_unsplit(ops, dtype):
     tol = 5e-4 if dtype == torch.float32 else 2e-2
     assert err(y0.cpu().numpy(), ref) < tol and err(y1.cpu().numpy(), ref) < tol
     assert err(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-3 and err(s1.cpu().numpy(), s0.cpu().numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("M", [1, 4, 5, 8])
+def test_gemm_decode_rows(ops, M):
+    """M <= 8 rows in bf16 take the weight-streaming kernel (decode step): plain, bias + GELU, fp32 residual, SwiGLU, ragged N."""
+    from ullsam_amd.packing import pack_w13
+    rng = np.random.default_rng(M)
+    for N, K in ((4096, 4096), (1003, 512), (2048, 14336 if M <= 4 else 1536)):
+        a = T(rng.standard_normal((M, K), dtype=np.float32), torch.bfloat16)
+        w = T((rng.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)).astype(np.float32), torch.bfloat16)
+        bias, res = T(rng.standard_normal(N, dtype=np.float32)), T(rng.standard_normal((M, N), dtype=np.float32))
+        af, wf = a.float().cpu().numpy(), w.float().cpu().numpy()
+        ref = af @ wf.T
+        assert err(ops.gemm(a, w, out_f32=True).cpu().numpy(), ref) < 2e-3
+        assert err(ops.gemm(a, w, bias=bias, act=ops.ACT_GELU).float().cpu().numpy(), O.gelu(ref + bias.cpu().numpy())) < 2e-2
+        y = res.clone()
+        ops.gemm(a, w, bias=bias, residual=y, out_f32=True, out=y)
+        assert err(y.cpu().numpy(), ref + bias.cpu().numpy() + res.cpu().numpy()) < 2e-3
+        if N % 256 == 0:
+            h = N // 2
+            s = ops.gemm(a, pack_w13(w[:h].contiguous(), w[h:].contiguous()), act=ops.ACT_SWIGLU, out_f32=True).cpu().numpy()
+            g, u = ref[:, :h], ref[:, h:]
+            assert err(s, g / (1 + np.exp(-g)) * u) < 2e-3
 
 
 @pytest.mark.parametrize("M,N,K", [(4324, 4096, 4096), (16384, 1280, 5120)])

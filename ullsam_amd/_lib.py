@@ -23,6 +23,7 @@ SIGNATURES = {
     "ullsam_causal_attention": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "ullsam_naive_attention": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32] + [i64] * 12 + [f32, vp],
     "ullsam_fewkeys_attention": [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i64, vp],
+    "ullsam_decode_attention": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, i32, vp],
     "ullsam_tok2img_attention": [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, f32, vp, i32, vp],
     "ullsam_patch_im2col": [i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "ullsam_im2col3x3": [i32, vp, vp, i32, i32, i32, i32, vp],

@@ -1058,6 +1058,11 @@ extern "C" int ullsam_naive_attention(int dtype, const void* q, const void* k, c
 // T queries of all heads are scored against each loaded row, online softmax per (query, head) in registers.  Keys are split
 // over `nsplit` workgroups per prompt (flash-decoding): each writes (max, sum, unnormalised o), `tok2img_merge_kernel` combines.
 // C = H*16 = 128 only (SAM's decoder); k/v batch stride 0 = one image shared by every prompt.
+__device__ __forceinline__ void bf16x8_to_f32_attn(const uint4 u, float (&o)[8]) {
+    const unsigned int d[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[2 * j] = __uint_as_float(d[j] << 16); o[2 * j + 1] = __uint_as_float(d[j] & 0xffff0000u); }
+}
 template <typename TK> struct KVRow;
 template <> struct KVRow<float> {
     static constexpr int EPL = 4;
@@ -1201,6 +1206,146 @@ extern "C" int ullsam_tok2img_attention(int kv_dtype, const float* q, const void
     else tok2img_partial_kernel<bf16, 8><<<grid, 256, 0, s>>>(q, k, v, workspace, T, N, k_batch_stride, v_batch_stride, scale, nsplit);
     ULLSAM_LAUNCH_CHECK();
     tok2img_merge_kernel<<<P * T, 128, 0, s>>>(workspace, out, P, T, nsplit);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- decode-step attention (q_len == 1, modeling_internlm2.py:383-419 with the mask of :834): one query per head against the cache.
+// The G = H / KVH query heads that share a KV head are handled together ("G queries"), the cached keys are split over nsplit
+// workgroups (flash-decoding) and merged by decode_attn_merge_kernel.  K / V rows are 256 bytes (hd 128, bf16): 16 lanes per row,
+// 4 rows per wave load, fully coalesced; the dot product reduces over the 16 lanes with four DPP steps.  Key padding is the
+// reference's additive finfo.min.
+template <int TQ>
+__global__ __launch_bounds__(256) void decode_attn_partial_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kc,
+                                                                  const bf16* __restrict__ vc, const int* __restrict__ key_mask,
+                                                                  float* __restrict__ ws, int G, int KVH, int Sk, long kv_bs,
+                                                                  long kv_hs, float scale, int nsplit) {
+    constexpr int HD = 128, EPL = 8, LPR = 16, RPW = 4;
+    __shared__ float so[4][TQ][HD];
+    __shared__ float sml[4][TQ][2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int split = blockIdx.x, pr = blockIdx.y;       // pr = b * KVH + kvh
+    const int b = pr / KVH, kvh = pr - b * KVH;
+    const int c = lane % LPR, r = lane / LPR;
+    const int per = (Sk + nsplit - 1) / nsplit;
+    const int s0 = split * per, s1 = min(Sk, s0 + per);
+    const float FMIN = -3.4028234663852886e38f;
+    float qf[TQ][EPL];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) {
+        float tmp[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tmp[e] = 0.f;
+        if (t < G) bf16x8_to_f32_attn(*reinterpret_cast<const uint4*>(q + ((long)pr * G + t) * HD + c * EPL), tmp);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) qf[t][e] = tmp[e];
+    }
+    float m[TQ], l[TQ], o[TQ][EPL];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) {
+        m[t] = -1e30f; l[t] = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[t][e] = 0.f;
+    }
+    const bf16* kb = kc + (long)b * kv_bs + (long)kvh * kv_hs;
+    const bf16* vb = vc + (long)b * kv_bs + (long)kvh * kv_hs;
+    const int* km = key_mask ? key_mask + (long)b * Sk : nullptr;
+    for (int row0 = s0 + wv * RPW; row0 < s1; row0 += 4 * RPW) {
+        const int row = row0 + r;
+        const bool valid = row < s1;
+        const long off = (long)min(row, Sk - 1) * HD + c * EPL;
+        float kf[EPL], vf[EPL];
+        bf16x8_to_f32_attn(*reinterpret_cast<const uint4*>(kb + off), kf);
+        bf16x8_to_f32_attn(*reinterpret_cast<const uint4*>(vb + off), vf);
+        const float add = (km && valid && km[row] == 0) ? FMIN : 0.f;
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+            float sc = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) sc += qf[t][e] * kf[e];
+#pragma unroll
+            for (int x = 1; x < LPR; x <<= 1) sc += __shfl_xor(sc, x, 64);
+            sc = sc * scale + add;
+            const float mn = fmaxf(m[t], sc);
+            const float al = __expf(m[t] - mn), pv = valid ? __expf(sc - mn) : 0.f;
+            l[t] = l[t] * al + pv;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[t][e] = o[t][e] * al + pv * vf[e];
+            m[t] = mn;
+        }
+    }
+#pragma unroll
+    for (int x = LPR; x < 64; x <<= 1) {  // merge the RPW row groups of the wave
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+            const float m2 = __shfl_xor(m[t], x, 64), l2 = __shfl_xor(l[t], x, 64);
+            const float mn = fmaxf(m[t], m2);
+            const float a1 = __expf(m[t] - mn), a2 = __expf(m2 - mn);
+            l[t] = l[t] * a1 + l2 * a2;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[t][e] = o[t][e] * a1 + __shfl_xor(o[t][e], x, 64) * a2;
+            m[t] = mn;
+        }
+    }
+    if (r == 0) {
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) so[wv][t][c * EPL + e] = o[t][e];
+            if (c == 0) { sml[wv][t][0] = m[t]; sml[wv][t][1] = l[t]; }
+        }
+    }
+    __syncthreads();
+    // partials: o [P][nsplit][G][HD], then ml [P][nsplit][G][2]
+    float* wo = ws + ((long)pr * nsplit + split) * G * HD;
+    float* wml = ws + (long)gridDim.y * nsplit * G * HD + ((long)pr * nsplit + split) * G * 2;
+    for (int i = tid; i < G * HD; i += 256) {
+        const int t = i / HD, cc = i - t * HD;
+        float mn = sml[0][t][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) mn = fmaxf(mn, sml[w][t][0]);
+        float acc = 0.f, ll = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a = __expf(sml[w][t][0] - mn);
+            acc += so[w][t][cc] * a;
+            ll += sml[w][t][1] * a;
+        }
+        wo[i] = acc;
+        if (cc == 0) { wml[t * 2] = mn; wml[t * 2 + 1] = ll; }
+    }
+}
+
+__global__ __launch_bounds__(128) void decode_attn_merge_kernel(const float* __restrict__ ws, bf16* __restrict__ out, int P, int G, int nsplit) {
+    constexpr int HD = 128;
+    const int pt = blockIdx.x, pr = pt / G, t = pt - pr * G, cc = threadIdx.x;
+    const float* wo = ws + (long)pr * nsplit * G * HD;
+    const float* wml = ws + (long)P * nsplit * G * HD + (long)pr * nsplit * G * 2;
+    float mn = -1e30f;
+    for (int s2 = 0; s2 < nsplit; ++s2) mn = fmaxf(mn, wml[((long)s2 * G + t) * 2]);
+    float acc = 0.f, ll = 0.f;
+    for (int s2 = 0; s2 < nsplit; ++s2) {
+        const float a = __expf(wml[((long)s2 * G + t) * 2] - mn);
+        acc += wo[((long)s2 * G + t) * HD + cc] * a;
+        ll += wml[((long)s2 * G + t) * 2 + 1] * a;
+    }
+    out[((long)pr * G + t) * HD + cc] = (bf16)(acc / ll);
+}
+
+// q bf16 [B, H*128]; kc / vc bf16 caches [B, KVH, cap, 128]; key_mask int32 [B, Sk] or NULL; out bf16 [B, H*128];
+// workspace f32 [B*KVH*nsplit*G*130], G = H / KVH <= 8.
+extern "C" int ullsam_decode_attention(const void* q, const void* kc, const void* vc, const int* key_mask, void* out, int B, int H,
+                                       int KVH, int hd, int Sk, int cap, float scale, float* workspace, int nsplit, void* stream) {
+    ULLSAM_CHECK(hd == 128 && KVH > 0 && H % KVH == 0 && H / KVH <= 8, "decode_attention: hd=%d H=%d KVH=%d (hd 128, group <= 8)", hd, H, KVH);
+    ULLSAM_CHECK(Sk >= 1 && Sk <= cap && nsplit >= 1, "decode_attention: Sk=%d cap=%d nsplit=%d", Sk, cap, nsplit);
+    const int G = H / KVH, P = B * KVH;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(nsplit, P);
+    const long kv_bs = (long)KVH * cap * hd, kv_hs = (long)cap * hd;
+    if (G <= 4) decode_attn_partial_kernel<4><<<grid, 256, 0, s>>>((const bf16*)q, (const bf16*)kc, (const bf16*)vc, key_mask, workspace, G, KVH, Sk, kv_bs, kv_hs, scale, nsplit);
+    else decode_attn_partial_kernel<8><<<grid, 256, 0, s>>>((const bf16*)q, (const bf16*)kc, (const bf16*)vc, key_mask, workspace, G, KVH, Sk, kv_bs, kv_hs, scale, nsplit);
+    ULLSAM_LAUNCH_CHECK();
+    decode_attn_merge_kernel<<<P * G, 128, 0, s>>>(workspace, (bf16*)out, P, G, nsplit);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }

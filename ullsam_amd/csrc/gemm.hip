@@ -761,6 +761,124 @@ static int launch_gemm(GemmArgs a, hipStream_t stream) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Skinny GEMM for the decode step (M <= 8 rows, bf16): every weight byte is needed once and nothing is reused across rows of W, so
+// this is a weight stream, not a tile problem -- the 128x128 kernel launches N/128 workgroups (32 for wo) and reads W at 0.27 TB/s.
+// Here a wave owns four rows of W and walks K in 1 KiB steps per row (16 bytes per lane, four rows = four independent loads in
+// flight per step, two steps unrolled); the M activation rows sit in LDS as bf16 and are read back 16 bytes per lane.  fp32
+// accumulation per lane, one wave reduction per (row of W, row of A) at the end, then the usual epilogue (bias, GELU / ReLU,
+// SwiGLU pair, fp32 residual) on lane 0.  For SwiGLU a wave takes two gate rows and their two up rows of the packed w13.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bf16x8_to_f32(const uint4 u, float (&o)[8]) {
+    const unsigned int d[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[2 * j] = __uint_as_float(d[j] << 16); o[2 * j + 1] = __uint_as_float(d[j] & 0xffff0000u); }
+}
+template <int MM>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // A as bf16 [MM][K]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int K = p.K, KC = K >> 3;                 // 16-byte chunks per row
+    const bf16* A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* W = reinterpret_cast<const bf16*>(p.W);
+    for (int idx = tid; idx < MM * KC; idx += 256) {
+        const int m = idx / KC, c = idx - m * KC;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (m < p.M) v = *reinterpret_cast<const uint4*>(A + (size_t)m * p.lda + c * 8);
+        *reinterpret_cast<uint4*>(smem + ((size_t)m * KC + c) * 16) = v;
+    }
+    __syncthreads();
+    const long wid = (long)blockIdx.x * 4 + (tid >> 6);
+    long rows[4];
+    if (p.act == 3) {  // packed w13: 128-row blocks [64 gate | 64 up]; this wave: gate rows g, g+1 and their up rows
+        const long blk = wid >> 5, wb = wid & 31;
+        rows[0] = blk * 128 + 2 * wb; rows[1] = rows[0] + 1; rows[2] = rows[0] + 64; rows[3] = rows[0] + 65;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rows[r] = wid * 4 + r;
+    }
+    if (rows[0] >= p.N) return;
+    const bf16* wr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wr[r] = W + (size_t)min(rows[r], (long)p.N - 1) * p.ldw + lane * 8;
+    float acc[4][MM];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < MM; ++m) acc[r][m] = 0.f;
+    const char* xa = smem + lane * 16;
+#pragma unroll 2
+    for (int k0 = 0; k0 < K; k0 += 512) {
+        uint4 wv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wv[r] = *reinterpret_cast<const uint4*>(wr[r] + k0);
+        float xf[MM][8];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) bf16x8_to_f32(*reinterpret_cast<const uint4*>(xa + ((size_t)m * KC + (k0 >> 3)) * 16), xf[m]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float wf[8];
+            bf16x8_to_f32(wv[r], wf);
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[r][m] += wf[e] * xf[m][e];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < MM; ++m) acc[r][m] = wave_sum(acc[r][m]);
+    if (lane != 0) return;
+    if (p.act == 3) {
+        const long oc = (rows[0] >> 7) * 64 + (rows[0] & 63);  // output column of gate row rows[0]
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            if (m >= p.M) break;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float o = silu_f(acc[j][m]) * acc[2 + j][m];
+                if (p.out_f32) reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + oc + j] = o;
+                else reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + oc + j] = (bf16)o;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long n = rows[r];
+        if (n >= p.N) break;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            if (m >= p.M) break;
+            float v = acc[r][m] + bv;
+            if (p.act == 1) v = gelu_erf(v);
+            else if (p.act == 2) v = fmaxf(v, 0.f);
+            if (p.residual) v += p.residual[(size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + n];
+            if (p.out_f32) reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n] = v;
+            else reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + n] = (bf16)v;
+        }
+    }
+}
+
+static int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
+    const int MM = a.M <= 4 ? 4 : 8;
+    const size_t lds = (size_t)MM * a.K * 2;
+    const long waves = a.act == 3 ? (long)a.N / 4 : ((long)a.N + 3) / 4;
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    static bool attr4 = false, attr8 = false;
+    if (MM == 4) {
+        if (!attr4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr4 = true; }
+        gemm_skinny_kernel<4><<<grid, 256, lds, stream>>>(a);
+    } else {
+        if (!attr8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr8 = true; }
+        gemm_skinny_kernel<8><<<grid, 256, lds, stream>>>(a);
+    }
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, long ldw, void* C, long ldc, int out_f32,
                            const float* bias, const float* residual, long ldr, int res_row_mod, int act, int M, int N,
                            int K, void* workspace, long ws_bytes, void* stream) {
@@ -792,6 +910,10 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     a.full_tiles = a.tiles_m * a.tiles_n;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int variant = g_gemm_variant;
+    // decode step: a handful of rows against the whole weight matrix
+    if (variant == 0 && dtype == ULLSAM_DT_BF16 && M <= 8 && K % 512 == 0 && lda % 8 == 0 && ldw % 8 == 0 &&
+        (size_t)(M <= 4 ? 4 : 8) * K * 2 <= 144 * 1024 && (act != 3 || N % 128 == 0))
+        return launch_gemm_skinny(a, s);
     // measured end to end (profiles/): the 256x128 3-stage kernel wins on the very wide SwiGLU GEMM, the 128x128 kernel elsewhere
     const bool v2 = variant == 2 || (variant == 0 && M > 512 && N >= 16384);
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);

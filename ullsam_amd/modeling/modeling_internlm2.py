@@ -175,6 +175,8 @@ class InternLM2Model(Packed):
             q = ops.rope_split(qkv, kc, vc, pos, cos, sin, B, S, KVH, G, hd, past)
             if S > 1:
                 a = ops.causal_attention(q, kc, vc, key_mask, B, H, KVH, hd, S, Sk, past)
+            elif dt == torch.bfloat16 and hd == 128 and G <= 8:  # decode step: streaming split-K kernel over the cache
+                a = ops.decode_attention(q, kc, vc, key_mask, B, H, KVH, hd, Sk)
             else:  # decode step: one query against the cache (no causal term: _prepare_decoder_attention_mask :834)
                 cap = kc.shape[2]
                 a = ops.naive_attention(q, kc, vc, B, H, KVH, hd, 1, Sk, (H * hd, H * hd, hd), (KVH * cap * hd, hd, cap * hd),

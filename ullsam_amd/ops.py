@@ -161,6 +161,20 @@ def fewkeys_attention(q, k, v, B, H, hd, Sq, Sk, scale, q_shared: bool = False):
     return out
 
 
+def decode_attention(q, kc, vc, key_mask, B, H, KVH, hd, Sk):
+    """q bf16 [B, H*hd] (one new token per sequence), kc / vc bf16 caches [B, KVH, cap, hd], key_mask int32 [B, Sk] | None -> bf16 [B, H*hd]."""
+    _chk(q, "q", torch.bfloat16); _chk(kc, "k cache", torch.bfloat16); _chk(vc, "v cache", torch.bfloat16)
+    if key_mask is not None:
+        _chk(key_mask, "key_mask", torch.int32)
+    G, P = H // KVH, B * KVH
+    nsplit = max(1, min(32, -(-512 // P), Sk // 64))
+    ws = torch.empty((P * nsplit * G * (hd + 2),), dtype=torch.float32, device=q.device)
+    out = torch.empty((B, H * hd), dtype=torch.bfloat16, device=q.device)
+    _lib.call("ullsam_decode_attention", q.data_ptr(), kc.data_ptr(), vc.data_ptr(), _p(key_mask), out.data_ptr(), B, H, KVH, hd, Sk,
+              kc.shape[2], float(hd) ** -0.5, ws.data_ptr(), nsplit, _stream())
+    return out
+
+
 def tok2img_attention(q, k, v, P, H, hd, T, N, scale, kv_shared: bool = False):
     """q fp32 [P*T, H*hd]; k, v [P (or 1 when kv_shared) * N, H*hd] fp32 or bf16 -> fp32 [P*T, H*hd]."""
     _chk(q, "q", torch.float32); _chk(k, "k"); _chk(v, "v", k.dtype)
