@@ -152,32 +152,40 @@ extern "C" int ullsam_rope_split(int dtype, const void* qkv, void* q_out, void* 
 }
 
 // ---- greedy argmax over fp32 logits [R, V] -> int64 (first maximum wins, like torch.argmax) ---------------------
-__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x, long long* __restrict__ out, long V, long ld) {
-    __shared__ float sv[256];
-    __shared__ long long si[256];
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ x, long long* __restrict__ out, long V, long ld) {
+    __shared__ float sv[16];
+    __shared__ long long si[16];
     const float* row = x + (long)blockIdx.x * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float best = -INFINITY;
     long long bi = 0x7fffffffffffffffLL;
-    for (long i = threadIdx.x; i < V; i += 256) {
-        const float v = row[i];
-        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    // four independent loads per trip; within a thread indices increase, so `>` keeps the first maximum
+    for (long i0 = tid; i0 < V; i0 += 4096) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (i0 + 1024 * u < V) ? row[i0 + 1024 * u] : -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (v[u] > best) { best = v[u]; bi = i0 + 1024 * u; }
     }
-    sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+    auto better = [](float v, long long j, float w, long long k) { return v > w || (v == w && j < k); };
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v = __shfl_xor(best, o, 64);
+        const long long j = __shfl_xor(bi, o, 64);
+        if (better(v, j, best, bi)) { best = v; bi = j; }
+    }
+    if (lane == 0) { sv[wv] = best; si[wv] = bi; }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            const float v = sv[threadIdx.x + s];
-            const long long j = si[threadIdx.x + s];
-            if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && j < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = j; }
-        }
-        __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (better(sv[w], si[w], best, bi)) { best = sv[w]; bi = si[w]; }
+        out[blockIdx.x] = bi;
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = si[0];
 }
 
 extern "C" int ullsam_argmax(const float* logits, long long* out, int rows, long V, long ld, void* stream) {
     if (rows == 0) return 0;
-    argmax_kernel<<<rows, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(logits, out, V, ld);
+    argmax_kernel<<<rows, 1024, 0, reinterpret_cast<hipStream_t>(stream)>>>(logits, out, V, ld);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }

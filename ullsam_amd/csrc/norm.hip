@@ -209,7 +209,8 @@ static int launch_norm(const NormArgs& a, hipStream_t s) {
     }
     // rows of >= 2048 elements, many of them (the LLM's RMSNorm): one workgroup per row -- [4324 x 4096] fp32 -> bf16 takes 26.7 us
     // (4.0 TB/s) against 37.9 us with a wave per row; at 1280 elements (ViT LayerNorm) the wave-per-row kernel stays ahead (33.6 vs 37.7)
-    if (g_norm_lds == 0 && a.rows >= 1024 && nv >= 512) {
+    // ... and so does a handful of long rows (the decode step: 4 rows x 4096 took 14.6 us with one wave per row)
+    if (g_norm_lds == 0 && (a.rows >= 1024 || a.rows <= 64) && nv >= 512) {
         const dim3 g((unsigned)a.rows);
         if (nv <= 512) norm_block_kernel<TI, TO, 2><<<g, block, 0, s>>>(a);
         else norm_block_kernel<TI, TO, 4><<<g, block, 0, s>>>(a);
