@@ -7,6 +7,9 @@ from bench import build_model
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 1081
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+if os.environ.get("ULLSAM_GEMM_VARIANT"):
+    from ullsam_amd import _lib
+    _lib.load().ullsam_set_gemm_variant(int(os.environ["ULLSAM_GEMM_VARIANT"]))
 m = build_model("b", "7b", torch.bfloat16, "cuda:0")
 lm = m.language_model
 ids = torch.randint(0, 90000, (B, S), device="cuda")
