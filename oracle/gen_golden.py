@@ -272,7 +272,40 @@ def case_amg():
     save("amg", input_seed=6, **out)
 
 
-CASES = {"amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
+def case_chat_prompt():
+    """Prompt strings the reference's chat() builds (modeling_internvl_sam.py:272-335 over conversation.py's "internlm2-chat"
+    template) for a first turn, a turn with history and a text-only turn: pins the host loop's query construction."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("ref_conversation", "/root/reference/modeling/conversation.py")
+    conv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(conv)
+    cases = []
+    for system, history, question, patches, n_img_tok in (
+            ("SYS", None, "Describe the cells.", [1], 3),
+            ("You are a microscopy assistant.", [("first?\n<image>", "an answer")], "and now?", [1], 2),
+            ("SYS", None, "<image>\n<image>\ncompare", [1, 2], 2),
+            ("SYS", None, "no picture here", [], 4)):
+        q = question
+        has_image = len(patches) > 0
+        if history is None and has_image and "<image>" not in q:
+            q = q + "\n<image>"
+        t = conv.get_conv_template("internlm2-chat")
+        t.system_message = system
+        for (oq, oa) in (history or []):
+            t.append_message(t.roles[0], oq)
+            t.append_message(t.roles[1], oa)
+        t.append_message(t.roles[0], q)
+        t.append_message(t.roles[1], None)
+        query = t.get_prompt()
+        for n in patches:
+            query = query.replace("<image>", "<img>" + "<IMG_CONTEXT>" * n_img_tok * n + "</img>", 1)
+        cases.append({"system": system, "history": history, "question": question, "num_patches_list": patches, "num_image_token": n_img_tok,
+                      "query": query, "sep": t.sep.strip()})
+    json.dump(cases, open(os.path.join(OUT, "chat_prompt.json"), "w"), ensure_ascii=False, indent=1)
+
+
+CASES = {"chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
          "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full}
 
 if __name__ == "__main__":

@@ -219,3 +219,41 @@ def test_checkpoint_loading_conventions(tmp_path):
     missing, unexpected = checkpoint.load_llm_safetensors(dst2, str(tmp_path))
     assert not unexpected and all(not k.startswith("language_model.") for k in missing)
     assert torch.equal(dst2.language_model.output.weight, src.language_model.output.weight)
+
+
+def test_chat_builds_the_reference_prompt():
+    """InternVLSAMModel.chat (modeling_internvl_sam.py:272-335): the query string handed to the tokenizer equals what the reference
+    builds with its "internlm2-chat" conversation template (tests/golden/chat_prompt.json, produced by the reference's own code);
+    eos = the template separator; the response is cut at the separator; history is appended."""
+    import json
+    import types
+    from ullsam_amd.modeling.modeling_internvl_sam import InternVLSAMModel
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "chat_prompt.json")))
+    for c in cases:
+        seen = {}
+
+        class Tok:
+            def convert_tokens_to_ids(self, t):
+                return {"<IMG_CONTEXT>": 92546, "<|im_end|>": 92542}[t]
+
+            def __call__(self, query, return_tensors="pt"):
+                seen["query"] = query
+                return {"input_ids": torch.zeros((1, 3), dtype=torch.long), "attention_mask": torch.ones((1, 3), dtype=torch.long)}
+
+            def batch_decode(self, out, skip_special_tokens=True):
+                return ["  the answer<|im_end|> trailing"]
+
+        def fake_generate(**kw):
+            seen["gen"] = kw
+            return torch.zeros((1, 2), dtype=torch.long)
+
+        me = types.SimpleNamespace(system_message=c["system"], num_image_token=c["num_image_token"], device="cpu", generate=fake_generate,
+                                   template="internlm2-chat")
+        n_img = sum(c["num_patches_list"])
+        pv = torch.zeros((n_img, 3, 8, 8)) if n_img else None
+        hist = [tuple(h) for h in c["history"]] if c["history"] else None
+        resp, new_hist = InternVLSAMModel.chat(me, Tok(), pv, c["question"], {"max_new_tokens": 4, "do_sample": False}, history=hist,
+                                               return_history=True, num_patches_list=c["num_patches_list"] or None)
+        assert seen["query"] == c["query"]
+        assert seen["gen"]["eos_token_id"] == 92542 and me.img_context_token_id == 92546
+        assert resp == "the answer" and new_hist[-1][1] == "the answer" and len(new_hist) == len(c["history"] or []) + 1

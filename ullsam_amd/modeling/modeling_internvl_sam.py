@@ -187,6 +187,9 @@ class InternVLSAMModel(Packed):
             question = question + "\n<image>"
         if num_patches_list is None:
             num_patches_list = [pixel_values.shape[0]] if pixel_values is not None else []
+        assert pixel_values is None or len(pixel_values) == sum(num_patches_list)
+        if getattr(self, "template", "internlm2-chat") != "internlm2-chat":
+            raise NotImplementedError(f"conversation template {self.template!r}: only 'internlm2-chat' (the one uLLSAM configures) is built in")
         self.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
         sep = "<|im_end|>"
         eos_token_id = tokenizer.convert_tokens_to_ids(sep)
