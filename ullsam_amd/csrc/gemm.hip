@@ -862,7 +862,77 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     }
 }
 
+// Narrow weight matrices (wo, w2, wqkv at decode: N <= 8192) give the kernel above only ~4 waves per CU.  Here a workgroup owns
+// four rows of W and its four waves split K; the activation rows are read straight from global memory (32..115 KB in total,
+// cache-resident) instead of being staged per workgroup, so nothing but 256 bytes of LDS is needed and a CU holds many workgroups.
+template <int MM>
+__global__ __launch_bounds__(256) void gemm_skinny_ksplit_kernel(GemmArgs p) {
+    __shared__ float red[4][4][MM];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int KQ = p.K >> 2;                          // this wave's K range (K % 2048 == 0)
+    const bf16* A = reinterpret_cast<const bf16*>(p.A) + (size_t)wv * KQ + lane * 8;
+    const bf16* W = reinterpret_cast<const bf16*>(p.W) + (size_t)wv * KQ + lane * 8;
+    const long n0 = (long)blockIdx.x * 4;
+    const bf16* wr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wr[r] = W + (size_t)min(n0 + r, (long)p.N - 1) * p.ldw;
+    const bf16* ar[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) ar[m] = A + (size_t)min(m, p.M - 1) * p.lda;
+    float acc[4][MM];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < MM; ++m) acc[r][m] = 0.f;
+#pragma unroll 2
+    for (int k0 = 0; k0 < KQ; k0 += 512) {
+        uint4 wv4[4], av[MM];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wv4[r] = *reinterpret_cast<const uint4*>(wr[r] + k0);
+#pragma unroll
+        for (int m = 0; m < MM; ++m) av[m] = *reinterpret_cast<const uint4*>(ar[m] + k0);
+        float xf[MM][8];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) bf16x8_to_f32(av[m], xf[m]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float wf[8];
+            bf16x8_to_f32(wv4[r], wf);
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[r][m] += wf[e] * xf[m][e];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            const float t = wave_sum(acc[r][m]);
+            if (lane == 0) red[wv][r][m] = t;
+        }
+    __syncthreads();
+    if (tid >= 4 * MM) return;
+    const int r = tid / MM, m = tid - r * MM;
+    const long n = n0 + r;
+    if (n >= p.N || m >= p.M) return;
+    float v = (red[0][r][m] + red[1][r][m]) + (red[2][r][m] + red[3][r][m]);
+    if (p.bias) v += p.bias[n];
+    if (p.act == 1) v = gelu_erf(v);
+    else if (p.act == 2) v = fmaxf(v, 0.f);
+    if (p.residual) v += p.residual[(size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + n];
+    if (p.out_f32) reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n] = v;
+    else reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + n] = (bf16)v;
+}
+
 static int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
+    if (a.act != 3 && a.N <= 8192 && a.K % 2048 == 0 && g_gemm_sched != 1) {  // narrow: K split over the waves of a workgroup (A/B: sched bits = 1)
+        const dim3 g((unsigned)((a.N + 3) / 4));
+        if (a.M <= 4) gemm_skinny_ksplit_kernel<4><<<g, 256, 0, stream>>>(a);
+        else gemm_skinny_ksplit_kernel<8><<<g, 256, 0, stream>>>(a);
+        ULLSAM_LAUNCH_CHECK();
+        return 0;
+    }
     const int MM = a.M <= 4 ? 4 : 8;
     const size_t lds = (size_t)MM * a.K * 2;
     const long waves = a.act == 3 ? (long)a.N / 4 : ((long)a.N + 3) / 4;
