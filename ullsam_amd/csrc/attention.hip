@@ -19,8 +19,12 @@
 //  "An accumulator tile as the next MFMA's operand"); V is read column-wise with ds_read_b64_tr_b16 (bf16)
 //  or 8 ds_read_b32 (f32).
 //
+//  win14_attn_kernel: SAM's 14x14 windows in bf16 (the production windowed path): whole window staged once per (window, head),
+//    rel-pos terms in registers; the generic MODE_VIT_WINDOW path above serves fp32 and other window sizes.
+//  decode_attn_*: q_len == 1 against the bf16 KV cache (GQA groups together, keys split over workgroups, softmax merge).
+//  tok2img_*: token -> image cross attention of the two-way mask decoder (few queries, 4096 keys streamed once).
 //  naive_attn_kernel / fewkeys_attn_kernel: small-shape attention for the two-way mask decoder
-//  (transformer.py:220-242) and the q_len==1 decode step.
+//  (transformer.py:220-242) and the fp32 / odd-shape q_len==1 decode step.
 #include "common.h"
 
 enum { MODE_PLAIN = 0, MODE_CAUSAL = 1, MODE_VIT_GLOBAL = 2, MODE_VIT_WINDOW = 3 };
