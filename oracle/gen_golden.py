@@ -305,8 +305,67 @@ def case_chat_prompt():
     json.dump(cases, open(os.path.join(OUT, "chat_prompt.json"), "w"), ensure_ascii=False, indent=1)
 
 
+def case_vit_h_d2():
+    """ViT-H-width encoder (D=1280, 16 heads, head_dim 80: build_sam.py:14-21) cut to depth 2 = one windowed (14x14, 25 padded
+    windows per image) + one global (64x64 grid) block at 1024^2 -- the attention-kernel instantiations the bench runs.  Also the
+    reference's own bf16 behaviour: the same module under torch.autocast("cpu", bfloat16), to bound our bf16 mode against it."""
+    from modeling.image_encoder import ImageEncoderViT
+    cfg = dict(img_size=1024, patch_size=16, embed_dim=1280, depth=2, num_heads=16, mlp_ratio=4, out_chans=256,
+               qkv_bias=True, use_rel_pos=True, window_size=14, global_attn_indexes=[1])
+    m = ImageEncoderViT(norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), **cfg).eval()
+    fill_module(m, seed=0)
+    x = torch.from_numpy(rand_image((1, 3, 1024, 1024), seed=1))
+    t = time.time()
+    y = m(x).numpy()
+    print(f"  reference ViT-H/2 forward {time.time() - t:.1f}s")
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        yb = m(x).float().numpy()
+    flat, fb = y.reshape(-1), yb.reshape(-1)
+    save("vit_h_d2", cfg=np.array(repr(cfg)), weight_seed=0, input_seed=1, stride=37, sample=flat[::37].copy(),
+         mean=np.float64(flat.mean()), std=np.float64(flat.std()), absmax=np.float64(np.abs(flat).max()),
+         autocast_bf16_max_err=np.float64(np.abs(fb - flat).max()), autocast_bf16_mean_err=np.float64(np.abs(fb - flat).mean()))
+
+
+LLM_7B_L1 = dict(architectures=["InternLM2ForCausalLM"], vocab_size=92553, hidden_size=4096, intermediate_size=14336,
+                 num_hidden_layers=1, num_attention_heads=32, num_key_value_heads=8, bias=False,
+                 max_position_embeddings=32768, rope_theta=1000000, rms_norm_eps=1e-5, attn_implementation="eager")
+
+
+def case_llm_7b_l1():
+    """One InternLM2 layer at the 7B shape the bench runs (hidden 4096, 32 heads / 8 KV heads, intermediate 14336), S = 1081,
+    batch 2 with left padding on the second sequence (modeling_internlm2.py:854-984)."""
+    from modeling.configuration_internlm2 import InternLM2Config
+    from modeling.modeling_internlm2 import InternLM2ForCausalLM
+    cfg = InternLM2Config(**LLM_7B_L1)
+    cfg.rope_scaling = None
+    lm = InternLM2ForCausalLM(cfg).eval()
+    fill_module(lm, seed=0, prefix="language_model.")
+    rng = np.random.default_rng(8)
+    B, S = 2, 1081
+    emb = rng.standard_normal((B, S, 4096), dtype=np.float32) * 0.5   # regenerable: default_rng(8), this draw
+    mask = np.ones((B, S), np.int64)
+    mask[1, :13] = 0
+    t = time.time()
+    o = lm(inputs_embeds=torch.from_numpy(emb), attention_mask=torch.from_numpy(mask), use_cache=False,
+           output_hidden_states=True, return_dict=True)
+    print(f"  reference 7B-shaped layer forward {time.time() - t:.1f}s")
+    hidden = o.hidden_states[-1].numpy()            # post-final-norm [B,S,4096]
+    logits_last = o.logits[:, -1].numpy()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ob = lm(inputs_embeds=torch.from_numpy(emb), attention_mask=torch.from_numpy(mask), use_cache=False,
+                output_hidden_states=True, return_dict=True)
+    hb = ob.hidden_states[-1].float().numpy()
+    valid = mask.astype(bool)
+    save("llm_7b_l1", weight_seed=0, input_seed=8, cfg=np.array(repr(LLM_7B_L1)), mask=mask,
+         hidden_sample=hidden[:, ::23, ::17].copy(), hidden_absmax=np.float64(np.abs(hidden[valid]).max()),
+         logits_last_sample=logits_last[:, ::97].copy(), logits_last_argmax=logits_last.argmax(-1),
+         autocast_bf16_max_err=np.float64(np.abs(hb - hidden)[valid].max()),
+         autocast_bf16_mean_err=np.float64(np.abs(hb - hidden)[valid].mean()))
+
+
 CASES = {"chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
-         "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full}
+         "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full,
+         "vit_h_d2": case_vit_h_d2, "llm_7b_l1": case_llm_7b_l1}
 
 if __name__ == "__main__":
     for n in (sys.argv[1:] or list(CASES)):

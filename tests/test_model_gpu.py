@@ -57,6 +57,54 @@ def test_vit_b_full_golden(dtype, tol):
     assert abs(float(y.mean()) - float(g["mean"])) < 1e-3 and abs(float(y.std()) - float(g["std"])) < 5e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vit_h_d2_golden(dtype):
+    """ViT-H width at 1024^2 (16 heads x 80, 64x64 grid, 25 padded 14x14 windows per image), depth 2: in-model check of the
+    attention / GEMM instantiations the bench runs.  bf16 is bounded by the reference's OWN bf16 (autocast) error on this fixture."""
+    g = U.gold("vit_h_d2")
+    enc = load(make_vit(U.VIT_H_D2), U.vit_params(U.VIT_H_D2, int(g["weight_seed"])), dtype)
+    x = torch.from_numpy(U.rand_image((1, 3, 1024, 1024), int(g["input_seed"]))).to(DEV)
+    y = enc(x).float().cpu().numpy()
+    d = np.abs(y.reshape(-1)[::int(g["stride"])].astype(np.float64) - g["sample"])
+    if dtype == torch.float32:
+        assert d.max() < 1e-3, d.max()
+        assert abs(float(y.mean()) - float(g["mean"])) < 1e-3 and abs(float(y.std()) - float(g["std"])) < 1e-3
+    else:  # reference autocast-bf16 vs its fp32: max 0.056, mean 0.0059; ours keeps statistics / residual in fp32
+        assert d.max() < 1.5 * float(g["autocast_bf16_max_err"]), (d.max(), float(g["autocast_bf16_max_err"]))
+        assert d.mean() < 1.2 * float(g["autocast_bf16_mean_err"]), (d.mean(), float(g["autocast_bf16_mean_err"]))
+
+
+def _llm(c, dtype):
+    from ullsam_amd.modeling.configuration_internlm2 import InternLM2Config
+    from ullsam_amd.modeling.modeling_internlm2 import InternLM2ForCausalLM
+    cfg = InternLM2Config(vocab_size=c["vocab"], hidden_size=c["hidden"], intermediate_size=c["inter"], num_hidden_layers=c["layers"],
+                          num_attention_heads=c["heads"], num_key_value_heads=c["kv_heads"], bias=False, max_position_embeddings=32768,
+                          rope_theta=c["rope_theta"], rms_norm_eps=c["eps"])
+    return load(InternLM2ForCausalLM(cfg), U.llm_params(c, 0), dtype, "language_model.")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_llm_7b_l1_golden(dtype):
+    """One InternLM2 layer at the 7B shape the bench runs (hidden 4096, 32 / 8 heads, intermediate 14336: wqkv 6144x4096,
+    packed w13 28672x4096 with the SwiGLU epilogue, w2 / wo with split-K tails), S = 1081, batch 2, left padding."""
+    g = U.gold("llm_7b_l1")
+    lm = _llm(U.LLM_7B_L1, dtype)
+    emb = torch.from_numpy(U.llm_7b_l1_inputs(int(g["input_seed"]))).to(DEV)
+    mask = torch.from_numpy(g["mask"]).to(DEV)
+    out = lm(inputs_embeds=emb, attention_mask=mask, use_cache=False, output_hidden_states=True)
+    hid = out.hidden_states[-1].float().cpu().numpy()
+    valid = g["mask"].astype(bool)[:, ::23]
+    d = np.abs(hid[:, ::23, ::17][valid].astype(np.float64) - g["hidden_sample"][valid])
+    logits = out.logits[:, -1].cpu().numpy()
+    if dtype == torch.float32:
+        assert d.max() < 1e-3, d.max()
+        assert err(logits[:, ::97], g["logits_last_sample"]) < 5e-3
+        assert (logits.argmax(-1) == g["logits_last_argmax"]).all()
+    else:  # reference autocast-bf16 vs its fp32 on the valid rows: max 0.030, mean 0.0037
+        assert d.max() < 1.5 * float(g["autocast_bf16_max_err"]), (d.max(), float(g["autocast_bf16_max_err"]))
+        assert d.mean() < 1.2 * float(g["autocast_bf16_mean_err"]), (d.mean(), float(g["autocast_bf16_mean_err"]))
+
+
 def _decoder_modules(dtype):
     from ullsam_amd.build_sam import _build_sam
     sam = _build_sam(128, 2, 2, [1])

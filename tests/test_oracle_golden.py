@@ -68,6 +68,31 @@ def test_llm_tiny_matches_reference():
     assert toks.tolist() == g["greedy_tokens"].tolist(), "greedy token ids must be bit-exact"
 
 
+def test_vit_h_d2_matches_reference():
+    """ViT-H width (16 heads x 80) at 1024^2, one windowed + one global block: the bench's attention shapes."""
+    g = U.gold("vit_h_d2")
+    P = U.vit_params(U.VIT_H_D2, int(g["weight_seed"]))
+    x = U.rand_image((1, 3, 1024, 1024), int(g["input_seed"]))
+    y = O.vit_encoder(x, P, **U.vit_run_cfg(U.VIT_H_D2))
+    assert y.shape == (1, 256, 64, 64)
+    _close(y.reshape(-1)[::int(g["stride"])], g["sample"], 5e-4, "vit_h_d2 sample")
+    assert abs(float(y.mean()) - float(g["mean"])) < 1e-4 and abs(float(y.std()) - float(g["std"])) < 1e-4
+
+
+def test_llm_7b_l1_matches_reference():
+    """One InternLM2 layer at the 7B shape (4096 / 32 heads / 8 KV heads / 14336), S = 1081, left padding on sequence 1."""
+    g = U.gold("llm_7b_l1")
+    c = U.LLM_7B_L1
+    P = U.llm_params(c, int(g["weight_seed"]))
+    emb, mask = U.llm_7b_l1_inputs(int(g["input_seed"])), g["mask"]
+    hid, _ = O.internlm2_model(P, c, emb, mask, prefix="language_model.")
+    valid = mask.astype(bool)[:, ::23]
+    _close(hid[:, ::23, ::17][valid], g["hidden_sample"][valid], 5e-4, "hidden sample (non-pad rows)")
+    logits = O.lm_head(P, hid[:, -1], "language_model.")
+    _close(logits[:, ::97], g["logits_last_sample"], 5e-3, "last logits")
+    assert (logits.argmax(-1) == g["logits_last_argmax"]).all()
+
+
 def test_pixel_shuffle_roundtrip_and_maps():
     rng = np.random.default_rng(0)
     x = rng.standard_normal((1, 64, 64, 256), dtype=np.float32)

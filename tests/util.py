@@ -32,6 +32,9 @@ VIT_SMALL = dict(img_size=1024, patch_size=16, embed_dim=128, depth=2, num_heads
                  window_size=14, global_attn_indexes=(1,))
 VIT_B = dict(img_size=1024, patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, out_chans=256,
              window_size=14, global_attn_indexes=(2, 5, 8, 11))
+VIT_H_D2 = dict(img_size=1024, patch_size=16, embed_dim=1280, depth=2, num_heads=16, mlp_ratio=4, out_chans=256,
+                window_size=14, global_attn_indexes=(1,))  # ViT-H width (build_sam.py:14-21), one windowed + one global block
+LLM_7B_L1 = dict(hidden=4096, layers=1, heads=32, kv_heads=8, inter=14336, vocab=92553, rope_theta=1000000.0, eps=1e-5)
 LLM_TINY = dict(hidden=256, layers=2, heads=2, kv_heads=1, inter=512, vocab=92553, rope_theta=1000000.0, eps=1e-5)
 
 
@@ -60,3 +63,8 @@ def ullsam_tiny_params(seed=0):
     P.update(llm_params(LLM_TINY, seed))
     P.update(O.fill_state(O.projector_shapes(LLM_TINY["hidden"]), seed))
     return P
+
+
+def llm_7b_l1_inputs(seed=8):
+    """Same draw as oracle/gen_golden.py::case_llm_7b_l1."""
+    return np.random.default_rng(seed).standard_normal((2, 1081, 4096), dtype=np.float32) * np.float32(0.5)
