@@ -1,6 +1,9 @@
 """Headline benchmark: images/s end-to-end through the uLLSAM mask path (app.py:580-645 call sequence) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+N > 1: one rank per GPU over RCCL.  Either the caller launches the ranks (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`, WORLD_SIZE set), or -- when WORLD_SIZE is unset -- this file starts that launcher itself as a child
+process BEFORE anything touches the GPU and relays its JSON line.
 
 A "step" is one pass of the hot path over one batch of synthetic 1024x1024 tiles resident in HBM:
   InternVLSAMModel.forward (SAM ViT encoder -> pixel-shuffle + mlp1 -> InternLM2 prefill -> mlp2 + inverse shuffle)
@@ -19,6 +22,8 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -65,7 +70,7 @@ def init_random_(model: torch.nn.Module, seed: int = 0):
                 p.normal_(0, 0.02, generator=g)
 
 
-def build_model(vit: str, llm: str, dtype: torch.dtype, device: str):
+def build_model(vit: str, llm: str, dtype: torch.dtype, device: str, init: bool = True):
     from ullsam_amd.build_sam import _build_sam
     from ullsam_amd.modeling.configuration_internvl_chat import InternVLChatConfig
     from ullsam_amd.modeling.modeling_internvl_sam import InternVLSAMModel
@@ -86,8 +91,18 @@ def build_model(vit: str, llm: str, dtype: torch.dtype, device: str):
     finally:
         torch.set_default_dtype(old)
     model = model.to(device).to(dtype).eval()
-    init_random_(model)
+    if init:
+        init_random_(model)
     return model
+
+
+def make_input_ids(n_text_pre: int, n_text_post: int, n_img: int = 1024, seed: int = 1, batch: int = 1) -> np.ndarray:
+    """Synthetic prompt ids with the layout chat() builds (modeling_internvl_sam.py:296-312; the tokenizer cannot be loaded
+    offline): bos, text, <img> = 92544, n_img x <IMG_CONTEXT> = 92546, </img> = 92545, text."""
+    rng = np.random.default_rng(seed)
+    rows = [np.concatenate([[1], rng.integers(3, 92000, n_text_pre), [92544], np.full(n_img, 92546), [92545],
+                            rng.integers(3, 92000, n_text_post)]) for _ in range(batch)]
+    return np.asarray(rows, np.int64)
 
 
 class GemmTimer:
@@ -117,63 +132,117 @@ class GemmTimer:
         return len(self.rec), ms, fl
 
 
-def make_step(model, B, S, device, dtype, world):
-    from ullsam_amd import ops, parallel
-    from oracle.ullsam_oracle import make_input_ids  # synthetic token ids only (data, not compute)
+def make_inputs(B, S, device, full: bool):
     rng = np.random.default_rng(1 + (int(os.environ.get("RANK", "0"))))
-    x = torch.from_numpy(rng.random((B, 3, 1024, 1024), dtype=np.float32)).to(device).to(dtype)
+    x = torch.from_numpy(rng.random((B, 3, 1024, 1024), dtype=np.float32)).to(device)
     pts = torch.from_numpy(rng.uniform(100, 900, (B, 1, 2)).astype(np.float32)).to(device)
     lbl = torch.ones((B, 1), dtype=torch.int32, device=device)
-    full = hasattr(model, "language_model")
+    ids = None
     if full:
         ids = torch.from_numpy(make_input_ids(20, S - 1047, seed=1, batch=B)).to(device)
         assert ids.shape[1] == S
+    return x, pts, lbl, ids
+
+
+def make_step(model, inputs, dtype, world, gather: bool = True):
+    """One pass of the hot path over the batch (app.py:580-645's call sequence; prompt encoder / mask decoder / upsample run once
+    over the B images -- one image per prompt)."""
+    from ullsam_amd import ops, parallel
+    x32, pts, lbl, ids = inputs
+    B = x32.shape[0]
+    x = x32.to(dtype)  # pixel values as the model dtype sees them (app.py:522 moves pixels to the GPU in the model dtype)
+    full = hasattr(model, "language_model")
+    if full:
         am = torch.ones_like(ids)
         flags = (ids == 92546)[..., None].long()
+    pending = [None]
 
     def step():
         if full:
             out = model(pixel_values=x, input_ids=ids, attention_mask=am, image_flags=flags, return_dict=True, use_cache=False,
                         output_hidden_states=True)
             pe, md = model.prompt_encoder, model.mask_decoder
-            image_pe = pe.get_dense_pe()
-            lows, mks = [], []
-            for b in range(B):
-                sp, de = pe(points=(pts[b:b + 1], lbl[b:b + 1]), boxes=None, masks=None, llm_hidden_states=out.hidden_states[b:b + 1])
-                low, iou = md(image_embeddings=out.image_embeddings[b:b + 1], image_pe=image_pe, sparse_prompt_embeddings=sp,
-                              dense_prompt_embeddings=de, multimask_output=False)
-                _, mk = ops.resize_bilinear(low.contiguous(), (1024, 1024), want_float=False, threshold=0.0)
-                lows.append(low); mks.append(mk)
-            low, mk = torch.cat(lows), torch.cat(mks)
+            sp, de = pe(points=(pts, lbl), boxes=None, masks=None, llm_hidden_states=out.hidden_states)
+            low, iou = md(image_embeddings=out.image_embeddings, image_pe=pe.get_dense_pe(), sparse_prompt_embeddings=sp,
+                          dense_prompt_embeddings=de, multimask_output=False)
+            _, mk = ops.resize_bilinear(low.contiguous(), (1024, 1024), want_float=False, threshold=0.0)
         else:  # configs[1]: Sam.forward, point prompt only
             recs = [{"image": x[b].float() * 255.0, "original_size": (1024, 1024), "point_coords": pts[b:b + 1], "point_labels": lbl[b:b + 1]}
                     for b in range(B)]
             outs = model(recs, multimask_output=False)
             low = torch.cat([o["low_res_logits"] for o in outs])
             mk = torch.cat([o["masks"] for o in outs]).to(torch.uint8)
-        if world > 1:
-            low, mk, _ = parallel.gather_mask_results(low, mk, None, counts=[B] * world)
+        if world > 1 and gather:
+            # the exchange of step k overlaps the compute of step k+1: at most one gather in flight
+            if pending[0] is not None:
+                pending[0].wait()
+            pending[0] = parallel.gather_mask_results_async(low, mk, None, counts=[B] * world)
         return low, mk
 
+    def drain():
+        if pending[0] is not None:
+            res = pending[0].wait()
+            pending[0] = None
+            return res
+        return None
+
+    step.drain = drain
     return step
 
 
-def cpu_baseline(vit: str, llm: str, S: int):
-    """Numpy oracle on the host cores, bounded sample: one image, depth-reduced, extrapolated linearly in depth."""
+def mask_iou_vs_fp32(model, vit, llm, inputs, device):
+    """IoU of the bf16 masks of the timed configuration against the SAME weights and inputs run once in fp32 mode (exact-fp32 MFMA,
+    the mode the parity tests pin to the reference within 1e-3): the `mask IoU vs ref` half of BASELINE.json's metric, on the
+    bench configuration itself.  Outside the timed region."""
+    from ullsam_amd import ops
+    with torch.no_grad():
+        low_b, mk_b = make_step(model, inputs, torch.bfloat16, 1, gather=False)()
+        m32 = build_model(vit, llm, torch.float32, device, init=False)
+        sd = {k: v.float() for k, v in model.state_dict().items()}
+        missing, unexpected = m32.load_state_dict(sd, strict=False)
+        assert not missing and not unexpected, (missing[:3], unexpected[:3])
+        del sd
+        x32, pts, lbl, ids = inputs
+        low_f, mk_f = make_step(m32, (x32.to(torch.bfloat16).float(), pts, lbl, ids), torch.float32, 1, gather=False)()
+        iou = ops.mask_iou(mk_b.contiguous(), mk_f.contiguous()).cpu().numpy()
+        d = (low_b.float() - low_f.float()).abs().max().item()
+        sc = low_f.float().abs().max().item()
+        frac = [float(m.float().mean().item()) for m in mk_f]
+    del m32
+    torch.cuda.empty_cache()
+    return {"mean": round(float(iou.mean()), 6), "min": round(float(iou.min()), 6), "images": int(iou.size),
+            "low_res_logit_max_abs_diff": round(d, 4), "low_res_logit_absmax": round(sc, 3),
+            "fp32_mask_fill_fraction": [round(f, 4) for f in frac],
+            "reference": "same random weights + inputs through the fp32 mode of this library (pinned to the reference within 1e-3 / IoU delta < 1e-4 by tests/)"}
+
+
+def cpu_baseline(vit: str, llm: str, S: int, reps: int = 3):
+    """The reference's algorithm (numpy fp32 oracle, `kind: port`) on the host cores, on a BOUNDED sample of the workload: one
+    image; one windowed + one global ViT block, one LLM layer, the projectors and the whole prompt-encoder / mask-decoder /
+    upsample tail are each timed `reps` times after one warm-up (median reported per stage) and the blocks / layers are
+    extrapolated linearly in depth (profiles/r02_cpu_baseline_full_depth.json validates the extrapolation on a full-depth run)."""
     from oracle import ullsam_oracle as O
     v = VIT[vit]
     D, H = v["dim"], v["heads"]
     rng = np.random.default_rng(0)
     t_all = time.time()
+    threads = None
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])
+    except Exception:
+        pass
     P = O.fill_state(O.vit_shapes(embed_dim=D, depth=2, num_heads=H, global_attn_indexes=(1,)), 0)
     xb = rng.standard_normal((1, 64, 64, D), dtype=np.float32)
 
-    def timed(fn, reps=1):
+    def timed(fn):
         fn()  # warm-up (BLAS thread pool, page faults)
-        t = time.time()
+        ts = []
         for _ in range(reps):
+            t = time.perf_counter()
             fn()
-        return (time.time() - t) / reps
+            ts.append(time.perf_counter() - t)
+        return float(np.median(ts))
 
     t_w = timed(lambda: O.vit_block(xb, P, "blocks.0.", H, 14, 1e-6))
     t_g = timed(lambda: O.vit_block(xb, P, "blocks.1.", H, 0, 1e-6))
@@ -181,7 +250,7 @@ def cpu_baseline(vit: str, llm: str, S: int):
     t_fix = timed(lambda: O.vit_encoder(img, P, depth=0, num_heads=H, global_attn_indexes=()))
     n_g = len(v["glob"])
     t_vit = t_fix + (v["depth"] - n_g) * t_w + n_g * t_g
-    t_llm = t_proj = 0.0
+    t_llm = t_proj = t_layer = 0.0
     if LLM[llm] is not None:
         c = LLM[llm]
         cfg = dict(hidden=c["hidden_size"], layers=1, heads=c["num_attention_heads"], kv_heads=c["num_key_value_heads"],
@@ -207,11 +276,42 @@ def cpu_baseline(vit: str, llm: str, S: int):
     t_dec = timed(dec)
     total = t_vit + t_llm + t_proj + t_dec
     cores = os.cpu_count() or 1
-    return {"value": round(1.0 / total, 6), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": (f"numpy fp32 oracle, 1 image: timed 1 windowed + 1 global ViT-{vit.upper()} block, patch-embed+neck, "
-                       f"1 InternLM2-{llm} layer at S={S}, mlp1+mlp2, prompt-encoder+mask-decoder+upsample; extrapolated linearly "
-                       f"to {v['depth']} blocks / {LLM[llm]['num_hidden_layers'] if LLM[llm] else 0} layers "
-                       f"(vit {t_vit:.1f}s + llm {t_llm:.1f}s + proj {t_proj:.2f}s + dec {t_dec:.2f}s); sampling took {time.time() - t_all:.0f}s")}
+    return {"value": round(1.0 / total, 6), "unit": "images/s", "cores": threads or cores, "host_cores": cores, "blas_threads": threads,
+            "kind": "port", "reps": reps, "statistic": "median after 1 warm-up",
+            "stages_s": {"vit_windowed_block": round(t_w, 4), "vit_global_block": round(t_g, 4), "vit_patch_embed_neck": round(t_fix, 4),
+                         "llm_layer": round(t_layer, 4), "projectors_mlp1_mlp2": round(t_proj, 4), "prompt_mask_decoder_upsample": round(t_dec, 4),
+                         "vit_total_extrapolated": round(t_vit, 2), "llm_total_extrapolated": round(t_llm, 2)},
+            "sample": (f"numpy fp32 oracle, 1 image: 1 windowed + 1 global ViT-{vit.upper()} block, patch-embed+neck, "
+                       f"1 InternLM2-{llm} layer at S={S}, mlp1+mlp2, prompt-encoder+mask-decoder+upsample, each the median of {reps} runs; "
+                       f"extrapolated linearly to {v['depth']} blocks / {LLM[llm]['num_hidden_layers'] if LLM[llm] else 0} layers; "
+                       f"sampling took {time.time() - t_all:.0f}s")}
+
+
+def _spawn_ranks(n: int, argv) -> int:
+    """WORLD_SIZE unset and --gpus N > 1: start the launcher as a CHILD process (this process never initialises the GPU) and
+    relay its output; exit with its code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def traffic_record():
+    """HBM-side bytes per GEMM launch: PMC counters cannot be read in-process, so the figure comes from the committed rocprofv3
+    --pmc passes over this file (tools/collect_evidence.py), valid only for the kernel sources it was measured on."""
+    tpath = os.path.join(ROOT, "profiles", "r02_pmc_bench_traffic.json")
+    if not os.path.exists(tpath):
+        return None, "no PMC record"
+    rec = json.load(open(tpath))
+    from ullsam_amd import build as _b
+    if rec.get("csrc_digest") != _b._digest():
+        return None, f"stale: {os.path.basename(tpath)} was measured on other kernel sources"
+    return round(rec["hbm_bytes_per_launch"]), f"rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per GEMM launch, profiles/{os.path.basename(tpath)} (same kernel sources)"
 
 
 def main():
@@ -225,42 +325,36 @@ def main():
     ap.add_argument("--seq", type=int, default=1081)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-iou", action="store_true", help="skip the fp32 run that gives mask_iou_vs_fp32")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(_spawn_ranks(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch one rank per GPU (or leave WORLD_SIZE unset)")
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
+    ranks_seen = [torch.cuda.get_device_name(local)]
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(device))
+        assert dist.get_world_size() == a.gpus
+        names = [None] * world
+        dist.all_gather_object(names, f"rank {rank}: cuda:{local} {torch.cuda.get_device_name(local)}")
+        ranks_seen = names
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 
     model = build_model(a.vit, a.llm, dtype, device)
-    if os.environ.get("ULLSAM_GEMM_VARIANT"):  # A/B switch for kernel experiments (0 auto, 1 = 128x128, 2 = 256x128)
+    if os.environ.get("ULLSAM_GEMM_VARIANT"):  # A/B switch for kernel experiments
         from ullsam_amd import _lib
         _lib.load().ullsam_set_gemm_variant(int(os.environ["ULLSAM_GEMM_VARIANT"]))
     timer = GemmTimer()
-    nstreams = int(os.environ.get("ULLSAM_STREAMS", "1"))
-    if nstreams > 1 and a.batch % nstreams == 0:
-        # the batch's images are independent: run them as `nstreams` sub-batches on separate HIP streams so one sub-batch's
-        # partially filled last wave of workgroups overlaps the other's next kernel
-        subs = [make_step(model, a.batch // nstreams, a.seq, device, dtype, 1) for _ in range(nstreams)]
-        streams = [torch.cuda.Stream() for _ in range(nstreams)]
-
-        def step():
-            cur = torch.cuda.current_stream()
-            outs = []
-            for st, fn in zip(streams, subs):
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    outs.append(fn())
-            for st in streams:
-                cur.wait_stream(st)
-            return outs
-    else:
-        step = make_step(model, a.batch, a.seq, device, dtype, world)
+    full = LLM[a.llm] is not None
+    inputs = make_inputs(a.batch, a.seq, device, full)
+    step = make_step(model, inputs, dtype, world)
 
     def barrier():
         torch.cuda.synchronize()
@@ -272,50 +366,55 @@ def main():
     with torch.no_grad():
         for _ in range(a.warmup):
             step()
+        step.drain()
         barrier()
         timer.on = True
         t0 = time.perf_counter()
         for _ in range(a.steps):
             step()
+        gathered = step.drain()  # the last step's exchange is inside the timed region
         barrier()
         dt = time.perf_counter() - t0
         timer.on = False
     if world > 1:
         import torch.distributed as dist
+        assert gathered is not None and gathered[0].shape[0] == a.batch * world and gathered[1].shape[0] == a.batch * world
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_launch, gemm_ms, gemm_flops = timer.summary()
-    traffic = None  # HBM-side bytes per GEMM launch: PMC counters cannot be read in-process; taken from the committed rocprofv3 passes
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_bench_traffic.json")
-    if os.path.exists(tpath) and a.vit == "h" and a.llm == "7b" and a.batch == 4 and a.dtype == "bf16":
-        traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
+    traffic, traffic_note = (None, "not the default workload")
+    if a.vit == "h" and a.llm == "7b" and a.batch == 4 and a.dtype == "bf16":
+        traffic, traffic_note = traffic_record()
     images = a.batch * world * a.steps
     value = images / dt
+    peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else 157.3
     ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     line = {
         "metric": "images/s end-to-end (ViT+LLM+mask) 1024^2", "value": round(value, 4), "unit": "images/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (uniform random 1024x1024 tiles, random-init weights, synthetic token ids)",
         "config": {"workload": (f"uLLSAM mask path (app.py:580-645): SAM ViT-{a.vit.upper()} + "
-                                + (f"InternLM2-{a.llm}-shaped prefill S={a.seq} + " if LLM[a.llm] else "")
+                                + (f"InternLM2-{a.llm}-shaped prefill S={a.seq} + " if full else "")
                                 + f"prompt encoder + mask decoder + x4 upsample/threshold, 1 point prompt/image, batch {a.batch}/GPU"),
-                   "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": a.seq if LLM[a.llm] else 0,
-                   "parallelism": f"dp{world} (images sharded, weights replicated, RCCL all-gather of masks)"},
-        "roofline": {"bound": "mfma", "kernel": "ullsam_gemm: gemm256_kernel / gemm128_kernel (every nn.Linear / conv-as-GEMM launch)", "achieved": round(ach, 2),
-                     "peak": PEAK_BF16_TFLOPS if a.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
-                     "frac": round(ach / (PEAK_BF16_TFLOPS if a.dtype == "bf16" else 157.3), 4), "traffic": traffic,
-                     "traffic_unit": "HBM-side bytes per GEMM launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_bench_traffic.json)",
+                   "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": a.seq if full else 0,
+                   "parallelism": f"dp{world} (images sharded, weights replicated, one RCCL all-gather of logits+masks per step, overlapped with the next step)",
+                   "ranks": ranks_seen},
+        "roofline": {"bound": "mfma", "kernel": "ullsam_gemm (every nn.Linear / conv-as-GEMM launch)", "achieved": round(ach, 2),
+                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": traffic_note,
                      "algorithmic_bytes_per_launch": round(timer.alg_bytes / max(n_launch, 1)),
                      "launches_per_step": n_launch // max(a.steps, 1), "avg_launch_us": round(gemm_ms * 1e3 / max(n_launch, 1), 2),
                      "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4)},
     }
+    if rank == 0 and world == 1 and full and a.dtype == "bf16" and not a.no_iou:
+        line["mask_iou_vs_fp32"] = mask_iou_vs_fp32(model, a.vit, a.llm, inputs, device)
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.vit, a.llm, a.seq)
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -105,7 +105,8 @@ int ullsam_embed_tokens(int dtype, const void* table, const long long* ids, cons
 int ullsam_gather_rows(const void* in, void* out, const int* range, int B, int S, int n, int row_bytes, void* stream);  /* :198-200 */
 int ullsam_rope_split(int dtype, const void* qkv, void* q_out, void* k_cache, void* v_cache, const int* pos,
                       const float* cos_tab, const float* sin_tab, int B, int S, int KVH, int G, int hd, int cap,
-                      int cache_pos0, void* stream);                                     /* modeling_internlm2.py:361-388,233-247 */
+                      int cache_pos0, int tab_rows, void* stream);                       /* modeling_internlm2.py:361-388,233-247;
+                                                                                            pos is clamped to [0, tab_rows) */
 int ullsam_argmax(const float* logits, long long* out, int rows, long V, long ld, void* stream);
 
 /* Prompt encoder / mask decoder */

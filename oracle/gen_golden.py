@@ -363,9 +363,48 @@ def case_llm_7b_l1():
          autocast_bf16_mean_err=np.float64(np.abs(hb - hidden)[valid].mean()))
 
 
+def case_rope_variants():
+    """cos/sin caches of the reference's three rotary modules (modeling_internlm2.py:147-229) incl. their stateful growth:
+    each entry = the table returned for a sequence of forward(seq_len) calls on ONE module instance."""
+    from modeling import modeling_internlm2 as M
+    out = {}
+    x = torch.zeros(1, 1, 1, 128)
+    for tag, cls, kw in (("plain", M.InternLM2RotaryEmbedding, {}),
+                         ("linear", M.InternLM2LinearScalingRotaryEmbedding, {"scaling_factor": 2.0}),
+                         ("dynamic", M.InternLM2DynamicNTKScalingRotaryEmbedding, {"scaling_factor": 4.0})):
+        m = cls(128, max_position_embeddings=64, base=1000000, **kw)
+        for i, sl in enumerate((40, 100, 70)):   # below max_pos, beyond it (dynamic: base rescaled from 100), then shorter again
+            cos, sin = m(x, seq_len=sl)
+            out[f"{tag}_{i}_cos"] = cos.numpy()[::3, ::5].copy()
+            out[f"{tag}_{i}_sin"] = sin.numpy()[::3, ::5].copy()
+    save("rope_variants", head_dim=128, max_pos=64, base=1000000.0, seq_lens=np.array([40, 100, 70]), **out)
+
+
+def case_llm_tiny_bias_linear():
+    """Tiny InternLM2 with config.bias=True (wqkv / wo biases, modeling_internlm2.py:300-308) and linear RoPE scaling (:184-200)."""
+    from modeling.configuration_internlm2 import InternLM2Config
+    from modeling.modeling_internlm2 import InternLM2ForCausalLM
+    c = dict(LLM_TINY)
+    c["bias"] = True
+    cfg = InternLM2Config(**c)
+    cfg.rope_scaling = {"type": "linear", "factor": 2.0}
+    lm = InternLM2ForCausalLM(cfg).eval()
+    assert type(lm.model.layers[0].attention.rotary_emb).__name__ == "InternLM2LinearScalingRotaryEmbedding"
+    fill_module(lm, seed=0, prefix="language_model.")
+    rng = np.random.default_rng(9)
+    emb = rng.standard_normal((2, 50, 256), dtype=np.float32) * 0.5
+    mask = np.ones((2, 50), np.int64)
+    mask[0, :6] = 0
+    o = lm(inputs_embeds=torch.from_numpy(emb), attention_mask=torch.from_numpy(mask), use_cache=False,
+           output_hidden_states=True, return_dict=True)
+    save("llm_tiny_bias_linear", weight_seed=0, input_seed=9, mask=mask, hidden=o.hidden_states[-1].numpy(),
+         logits_last_argmax=o.logits[:, -1].numpy().argmax(-1))
+
+
 CASES = {"chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
          "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full,
-         "vit_h_d2": case_vit_h_d2, "llm_7b_l1": case_llm_7b_l1}
+         "vit_h_d2": case_vit_h_d2, "llm_7b_l1": case_llm_7b_l1,
+         "rope_variants": case_rope_variants, "llm_tiny_bias_linear": case_llm_tiny_bias_linear}
 
 if __name__ == "__main__":
     for n in (sys.argv[1:] or list(CASES)):

@@ -195,7 +195,7 @@ def mask_decoder_shapes(dim=256, depth=2, mlp_dim=2048, num_mask_tokens=4, iou_h
 
 
 def internlm2_shapes(hidden=2048, layers=24, heads=16, kv_heads=8, inter=8192, vocab=92553,
-                     prefix="") -> Dict[str, Tuple[int, ...]]:
+                     prefix="", bias=False) -> Dict[str, Tuple[int, ...]]:
     p = prefix
     hd = hidden // heads
     s: Dict[str, Tuple[int, ...]] = {p + "model.tok_embeddings.weight": (vocab, hidden)}
@@ -203,6 +203,9 @@ def internlm2_shapes(hidden=2048, layers=24, heads=16, kv_heads=8, inter=8192, v
         b = f"{p}model.layers.{i}."
         s[b + "attention.wqkv.weight"] = ((heads + 2 * kv_heads) * hd, hidden)
         s[b + "attention.wo.weight"] = (hidden, heads * hd)
+        if bias:  # config.bias (modeling_internlm2.py:300-308)
+            s[b + "attention.wqkv.bias"] = ((heads + 2 * kv_heads) * hd,)
+            s[b + "attention.wo.bias"] = (hidden,)
         s[b + "feed_forward.w1.weight"] = (inter, hidden)
         s[b + "feed_forward.w3.weight"] = (inter, hidden)
         s[b + "feed_forward.w2.weight"] = (hidden, inter)
@@ -632,10 +635,22 @@ def rms_norm(x: np.ndarray, w: np.ndarray, eps: float) -> np.ndarray:
     return (w * (x * (1.0 / np.sqrt(v + F32(eps))))).astype(F32)
 
 
-def rope_tables(head_dim: int, n_pos: int, base: float) -> Tuple[np.ndarray, np.ndarray]:
-    """InternLM2RotaryEmbedding modeling_internlm2.py:147-180 (fp32 cache)."""
+def rope_tables(head_dim: int, n_pos: int, base: float, scaling: Optional[dict] = None, max_pos: int = 32768,
+                seq_len: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """InternLM2RotaryEmbedding modeling_internlm2.py:147-180 (fp32 cache); `scaling` = config.rope_scaling:
+    {"type": "linear"} divides the positions by the factor (:184-200); {"type": "dynamic"} rescales the base once the sequence
+    length `seq_len` of the call that (re)builds the cache exceeds max_position_embeddings (:204-229)."""
+    scale_t = F32(1.0)
+    if scaling is not None:
+        f = float(scaling["factor"])
+        if scaling["type"] == "linear":
+            scale_t = F32(f)
+        else:
+            sl = n_pos if seq_len is None else seq_len
+            if sl > max_pos:
+                base = float(base) * ((f * sl / max_pos) - (f - 1)) ** (head_dim / (head_dim - 2))
     inv = (1.0 / (F32(base) ** (np.arange(0, head_dim, 2, dtype=F32) / F32(head_dim)))).astype(F32)
-    t = np.arange(n_pos, dtype=F32)
+    t = np.arange(n_pos, dtype=F32) / scale_t
     fr = np.einsum("i,j->ij", t, inv).astype(F32)
     emb = np.concatenate([fr, fr], -1)
     return np.cos(emb).astype(F32), np.sin(emb).astype(F32)
@@ -652,12 +667,13 @@ def internlm2_attention(P: Params, pre: str, x: np.ndarray, mask4d: Optional[np.
     B, S, _ = x.shape
     H, KV, hd = cfg["heads"], cfg["kv_heads"], cfg["hidden"] // cfg["heads"]
     g = H // KV
-    qkv = linear(x, P[pre + "wqkv.weight"]).reshape(B, S, KV, g + 2, hd)  # 'b q (h gs d)' :361-366
+    qkv = linear(x, P[pre + "wqkv.weight"], P.get(pre + "wqkv.bias")).reshape(B, S, KV, g + 2, hd)  # 'b q (h gs d)' :361-366
     q = qkv[..., :g, :].reshape(B, S, H, hd).transpose(0, 2, 1, 3)
     k = qkv[..., -2, :].transpose(0, 2, 1, 3)
     v = qkv[..., -1, :].transpose(0, 2, 1, 3)
     kv_len = S + (past[0].shape[2] if past is not None else 0)
-    cos, sin = rope_tables(hd, max(kv_len, int(pos_ids.max()) + 1), cfg["rope_theta"])
+    cos, sin = rope_tables(hd, max(kv_len, int(pos_ids.max()) + 1), cfg["rope_theta"], cfg.get("rope_scaling"),
+                           cfg.get("max_pos", 32768), seq_len=kv_len)
     c = cos[pos_ids][:, None]
     s = sin[pos_ids][:, None]
     q = q * c + _rotate_half(q) * s
@@ -673,7 +689,7 @@ def internlm2_attention(P: Params, pre: str, x: np.ndarray, mask4d: Optional[np.
         a = a + mask4d
     a = softmax(a.astype(F32), -1)
     o = np.matmul(a, vr).transpose(0, 2, 1, 3).reshape(B, S, H * hd)
-    return linear(o, P[pre + "wo.weight"]), present
+    return linear(o, P[pre + "wo.weight"], P.get(pre + "wo.bias")), present
 
 
 def decoder_mask(attention_mask: np.ndarray, q_len: int, past_len: int) -> Optional[np.ndarray]:

@@ -147,6 +147,15 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
 
 
+def _fake_step(images: torch.Tensor):
+    """Stand-in for the per-image path (images are independent units): a deterministic per-image function with the real
+    output shapes' structure (fp32 logits, u8 masks, int64 token ids)."""
+    low = torch.stack([torch.sin(im * 3.0 + im.flip(-1)).reshape(1, 8, 8) for im in images])
+    mk = (low > 0.1).to(torch.uint8).repeat(1, 1, 2, 2)
+    tok = torch.stack([(im.reshape(-1)[:5] * 1000).long() for im in images])
+    return low, mk, tok
+
+
 def _gloo_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
@@ -161,8 +170,22 @@ def _gloo_worker(rank, world, port, q):
         glow, gmk, gtok = parallel.gather_mask_results(low, mk, tok)
         ok = glow.shape[0] == n_total and all(float(glow[i, 0, 0, 0]) == i for i in range(n_total))
         ok = ok and gmk.sum().item() == 3 * 16 and gtok[:, 0].tolist() == list(range(n_total))
+        ok = ok and glow.dtype == torch.float32 and gmk.dtype == torch.uint8 and gtok.dtype == torch.int64
         eq = parallel.all_gather_rows(torch.full((2, 2), float(rank)), counts=[2, 2])  # equal shards: single collective
         ok = ok and eq[:, 0].tolist() == [0.0, 0.0, 1.0, 1.0]
+        # DP equivalence (distributed level): sharded run + gather == the unsharded run, bit for bit,
+        # for an even and a ragged split, through the blocking and the overlapped (async) exchange
+        for n_img in (4, 7):
+            imgs = torch.from_numpy(np.random.default_rng(n_img).random((n_img, 8, 8), dtype=np.float32))
+            full = _fake_step(imgs)
+            a, b = parallel.shard_range(n_img, rank, world)
+            mine = _fake_step(imgs[a:b])
+            counts = [parallel.shard_range(n_img, r, world)[1] - parallel.shard_range(n_img, r, world)[0] for r in range(world)]
+            got = parallel.gather_mask_results(*mine, counts=counts)
+            pend = parallel.gather_mask_results_async(mine[0], mine[1], None, counts=counts)
+            got_async = pend.wait()
+            ok = ok and all(torch.equal(g, f) for g, f in zip(got, full))
+            ok = ok and torch.equal(got_async[0], full[0]) and torch.equal(got_async[1], full[1]) and got_async[2] is None
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
@@ -183,6 +206,14 @@ def test_gloo_world2_gather_is_rank_ordered():
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+def test_packed_gather_without_process_group_is_identity():
+    from ullsam_amd import parallel
+    low = torch.randn(3, 1, 4, 4)
+    mk = (low > 0).to(torch.uint8)
+    a, b, c = parallel.gather_mask_results(low, mk, None)
+    assert torch.equal(a, low) and torch.equal(b, mk) and c is None
 
 
 def test_checkpoint_loading_conventions(tmp_path):
@@ -211,13 +242,26 @@ def test_checkpoint_loading_conventions(tmp_path):
     missing, unexpected = checkpoint.load_ullsam_checkpoint(dst, str(tmp_path / "final.pt"))
     assert not missing and not unexpected
     assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
-    # safetensors with bare InternLM2 keys + foreign InternViT keys that must be ignored
+    # a checkpoint exactly as the reference's save_checkpoint writes it (train_joint_v2.py:1254-1263): optimizer + scheduler
+    # state and the argparse.Namespace of the run (with a pathlib path inside) next to the weights
+    import argparse, pathlib
+    opt = torch.optim.AdamW([p for p in src.parameters()][:2], lr=1e-4)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s_: 1.0)
+    torch.save({"model": sd, "optimizer": opt.state_dict(), "scheduler": sched.state_dict(), "epoch": 23, "step": 100,
+                "args": argparse.Namespace(save_dir=pathlib.Path("out"), training_mode="all", lr=1e-4)}, tmp_path / "ref_shaped.pt")
+    dst3 = make()
+    missing, unexpected = checkpoint.load_ullsam_checkpoint(dst3, str(tmp_path / "ref_shaped.pt"))
+    assert not missing and not unexpected
+    assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst3.state_dict().values()))
+    # safetensors with bare InternLM2 keys + foreign InternViT keys that must be ignored + one tensor of the wrong shape that must
+    # be skipped rather than raise (the reference's shape filter, train_joint_v2.py:1534-1545)
     dst2 = make()
     llm = {k[len("language_model."):]: v.contiguous() for k, v in sd.items() if k.startswith("language_model.")}
     llm["vision_model.embeddings.foo"] = torch.zeros(2)
+    llm["model.norm.weight"] = torch.zeros(7)
     save_file(llm, str(tmp_path / "model.safetensors"))
     missing, unexpected = checkpoint.load_llm_safetensors(dst2, str(tmp_path))
-    assert not unexpected and all(not k.startswith("language_model.") for k in missing)
+    assert not unexpected and [k for k in missing if k.startswith("language_model.")] == ["language_model.model.norm.weight"]
     assert torch.equal(dst2.language_model.output.weight, src.language_model.output.weight)
 
 

@@ -105,6 +105,26 @@ def test_llm_7b_l1_golden(dtype):
         assert d.mean() < 1.2 * float(g["autocast_bf16_mean_err"]), (d.mean(), float(g["autocast_bf16_mean_err"]))
 
 
+def test_llm_tiny_bias_and_linear_rope_golden():
+    """config.bias=True (wqkv / wo bias in the GEMM epilogue) and linear RoPE scaling (modeling_internlm2.py:184-200,300-308)."""
+    from ullsam_amd.modeling.configuration_internlm2 import InternLM2Config
+    from ullsam_amd.modeling.modeling_internlm2 import InternLM2ForCausalLM
+    g = U.gold("llm_tiny_bias_linear")
+    c = U.LLM_TINY
+    cfg = InternLM2Config(vocab_size=c["vocab"], hidden_size=c["hidden"], intermediate_size=c["inter"], num_hidden_layers=c["layers"],
+                          num_attention_heads=c["heads"], num_key_value_heads=c["kv_heads"], bias=True, max_position_embeddings=32768,
+                          rope_theta=c["rope_theta"], rms_norm_eps=c["eps"], rope_scaling={"type": "linear", "factor": 2.0})
+    P = O.fill_state(O.internlm2_shapes(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["inter"], c["vocab"],
+                                        prefix="language_model.", bias=True), int(g["weight_seed"]))
+    lm = load(InternLM2ForCausalLM(cfg), P, torch.float32, "language_model.")
+    emb = np.random.default_rng(int(g["input_seed"])).standard_normal((2, 50, 256), dtype=np.float32) * np.float32(0.5)
+    out = lm(inputs_embeds=torch.from_numpy(emb).to(DEV), attention_mask=torch.from_numpy(g["mask"]).to(DEV), use_cache=False,
+             output_hidden_states=True)
+    valid = g["mask"].astype(bool)
+    assert err(out.hidden_states[-1].float().cpu().numpy()[valid], g["hidden"][valid]) < 1e-3
+    assert (out.logits[:, -1].cpu().numpy().argmax(-1) == g["logits_last_argmax"]).all()
+
+
 def _decoder_modules(dtype):
     from ullsam_amd.build_sam import _build_sam
     sam = _build_sam(128, 2, 2, [1])

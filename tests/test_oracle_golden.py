@@ -93,6 +93,43 @@ def test_llm_7b_l1_matches_reference():
     assert (logits.argmax(-1) == g["logits_last_argmax"]).all()
 
 
+def test_rope_variants_match_reference_oracle_and_host():
+    """Plain / linear-scaled / dynamic-NTK rotary tables (modeling_internlm2.py:147-229) incl. the reference modules' stateful
+    cache growth (a table built for a longer sequence is reused for shorter ones): the oracle and the host-side table builder of
+    the product (InternLM2Model.rope_tables, plain torch on the CPU here) against tables produced by the reference's modules."""
+    from ullsam_amd.modeling.configuration_internlm2 import InternLM2Config
+    from ullsam_amd.modeling.modeling_internlm2 import InternLM2Model
+    g = U.gold("rope_variants")
+    hd, mp, base = int(g["head_dim"]), int(g["max_pos"]), float(g["base"])
+    for tag, rs in (("plain", None), ("linear", {"type": "linear", "factor": 2.0}), ("dynamic", {"type": "dynamic", "factor": 4.0})):
+        cfg = InternLM2Config(vocab_size=8, hidden_size=hd, intermediate_size=8, num_hidden_layers=0, num_attention_heads=1,
+                              num_key_value_heads=1, max_position_embeddings=mp, rope_theta=base, rope_scaling=rs)
+        m = InternLM2Model(cfg)
+        built_for = 0   # the sequence length the reference module's cache was last (re)built for
+        for i, sl in enumerate(g["seq_lens"].tolist()):
+            if sl > max(built_for, mp):
+                built_for = sl
+            cos, sin = O.rope_tables(hd, sl, base, rs, mp, seq_len=max(built_for, 1))
+            _close(cos[::3, ::5], g[f"{tag}_{i}_cos"], 2e-5, f"oracle {tag} cos #{i}")
+            _close(sin[::3, ::5], g[f"{tag}_{i}_sin"], 2e-5, f"oracle {tag} sin #{i}")
+            c2, s2 = m.rope_tables(sl, "cpu")
+            _close(c2[:sl].numpy()[::3, ::5], g[f"{tag}_{i}_cos"], 2e-5, f"host {tag} cos #{i}")
+            _close(s2[:sl].numpy()[::3, ::5], g[f"{tag}_{i}_sin"], 2e-5, f"host {tag} sin #{i}")
+
+
+def test_llm_tiny_bias_linear_matches_reference():
+    """config.bias=True (wqkv / wo biases) + linear RoPE scaling through the oracle."""
+    g = U.gold("llm_tiny_bias_linear")
+    c = dict(U.LLM_TINY, rope_scaling={"type": "linear", "factor": 2.0})
+    P = O.fill_state(O.internlm2_shapes(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["inter"], c["vocab"],
+                                        prefix="language_model.", bias=True), int(g["weight_seed"]))
+    emb = np.random.default_rng(int(g["input_seed"])).standard_normal((2, 50, 256), dtype=np.float32) * np.float32(0.5)
+    hid, _ = O.internlm2_model(P, c, emb, g["mask"], prefix="language_model.")
+    valid = g["mask"].astype(bool)
+    _close(hid[valid], g["hidden"][valid], 2e-4, "hidden (non-pad rows)")
+    assert (O.lm_head(P, hid[:, -1], "language_model.").argmax(-1) == g["logits_last_argmax"]).all()
+
+
 def test_pixel_shuffle_roundtrip_and_maps():
     rng = np.random.default_rng(0)
     x = rng.standard_normal((1, 64, 64, 256), dtype=np.float32)

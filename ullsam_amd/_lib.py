@@ -34,7 +34,7 @@ SIGNATURES = {
     "ullsam_scan_image_tokens": [vp, vp, vp, i32, i32, C.c_longlong, vp],
     "ullsam_embed_tokens": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, vp],
     "ullsam_gather_rows": [vp, vp, vp, i32, i32, i32, i32, vp],
-    "ullsam_rope_split": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "ullsam_rope_split": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "ullsam_argmax": [vp, vp, i32, i64, i64, vp],
     "ullsam_small_linear": [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp],
     "ullsam_skinny_linear": [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp],

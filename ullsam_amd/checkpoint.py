@@ -10,7 +10,9 @@ files with the real key layout (tests/test_host_cpu.py).
 """
 from __future__ import annotations
 
+import argparse
 import os
+import pathlib
 from typing import Dict, Iterable, Tuple
 
 import torch
@@ -21,9 +23,23 @@ def _report(model: torch.nn.Module, sd: Dict[str, torch.Tensor]) -> Tuple[list, 
     return list(res.missing_keys), list(res.unexpected_keys)
 
 
-def load_ullsam_checkpoint(model: torch.nn.Module, path: str) -> Tuple[list, list]:
+def _torch_load(path: str, trusted: bool = False):
+    """The reference saves {"model", "optimizer", "scheduler", "epoch", "step", "args": argparse.Namespace}
+    (train_joint_v2.py:1254-1263): the Namespace (and any pathlib paths inside it) must be allow-listed for the weights-only
+    unpickler.  `trusted=True` falls back to the full unpickler for files the caller vouches for."""
+    allow = [argparse.Namespace, pathlib.PosixPath, pathlib.PurePosixPath, pathlib.Path]
+    try:
+        with torch.serialization.safe_globals(allow):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
+        if not trusted:
+            raise
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
+def load_ullsam_checkpoint(model: torch.nn.Module, path: str, trusted: bool = False) -> Tuple[list, list]:
     """`checkpoint["model"]` with strict=False (train_joint_v2.py:1472-1479); also accepts a bare state_dict."""
-    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    ckpt = _torch_load(path, trusted)
     sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt and isinstance(ckpt["model"], dict) else ckpt
     sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}  # DDP-wrapped saves
     return _report(model, sd)
@@ -44,4 +60,7 @@ def load_llm_safetensors(model: torch.nn.Module, path_or_dir: str, prefix: str =
                 sd[k] = v
             elif k.startswith(("model.", "output.")):
                 sd[prefix + k] = v
+    # the reference keeps only keys that exist with the same shape (train_joint_v2.py:1534-1545); the rest are skipped, not fatal
+    have = model.state_dict()
+    sd = {k: v for k, v in sd.items() if k in have and tuple(have[k].shape) == tuple(v.shape)}
     return _report(model, sd)

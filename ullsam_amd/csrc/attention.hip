@@ -575,11 +575,10 @@ static int launch_flash_impl(const AttnArgs& a, hipStream_t s) {
     constexpr int RELROWS = (MODE == MODE_VIT_WINDOW) ? 16 : 64;
     const size_t lds = KT::BYTES + KT::VBYTES + 16 * KT::RSV + 512 + (REL ? (size_t)NWAVES * (FAST64 ? 1 : 2) * RELROWS * 32 * 4 : 0);
     ULLSAM_CHECK(lds <= 160 * 1024, "flash_attn: LDS %zu exceeds 160 KiB", lds);
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<T, HD, MODE, NWAVES, FAST64>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
     }
     const int qtiles = (a.Sq + NWAVES * 32 - 1) / (NWAVES * 32);
     const int nz = MODE == MODE_VIT_WINDOW ? a.B * a.nwin : a.B;
@@ -884,10 +883,9 @@ __global__ __launch_bounds__(256, 2) void win14_attn_kernel(AttnArgs p) {
 static int launch_win14(const AttnArgs& a, hipStream_t s) {
     constexpr int HD = 80;
     const size_t lds = 196 * (HD * 2 + 16) + 224 * 192;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(win14_attn_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
     }
     win14_attn_kernel<HD><<<dim3(a.H * a.B * a.nwin), dim3(256), lds, s>>>(a);
     ULLSAM_LAUNCH_CHECK();
@@ -1044,12 +1042,12 @@ extern "C" int ullsam_naive_attention(int dtype, const void* q, const void* k, c
     NaiveArgs a{q, k, v, out, q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs, H, H / KVH, Sq, Sk, hd, scale, key_mask};
     const size_t lds = (size_t)(((Sk + 3) & ~3) + hd + 256) * 4;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static bool attr0 = false, attr1 = false;
+    static PerDeviceOnce attr0, attr1;
     if (dtype == 0) {
-        if (!attr0) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(naive_attn_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr0 = true; }
+        if (attr0.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(naive_attn_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         naive_attn_kernel<float><<<dim3(Sq, H, B), dim3(256), lds, s>>>(a);
     } else {
-        if (!attr1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(naive_attn_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+        if (attr1.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(naive_attn_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         naive_attn_kernel<bf16><<<dim3(Sq, H, B), dim3(256), lds, s>>>(a);
     }
     ULLSAM_LAUNCH_CHECK();

@@ -128,6 +128,20 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 // row of a 32x32 accumulator register for lane-half h
 __device__ __forceinline__ int crow32(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
+// hipFuncSetAttribute applies to the function object of the CURRENT device: one "done" flag per device (a process may drive
+// several GPUs).  A benign race (two host threads setting the same attribute) is possible and harmless.
+struct PerDeviceOnce {
+    bool done[32] = {};
+    bool first() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        d &= 31;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+
 // Error plumbing for the C ABI (never throws; see include/ullsam_hip.h)
 void ullsam_set_error(const char* fmt, ...);
 #define ULLSAM_CHECK(cond, ...)            \

@@ -664,10 +664,9 @@ __global__ __launch_bounds__(NT) void gemm256_tail_reduce_kernel(GemmArgs p) {
 
 template <typename T, int EXP>
 static int launch_gemm_v3_impl(GemmArgs a, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<T, EXP>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        attr_set = true;
     }
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (a.N + 255) / 256;
@@ -714,10 +713,9 @@ extern "C" int ullsam_set_gemm_variant(int v) {
 
 template <typename T>
 static int launch_gemm_v2(GemmArgs a, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
-        attr_set = true;
     }
     a.tiles_m = (a.M + 255) / 256;
     gemm256x128_kernel<T><<<dim3(a.tiles_m * a.tiles_n), dim3(512), 147456, stream>>>(a);
@@ -727,10 +725,9 @@ static int launch_gemm_v2(GemmArgs a, hipStream_t stream) {
 
 template <typename T>
 static int launch_gemm(GemmArgs a, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        attr_set = true;
     }
     // Split-K tail: with 2 workgroups per CU the chip runs 512 tiles per wave; when the last wave is at most half full, cut each
     // of its tiles into S K-ranges (fp32 partials + a reduce kernel).  Measured (tools/gemm_bench.py, variant 65 vs 1): pays only
@@ -937,12 +934,12 @@ static int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)MM * a.K * 2;
     const long waves = a.act == 3 ? (long)a.N / 4 : ((long)a.N + 3) / 4;
     const dim3 grid((unsigned)((waves + 3) / 4));
-    static bool attr4 = false, attr8 = false;
+    static PerDeviceOnce attr4, attr8;
     if (MM == 4) {
-        if (!attr4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr4 = true; }
+        if (attr4.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         gemm_skinny_kernel<4><<<grid, 256, lds, stream>>>(a);
     } else {
-        if (!attr8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr8 = true; }
+        if (attr8.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         gemm_skinny_kernel<8><<<grid, 256, lds, stream>>>(a);
     }
     ULLSAM_LAUNCH_CHECK();

@@ -101,7 +101,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void rope_split_kernel(const T* __restrict__ qkv, T* __restrict__ q_out, T* __restrict__ k_cache,
                                                          T* __restrict__ v_cache, const int* __restrict__ pos, const float* __restrict__ cosT,
                                                          const float* __restrict__ sinT, int B, int S, int KVH, int G, int hd, int cap,
-                                                         int cache_pos0) {
+                                                         int cache_pos0, int tab_rows) {
     const int half = hd / 2, hq = half / 4;
     const int gs = G + 2;
     const long total = (long)B * S * KVH * gs * hq;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const T* __restrict__ q
             store4(dst + half + d4, x2);
             continue;
         }
-        const int p = pos[tok];
+        const int p = min(max(pos[tok], 0), tab_rows - 1);  // never read outside the tables (the reference would raise IndexError)
         const float4 c1 = *reinterpret_cast<const float4*>(cosT + (long)p * hd + d4);
         const float4 c2 = *reinterpret_cast<const float4*>(cosT + (long)p * hd + half + d4);
         const float4 s1 = *reinterpret_cast<const float4*>(sinT + (long)p * hd + d4);
@@ -138,15 +138,16 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const T* __restrict__ q
 
 extern "C" int ullsam_rope_split(int dtype, const void* qkv, void* q_out, void* k_cache, void* v_cache, const int* pos,
                                  const float* cos_tab, const float* sin_tab, int B, int S, int KVH, int G, int hd, int cap,
-                                 int cache_pos0, void* stream) {
+                                 int cache_pos0, int tab_rows, void* stream) {
     ULLSAM_CHECK(hd % 8 == 0, "rope_split: hd %% 8 != 0");
+    ULLSAM_CHECK(tab_rows > 0, "rope_split: empty cos/sin tables");
     ULLSAM_CHECK(cache_pos0 + S <= cap, "rope_split: cache overflow (%d + %d > %d)", cache_pos0, S, cap);
     const long total = (long)B * S * KVH * (G + 2) * (hd / 8);
     if (total == 0) return 0;
     const int grid = (int)min((total + 255) / 256, (long)2048 * 8);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == 0) rope_split_kernel<float><<<grid, 256, 0, s>>>((const float*)qkv, (float*)q_out, (float*)k_cache, (float*)v_cache, pos, cos_tab, sin_tab, B, S, KVH, G, hd, cap, cache_pos0);
-    else rope_split_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)qkv, (bf16*)q_out, (bf16*)k_cache, (bf16*)v_cache, pos, cos_tab, sin_tab, B, S, KVH, G, hd, cap, cache_pos0);
+    if (dtype == 0) rope_split_kernel<float><<<grid, 256, 0, s>>>((const float*)qkv, (float*)q_out, (float*)k_cache, (float*)v_cache, pos, cos_tab, sin_tab, B, S, KVH, G, hd, cap, cache_pos0, tab_rows);
+    else rope_split_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)qkv, (bf16*)q_out, (bf16*)k_cache, (bf16*)v_cache, pos, cos_tab, sin_tab, B, S, KVH, G, hd, cap, cache_pos0, tab_rows);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }

@@ -95,8 +95,9 @@ class KVCache:
     `to_tuple()` gives the reference's tuple-of-(k, v) views [B, KVH, len, hd] (modeling_internlm2.py:383-388)."""
 
     def __init__(self, layers, B, kvh, cap, hd, dtype, device):
-        self.k = [torch.zeros((B, kvh, cap, hd), dtype=dtype, device=device) for _ in range(layers)]
-        self.v = [torch.zeros((B, kvh, cap, hd), dtype=dtype, device=device) for _ in range(layers)]
+        # only rows below `len` are ever read (every kernel takes the live length), so no zero fill
+        self.k = [torch.empty((B, kvh, cap, hd), dtype=dtype, device=device) for _ in range(layers)]
+        self.v = [torch.empty((B, kvh, cap, hd), dtype=dtype, device=device) for _ in range(layers)]
         self.len, self.cap = 0, cap
 
     def to_tuple(self):
@@ -123,27 +124,33 @@ class InternLM2Model(Packed):
         return self.layers[0].attention.wqkv.weight.dtype
 
     # -- RoPE tables (InternLM2RotaryEmbedding :147-180, Linear :184-200, DynamicNTK :204-229), fp32 ---------------------
-    def rope_tables(self, n_pos: int, device):
+    def rope_tables(self, seq_len: int, device):
+        """cos / sin [rows >= seq_len, head_dim] fp32.  Cached like the reference's rotary modules: rebuilt only when a longer
+        sequence arrives (:172-175); with dynamic-NTK scaling the base is rescaled from the sequence length of the call that
+        rebuilds the cache, and only when that exceeds max_position_embeddings (:216-221)."""
         cfg = self.config
         hd = cfg.hidden_size // cfg.num_attention_heads
-        n_pos = max(n_pos, 2048)
-        key = (n_pos, str(device))
-        if self._rope is not None and self._rope[0][0] >= n_pos and self._rope[0][1] == str(device):
+        rs = cfg.rope_scaling
+        dynamic = rs is not None and rs["type"] == "dynamic"
+        if self._rope is not None and self._rope[0][0] >= seq_len and self._rope[0][1] == str(device):
             return self._rope[1], self._rope[2]
         base = float(cfg.rope_theta)
         scale_t = 1.0
-        if cfg.rope_scaling is not None:
-            if cfg.rope_scaling["type"] == "linear":
-                scale_t = float(cfg.rope_scaling["factor"])
-            elif n_pos > cfg.max_position_embeddings:  # dynamic NTK (:216-221)
-                f = float(cfg.rope_scaling["factor"])
-                base = base * ((f * n_pos / cfg.max_position_embeddings) - (f - 1)) ** (hd / (hd - 2))
+        rows = max(seq_len, 2048)  # rows do not depend on the table length: build a few more than asked for
+        if rs is not None and rs["type"] == "linear":
+            scale_t = float(rs["factor"])
+        elif dynamic and seq_len > cfg.max_position_embeddings:
+            f = float(rs["factor"])
+            base = base * ((f * seq_len / cfg.max_position_embeddings) - (f - 1)) ** (hd / (hd - 2))
+            rows = seq_len
+        elif dynamic:
+            rows = min(rows, cfg.max_position_embeddings)  # a longer sequence later must trigger the rescale, as in the reference
         inv_freq = 1.0 / (base ** (torch.arange(0, hd, 2).float() / hd))
-        t = torch.arange(n_pos, dtype=inv_freq.dtype) / scale_t
+        t = torch.arange(rows, dtype=inv_freq.dtype) / scale_t
         freqs = torch.einsum("i,j->ij", t, inv_freq)
         emb = torch.cat((freqs, freqs), dim=-1)
         cos, sin = emb.cos().to(device).contiguous(), emb.sin().to(device).contiguous()
-        self._rope = (key, cos, sin)
+        self._rope = ((rows, str(device)), cos, sin)
         return cos, sin
 
     def new_cache(self, B: int, cap: int, device) -> KVCache:

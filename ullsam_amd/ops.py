@@ -33,6 +33,10 @@ def _p(t: Optional[torch.Tensor]):
 def _chk(t: torch.Tensor, name: str, dtype=None):
     if not t.is_cuda:
         raise _lib.UllsamError(f"{name} must live on the GPU (ullsam_amd has no CPU path)")
+    if t.device.index != torch.cuda.current_device():
+        # kernels launch on the current device's current stream: a tensor of another GPU would be dereferenced on the wrong one
+        raise _lib.UllsamError(f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                               f"run the call under `with torch.cuda.device({t.device.index}):`")
     if not t.is_contiguous():
         raise ValueError(f"{name} must be contiguous")
     if dtype is not None and t.dtype != dtype:
@@ -289,7 +293,7 @@ def rope_split(qkv, k_cache, v_cache, pos, cos_tab, sin_tab, B, S, KVH, G, hd, c
     _chk(qkv, "qkv"); _chk(pos, "position_ids", torch.int32); _chk(cos_tab, "cos", torch.float32); _chk(sin_tab, "sin", torch.float32)
     q = torch.empty((B * S, KVH * G * hd), dtype=qkv.dtype, device=qkv.device)
     _lib.call("ullsam_rope_split", dt_code(qkv.dtype), qkv.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
-              pos.data_ptr(), cos_tab.data_ptr(), sin_tab.data_ptr(), B, S, KVH, G, hd, k_cache.shape[2], cache_pos0, _stream())
+              pos.data_ptr(), cos_tab.data_ptr(), sin_tab.data_ptr(), B, S, KVH, G, hd, k_cache.shape[2], cache_pos0, cos_tab.shape[0], _stream())
     return q
 
 

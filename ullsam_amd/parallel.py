@@ -1,12 +1,19 @@
 """Image-level data parallelism for inference: one process per GPU, weights replicated, images sharded, ONE exchange step
 (an RCCL all-gather over xGMI of the masks / token ids) at the end.  SURVEY.md section 8(e): the reference has nothing
-comparable (app.py:39 hard-codes one GPU, batch 1), so this is the build's own, minimal, collective.
+comparable (app.py:39 hard-codes one GPU, batch 1; its only launcher is scripts/train_all_joint_v2.sh:1, torchrun for
+training), so this is the build's own, minimal, collective.
 
 Works with any torch.distributed backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the CPU tests.
+
+The exchange is ONE collective per step: logits (fp32), masks (u8) and token ids (int64) of a rank's images are packed
+per image into one byte record, the records of all ranks are gathered with a single all_gather_into_tensor (flat
+all-gather: every rank's slice travels over its 7 direct xGMI links; at 4 images per rank it is 5 MiB per rank,
+latency-bound), and unpacked on arrival.  `gather_mask_results_async` returns a handle so the caller can overlap the
+exchange of step k with the compute of step k+1.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -25,37 +32,91 @@ def shard_range(n_items: int, rank: int, world_size: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
-def all_gather_rows(local: torch.Tensor, counts: Optional[List[int]] = None, group=None) -> torch.Tensor:
-    """Concatenate every rank's rows (dim 0) in rank order.
-
-    Equal shards use a single all_gather_into_tensor (one flat all-gather: each rank's slice goes to all 7 peers over its
-    direct xGMI links).  Ragged shards (counts differ) are padded to the largest shard for the collective and trimmed after."""
-    rank, ws = world()
+def exchange_counts(n_local: int, device, group=None) -> List[int]:
+    """Rows held by every rank (one tiny collective; callers that know the split pass `counts` and skip it)."""
+    _, ws = world()
     if ws == 1:
-        return local
-    local = local.contiguous()
+        return [n_local]
+    c = torch.tensor([n_local], dtype=torch.int64, device=device)
+    allc = torch.empty((ws,), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(allc, c, group=group)
+    return [int(v) for v in allc.tolist()]
+
+
+class _Pending:
+    """Handle of an in-flight packed all-gather: wait() -> the gathered tensors, rows in rank order."""
+
+    def __init__(self, work, out, specs, counts, mx):
+        self.work, self.out, self.specs, self.counts, self.mx = work, out, specs, counts, mx
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()  # the current stream waits for the collective (nccl) / the call blocks (gloo)
+        ws = len(self.counts)
+        rec = self.out.reshape(ws, self.mx, -1)
+        if any(n != self.mx for n in self.counts):
+            rec = torch.cat([rec[r, : self.counts[r]] for r in range(ws)], 0)
+        else:
+            rec = rec.reshape(ws * self.mx, -1)
+        res, off = [], 0
+        for shape, dtype, nbytes in self.specs:
+            if shape is None:
+                res.append(None)
+                continue
+            res.append(rec[:, off:off + nbytes].contiguous().view(dtype).reshape((rec.shape[0],) + shape))
+            off += nbytes
+        return res
+
+
+def packed_all_gather(tensors: Sequence[Optional[torch.Tensor]], counts: Optional[List[int]] = None, group=None,
+                      async_op: bool = False):
+    """Gather several per-image tensors (same dim 0 on a rank) with ONE all_gather_into_tensor.  Ragged shards are padded to the
+    largest shard for the collective and trimmed after.  Returns a handle (async_op) or the list of gathered tensors."""
+    rank, ws = world()
+    live = [t for t in tensors if t is not None]
+    n = live[0].shape[0]
+    dev = live[0].device
     if counts is None:
-        c = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-        allc = [torch.zeros_like(c) for _ in range(ws)]
-        dist.all_gather(allc, c, group=group)
-        counts = [int(t.item()) for t in allc]
+        counts = exchange_counts(n, dev, group)
+    assert counts[rank] == n, (counts, rank, n)
     mx = max(counts)
-    if all(n == mx for n in counts):
-        out = torch.empty((ws * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local, group=group)
-        return out
-    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    out = torch.empty((ws * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
-    return torch.cat([out[r * mx: r * mx + counts[r]] for r in range(ws)], 0)
+    specs, parts = [], []
+    for t in tensors:
+        if t is None:
+            specs.append((None, None, 0))
+            continue
+        assert t.shape[0] == n
+        b = t.contiguous().reshape(n, -1).view(torch.uint8)
+        specs.append((tuple(t.shape[1:]), t.dtype, b.shape[1]))
+        parts.append(b)
+    rec = parts[0] if len(parts) == 1 else torch.cat(parts, 1)
+    if n != mx:
+        pad = torch.zeros((mx, rec.shape[1]), dtype=torch.uint8, device=dev)
+        pad[:n] = rec
+        rec = pad
+    if not (dist.is_available() and dist.is_initialized()):
+        p = _Pending(None, rec, specs, counts, mx)
+        return p if async_op else p.wait()
+    out = torch.empty((ws * mx, rec.shape[1]), dtype=torch.uint8, device=dev)
+    work = dist.all_gather_into_tensor(out, rec.contiguous(), group=group, async_op=async_op)
+    p = _Pending(work if async_op else None, out, specs, counts, mx)
+    return p if async_op else p.wait()
+
+
+def all_gather_rows(local: torch.Tensor, counts: Optional[List[int]] = None, group=None) -> torch.Tensor:
+    """Concatenate every rank's rows (dim 0) in rank order (single collective when `counts` is given)."""
+    return packed_all_gather([local], counts, group)[0]
 
 
 def gather_mask_results(low_res_logits: torch.Tensor, masks_u8: torch.Tensor, token_ids: Optional[torch.Tensor] = None,
-                        counts: Optional[List[int]] = None):
+                        counts: Optional[List[int]] = None, group=None):
     """The final exchange of the path: low-res logits [b,1,256,256] fp32 (256 KiB/img), thresholded masks [b,1,1024,1024] u8
-    (1 MiB/img) and, for caption runs, greedy token ids padded to a common length."""
-    low = all_gather_rows(low_res_logits, counts)
-    mk = all_gather_rows(masks_u8, counts)
-    tok = all_gather_rows(token_ids, counts) if token_ids is not None else None
+    (1 MiB/img) and, for caption runs, greedy token ids padded to a common length -- one collective for all three."""
+    low, mk, tok = packed_all_gather([low_res_logits, masks_u8, token_ids], counts, group)
     return low, mk, tok
+
+
+def gather_mask_results_async(low_res_logits: torch.Tensor, masks_u8: torch.Tensor, token_ids: Optional[torch.Tensor] = None,
+                              counts: Optional[List[int]] = None, group=None) -> _Pending:
+    """Same exchange, returned as a handle: `.wait()` gives (logits, masks, token ids).  Lets step k+1's compute overlap it."""
+    return packed_all_gather([low_res_logits, masks_u8, token_ids], counts, group, async_op=True)
