@@ -77,6 +77,69 @@ def test_gemm_swiglu_pair(ops, dtype):
     assert err(y, ref) < (2e-4 if dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("M,N,K,mode", [
+    (1500, 512, 512, "bias_gelu"),        # 12 units in one round, ragged M (last tile row shifted to end at M)
+    (1500, 512, 512, "res"),              # fp32 in-place residual on the shifted tile: rows shared with the tile above stored exactly once
+    (16384, 4096, 512, "plain"),          # 1024 tiles = 4 rounds per workgroup with the shortest K loop (8 K-tiles): unit-to-unit pipelining
+    (16384, 1280, 5120, "res"),           # ViT lin2: 320 tiles = 256 + 64 tail tiles cut 4 ways along K (partials + reduce kernel)
+    (4324, 4096, 4096, "res"),            # LLM wo: 272 tiles, 16 tail tiles x 8 K-ranges, ragged M through the split tail
+    (4324, 4096, 4096, "bias_relu"),
+    (4324, 7168, 1024, "swiglu"),         # packed [gate | up] pairs, ragged M
+    (16384, 1280, 768, "rowmod"),         # patch embedding: fp32 out + bias + row-broadcast residual (pos_embed)
+    (2048, 256, 2304, "f32out"),          # neck 3x3: fp32 out, nothing else
+])
+def test_gemm_persistent_kernel(ops, M, N, K, mode):
+    """The persistent 256x256 bf16 kernel (v4: direct epilogues, cross-unit DMA pipelining, counted store waits) forced by the
+    variant switch, against torch's fp32 matmul of the same bf16-rounded operands; every epilogue and the split-K tail."""
+    from ullsam_amd import _lib
+    from ullsam_amd.packing import pack_w13
+    lib = _lib.load()
+    g = torch.Generator(device=DEV); g.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g)
+    ref = a.float() @ w.float().T
+    try:
+        lib.ullsam_set_gemm_variant(4)
+        if mode == "plain":
+            got, want, tol = ops.gemm(a, w).float(), ref, 3e-2
+        elif mode == "bias_gelu":
+            got, want, tol = ops.gemm(a, w, bias, act=ops.ACT_GELU).float(), torch.nn.functional.gelu(ref + bias), 3e-2
+        elif mode == "bias_relu":
+            got, want, tol = ops.gemm(a, w, bias, act=ops.ACT_RELU).float(), torch.relu(ref + bias), 3e-2
+        elif mode == "res":
+            x = torch.randn(M, N, device=DEV, generator=g)
+            want = ref + bias + x
+            ops.gemm(a, w, bias, residual=x, out_f32=True, out=x)
+            got, tol = x, 2e-3
+        elif mode == "rowmod":
+            r = torch.randn(4096, N, device=DEV, generator=g)
+            got = ops.gemm(a, w, bias, residual=r, res_row_mod=4096, out_f32=True)
+            want, tol = ref + bias + r.repeat(M // 4096, 1), 2e-3
+        elif mode == "f32out":
+            got, want, tol = ops.gemm(a, w, out_f32=True), ref, 2e-3
+        else:
+            I = N // 2
+            w13 = pack_w13(w[:I].contiguous(), w[I:].contiguous())
+            got = ops.gemm(a, w13, act=ops.ACT_SWIGLU).float()
+            want, tol = torch.nn.functional.silu(ref[:, :I]) * ref[:, I:], 3e-2
+        torch.cuda.synchronize()
+    finally:
+        lib.ullsam_set_gemm_variant(0)
+    d = (got - want).abs()
+    assert got.shape == want.shape
+    assert float(d.max()) < tol * max(1.0, float(want.abs().max()) / 4), (float(d.max()), float(want.abs().max()))
+    # run-to-run determinism (the unit order is static) and agreement with the non-persistent kernels on the same problem
+    if mode == "plain":
+        lib.ullsam_set_gemm_variant(4)
+        again = ops.gemm(a, w).float()
+        lib.ullsam_set_gemm_variant(128)
+        old = ops.gemm(a, w).float()
+        lib.ullsam_set_gemm_variant(0)
+        assert torch.equal(again, got)
+        assert float((old - got).abs().max()) < 1e-2
+
+
 @pytest.mark.parametrize("D", [64, 256, 768, 1280, 4096])
 def test_norms(ops, D):
     rng = np.random.default_rng(D)

@@ -6,15 +6,24 @@
 // K16 lm_head (:1081), K17 mlp2 (modeling_internvl_sam.py:95-100), decoder image-side projections
 // (transformer.py:220-227) and the two ConvTranspose2d of mask_decoder.py:53-59 (stride == kernel => GEMM).
 //
-// Layout: A row-major [M, lda], W row-major [N, ldw] (nn.Linear's native [out, in]) so both operands are
-// K-contiguous ("B^T input").  Tile 128x128, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16 tiles.
-// K-tile = 128 bytes per row (64 bf16 / 32 f32).  Global->LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
-// wave instruction = 8 rows), double buffered, one barrier per K-tile.  LDS image: 128-byte rows, 16-byte
-// chunk index XOR (row & 7): the DMA writes lane-linear, so the swizzle is applied to the per-lane SOURCE
-// address and again on the ds_read_b128 (cdna guide 5.4 rule 21) -> conflict-free fragment reads.
-// Epilogue: accumulators -> LDS (fp32) -> coalesced 16/32-byte row stores with bias / GELU(erf) / ReLU /
-// SwiGLU-pair / fp32 residual (optionally row-broadcast, for pos_embed) fused.
+// Layout: A row-major [M, lda], W row-major [N, ldw] (nn.Linear's native [out, in]) so both operands are K-contiguous
+// ("B^T input").  K-tile = 128 bytes per row (64 bf16 / 32 f32).  Global->LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
+// wave instruction = 8 rows).  LDS image: 128-byte rows, 16-byte chunk index XOR (row & 7): the DMA writes lane-linear, so the
+// swizzle is applied to the per-lane SOURCE address and again on the ds_read_b128 (cdna guide 5.4 rule 21) -> conflict-free reads.
+// Kernels in this file (dispatch at the bottom, ullsam_gemm):
+//   gemm256_kernel      256x256 tile, 8 waves (2x4, 128x64 per wave), two 64 KiB stages, staggered two-group schedule (L0|C0|L1|C1),
+//                       split-K tail + gemm256_tail_reduce_kernel, LDS-staged epilogue in two 128-row halves.  The production kernel
+//                       for every large launch (and the only one for fp32).
+//   gemm256p_kernel     the same main loop made PERSISTENT (one workgroup per CU walks a unit list, DMA pipelined across units,
+//                       swapped MFMA operands + permuted W rows + lane-pair swap = direct full-line stores from the accumulators,
+//                       counted store waits).  bf16 only.  Auto mode uses it where it measured faster (GELU epilogue).
+//   gemm128_kernel      128x128 tile, 4 waves, 2 workgroups per CU, one barrier per K-tile: small M / narrow N / short K and
+//                       launches whose 256x256 tile count would leave the last round < 74 % full.
+//   gemm256x128_kernel  3-stage ring; never faster than the above in the pipeline, kept selectable for A/B only.
+//   gemm_skinny_*       M <= 8 (decode step): weight-streaming, no tiles.
+// Epilogues: bias / GELU(erf) / ReLU / SwiGLU pair / fp32 residual (optionally row-broadcast, for pos_embed), fused.
 #include "common.h"
+#include <type_traits>
 
 struct GemmArgs {
     const void* A;
@@ -35,11 +44,20 @@ struct GemmArgs {
     int full_tiles, ksplit;
     float* ws;
     size_t ws_bytes;
+    int store_nt;    // A/B: non-temporal output stores
+    int late;        // v3 DMA lead (A/B): bit 0 = group 0 waits for its DMA at the end of C1 instead of L1, bit 1 = group 1 requests tile kt+2 at the end of its C1
+    int skew_ticks;  // v4: start-time spread of the workgroups in s_memrealtime ticks (10 ns)
+    int shift_edge;  // v4: the last tile row of a ragged M starts at M-256 (rows it shares with the tile above are not stored again)
 };
 
 static int g_split_tail = 1;   // ullsam_set_gemm_variant(v | 64) disables the split-K tail (A/B)
 static int g_gemm_variant = 0; // bits 0-3: 0 auto, 1 = 128x128, 2 = 256x128 ring, 3 = 256x256
 static int g_gemm_ablate = 0;  // timing-only ablations: bit0 no in-loop staging, bit1 no barrier (outputs are garbage)
+static int g_persistent = 1;   // ullsam_set_gemm_variant(v | 128): keep the non-persistent 256x256 kernel in auto mode (A/B)
+static int g_skew_half_us = 0;  // ullsam_set_gemm_variant bits 16-23: v4 start-time spread in units of 0.5 us (A/B)
+static int g_late = 0;         // ullsam_set_gemm_variant bits 24-25 (A/B of the v3 DMA lead)
+static int g_store_nt = 1;     // non-temporal bf16 output stores in the non-persistent kernels (same-process A/B: vit.qkv -3.4 %, vit.lin1 -3.6 %, llm.w13 -0.9 %);
+                               // ullsam_set_gemm_variant bit 14 turns them off (A/B)
 static int g_gemm_sched = 0;   // 256x256 kernel main-loop schedule: 0 production, 1 plain interleave, 2 fragments-first / 1 barrier
 
 template <typename T>
@@ -85,7 +103,7 @@ __device__ __forceinline__ void store_row8<bf16>(bf16* dst, const float* v, int 
 }
 
 template <typename T, typename OutT, int BM, int NTHREADS, int BN = 128>
-__device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs, int m0, int n0, int tn, int tid) {
+__device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs, int m0, int n0, int tn, int tid, int m_lo = 0) {
     constexpr int TPR = BN / 8;             // threads per row (each owns 8 accumulator columns)
     constexpr int RPP = NTHREADS / TPR;     // rows per pass
     constexpr int PASSES = BM / RPP;        // BM = rows staged in Cs (row stride BN floats)
@@ -99,7 +117,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
             const int t = tid % TPR;
             const int grp = t >> 4, j0 = (t & 15) * 4;  // every 128 accumulator columns = [64 gate | 64 up]
             const int gm = m0 + row;
-            if (gm >= p.M) continue;
+            if (gm >= p.M || gm < m_lo) continue;
             const float4 g = *reinterpret_cast<const float4*>(Cs + row * BN + grp * 128 + j0);
             const float4 u = *reinterpret_cast<const float4*>(Cs + row * BN + grp * 128 + 64 + j0);
             float4 o = make_float4(silu_f(g.x) * u.x, silu_f(g.y) * u.y, silu_f(g.z) * u.z, silu_f(g.w) * u.w);
@@ -134,7 +152,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
     for (int pass = 0; pass < PASSES; ++pass) {
         const int row = pass * RPP + tid / TPR;
         const int gm = m0 + row;
-        if (gm >= p.M) continue;
+        if (gm >= p.M || gm < m_lo) continue;
         float v[8];
         const float4 a = *reinterpret_cast<const float4*>(Cs + row * BN + c0);
         const float4 b = *reinterpret_cast<const float4*>(Cs + row * BN + c0 + 4);
@@ -161,6 +179,12 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
             }
         }
         if ((p.ablate & 8) && v[0] != 12345.678f) continue;  // timing-only: everything but the global stores
+        if (p.store_nt && p.vec_ok && n_valid == 8 && sizeof(OutT) == 2) {
+            bf16x8_t o8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] = (bf16)v[e];
+            __builtin_nontemporal_store(o8, reinterpret_cast<bf16x8_t*>(C + (size_t)gm * p.ldc + gn));
+        } else
         store_row8<OutT>(C + (size_t)gm * p.ldc + gn, v, n_valid, p.vec_ok != 0);
     }
 }
@@ -508,6 +532,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         //        tile kt+1 is at slot 4kt+4, behind the barrier that ends slot 4kt+3.
         //   WAR: buffer (kt+1)&1 was last read (tile kt-1, k-step 1) at slots 4kt-2 / 4kt-1; the DMA into it starts at slot 4kt.
         const int grp = wave >> 2;
+        // DMA lead (p.late): the DMA of tile kt+1 may start once buffer (kt+1)&1 is free = behind the barrier that ends slot 4kt-1, and must
+        // have landed by the barrier that ends slot 4kt+3.  Group 0 issues in slot 4kt (its L0) and may wait as late as the end of its C1
+        // (slot 4kt+3) instead of its L1 (bit 0); group 1 sits in its C1(kt-1) during slot 4kt and may issue there, behind its MFMAs
+        // (its own reads of that buffer are consumed by then), instead of in its L0 one slot later (bit 1).
+        const bool late0 = grp == 0 && (p.late & 1), early1 = grp == 1 && (p.late & 2);
         stage(kt0 & 1, kt0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -517,7 +546,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             const char* Bb = Ab + 32768;
             Frag<T> a8[8], b[4];
             // ---- L0
-            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+            if (kt + 1 < nk && (!early1 || kt == kt0)) stage((kt + 1) & 1, kt + 1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), 0, lane >> 4);
 #pragma unroll
@@ -538,7 +567,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), 1, lane >> 4);
 #pragma unroll
             for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + (lane & 15), 1, lane >> 4);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!late0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             // ---- C1
@@ -548,6 +577,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mma16(a8[i], b[j], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (early1 && kt + 2 < nk) stage(kt & 1, kt + 2);
+            if (late0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
         }
@@ -656,10 +688,410 @@ __global__ __launch_bounds__(NT) void gemm256_tail_reduce_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < VPT; ++i) reinterpret_cast<float4*>(Cs)[i * NT + tid] = acc[i];
     __syncthreads();
+    int mrow = tm * 256 + slab * ROWS, m_lo = 0;
+    if (p.shift_edge && tm * 256 + 256 > p.M) {  // v4 partials of the shifted last tile row: local row l is global row M - 256 + l;
+        mrow = p.M - 256 + slab * ROWS;          // rows below tm * 256 belong to the tile above
+        m_lo = tm * 256;
+        if (mrow + ROWS <= m_lo) return;
+    }
     if (p.out_f32)
-        epilogue_rows<T, float, ROWS, NT, 256>(p, Cs, tm * 256 + slab * ROWS, tn * 256, tn, tid);
+        epilogue_rows<T, float, ROWS, NT, 256>(p, Cs, mrow, tn * 256, tn, tid, m_lo);
     else
-        epilogue_rows<T, T, ROWS, NT, 256>(p, Cs, tm * 256 + slab * ROWS, tn * 256, tn, tid);
+        epilogue_rows<T, T, ROWS, NT, 256>(p, Cs, mrow, tn * 256, tn, tid, m_lo);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// v4: PERSISTENT 256x256 kernel (bf16).  One workgroup per CU walks a list of units (whole tiles, then the K-ranges of the
+// split tail); the main loop is v3's staggered four-slot schedule and runs CONTINUOUSLY across units:
+//   * the LDS-DMA of the next unit's first K-tile is issued in the last K-step of the current unit, the DMA of its second
+//     K-tile right after the last MFMA, BEFORE the epilogue -- no unit starts with an empty pipeline;
+//   * the epilogue goes straight from the accumulators to memory (no LDS round trip, no barrier): the MFMA operands are
+//     swapped (D^T = W . A^T), so a lane owns 4 consecutive output columns per 16x16 tile, and the DMA places the rows of W
+//     in LDS in a permuted order so that a lane's registers form runs of 8 consecutive bf16 columns: every store instruction
+//     writes 64 contiguous bytes per row (fp32 output: identity order, 4 fp32 = 16 B per lane and tile, also 64 B per row);
+//   * the stores are fire-and-forget: they are YOUNGER than the next unit's second-K-tile DMA, whose wait is a counted
+//     vmcnt(#stores), so a wave first waits for a store acknowledgement one and a half K-steps later.  HBM writes of unit i
+//     drain under the main loop of unit i+1 instead of in a chip-wide burst at the end of every round of tiles;
+//   * the bias of a tile (256 floats) arrives by one extra 1 KiB LDS-DMA with the tile's first K-tile: no register is held
+//     across the K loop for the epilogue and the epilogue has no vector-memory load to wait for.
+// Ragged M: the last tile row starts at M - 256 (all loads in bounds, no clamping); the rows it shares with the tile above
+// are computed twice and stored once (by the tile above).
+// Hazards (slot numbering of v3, s = global K-step count of the workgroup, buffer = s & 1):
+//   RAW  DMA for step s+1 is issued in slot 4s (or between slots 4s+3 and 4s+4 at a unit boundary, for step s+2) and waited for by
+//        the issuing wave in its L1 slot, before the barrier that precedes the first read (slot 4s+4 / 4s+8).
+//   WAR  the boundary DMA overwrites the buffer of the unit's last step s, last read in slots 4s+2 / 4s+3: it is issued behind the barrier that ends 4s+3
+//        (group 0; group 1 one slot later) -- the same distance as v3's regular in-loop DMA.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ void gstore16(void* ptr, u32x4 v) {   // exactly one global_store_dwordx4 (the counted vmcnt waits rely on it)
+    *reinterpret_cast<u32x4*>(ptr) = v;
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    bf16x2_t v;
+    v[0] = (bf16)lo; v[1] = (bf16)hi;
+    return __builtin_bit_cast(unsigned int, v);
+}
+
+__device__ __forceinline__ unsigned int lane_xor1(unsigned int v) {   // value of lane ^ 1 (DPP quad_perm [1,0,3,2], one VALU op)
+    return (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+// Full-line stores.  After the MFMA a row's 128 B line (bf16: 64 columns, fp32: 32 columns) sits in FOUR lanes (g4 = 0..3) as two 16 B
+// pieces each, so a store instruction could only write 64 B pieces -- measured at 28 GB/s per CU against 50 GB/s for whole lines
+// (tools/store_probe.hip).  Neighbouring lanes (rows m, m+1) therefore trade one piece: the even lane ends up with the LOW 64 B halves of
+// both rows, the odd lane with the HIGH halves, and one instruction writes 8 rows x 128 B.   lo / hi: this lane's two pieces.
+// Returns the pieces to store at (row = m & ~1, then row + 1), column piece (odd ? 4 : 0) + g4.
+__device__ __forceinline__ void pair_swap(const u32x4& lo, const u32x4& hi, bool odd, u32x4& first, u32x4& second) {
+    u32x4 send, recv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) send[e] = odd ? lo[e] : hi[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) recv[e] = lane_xor1(send[e]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { first[e] = odd ? recv[e] : lo[e]; second[e] = odd ? hi[e] : recv[e]; }
+}
+
+struct UnitPos { int m0, mfirst, n0, kt0, kt1, part, slot; bool valid; };
+
+// EPI: 0 = bf16 output (+bias, +GELU/ReLU)   1 = SwiGLU pair, bf16 output   2 = fp32 output (+bias, +act, +fp32 residual)
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = 65536;  // 32 KiB A + 32 KiB B; behind the two stages: 2 x 1 KiB of bias
+    typedef bf16 T;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
+    const int g4 = lane >> 4, mm = lane & 15;
+    const int G = gridDim.x;
+    const int nk_all = p.K >> 6;
+    const bool nostore = (p.ablate & 8) != 0;   // timing-only: everything but the global stores
+    const bool store_nt = p.store_nt != 0;
+    auto gst = [&](void* ptr, u32x4 v) {
+        if (nostore && v[0] != 0x9E3779B9u) return;
+        if (store_nt) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(ptr)); else gstore16(ptr, v);  // (nt measured slower here: the launcher leaves it off)
+    };
+    const int n_units = p.full_tiles + (p.tiles_m * p.tiles_n - p.full_tiles) * p.ksplit;
+    // position inside a round of G units: workgroups b, b+8, ... share an XCD (round-robin dispatch; speed only) -> give them
+    // neighbouring tiles.  A round of c = min(G, units left) units is dealt to the 8 XCDs in 8 equal runs of consecutive units
+    // (4 tile rows x 8 tile columns per XCD in a full round at G = 256; a partial last round still loads every XCD's L2 and
+    // fabric port equally instead of filling XCD 0, 1, ... first)
+    const int b = blockIdx.x;
+    const int xcd = b & 7, li = b >> 3;
+
+    auto unit_at = [&](int round) -> UnitPos {
+        UnitPos u;
+        const int left = n_units - round * G;
+        int s_ = n_units;  // invalid
+        if ((G & 7) == 0) {
+            const int c = min(left, G);
+            const int q = c >> 3, rem = c & 7;
+            if (c > 0 && li < q + (xcd < rem ? 1 : 0)) s_ = round * G + xcd * q + min(xcd, rem) + li;
+        } else if (b < left) {
+            s_ = round * G + b;
+        }
+        u.valid = s_ < n_units;
+        int swz = s_;
+        u.part = -1; u.slot = 0; u.kt0 = 0; u.kt1 = nk_all;
+        if (s_ >= p.full_tiles) {
+            const int t = s_ - p.full_tiles;
+            const int tail_idx = t / p.ksplit;
+            u.part = t - tail_idx * p.ksplit;
+            u.slot = t;
+            swz = p.full_tiles + tail_idx;
+            u.kt0 = (int)((long)u.part * nk_all / p.ksplit);
+            u.kt1 = (int)((long)(u.part + 1) * nk_all / p.ksplit);
+        }
+        const int GM = 4;
+        const int width = GM * p.tiles_n;
+        const int group = swz / width;
+        const int first_m = group * GM;
+        const int gsize = min(p.tiles_m - first_m, GM);
+        u.mfirst = (first_m + (swz % width) % gsize) * 256;
+        u.m0 = min(u.mfirst, p.M - 256);       // rows [m0, mfirst) belong to the tile above and are not stored by this one
+        u.n0 = ((swz % width) / gsize) * 256;
+        return u;
+    };
+
+    // DMA sources: LDS row R = 8 (4 wave + i) + lane/8 takes 16-byte chunk (lane & 7) ^ (R & 7) of a source row.  R & 7 = lane / 8 does not
+    // depend on i, and the source row splits into a wave-uniform part (SGPR arithmetic, per i) plus a lane part (one VGPR per operand):
+    //   A: source row = R.   W: the wave's 64 LDS rows (tile j = (R >> 4) & 3, row r = R & 15) are a permutation of its 64 weight rows:
+    //   EPI 0 (bf16 out)   n = 64 wb + 32 (j >> 1) + 8 (r >> 2) + 4 (j & 1) + (r & 3)      -> runs of 8 consecutive columns per lane
+    //   EPI 1 (SwiGLU)     n = 128 (wb >> 1) + 64 (j >> 1) + 32 (wb & 1) + 8 (r >> 2) + 4 (j & 1) + (r & 3)   -> [gate | up] of the same 8 columns
+    //   EPI 2 (fp32 out)   n = R                                                         -> 4 fp32 = 16 B per lane and tile
+    const long lda2 = p.lda * 2, ldw2 = p.ldw * 2;
+    const int lr = lane >> 3;                                   // R & 7
+    const int chunk = ((lane & 7) ^ lr) << 4;
+    const unsigned int a_lane = (unsigned int)(lr * lda2) + chunk;
+    const unsigned int b_lane = (unsigned int)((EPI == 2 ? lr : 8 * (lr >> 2) + (lr & 3)) * ldw2) + chunk;
+    unsigned int a_uni[4], b_uni[4];          // wave-uniform byte offsets of DMA piece i (SGPRs; < 2^31, checked by the launcher)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wave * 4 + i;           // R >> 3
+        const int wb = q >> 3, j = (q >> 1) & 3, rh = q & 1;  // r >> 2 = 2 rh + (lr >> 2)
+        int wr;
+        if (EPI == 2) wr = q * 8;
+        else if (EPI == 0) wr = wb * 64 + 32 * (j >> 1) + 16 * rh + 4 * (j & 1);
+        else wr = (wb >> 1) * 128 + 64 * (j >> 1) + (wb & 1) * 32 + 16 * rh + 4 * (j & 1);
+        a_uni[i] = __builtin_amdgcn_readfirstlane((unsigned int)(q * 8 * lda2));
+        b_uni[i] = __builtin_amdgcn_readfirstlane((unsigned int)(wr * ldw2));
+    }
+    const char* Abase = reinterpret_cast<const char*>(p.A);
+    const char* Wbase = reinterpret_cast<const char*>(p.W);
+
+    auto stage = [&](int buf, int m0, int n0, int kt) {
+        char* base = smem + buf * STAGE;
+        const char* ak = Abase + (size_t)m0 * lda2 + (size_t)kt * 128;   // wave-uniform (SGPR) base + 32-bit offset (uniform part + lane part)
+        const char* bk = Wbase + (size_t)n0 * ldw2 + (size_t)kt * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned int ao = a_lane + a_uni[i], bo = b_lane + b_uni[i];
+            asm volatile("" : "+v"(ao), "+v"(bo));  // keep base + offset apart: no hoisted 64-bit per-lane pointers (register pressure)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(ak + ao), LDS_PTR(base + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(bk + bo), LDS_PTR(base + 32768 + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
+    };
+    auto stage_bias = [&](int slot, const UnitPos& u) {
+        if (p.bias && wave == 0 && u.part < 0)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(reinterpret_cast<const char*>(p.bias + u.n0) + lane * 16), LDS_PTR(smem + 2 * STAGE + slot * 1024), 16, 0, 0);
+    };
+
+    // Desynchronise the CUs: every tile costs every CU the same time, so without this all 256 workgroups reach their epilogues together
+    // and each round of tiles ends in a chip-wide store burst (32 MiB of bf16 at the HBM write rate = ~10 us with every matrix pipe idle:
+    // the queued stores hold back the next tile's DMA).  Workgroup b starts p.skew_ticks * (position of b among the G workgroups) / G
+    // late (s_memrealtime ticks, 100 MHz); the offsets persist, the bursts become a steady stream under the other CUs' main loops.
+    // Workgroups with the lowest in-XCD index start first and are the ones that get a unit of a partial last round.
+    if (p.skew_ticks > 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)p.skew_ticks * (unsigned)(li * 8 + xcd) / (unsigned)G;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(4);
+    }
+    f32x4 acc[8][4];
+    int round = 0;
+    UnitPos cur = unit_at(0);
+    if (!cur.valid) return;
+    int s = 0;          // global K-step counter: buffer = s & 1
+    int wcnt = 0;       // stores this wave has in flight behind the boundary DMA (0: wait for everything)
+    stage(0, cur.m0, cur.n0, cur.kt0);
+    stage_bias(0, cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    stage(1, cur.m0, cur.n0, cur.kt0 + 1);
+
+    for (;;) {
+        const UnitPos nxt = unit_at(round + 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = cur.kt0; kt < cur.kt1; ++kt, ++s) {
+            const char* Ab = smem + (s & 1) * STAGE;
+            const char* Bb = Ab + 32768;
+            Frag<T> a8[8], bq[4];
+            // ---- L0
+            if (kt != cur.kt0) {  // (the first step's successor was requested at the unit boundary)
+                const bool last = kt + 1 >= cur.kt1;
+                if (!last || nxt.valid) stage((s + 1) & 1, last ? nxt.m0 : cur.m0, last ? nxt.n0 : cur.n0, last ? nxt.kt0 : kt + 1);
+                if (last && nxt.valid) stage_bias((round + 1) & 1, nxt);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bq[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + mm, 0, g4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + mm, 0, g4);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- C0
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(bq[j], a8[i], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- L1
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bq[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + mm, 1, g4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + mm, 1, g4);
+            if (kt != cur.kt0 || wcnt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (wcnt == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (wcnt == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- C1
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(bq[j], a8[i], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+
+        // ---- unit boundary: fetch the tile's bias from LDS (the compiler orders every LDS read behind every LDS-DMA in flight with a
+        // vmcnt(0): nothing is in flight here, after the DMA below it would wait for it), request the next unit's second K-tile, then drain
+        // the accumulators (stores only: nothing to wait for)
+        const bool full_rows = cur.m0 == cur.mfirst;   // false only for the shifted last tile row of a ragged M
+        // (the epilogue's per-lane address pieces are recomputed from an opaque copy of the lane id, so that nothing but `lane` itself stays
+        // live across the K loop for them: the loop runs at the register limit)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int g4 = lane_e >> 4, mm = lane_e & 15;
+        const int row0 = cur.m0 + wm * 128 + mm;       // this lane's row in sub-tile i is row0 + 16 i
+        float bv[16];
+        if (EPI != 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) bv[e] = 0.f;
+            if (p.bias && cur.part < 0) {
+                const float* bl = reinterpret_cast<const float*>(smem + 2 * STAGE + (round & 1) * 1024) + wn * 64;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {  // EPI 0: columns 32 (q >> 1) + 8 g4 + 4 (q & 1) .. +3;  EPI 2: 16 q + 4 g4 .. +3
+                    const float4 x0 = *reinterpret_cast<const float4*>(bl + (EPI == 0 ? 32 * (q >> 1) + 8 * g4 + 4 * (q & 1) : 16 * q + 4 * g4));
+                    bv[4 * q + 0] = x0.x; bv[4 * q + 1] = x0.y; bv[4 * q + 2] = x0.z; bv[4 * q + 3] = x0.w;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (nxt.valid) stage((s + 1) & 1, nxt.m0, nxt.n0, nxt.kt0 + 1);  // s = the next unit's first step (its tile is in buffer s & 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if ((p.ablate & 4) && acc[0][0][0] != 12345.678f) {   // timing-only: no epilogue (the accumulators stay live)
+            wcnt = 0;
+        } else
+        if (EPI == 0 && cur.part < 0) {
+            const bool odd = mm & 1;
+            const int rowp = row0 & ~1;   // the lane pair's first row (sub-tile i: + 16 i); this lane writes 16 B piece (odd ? 4 : 0) + g4 of both rows
+            T* cp = reinterpret_cast<T*>(p.C) + (size_t)rowp * p.ldc + cur.n0 + wn * 64 + (odd ? 32 : 0) + 8 * g4;
+            auto drain = [&](auto ACT, auto FULL) {   // compile-time activation / row predicate: straight-line code per variant
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    unsigned int o[8];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float v0 = acc[i][2 * h + (q >> 1)][2 * (q & 1)] + bv[8 * h + 2 * q];
+                            float v1 = acc[i][2 * h + (q >> 1)][2 * (q & 1) + 1] + bv[8 * h + 2 * q + 1];
+                            if constexpr (decltype(ACT)::value == 1) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); }
+                            if constexpr (decltype(ACT)::value == 2) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                            o[4 * h + q] = pack_bf16x2(v0, v1);
+                        }
+                    u32x4 s0, s1;
+                    pair_swap((u32x4){o[0], o[1], o[2], o[3]}, (u32x4){o[4], o[5], o[6], o[7]}, odd, s0, s1);
+                    if (decltype(FULL)::value || rowp + 16 * i >= cur.mfirst) gst(cp + (size_t)(16 * i) * p.ldc, s0);
+                    if (decltype(FULL)::value || rowp + 16 * i + 1 >= cur.mfirst) gst(cp + (size_t)(16 * i + 1) * p.ldc, s1);
+                }
+            };
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+            if (full_rows) {
+                if (p.act == 1) drain(I1{}, std::true_type{});
+                else if (p.act == 2) drain(I2{}, std::true_type{});
+                else drain(I0{}, std::true_type{});
+            } else {
+                if (p.act == 1) drain(I1{}, std::false_type{});
+                else if (p.act == 2) drain(I2{}, std::false_type{});
+                else drain(I0{}, std::false_type{});
+            }
+            wcnt = full_rows ? 16 : 0;
+        } else if (EPI == 1 && cur.part < 0) {
+            // out[:, n0/2 + 64 (wn>>1) + 32 (wn&1) + 8 g4 + e] = silu(gate_e) * up_e, gate = tiles 0/1, up = tiles 2/3   (modeling_internlm2.py:261-264)
+            T* cp = reinterpret_cast<T*>(p.C) + (size_t)row0 * p.ldc + (cur.n0 >> 1) + (wn >> 1) * 64 + (wn & 1) * 32 + 8 * g4;
+            auto drain = [&](auto FULL) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    unsigned int o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float g0 = acc[i][q >> 1][2 * (q & 1)], g1 = acc[i][q >> 1][2 * (q & 1) + 1];
+                        const float u0 = acc[i][2 + (q >> 1)][2 * (q & 1)], u1 = acc[i][2 + (q >> 1)][2 * (q & 1) + 1];
+                        o[q] = pack_bf16x2(silu_f(g0) * u0, silu_f(g1) * u1);
+                    }
+                    if (decltype(FULL)::value || row0 + 16 * i >= cur.mfirst) gst(cp + (size_t)(16 * i) * p.ldc, (u32x4){o[0], o[1], o[2], o[3]});
+                }
+            };
+            if (full_rows) drain(std::true_type{}); else drain(std::false_type{});
+            wcnt = full_rows ? 8 : 0;
+        } else if (EPI == 2 && cur.part < 0) {
+            // fp32 residual stream: C = acc + bias + residual[row (mod res_row_mod)]  (no activation on this path: checked by the launcher).
+            // Two register sets alternate: the residual rows of sub-tile i+1 are requested before sub-tile i is stored (counted waits).
+            // whole-line accesses: tiles (0, 1) and (2, 3) of a sub-tile are the two 64 B halves of a 128 B line -> pair_swap per tile pair;
+            // afterwards this lane owns piece (odd ? 4 : 0) + g4 of line jp = 0, 1 in the rows rowp + 16 i and rowp + 16 i + 1
+            const bool odd = mm & 1;
+            const int rowp = row0 & ~1;
+            const int colp = cur.n0 + wn * 64 + (odd ? 16 : 0) + 4 * g4;
+            float* cp = reinterpret_cast<float*>(p.C) + (size_t)rowp * p.ldc + colp;
+            auto load_res = [&](int i, float4 (&r)[4]) {   // r[2 jp + rsel]: line jp of row rowp + 16 i + rsel
+#pragma unroll
+                for (int rsel = 0; rsel < 2; ++rsel) {
+                    const int gm = rowp + 16 * i + rsel;
+                    const int rr = p.res_row_mod > 0 ? gm % p.res_row_mod : gm;
+                    const float* rp = p.residual + (size_t)rr * p.ldr + colp;
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) r[2 * jp + rsel] = *reinterpret_cast<const float4*>(rp + 32 * jp);
+                }
+            };
+            auto put = [&](int i, const float4 (&r)[4], auto FULL) {
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    u32x4 lo, hi, s0, s1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lo[e] = __float_as_uint(acc[i][2 * jp][e] + bv[8 * jp + e]);
+                        hi[e] = __float_as_uint(acc[i][2 * jp + 1][e] + bv[8 * jp + 4 + e]);
+                    }
+                    pair_swap(lo, hi, odd, s0, s1);
+                    const float4 r0 = r[2 * jp], r1 = r[2 * jp + 1];
+                    s0 = (u32x4){__float_as_uint(__uint_as_float(s0[0]) + r0.x), __float_as_uint(__uint_as_float(s0[1]) + r0.y),
+                                 __float_as_uint(__uint_as_float(s0[2]) + r0.z), __float_as_uint(__uint_as_float(s0[3]) + r0.w)};
+                    s1 = (u32x4){__float_as_uint(__uint_as_float(s1[0]) + r1.x), __float_as_uint(__uint_as_float(s1[1]) + r1.y),
+                                 __float_as_uint(__uint_as_float(s1[2]) + r1.z), __float_as_uint(__uint_as_float(s1[3]) + r1.w)};
+                    if (decltype(FULL)::value || rowp + 16 * i >= cur.mfirst) gst(cp + (size_t)(16 * i) * p.ldc + 32 * jp, s0);
+                    if (decltype(FULL)::value || rowp + 16 * i + 1 >= cur.mfirst) gst(cp + (size_t)(16 * i + 1) * p.ldc + 32 * jp, s1);
+                }
+            };
+            auto drain = [&](auto RES, auto FULL) {
+                float4 ra[4], rb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ra[j] = rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (decltype(RES)::value) load_res(0, ra);
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    if constexpr (decltype(RES)::value) { load_res(i + 1, rb); __builtin_amdgcn_sched_barrier(0); }
+                    put(i, ra, FULL);
+                    if constexpr (decltype(RES)::value) { if (i + 2 < 8) load_res(i + 2, ra); __builtin_amdgcn_sched_barrier(0); }
+                    put(i + 1, rb, FULL);
+                }
+            };
+            if (p.residual) { if (full_rows) drain(std::true_type{}, std::true_type{}); else drain(std::true_type{}, std::false_type{}); }
+            else { if (full_rows) drain(std::false_type{}, std::true_type{}); else drain(std::false_type{}, std::false_type{}); }
+            wcnt = (full_rows && !p.residual) ? 32 : 0;  // with a residual the loads' waits have drained the queue anyway
+        } else {
+            // K-range of a split tail tile: raw fp32 partial tile -> workspace [slot][256][256] (finished by gemm256_tail_reduce_kernel)
+            float* wp = p.ws + (size_t)cur.slot * 65536 + (size_t)(wm * 128 + mm) * 256;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int nl;
+                    if (EPI == 2) nl = wn * 64 + 16 * j + 4 * g4;
+                    else if (EPI == 0) nl = wn * 64 + 32 * (j >> 1) + 8 * g4 + 4 * (j & 1);
+                    else nl = (wn >> 1) * 128 + 64 * (j >> 1) + (wn & 1) * 32 + 8 * g4 + 4 * (j & 1);
+                    gst(wp + (size_t)(16 * i) * 256 + nl, (u32x4){__float_as_uint(acc[i][j][0]), __float_as_uint(acc[i][j][1]),
+                                                                          __float_as_uint(acc[i][j][2]), __float_as_uint(acc[i][j][3])});
+                }
+            wcnt = 32;
+        }
+        if (!nxt.valid) break;
+        cur = nxt;
+        ++round;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
 }
 
 template <typename T, int EXP>
@@ -705,9 +1137,73 @@ static int launch_gemm_v3(GemmArgs a, hipStream_t stream) {
     return launch_gemm_v3_impl<T, 1>(a, stream);                            // fp32 has one k-step per K-tile: no second segment pair
 }
 
+static int num_cus() {
+    static int n[32] = {};
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 31;
+    if (n[d] == 0) {
+        hipDeviceProp_t prop;
+        n[d] = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return n[d];
+}
+
+template <int EPI>
+static int launch_gemm_v4_impl(GemmArgs a, hipStream_t stream) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 133120);
+    }
+    const int cus = num_cus();
+    a.shift_edge = 1;
+    a.store_nt = 0;
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = a.N / 256;
+    const int T_ = a.tiles_m * a.tiles_n;
+    const int nk = a.K / 64;
+    // the tiles left over after the last full round of `cus` tiles are cut along K so that they fill the chip once more
+    const int tail = T_ % cus;
+    a.full_tiles = T_;
+    a.ksplit = 1;
+    if (g_split_tail && a.ws && T_ > cus && tail > 0 && tail <= cus / 4 && nk >= 64) {
+        int S = cus / tail;
+        if (S > 8) S = 8;
+        if (S > nk / 8) S = nk / 8;
+        if (S >= 2 && (size_t)tail * S * 262144 <= a.ws_bytes) {
+            a.full_tiles = T_ - tail;
+            a.ksplit = S;
+        }
+    }
+    const int n_units = a.full_tiles + (T_ - a.full_tiles) * a.ksplit;
+    // start-time spread of the workgroups (see the kernel): measured neutral at 5 / 10 / 20 us on every shape (the per-CU store path, not
+    // the chip-wide burst, bounds the epilogue: tools/store_probe.hip), so it is off unless the A/B switch sets it
+    a.skew_ticks = 0;
+    if (g_skew_half_us > 0) a.skew_ticks = g_skew_half_us * 50;
+    gemm256p_kernel<EPI><<<dim3(n_units < cus ? n_units : cus), dim3(512), 133120, stream>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    if (a.ksplit > 1) {
+        const int tail_tiles = T_ - a.full_tiles;
+        if (tail_tiles * a.ksplit <= 128) gemm256_tail_reduce_kernel<bf16, 4, 128><<<dim3(tail_tiles * 64), dim3(128), 0, stream>>>(a);
+        else gemm256_tail_reduce_kernel<bf16, 16, 256><<<dim3(tail_tiles * 16), dim3(256), 0, stream>>>(a);
+        ULLSAM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+static bool v4_ok(const GemmArgs& a, int dtype) {
+    return dtype == ULLSAM_DT_BF16 && a.vec_ok && a.M >= 256 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 512 && (a.lda % 8 == 0) && (a.ldw % 8 == 0) &&
+           (!a.bias || ((uintptr_t)a.bias & 15) == 0) && (!a.out_f32 || a.act == 0) &&
+           (size_t)a.lda * 2 * 256 < (1ull << 31) && (size_t)a.ldw * 2 * 256 < (1ull << 31);
+}
+static int launch_gemm_v4(const GemmArgs& a, hipStream_t stream) {
+    if (a.act == 3) return launch_gemm_v4_impl<1>(a, stream);
+    if (a.out_f32) return launch_gemm_v4_impl<2>(a, stream);
+    return launch_gemm_v4_impl<0>(a, stream);
+}
+
 // v: bits 0-3 kernel (0 auto), +64 no split-K tail, bits 8-11 timing-only ablations (1 no staging, 2 no barrier, 4 no epilogue, 8 no stores), bits 12-13 schedule of the 256x256 kernel
 extern "C" int ullsam_set_gemm_variant(int v) {
-    g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_gemm_ablate = (v >> 8) & 15; g_gemm_sched = (v >> 12) & 3;
+    g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_persistent = (v & 128) ? 0 : 1; g_skew_half_us = (v >> 16) & 255; g_store_nt = ((v >> 14) & 1) ^ 1; g_late = (v >> 24) & 3; g_gemm_ablate = (v >> 8) & 15; g_gemm_sched = (v >> 12) & 3;
     return 0;
 }
 
@@ -971,6 +1467,10 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     a.ablate = g_gemm_ablate;
     a.ws = reinterpret_cast<float*>(workspace);
     a.ws_bytes = workspace ? (size_t)ws_bytes : 0;
+    a.shift_edge = 0;
+    a.skew_ticks = 0;
+    a.store_nt = g_store_nt;
+    a.late = g_late;
     a.ksplit = 1;
     a.tiles_m = (M + 127) / 128;
     a.tiles_n = (N + 127) / 128;
@@ -981,8 +1481,7 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     if (variant == 0 && dtype == ULLSAM_DT_BF16 && M <= 8 && K % 512 == 0 && lda % 8 == 0 && ldw % 8 == 0 &&
         (size_t)(M <= 4 ? 4 : 8) * K * 2 <= 144 * 1024 && (act != 3 || N % 128 == 0))
         return launch_gemm_skinny(a, s);
-    // measured end to end (profiles/): the 256x128 3-stage kernel wins on the very wide SwiGLU GEMM, the 128x128 kernel elsewhere
-    const bool v2 = variant == 2 || (variant == 0 && M > 512 && N >= 16384);
+    const bool v2 = variant == 2;  // the 256x128 ring is never picked automatically (slower than the 256x256 kernel on every shape)
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     // 256x256 tiles run one per CU: use them when the last wave of tiles is >= 74 % full (measured crossover, tools/gemm_bench.py:
     // 408 / 960 / 1280 / 1904 tiles win, 272 / 320 lose to the 128x128 kernel's finer granularity)
@@ -991,6 +1490,13 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     const bool v3_split = g_split_tail && workspace && t256 > 256 && tail256 > 0 && tail256 <= 64 && K >= 64 * bk;  // see launch_gemm_v3_impl
     const bool v3 = variant == 3 || (variant == 0 && M >= 1024 && N >= 256 && K >= 8 * bk && (fill >= 0.74 || v3_split) && (act != 3 || N % 256 == 0));  // short K / narrow N: the 256^2 tile's fixed cost or its empty half dominates
     if (act == 3 && (variant == 3) && N % 256 != 0) { ullsam_set_error("ullsam_gemm: v3 swiglu needs N%%256==0"); return -1; }
+    if (variant == 4) {
+        if (!v4_ok(a, dtype)) { ullsam_set_error("ullsam_gemm: the persistent kernel needs bf16, N%%256==0, K%%64==0, K>=512, 16-byte aligned rows"); return -1; }
+        return launch_gemm_v4(a, s);
+    }
+    // persistent kernel in auto mode: only where it measured faster in the same process -- bf16 output with the GELU epilogue (vit.lin1
+    // 214 vs 232 us: the erf arithmetic of one wave group overlaps the other group's matrix segment); elsewhere it ties or loses 0-3 %
+    if (v3 && variant == 0 && g_persistent && a.act == 1 && !a.out_f32 && v4_ok(a, dtype)) return launch_gemm_v4(a, s);
     if (v3) return dtype == ULLSAM_DT_F32 ? launch_gemm_v3<float>(a, s) : launch_gemm_v3<bf16>(a, s);
     if (v2) return dtype == ULLSAM_DT_F32 ? launch_gemm_v2<float>(a, s) : launch_gemm_v2<bf16>(a, s);
     return dtype == ULLSAM_DT_F32 ? launch_gemm<float>(a, s) : launch_gemm<bf16>(a, s);
