@@ -287,6 +287,45 @@ def cpu_baseline(vit: str, llm: str, S: int, reps: int = 3):
                        f"sampling took {time.time() - t_all:.0f}s")}
 
 
+def decode_mode(a, device):
+    """`--mode decode`: greedy decode throughput of the InternLM2-7B-shaped LLM (the caption path, app.py:431-495 ->
+    modeling_internvl_sam.py:394-442): prefill S tokens, then K timed single-token steps at batch `--batch`.  A decode step streams
+    every layer weight + the lm_head + the KV cache once, so the bound is HBM: achieved = those bytes / step time."""
+    model = build_model("b", a.llm, torch.bfloat16, device)
+    lm = model.language_model
+    B, S, n = a.batch, a.seq, max(2, a.steps)
+    ids = torch.randint(3, 90000, (B, S), device=device)
+
+    def run(k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = lm.generate(input_ids=ids, max_new_tokens=k, eos_token_id=-1)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, out
+
+    for _ in range(max(1, a.warmup // 2)):
+        run(4)
+    t1, _ = run(1)
+    tn, out = run(n + 1)
+    per = (tn - t1) / n
+    c = lm.config
+    hd = c.hidden_size // c.num_attention_heads
+    layer_w = ((c.num_attention_heads + 2 * c.num_key_value_heads) * hd * c.hidden_size + c.num_attention_heads * hd * c.hidden_size
+               + 3 * c.intermediate_size * c.hidden_size)
+    w_bytes = 2 * (c.num_hidden_layers * layer_w + c.vocab_size * c.hidden_size)
+    kv_bytes = 2 * 2 * c.num_hidden_layers * B * c.num_key_value_heads * hd * (S + n // 2)
+    ach = (w_bytes + kv_bytes) / per / 1e9
+    line = {"metric": "greedy decode tokens/s (InternLM2-7B-shaped, bf16)", "value": round(B / per, 2), "unit": "tokens/s", "n_gpus": 1,
+            "steps": n, "warmup": a.warmup, "ms_per_step": round(per * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (random token ids, random-init weights)",
+            "config": {"workload": f"InternVLSAMModel.generate's LLM loop: prefill {S} tokens then {n} greedy steps, batch {B}", "batch_per_gpu": B,
+                       "seq_len": S, "prefill_plus_first_token_ms": round(t1 * 1e3, 1)},
+            "roofline": {"bound": "hbm", "kernel": "decode step (gemm_skinny_* weight streams + decode_attn_* over the KV cache)", "achieved": round(ach, 1),
+                         "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                         "algorithmic_bytes_per_step": int(w_bytes + kv_bytes)}}
+    print(json.dumps(line), flush=True)
+
+
 def _spawn_ranks(n: int, argv) -> int:
     """WORLD_SIZE unset and --gpus N > 1: start the launcher as a CHILD process (this process never initialises the GPU) and
     relay its output; exit with its code."""
@@ -326,6 +365,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-iou", action="store_true", help="skip the fp32 run that gives mask_iou_vs_fp32")
+    ap.add_argument("--mode", default="mask", choices=["mask", "decode"], help="mask: the headline images/s path; decode: greedy tokens/s of the caption path")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -346,6 +386,12 @@ def main():
         dist.all_gather_object(names, f"rank {rank}: cuda:{local} {torch.cuda.get_device_name(local)}")
         ranks_seen = names
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    if a.mode == "decode":
+        if world != 1:
+            raise SystemExit("bench.py --mode decode is a single-GPU measurement")
+        with torch.no_grad():
+            decode_mode(a, device)
+        return
 
     model = build_model(a.vit, a.llm, dtype, device)
     if os.environ.get("ULLSAM_GEMM_VARIANT"):  # A/B switch for kernel experiments

@@ -246,3 +246,29 @@ def test_generator_fused_and_helper_chain_agree_with_crops():
         assert ra["segmentation"] == rb["segmentation"] and ra["bbox"] == rb["bbox"] and ra["area"] == rb["area"]
         assert ra["crop_box"] == rb["crop_box"] and ra["point_coords"] == rb["point_coords"]
         assert ra["stability_score"] == rb["stability_score"] and ra["predicted_iou"] == rb["predicted_iou"]
+
+
+def test_generator_min_mask_region_area_and_coco_rle():
+    """min_mask_region_area: every surviving mask has no island and no hole smaller than the threshold (remove_small_regions is
+    idempotent on it), areas / boxes are recomputed for changed masks; output_mode="coco_rle" round-trips to the same masks."""
+    from ullsam_amd.automatic_mask_generator import SamAutomaticMaskGenerator
+    from ullsam_amd.utils import amg as A
+    sam, _ = _small_sam()
+    img = torch.from_numpy(U.rand_image((3, 512, 640), 23, 255.0))
+    kw = dict(points_per_side=4, points_per_batch=64, pred_iou_thresh=-1e3, stability_score_thresh=0.3, stability_score_offset=0.05)
+    plain = SamAutomaticMaskGenerator(sam, **kw).generate(img)
+    clean = SamAutomaticMaskGenerator(sam, min_mask_region_area=200, **kw).generate(img)
+    assert 0 < len(clean) <= len(plain)
+    for r in clean:
+        seg = r["segmentation"]
+        for mode in ("holes", "islands"):
+            again, changed = A.remove_small_regions(seg, 200, mode)
+            assert not changed or np.array_equal(again, seg)   # (only the "keep the largest island" rule may report a change)
+        assert r["area"] == int(seg.sum())
+        b = AO.batched_mask_to_box(seg[None])[0]
+        assert r["bbox"] == [int(b[0]), int(b[1]), int(b[2] - b[0]), int(b[3] - b[1])]
+    coco = SamAutomaticMaskGenerator(sam, output_mode="coco_rle", **kw).generate(img)
+    assert len(coco) == len(plain)
+    for rc, rp in zip(coco, plain):
+        assert isinstance(rc["segmentation"]["counts"], str)
+        assert np.array_equal(A.rle_to_mask(A.coco_decode_rle(rc["segmentation"])), rp["segmentation"])

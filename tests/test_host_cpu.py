@@ -216,6 +216,74 @@ def test_packed_gather_without_process_group_is_identity():
     assert torch.equal(a, low) and torch.equal(b, mk) and c is None
 
 
+def _bfs_regions(work):
+    """8-connected components by flood fill (the tests' own labeller), labels in raster order of each region's first pixel."""
+    H, W = work.shape
+    lab = np.zeros((H, W), np.int32)
+    n = 0
+    for y in range(H):
+        for x in range(W):
+            if work[y, x] and lab[y, x] == 0:
+                n += 1
+                stack = [(y, x)]
+                lab[y, x] = n
+                while stack:
+                    cy, cx = stack.pop()
+                    for dy in (-1, 0, 1):
+                        for dx in (-1, 0, 1):
+                            yy, xx = cy + dy, cx + dx
+                            if 0 <= yy < H and 0 <= xx < W and work[yy, xx] and lab[yy, xx] == 0:
+                                lab[yy, xx] = n
+                                stack.append((yy, xx))
+    return lab, n
+
+
+def _remove_small_regions_oracle(mask, area_thresh, mode):
+    """utils/amg.py:267-291 restated over the flood-fill labeller."""
+    correct_holes = mode == "holes"
+    regions, n = _bfs_regions(correct_holes ^ mask)
+    sizes = np.array([(regions == i).sum() for i in range(1, n + 1)])
+    small = [i + 1 for i, s_ in enumerate(sizes) if s_ < area_thresh]
+    if not small:
+        return mask, False
+    fill = [0] + small
+    if not correct_holes:
+        fill = [i for i in range(n + 1) if i not in fill]
+        if not fill:
+            fill = [int(np.argmax(sizes)) + 1]
+    return np.isin(regions, fill), True
+
+
+def test_remove_small_regions_and_coco_rle():
+    from ullsam_amd.utils import amg as A
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:48, 0:64]
+    blob = ((yy - 20) ** 2 + (xx - 30) ** 2) < 150
+    cases = [rng.random((48, 64)) > 0.55, blob | (rng.random((48, 64)) > 0.97), blob & ~(rng.random((48, 64)) > 0.9),
+             np.zeros((8, 8), bool), np.ones((8, 8), bool), np.eye(9, dtype=bool)]   # eye: diagonal pixels are ONE 8-connected region
+    for m in cases:
+        for mode in ("islands", "holes"):
+            for thresh in (1, 6, 40, 10 ** 6):
+                got, ch = A.remove_small_regions(m, thresh, mode)
+                ref, ch_ref = _remove_small_regions_oracle(m, thresh, mode)
+                assert ch == ch_ref and np.array_equal(got, ref), (mode, thresh)
+    # COCO compressed RLE: round trip through the decoder, negative differences and multi-group values included
+    for shape in ((37, 53), (5, 4)):
+        m = rng.random(shape) > 0.5
+        rle = A.mask_to_rle_numpy(m) if hasattr(A, "mask_to_rle_numpy") else None
+        flat = m.T.reshape(-1)
+        change = np.flatnonzero(flat[1:] != flat[:-1]) + 1
+        counts = np.diff(np.concatenate([[0], change, [flat.size]])).tolist()
+        if flat[0]:
+            counts = [0] + counts
+        enc = A.coco_encode_rle({"size": list(shape), "counts": counts})
+        assert isinstance(enc["counts"], str) and all(48 <= ord(c) < 48 + 64 for c in enc["counts"])
+        assert A.coco_decode_rle(enc)["counts"] == counts
+        assert np.array_equal(A.rle_to_mask({"size": list(shape), "counts": A.coco_decode_rle(enc)["counts"]}), m)
+    enc = A.coco_encode_rle({"size": [2048, 2048], "counts": [0, 5, 100000, 3, 2000000, 7, 2094289]})
+    assert enc["counts"][:2] == "05" and A.coco_decode_rle(enc)["counts"] == [0, 5, 100000, 3, 2000000, 7, 2094289]
+
+
 def test_checkpoint_loading_conventions(tmp_path):
     """Reference-layout checkpoints load without key surgery: {"model": sd} torch files, DDP 'module.' prefixes, and
     InternLM2 safetensors re-prefixed with language_model. (train_joint_v2.py:1466-1555)."""

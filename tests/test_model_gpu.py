@@ -306,6 +306,51 @@ def test_sam_forward_golden():
     assert 1.0 - O.calc_iou(got, ref) < 1e-4
 
 
+def test_checkpoint_files_load_and_run(tmp_path):
+    """Checkpoint I/O end to end on the GPU (train_joint_v2.py:1254-1263 save format, :1466-1555 loading order, build_sam.py:103-106):
+    a reference-shaped uLLSAM checkpoint file, a plain SAM state_dict file through the registry-style loader and an InternLM2
+    safetensors file are written, loaded into freshly initialised models with the package's loaders, and the loaded models must
+    reproduce the source model's forward bit for bit."""
+    import argparse
+    import pathlib
+    from safetensors.torch import save_file
+    from ullsam_amd import checkpoint
+    src = _ullsam_tiny(torch.float32)
+    sd = {k: v.detach().cpu() for k, v in src.state_dict().items()}
+    opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(2))], lr=1e-4)
+    torch.save({"model": sd, "optimizer": opt.state_dict(), "scheduler": {"last_epoch": 3}, "epoch": 23, "step": 7,
+                "args": argparse.Namespace(save_dir=pathlib.Path("out"), training_mode="all")}, tmp_path / "final_all_e24.pt")
+    x = torch.from_numpy(U.rand_image((1, 3, 1024, 1024), 21)).to(DEV)
+    ids = torch.from_numpy(O.make_input_ids(20, 34, seed=9)).to(DEV)
+    pts, lbl = torch.tensor([[[400.0, 300.0]]], device=DEV), torch.ones((1, 1), dtype=torch.int32, device=DEV)
+    _, low_src, iou_src, _, mk_src = _app_mask_path(src, x, ids, pts, lbl)
+
+    dst = _ullsam_tiny(torch.float32)
+    with torch.no_grad():
+        for p_ in dst.parameters():
+            p_.normal_()                                   # scramble: everything must come from the file
+    missing, unexpected = checkpoint.load_ullsam_checkpoint(dst, str(tmp_path / "final_all_e24.pt"))
+    assert not missing and not unexpected
+    _, low, iou, _, mk = _app_mask_path(dst, x, ids, pts, lbl)
+    assert torch.equal(low, low_src) and torch.equal(iou, iou_src) and torch.equal(mk, mk_src)
+
+    # the order of init_model_and_tokenizer (train_joint_v2.py:1362-1562): SAM weights, then the LLM's safetensors under language_model.
+    dst2 = _ullsam_tiny(torch.float32)
+    with torch.no_grad():
+        for p_ in dst2.parameters():
+            p_.normal_()
+    rest = {k: v for k, v in sd.items() if not k.startswith("language_model.")}
+    torch.save(rest, tmp_path / "rest.pt")
+    save_file({k[len("language_model."):]: v.contiguous() for k, v in sd.items() if k.startswith("language_model.")},
+              str(tmp_path / "model.safetensors"))
+    m1, u1 = checkpoint.load_ullsam_checkpoint(dst2, str(tmp_path / "rest.pt"))
+    assert not u1 and all(k.startswith("language_model.") for k in m1)
+    m2, u2 = checkpoint.load_llm_safetensors(dst2, str(tmp_path / "model.safetensors"))
+    assert not u2 and not [k for k in m2 if k.startswith("language_model.")]
+    _, low2, _, _, mk2 = _app_mask_path(dst2, x, ids, pts, lbl)
+    assert torch.equal(low2, low_src) and torch.equal(mk2, mk_src)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from ullsam_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

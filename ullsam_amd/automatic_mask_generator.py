@@ -9,7 +9,8 @@ small crops).  Helper parity is pinned (tests/golden/amg.npz); driver parity is 
 flow over the oracle (tests/test_amg_gpu.py).
 
 Deviations, stated: images are resized with the bilinear kernel (align_corners=False, no antialias) instead of PIL's antialiased
-uint8 resize; `min_mask_region_area` post-processing needs OpenCV and is not available; the predicted-IoU filter is applied before
+uint8 resize; `min_mask_region_area` post-processing labels regions with scipy instead of OpenCV (utils.amg.remove_small_regions);
+the predicted-IoU filter is applied before
 the masks are upsampled (it depends only on the IoU head, so the surviving set is identical, and the 3x1024^2-per-prompt logits of
 rejected masks are never materialised).  With `fused_postprocess=True` (default) the upsample, stability score, mask->box and RLE
 steps of a batch run as one kernel over the low-res logits (`utils.amg.postprocess_low_res`): the full-resolution fp32 logits and
@@ -36,9 +37,8 @@ class SamAutomaticMaskGenerator:
         assert (points_per_side is None) != (point_grids is None), "Exactly one of points_per_side or point_grid must be provided."
         self.point_grids = (A.build_all_layer_point_grids(points_per_side, crop_n_layers, crop_n_points_downscale_factor)
                             if points_per_side is not None else point_grids)
-        assert output_mode in ("binary_mask", "uncompressed_rle"), f"Unknown or unavailable output_mode {output_mode}."
-        if min_mask_region_area > 0:
-            raise ImportError("min_mask_region_area > 0 needs OpenCV's connected components (remove_small_regions), not installed")
+        assert output_mode in ("binary_mask", "uncompressed_rle", "coco_rle"), f"Unknown output_mode {output_mode}."
+        self.min_mask_region_area = int(min_mask_region_area)
         self.model = model
         self.points_per_batch = points_per_batch
         self.pred_iou_thresh = pred_iou_thresh
@@ -133,6 +133,31 @@ class SamAutomaticMaskGenerator:
         data["rles"] = pp.rles(sel, as_list=False) if len(sel) else []
         return data
 
+    def postprocess_small_regions(self, data: A.MaskData, min_area: int, nms_thresh: float) -> A.MaskData:
+        """Remove small islands / fill small holes of every mask, then re-run box NMS preferring masks that needed no change
+        (the generator step the reference's remove_small_regions helper, utils/amg.py:267-291, exists for)."""
+        if len(data["rles"]) == 0:
+            return data
+        dev = data["boxes"].device
+        new_masks, scores = [], []
+        for rle in data["rles"]:
+            mask = A.rle_to_mask(rle)
+            mask, changed = A.remove_small_regions(mask, min_area, mode="holes")
+            unchanged = not changed
+            mask, changed = A.remove_small_regions(mask, min_area, mode="islands")
+            unchanged = unchanged and not changed
+            new_masks.append(torch.from_numpy(np.ascontiguousarray(mask)).unsqueeze(0))
+            scores.append(float(unchanged))
+        masks = torch.cat(new_masks, 0).to(dev)
+        boxes = A.batched_mask_to_box(masks)
+        keep = A.batched_nms(boxes.float(), torch.as_tensor(scores, device=dev), torch.zeros_like(boxes[:, 0]), nms_thresh)
+        for i in keep.tolist():
+            if scores[i] == 0.0:
+                data["rles"][i] = A.mask_to_rle_pytorch(masks[i:i + 1])[0]
+                data["boxes"][i] = boxes[i]
+        data.filter(keep)
+        return data
+
     def _process_crop(self, image: torch.Tensor, crop_box, layer_idx: int, orig_size) -> A.MaskData:
         x0, y0, x1, y1 = crop_box
         img_tok, input_size = self._encode(image[:, y0:y1, x0:x1])
@@ -165,12 +190,16 @@ class SamAutomaticMaskGenerator:
             scores = 1.0 / ((cb[:, 2] - cb[:, 0]) * (cb[:, 3] - cb[:, 1]))  # prefer masks from smaller crops
             keep = A.batched_nms(data["boxes"].float(), scores, torch.zeros_like(data["boxes"][:, 0]), self.crop_nms_thresh)
             data.filter(keep)
+        if self.min_mask_region_area > 0:
+            if not isinstance(data["rles"], list):
+                data["rles"] = list(data["rles"])
+            data = self.postprocess_small_regions(data, self.min_mask_region_area, max(self.box_nms_thresh, self.crop_nms_thresh))
         data.to_numpy()
         out = []
         for i, rle in enumerate(data["rles"]):
             if not isinstance(rle["counts"], list):
                 rle = {"size": rle["size"], "counts": rle["counts"].tolist()}
-            seg = A.rle_to_mask(rle) if self.output_mode == "binary_mask" else rle
+            seg = A.rle_to_mask(rle) if self.output_mode == "binary_mask" else (A.coco_encode_rle(rle) if self.output_mode == "coco_rle" else rle)
             out.append({"segmentation": seg, "area": A.area_from_rle(rle), "bbox": A.box_xyxy_to_xywh(data["boxes"][i]).tolist(),
                         "predicted_iou": float(data["iou_preds"][i]), "point_coords": [data["points"][i].tolist()],
                         "stability_score": float(data["stability_score"][i]), "crop_box": A.box_xyxy_to_xywh(data["crop_boxes"][i]).tolist()})

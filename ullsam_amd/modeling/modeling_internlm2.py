@@ -311,6 +311,16 @@ class InternLM2ForCausalLM(Packed):
         done = torch.zeros(B, dtype=torch.bool, device=dev)
         new: List[torch.Tensor] = []
         h_last = out.last_hidden_state[:, -1]
+        # The stop test ("every sequence has emitted eos") needs the token values on the host.  It is evaluated on a copy made
+        # `eos_check_every` steps earlier (pinned buffer + event, no stream sync): the host keeps enqueueing steps while the GPU works,
+        # and at most that many surplus steps run after the last eos; their tokens are `pad` and are trimmed below, so the returned
+        # ids are exactly those of a loop that tests every step.
+        every = max(1, int(kwargs.get("eos_check_every", 8)))
+        pending = []  # (step index, pinned flag, event)
+        stop_at = None
+        mask_full = torch.ones((B, S + max_new_tokens), dtype=torch.long, device=dev)
+        mask_full[:, :S] = mask
+        pos_next = mask.sum(-1, keepdim=True)  # = cumsum(mask)[:, -1]: position id of the next token (cumsum - 1 of the extended mask)
         for step in range(max_new_tokens):
             logits = self.lm_head(h_last)  # fp32 [B, V], last position only
             if do_sample:
@@ -321,12 +331,33 @@ class InternLM2ForCausalLM(Packed):
             new.append(tok)
             for e in eos_set:
                 done = done | (tok == e)
-            if bool(done.all()) or step == max_new_tokens - 1:
+            if eos_set != {-1}:
+                flag = torch.empty((1,), dtype=torch.bool, pin_memory=True)
+                flag.copy_(done.all().reshape(1), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                pending.append((step, flag, ev))
+                while pending and (pending[0][2].query() or len(pending) > every):
+                    st, fl, ev0 = pending.pop(0)
+                    ev0.synchronize()
+                    if bool(fl[0]):
+                        stop_at = st
+                        break
+            if stop_at is not None or step == max_new_tokens - 1:
                 break
-            mask = torch.cat([mask, torch.ones((B, 1), dtype=torch.long, device=dev)], 1)
-            pos = (mask.cumsum(-1) - 1)[:, -1:]
-            out = self.model(input_ids=tok.reshape(B, 1), attention_mask=mask, position_ids=pos, past_key_values=cache, use_cache=True)
+            cur = S + step + 1
+            out = self.model(input_ids=tok.reshape(B, 1), attention_mask=mask_full[:, :cur], position_ids=pos_next, past_key_values=cache,
+                             use_cache=True)
+            pos_next = pos_next + 1
             h_last = out.last_hidden_state[:, -1]
+        if stop_at is None:
+            for st, fl, ev0 in pending:  # the loop ran out: the earliest step at which everything was done, if any
+                ev0.synchronize()
+                if bool(fl[0]):
+                    stop_at = st
+                    break
+        if stop_at is not None:
+            new = new[:stop_at + 1]
         gen = torch.stack(new, 1)
         return gen if inputs_embeds is not None else torch.cat([input_ids, gen], 1)
 

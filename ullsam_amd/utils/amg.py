@@ -166,13 +166,72 @@ def area_from_rle(rle: Dict[str, Any]) -> int:
     return int(np.sum(np.asarray(rle["counts"][1::2], dtype=np.int64)))
 
 
-def remove_small_regions(mask: np.ndarray, area_thresh: float, mode: str):
-    raise ImportError("remove_small_regions needs OpenCV (cv2.connectedComponentsWithStats), which is not installed; "
-                      "the reference fails the same way (utils/amg.py:274)")
+def remove_small_regions(mask: np.ndarray, area_thresh: float, mode: str) -> Tuple[np.ndarray, bool]:
+    """Remove small disconnected regions ("islands") or fill small holes ("holes") of a boolean mask; returns (mask, modified)
+    (utils/amg.py:267-291).  The reference is a host (numpy) helper built on cv2.connectedComponentsWithStats(mask, 8), which is
+    not installed here; the 8-connected labelling comes from scipy.ndimage.label instead.  Only region sizes and membership are
+    used, and both labellers number regions in raster order of their first pixel, so the largest-region tie-break is the same."""
+    from scipy import ndimage
+    assert mode in ["holes", "islands"]
+    correct_holes = mode == "holes"
+    mask = np.asarray(mask).astype(bool)
+    working_mask = correct_holes ^ mask
+    regions, n_regions = ndimage.label(working_mask, structure=np.ones((3, 3), dtype=np.uint8))
+    n_labels = n_regions + 1                                   # label 0 is the background, as in cv2's stats row 0
+    sizes = np.bincount(regions.reshape(-1), minlength=n_labels)[1:]
+    small_regions = [i + 1 for i, s_ in enumerate(sizes) if s_ < area_thresh]
+    if len(small_regions) == 0:
+        return mask, False
+    fill_labels = [0] + small_regions
+    if not correct_holes:
+        fill_labels = [i for i in range(n_labels) if i not in fill_labels]
+        if len(fill_labels) == 0:                              # every region is below the threshold: keep the largest
+            fill_labels = [int(np.argmax(sizes)) + 1]
+    return np.isin(regions, fill_labels), True
 
 
-def coco_encode_rle(uncompressed_rle: Dict[str, Any]):
-    raise ImportError("coco_encode_rle needs pycocotools, which is not installed (utils/amg.py:295)")
+def coco_encode_rle(uncompressed_rle: Dict[str, Any]) -> Dict[str, Any]:
+    """Uncompressed column-major RLE {"size": [h, w], "counts": [...]} -> COCO's compressed form with a utf-8 `counts` string
+    (utils/amg.py:294-300 calls pycocotools.mask.frPyObjects, absent here).  Restates the published encoder (cocoapi maskApi.c
+    rleToString): from the third run on, a run is stored as the difference to the run two places back; each value is emitted in
+    5-bit groups, low group first, bit 5 = continuation, bit 4 of the last group = sign, offset by 48 into printable ASCII."""
+    h, w = uncompressed_rle["size"]
+    cnts = [int(c) for c in uncompressed_rle["counts"]]
+    out = []
+    for i, x in enumerate(cnts):
+        if i > 2:
+            x -= cnts[i - 2]
+        more = True
+        while more:
+            c = x & 0x1F
+            x >>= 5
+            more = (x != -1) if (c & 0x10) else (x != 0)
+            if more:
+                c |= 0x20
+            out.append(chr(c + 48))
+    return {"size": [int(h), int(w)], "counts": "".join(out)}
+
+
+def coco_decode_rle(rle: Dict[str, Any]) -> Dict[str, Any]:
+    """Inverse of coco_encode_rle (cocoapi maskApi.c rleFrString): compressed string -> uncompressed counts."""
+    s_ = rle["counts"]
+    s_ = s_.decode("utf-8") if isinstance(s_, (bytes, bytearray)) else s_
+    cnts: List[int] = []
+    p = 0
+    while p < len(s_):
+        x, k, more = 0, 0, True
+        while more:
+            c = ord(s_[p]) - 48
+            x |= (c & 0x1F) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(cnts) > 2:
+            x += cnts[-2]
+        cnts.append(x)
+    return {"size": list(rle["size"]), "counts": cnts}
 
 
 # ---- device work ----------------------------------------------------------------------------------------------------
