@@ -142,6 +142,14 @@ int ullsam_amg_postprocess(const float* low, const int* index, long M, int LH, i
 int ullsam_nms_mask(const float* boxes, int N, float iou_threshold, unsigned long long* mask, void* stream); /* torchvision.ops.nms (absent dependency) */
 int ullsam_threshold_u8(const float* in, unsigned char* out, long n, float thr, void* stream); /* masks > mask_threshold */
 
+/* fp8 (OCP e4m3) ViT path -- BASELINE.json configs[4]; the reference's bf16 encoder linears image_encoder.py:227,171-181 with
+   8-bit operands: rows quantised with a per-row scale (optionally behind the block's LayerNorm :166,180), GEMM on the
+   block-scaled fp8 MFMA, scales applied in the epilogue */
+int ullsam_rows_fp8(const void* in, int in_dtype, long in_stride, void* out_e4m3, long out_stride, float* row_scale, const float* ln_w,
+                    const float* ln_b, long rows, int D, float eps, void* stream);
+int ullsam_gemm_fp8(const void* A8, long lda, const float* a_scale, const void* W8, long ldw, const float* w_scale, void* C, long ldc,
+                    int out_f32, const float* bias, const float* residual, long ldr, int act, int M, int N, int K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,6 +140,50 @@ def test_gemm_persistent_kernel(ops, M, N, K, mode):
         assert float((old - got).abs().max()) < 1e-2
 
 
+def _e4m3_decode(u8: np.ndarray) -> np.ndarray:
+    """OCP e4m3fn bytes -> float32 (the tests' own decoder: sign, 4-bit exponent bias 7, 3-bit mantissa, subnormals, 0x7f = NaN)."""
+    u = u8.astype(np.int32)
+    s_ = np.where(u & 0x80, -1.0, 1.0)
+    e = (u >> 3) & 0xF
+    m = u & 7
+    v = np.where(e == 0, m / 8.0 * 2.0 ** -6, (1 + m / 8.0) * 2.0 ** (e - 7.0))
+    return (s_ * v).astype(np.float32)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(300, 256, 256, 0), (2048, 768, 1280, 1), (1000, 512, 128, 2)])
+def test_fp8_rows_and_gemm(ops, M, N, K, act):
+    """fp8 (OCP e4m3) path of BASELINE configs[4]: the row quantiser (with and without the fused LayerNorm) against a numpy
+    re-statement, and the block-scaled-MFMA GEMM against an fp32 matmul of the DEQUANTISED operands (so only accumulation order and
+    the bf16 output rounding remain)."""
+    rng = np.random.default_rng(M + K)
+    x = (rng.standard_normal((M, K), dtype=np.float32) * 2 + 0.3).astype(np.float32)
+    lw = rng.standard_normal(K, dtype=np.float32); lb = rng.standard_normal(K, dtype=np.float32) * 0.1
+    w = (rng.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N, dtype=np.float32)
+    # quantiser: scale = amax / 448, values within half an e4m3 ulp of y / scale
+    q, sc = ops.rows_fp8(T(x), T(lw), T(lb), 1e-6)
+    y = O.layer_norm(x, lw, lb, 1e-6)
+    sc_ref = np.abs(y).max(-1) / 448.0
+    assert err(sc.cpu().numpy(), sc_ref) < 1e-6 * float(sc_ref.max()) + 1e-9
+    deq = _e4m3_decode(q.cpu().numpy()) * sc.cpu().numpy()[:, None]
+    ulp = np.maximum(2.0 ** (np.floor(np.log2(np.maximum(np.abs(y / sc_ref[:, None]), 2.0 ** -6))) - 3), 2.0 ** -9)  # e4m3 spacing at |v|
+    assert (np.abs(deq - y) <= (0.5 * ulp + 1e-6) * sc_ref[:, None] * 1.001).all()
+    qw, sw = ops.rows_fp8(T(w))                                         # weights: no norm
+    wdeq = _e4m3_decode(qw.cpu().numpy()) * sw.cpu().numpy()[:, None]
+    assert err(sw.cpu().numpy(), np.abs(w).max(-1) / 448.0) < 1e-9 and np.abs(wdeq - w).max() <= np.abs(w).max() / 16
+    # GEMM
+    ref = deq @ wdeq.T + bias
+    if act == 1:
+        ref = O.gelu(ref)
+    elif act == 2:
+        ref = np.maximum(ref, 0)
+    got = ops.gemm_fp8(q, sc, qw, sw, T(bias), act=act).float().cpu().numpy()
+    assert got.shape == (M, N)
+    assert err(got, ref) < 2e-2 * max(1.0, float(np.abs(ref).max()) / 4)
+    got32 = ops.gemm_fp8(q, sc, qw, sw, T(bias), act=act, out_dtype=torch.float32).cpu().numpy()
+    assert err(got32, ref) < 2e-4 * max(1.0, float(np.abs(ref).max()))
+
+
 @pytest.mark.parametrize("D", [64, 256, 768, 1280, 4096])
 def test_norms(ops, D):
     rng = np.random.default_rng(D)

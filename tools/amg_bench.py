@@ -1,6 +1,7 @@
-"""Throughput of the automatic mask generator (BASELINE.json configs[4] shape: 64x64 point grid on a 2048^2 tile, SAM ViT-H,
-bf16 here -- the fp8 ViT path of that config is not built).  Random-init weights: thresholds are relaxed so masks survive.
-usage: python tools/amg_bench.py [points_per_side] [tile] [vit] [stability_thresh] [stability_offset] [iters]"""
+"""Throughput of the automatic mask generator (BASELINE.json configs[4] shape: 64x64 point grid on a 2048^2 tile, SAM ViT-H;
+ULLSAM_FP8=1 switches the encoder's LayerNorm-fed linears to the fp8 (e4m3) MFMA path of that config).  Random-init weights:
+thresholds are relaxed so masks survive.
+usage: [ULLSAM_FP8=1] python tools/amg_bench.py [points_per_side] [tile] [vit] [stability_thresh] [stability_offset] [iters]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -18,6 +19,8 @@ if os.environ.get("ULLSAM_GEMM_VARIANT"):
     from ullsam_amd import _lib
     _lib.load().ullsam_set_gemm_variant(int(os.environ["ULLSAM_GEMM_VARIANT"]))
 sam = build_model(vit, "none", torch.bfloat16, "cuda:0")
+fp8 = os.environ.get("ULLSAM_FP8") == "1"
+sam.image_encoder.fp8_linears = fp8
 gen = SamAutomaticMaskGenerator(sam, points_per_side=side, points_per_batch=64, pred_iou_thresh=-1e9, stability_score_thresh=stab,
                                 stability_score_offset=off, box_nms_thresh=0.7, output_mode="uncompressed_rle")
 img = torch.from_numpy(np.random.default_rng(0).random((3, tile, tile), dtype=np.float32) * 255).cuda()
@@ -30,6 +33,6 @@ for it in range(iters):
     torch.cuda.synchronize(); t2 = time.perf_counter()
     if it:
         t_enc += t1 - t0; t_all += t2 - t1
-print(json.dumps({"workload": f"AMG {side}x{side} points on a {tile}^2 tile, SAM ViT-{vit.upper()}, bf16, 64 prompts/batch, multimask",
+print(json.dumps({"workload": f"AMG {side}x{side} points on a {tile}^2 tile, SAM ViT-{vit.upper()}, {'fp8 (e4m3) qkv/lin1 + bf16' if fp8 else 'bf16'}, 64 prompts/batch, multimask",
                   "seconds_per_tile": round(t_all / (iters - 1), 4), "encoder_seconds": round(t_enc / (iters - 1), 4), "prompts_per_s": round(side * side / (t_all / (iters - 1)), 1),
                   "masks_kept": len(recs)}))

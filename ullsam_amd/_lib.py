@@ -51,6 +51,8 @@ SIGNATURES = {
     "ullsam_amg_postprocess": [vp, vp, i64] + [i32] * 11 + [f32, f32, vp, vp, vp, vp, vp, vp],
     "ullsam_nms_mask": [vp, i32, f32, vp, vp],
     "ullsam_threshold_u8": [vp, vp, i64, f32, vp],
+    "ullsam_rows_fp8": [vp, i32, i64, vp, i64, vp, vp, vp, i64, i32, f32, vp],
+    "ullsam_gemm_fp8": [vp, i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, vp],
 }
 PLAIN = {"ullsam_last_error_string": ([], C.c_char_p), "ullsam_abi_version": ([], i32), "ullsam_device_count": ([], i32),
          "ullsam_set_gemm_variant": ([i32], i32), "ullsam_set_attn_variant": ([i32], i32),

@@ -44,6 +44,8 @@ struct GemmArgs {
     int full_tiles, ksplit;
     float* ws;
     size_t ws_bytes;
+    const float* row_scale;  // fp8 path: per-row scale of A (activation quantisation), per-column scale of W; null elsewhere
+    const float* col_scale;
     int store_nt;    // A/B: non-temporal output stores
     int late;        // v3 DMA lead (A/B): bit 0 = group 0 waits for its DMA at the end of C1 instead of L1, bit 1 = group 1 requests tile kt+2 at the end of its C1
     int skew_ticks;  // v4: start-time spread of the workgroups in s_memrealtime ticks (10 ns)
@@ -148,6 +150,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
             for (int e = 0; e < n_valid; ++e) bv[e] = p.bias[gn + e];
         }
     }
+    float cs[8];   // fp8 path: this thread's 8 column scales, fetched once like the bias
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = (p.col_scale && e < n_valid) ? p.col_scale[gn + e] : 0.f;
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
         const int row = pass * RPP + tid / TPR;
@@ -157,6 +162,11 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
         const float4 a = *reinterpret_cast<const float4*>(Cs + row * BN + c0);
         const float4 b = *reinterpret_cast<const float4*>(Cs + row * BN + c0 + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        if (p.row_scale) {  // fp8 operands: acc * scale_A[row] * scale_W[col]
+            const float rs = p.row_scale[gm];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= rs * cs[e];
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bv[e];
         if (p.act == 1) {
@@ -1137,6 +1147,154 @@ static int launch_gemm_v3(GemmArgs a, hipStream_t stream) {
     return launch_gemm_v3_impl<T, 1>(a, stream);                            // fp32 has one k-step per K-tile: no second segment pair
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) GEMM for the ViT's LayerNorm-fed linears (BASELINE configs[4], "fp8 MFMA ViT path"): the 256x256 staggered
+// kernel with v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; 2x the bf16 FLOP per clock).  A = activations quantised per
+// ROW by the preceding LayerNorm kernel (norm.hip: ullsam_norm_fp8), W = weights quantised per OUTPUT CHANNEL once; the epilogue
+// multiplies acc by scale_A[row] * scale_W[col] and continues as usual (bias, GELU, ...).  A K-tile is still 128 bytes per row
+// = 128 fp8 elements = ONE MFMA k-step; its 32 MFMAs per wave are issued as two segments of 16 (sub-tile rows 0-3 / 4-7).
+// Fragment: lane l holds row l & 15, k = 32 (l >> 4) .. +31 = two adjacent 16-byte chunks (checked with exact integer data:
+// tools/probes/fp8_mfma_layout.hip).  LDS swizzle for that access: chunk c of row r sits at c ^ f(r), f(r) = (r & 6) | ((r >> 3) & 1)
+// (the bf16 kernels' r & 7 would collide: lanes of one ds_read_b128 group differ by 2 in c here, not by 1).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+__device__ __forceinline__ int f8_swz(int row) { return (row & 6) | ((row >> 3) & 1); }
+__device__ __forceinline__ i32x8 lds_frag8(const char* tile, int row, int g) {
+    const int f = f8_swz(row);
+    const int4 lo = *reinterpret_cast<const int4*>(tile + row * 128 + (((2 * g) ^ f) << 4));
+    const int4 hi = *reinterpret_cast<const int4*>(tile + row * 128 + (((2 * g + 1) ^ f) << 4));
+    return (i32x8){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+}
+__global__ __launch_bounds__(512) void gemm256f8_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = 65536;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int GM = 4;
+    const int width = GM * p.tiles_n;
+    const int group = swz / width;
+    const int first_m = group * GM;
+    const int gsize = min(p.tiles_m - first_m, GM);
+    const int tm = first_m + (swz % width) % gsize;
+    const int tn = (swz % width) / gsize;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
+    const int g4 = lane >> 4, mm = lane & 15;
+
+    const char* a_base = reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda;   // 1 byte per element
+    const char* b_base = reinterpret_cast<const char*>(p.W) + (size_t)n0 * p.ldw;
+    unsigned int a_off[4], b_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ f8_swz(row);
+        a_off[i] = (unsigned int)((size_t)(min(m0 + row, p.M - 1) - m0) * p.lda) + (c << 4);
+        b_off[i] = (unsigned int)((size_t)(min(n0 + row, p.N - 1) - n0) * p.ldw) + (c << 4);
+    }
+    const int nk = p.K >> 7;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE;
+        const char* ak = a_base + (size_t)kt * 128;
+        const char* bk = b_base + (size_t)kt * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_off[i]), LDS_PTR(base + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + 32768 + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
+    };
+    const int one = 0x7f7f7f7f;  // E8M0 block scales of 2^0
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {   // slots L0 | C0 | L1 | C1 as in gemm256_kernel (same RAW / WAR argument)
+        const char* Ab = smem + (kt & 1) * STAGE;
+        const char* Bb = Ab + 32768;
+        i32x8 a[4], b[4];
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = lds_frag8(Bb, wn * 64 + j * 16 + mm, g4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = lds_frag8(Ab, wm * 128 + i * 16 + mm, g4);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j], acc[i][j], 0, 0, 0, one, 0, one);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = lds_frag8(Ab, wm * 128 + (4 + i) * 16 + mm, g4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j], acc[4 + i][j], 0, 0, 0, one, 0, one);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+
+    float* Cs = reinterpret_cast<float*>(smem);  // [128][256] fp32, one 128-row half at a time
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * g4 + r) * 256 + wn * 64 + j * 16 + mm] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (p.out_f32) epilogue_rows<bf16, float, 128, 512, 256>(p, Cs, m0 + half * 128, n0, tn, tid);
+        else epilogue_rows<bf16, bf16, 128, 512, 256>(p, Cs, m0 + half * 128, n0, tn, tid);
+    }
+}
+
+// A8 [M, lda] / W8 [N, ldw] e4m3 bytes, a_scale fp32 [M], w_scale fp32 [N]; C bf16 (or fp32) [M, ldc] = act(acc * a_scale * w_scale + bias) (+ residual)
+extern "C" int ullsam_gemm_fp8(const void* A8, long lda, const float* a_scale, const void* W8, long ldw, const float* w_scale, void* C,
+                               long ldc, int out_f32, const float* bias, const float* residual, long ldr, int act, int M, int N, int K,
+                               void* stream) {
+    ULLSAM_CHECK(M > 0 && N > 0 && K > 0 && K % 128 == 0, "ullsam_gemm_fp8: K=%d must be a positive multiple of 128", K);
+    ULLSAM_CHECK(((uintptr_t)A8 & 15) == 0 && ((uintptr_t)W8 & 15) == 0 && lda % 16 == 0 && ldw % 16 == 0, "ullsam_gemm_fp8: 16-byte aligned rows needed");
+    ULLSAM_CHECK(a_scale && w_scale, "ullsam_gemm_fp8: scales are required");
+    ULLSAM_CHECK(act >= 0 && act <= 2, "ullsam_gemm_fp8: bad act %d", act);
+    GemmArgs a;
+    a.A = A8; a.W = W8; a.C = C; a.bias = bias; a.residual = residual;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
+    a.res_row_mod = 0; a.act = act; a.out_f32 = out_f32;
+    const int osz = out_f32 ? 4 : 2;
+    bool vec = ((uintptr_t)C & 15) == 0 && (ldc * osz) % 16 == 0 && (N % 8 == 0);
+    if (residual) vec = vec && ((uintptr_t)residual & 15) == 0 && (ldr % 4 == 0);
+    a.vec_ok = vec ? 1 : 0;
+    a.ablate = 0; a.ws = nullptr; a.ws_bytes = 0; a.shift_edge = 0; a.skew_ticks = 0; a.store_nt = 0; a.late = 0; a.ksplit = 1;
+    a.row_scale = a_scale; a.col_scale = w_scale;
+    a.tiles_m = (M + 255) / 256; a.tiles_n = (N + 255) / 256; a.full_tiles = a.tiles_m * a.tiles_n;
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256f8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    gemm256f8_kernel<<<dim3(a.full_tiles), dim3(512), 131072, reinterpret_cast<hipStream_t>(stream)>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
 static int num_cus() {
     static int n[32] = {};
     int d = 0;
@@ -1469,6 +1627,8 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     a.ws_bytes = workspace ? (size_t)ws_bytes : 0;
     a.shift_edge = 0;
     a.skew_ticks = 0;
+    a.row_scale = nullptr;
+    a.col_scale = nullptr;
     a.store_nt = g_store_nt;
     a.late = g_late;
     a.ksplit = 1;

@@ -290,3 +290,90 @@ extern "C" int ullsam_norm(const void* in, int in_dtype, long in_stride, void* o
     if (in_dtype == 1 && out_dtype == 0) return launch_norm<bf16, float>(a, s);
     ULLSAM_CHECK(false, "ullsam_norm: bad dtypes %d %d", in_dtype, out_dtype);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) row quantisation for the fp8 ViT path (gemm.hip: gemm256f8_kernel): optional LayerNorm (the ViT's norm1 / norm2,
+// image_encoder.py:166,180) followed by a per-row scale = amax / 448 and a saturating round-to-nearest-even conversion.  One wave
+// per row, the row stays in registers between the passes.  The same kernel without the norm quantises weight rows (per output
+// channel scales), so activations and weights share one rounding.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename TI, int MAXV>
+__global__ __launch_bounds__(256) void rows_fp8_kernel(const TI* __restrict__ in, long in_stride, unsigned char* __restrict__ out, long out_stride,
+                                                      float* __restrict__ scale, const float* __restrict__ w, const float* __restrict__ b, long rows, int D,
+                                                      float eps, int do_norm) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const TI* x = in + row * in_stride;
+    const int nv = D >> 2;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = i * 64 + lane;
+        v[i] = idx < nv ? load4(x + idx * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    if (do_norm) {
+        const float mean = wave_sum(s) / (float)D;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (i * 64 + lane < nv) {
+                const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+                ss += (a * a + bb * bb) + (c * c + d * d);
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int idx = i * 64 + lane;
+            if (idx < nv) {
+                const float4 g = *reinterpret_cast<const float4*>(w + idx * 4), be = *reinterpret_cast<const float4*>(b + idx * 4);
+                v[i].x = (v[i].x - mean) * rstd * g.x + be.x; v[i].y = (v[i].y - mean) * rstd * g.y + be.y;
+                v[i].z = (v[i].z - mean) * rstd * g.z + be.z; v[i].w = (v[i].w - mean) * rstd * g.w + be.w;
+            }
+        }
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;   // e4m3: largest finite value 448
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+    unsigned int* y = reinterpret_cast<unsigned int*>(out + row * out_stride);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = i * 64 + lane;
+        if (idx < nv) {
+            const float q0 = fminf(fmaxf(v[i].x * inv, -448.f), 448.f), q1 = fminf(fmaxf(v[i].y * inv, -448.f), 448.f);
+            const float q2 = fminf(fmaxf(v[i].z * inv, -448.f), 448.f), q3 = fminf(fmaxf(v[i].w * inv, -448.f), 448.f);
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q0, q1, 0, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(q2, q3, pk, true);
+            y[idx] = (unsigned int)pk;
+        }
+    }
+}
+
+// in: fp32 / bf16 [rows, D] (in_dtype 0 / 1, row stride in elements); out: e4m3 bytes [rows, out_stride]; scale fp32 [rows];
+// w / b non-null: LayerNorm(eps) first (image_encoder.py:166,180), else plain quantisation (weights).
+extern "C" int ullsam_rows_fp8(const void* in, int in_dtype, long in_stride, void* out, long out_stride, float* scale, const float* w,
+                               const float* b, long rows, int D, float eps, void* stream) {
+    ULLSAM_CHECK(D % 4 == 0 && D <= 8192 && rows >= 0, "ullsam_rows_fp8: D=%d must be a multiple of 4, <= 8192", D);
+    ULLSAM_CHECK((w == nullptr) == (b == nullptr), "ullsam_rows_fp8: weight and bias go together");
+    ULLSAM_CHECK(out_stride % 4 == 0 && ((uintptr_t)out & 3) == 0, "ullsam_rows_fp8: output rows must be 4-byte aligned");
+    if (rows == 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    const int nv = D / 4, maxv = (nv + 63) / 64;
+    const int dn = w != nullptr;
+#define ULLSAM_RF8(TI, MV) rows_fp8_kernel<TI, MV><<<grid, 256, 0, s>>>(reinterpret_cast<const TI*>(in), in_stride, reinterpret_cast<unsigned char*>(out), out_stride, scale, w, b, rows, D, eps, dn)
+    if (in_dtype == ULLSAM_DT_F32) {
+        if (maxv <= 4) ULLSAM_RF8(float, 4); else if (maxv <= 8) ULLSAM_RF8(float, 8); else if (maxv <= 16) ULLSAM_RF8(float, 16); else ULLSAM_RF8(float, 32);
+    } else {
+        if (maxv <= 4) ULLSAM_RF8(bf16, 4); else if (maxv <= 8) ULLSAM_RF8(bf16, 8); else if (maxv <= 16) ULLSAM_RF8(bf16, 16); else ULLSAM_RF8(bf16, 32);
+    }
+#undef ULLSAM_RF8
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}

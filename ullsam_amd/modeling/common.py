@@ -72,6 +72,11 @@ class Linear(Packed):
     def b(self):
         return None if self.bias is None else self.f32("b", self.bias)
 
+    def w8(self):
+        """(e4m3 bytes [out, in], fp32 per-output-channel scales [out]) for the fp8 GEMM; quantised once per weight version."""
+        pair = self.pk("w8", self.weight, lambda: ops.rows_fp8(self.weight.detach().contiguous()))
+        return pair
+
     def tok(self, x: torch.Tensor, act: int = ops.ACT_NONE, res: Optional[torch.Tensor] = None) -> torch.Tensor:
         """fp32 token-side application (decoder tokens, hypernetwork / IoU MLPs): one wave per output for a handful of rows,
         the row-blocked kernel over the transposed weight from 64 rows up (many prompts)."""

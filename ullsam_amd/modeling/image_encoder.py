@@ -105,6 +105,10 @@ class ImageEncoderViT(Packed):
                                   _Conv2dParams(out_chans, out_chans, 3, bias=False), LayerNorm2d(out_chans))
         if not use_rel_pos:
             raise NotImplementedError("the HIP attention kernel implements SAM's use_rel_pos=True configuration")
+        # fp8 (OCP e4m3) operands for the LayerNorm-fed linears (qkv, lin1) of a bf16 model: BASELINE.json configs[4] "fp8 MFMA ViT path".
+        # Off by default (the headline metric is bf16); not part of the state_dict.  proj / lin2 stay bf16: their inputs are not
+        # row-normalised, a per-row scale would have to be found in the producing kernel's epilogue.
+        self.fp8_linears = False
 
     @property
     def compute_dtype(self) -> torch.dtype:
@@ -126,16 +130,25 @@ class ImageEncoderViT(Packed):
         wp = self.pk("patch_w", pe.weight, lambda: pe.weight.detach().reshape(D, -1).to(dt).contiguous())
         pos = None if self.pos_embed is None else self.f32("pos", self.pos_embed).reshape(N, D)
         xres = ops.gemm(cols, wp, None if pe.bias is None else self.f32("patch_b", pe.bias), residual=pos, res_row_mod=N, out_f32=True)
+        fp8 = bool(self.fp8_linears) and dt == torch.bfloat16 and D % 128 == 0
         for blk in self.blocks:
             at = blk.attn
-            xn = ops.norm(xres, *blk.norm1.wb(), blk.norm1.eps, dt)
-            qkv = ops.gemm(xn, at.qkv.w(dt), at.qkv.b())
+            if fp8:
+                q8, sa = ops.rows_fp8(xres, *blk.norm1.wb(), blk.norm1.eps)
+                qkv = ops.gemm_fp8(q8, sa, *at.qkv.w8(), at.qkv.b())
+            else:
+                xn = ops.norm(xres, *blk.norm1.wb(), blk.norm1.eps, dt)
+                qkv = ops.gemm(xn, at.qkv.w(dt), at.qkv.b())
             qb = at.qkv.bias if at.qkv.bias is not None else torch.zeros(3 * D, device=x.device)
             att = ops.vit_attention(qkv, at.cdt("rh", at.rel_pos_h, dt), at.cdt("rw", at.rel_pos_w, dt), at.cdt("qb", qb, dt),
                                     B, self.num_heads, at.head_dim, g, g, blk.window_size)
             ops.gemm(att, at.proj.w(dt), at.proj.b(), residual=xres, out_f32=True, out=xres)
-            xn = ops.norm(xres, *blk.norm2.wb(), blk.norm2.eps, dt)
-            h = ops.gemm(xn, blk.mlp.lin1.w(dt), blk.mlp.lin1.b(), act=blk.mlp.act_code)
+            if fp8:
+                q8, sa = ops.rows_fp8(xres, *blk.norm2.wb(), blk.norm2.eps)
+                h = ops.gemm_fp8(q8, sa, *blk.mlp.lin1.w8(), blk.mlp.lin1.b(), act=blk.mlp.act_code)
+            else:
+                xn = ops.norm(xres, *blk.norm2.wb(), blk.norm2.eps, dt)
+                h = ops.gemm(xn, blk.mlp.lin1.w(dt), blk.mlp.lin1.b(), act=blk.mlp.act_code)
             ops.gemm(h, blk.mlp.lin2.w(dt), blk.mlp.lin2.b(), residual=xres, out_f32=True, out=xres)
         n0, n1, n2, n3 = self.neck[0], self.neck[1], self.neck[2], self.neck[3]
         C = self.out_chans

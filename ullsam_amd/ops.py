@@ -83,6 +83,39 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def rows_fp8(x: torch.Tensor, ln_w: Optional[torch.Tensor] = None, ln_b: Optional[torch.Tensor] = None, eps: float = 0.0):
+    """(optional LayerNorm, then) per-row e4m3 quantisation: x fp32 / bf16 [rows, D] -> (uint8 [rows, D] holding e4m3 bytes, fp32 scales [rows])."""
+    _chk(x, "x")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    q = torch.empty((rows, D), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    if ln_w is not None:
+        _chk(ln_w, "ln_w", torch.float32); _chk(ln_b, "ln_b", torch.float32)
+    _lib.call("ullsam_rows_fp8", x.data_ptr(), dt_code(x.dtype), D, q.data_ptr(), D, sc.data_ptr(), _p(ln_w), _p(ln_b), rows, D, float(eps), _stream())
+    return q, sc
+
+
+def gemm_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor] = None,
+             act: int = ACT_NONE, out_dtype: torch.dtype = torch.bfloat16, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N] = act((a8 @ w8^T) * a_scale[:, None] * w_scale[None, :] + bias) (+ residual); a8 / w8 are e4m3 bytes."""
+    _chk(a8, "a8", torch.uint8); _chk(w8, "w8", torch.uint8); _chk(a_scale, "a_scale", torch.float32); _chk(w_scale, "w_scale", torch.float32)
+    M, K = a8.shape
+    N = w8.shape[0]
+    assert w8.shape[1] == K and a_scale.numel() == M and w_scale.numel() == N
+    out_f32 = out_dtype == torch.float32
+    out = torch.empty((M, N), dtype=out_dtype, device=a8.device)
+    if bias is not None:
+        _chk(bias, "bias", torch.float32)
+    ldr = 0
+    if residual is not None:
+        _chk(residual, "residual", torch.float32)
+        ldr = residual.shape[-1]
+    _lib.call("ullsam_gemm_fp8", a8.data_ptr(), K, a_scale.data_ptr(), w8.data_ptr(), K, w_scale.data_ptr(), out.data_ptr(), N, int(out_f32),
+              _p(bias), _p(residual), ldr, act, M, N, K, _stream())
+    return out
+
+
 def norm(x: torch.Tensor, w: Optional[torch.Tensor], b: Optional[torch.Tensor], eps: float, out_dtype: torch.dtype,
          rms: bool = False, act: int = ACT_NONE, post_scale: Optional[torch.Tensor] = None,
          post_shift: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
