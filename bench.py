@@ -206,12 +206,16 @@ def mask_iou_vs_fp32(model, vit, llm, inputs, device):
         low_f, mk_f = make_step(m32, (x32.to(torch.bfloat16).float(), pts, lbl, ids), torch.float32, 1, gather=False)()
         iou = ops.mask_iou(mk_b.contiguous(), mk_f.contiguous()).cpu().numpy()
         d = (low_b.float() - low_f.float()).abs().max().item()
+        dm = (low_b.float() - low_f.float()).abs().mean().item()
         sc = low_f.float().abs().max().item()
+        scm = low_f.float().abs().mean().item()
         frac = [float(m.float().mean().item()) for m in mk_f]
     del m32
     torch.cuda.empty_cache()
     return {"mean": round(float(iou.mean()), 6), "min": round(float(iou.min()), 6), "images": int(iou.size),
             "low_res_logit_max_abs_diff": round(d, 4), "low_res_logit_absmax": round(sc, 3),
+            "low_res_logit_mean_abs_diff": round(dm, 5), "low_res_logit_mean_abs": round(scm, 4),
+            "note": "random-init weights give logits with almost no margin (mean |logit| above), so pixels within the bf16 error of zero flip; the tests gate IoU on the reference-generated fixtures",
             "fp32_mask_fill_fraction": [round(f, 4) for f in frac],
             "reference": "same random weights + inputs through the fp32 mode of this library (pinned to the reference within 1e-3 / IoU delta < 1e-4 by tests/)"}
 

@@ -44,6 +44,13 @@ int ullsam_gemm(int dtype, const void* A, long lda, const void* W, long ldw, voi
                 const float* bias, const float* residual, long ldr, int res_row_mod, int act, int M, int N, int K,
                 void* workspace, long ws_bytes, void* stream);
 
+/* InternLM2Attention's wqkv projection with `rearrange 'b q (h gs d)'`, apply_rotary_pos_emb and the KV-cache append in the GEMM
+ * epilogue (modeling_internlm2.py:359-388, 233-247): q_out T [B*S, KVH*G*128] rotated, k_cache (rotated) / v_cache T [B, KVH, cap, 128]
+ * rows cache_pos0..cache_pos0+S-1; pos int32 [B*S] rows of the fp32 cos / sin tables [tab_rows, 128] (clamped).  head_dim = 128. */
+int ullsam_gemm_qkv_rope(int dtype, const void* A, long lda, const void* W, long ldw, const float* bias, int B, int S, int K, int KVH,
+                         int G, const int* pos, const float* cos_tab, const float* sin_tab, int tab_rows, void* q_out, void* k_cache,
+                         void* v_cache, int cap, int cache_pos0, void* workspace, long ws_bytes, void* stream);
+
 /* Row LayerNorm / RMSNorm, fp32 statistics.  image_encoder.py:151,161; common.py:38-43 (LayerNorm2d on NHWC rows);
  * modeling_internlm2.py:138-143 (rms=1); prompt_encoder.py:142-149 (no affine + post scale/shift); transformer.py norms. */
 int ullsam_norm(const void* in, int in_dtype, long in_stride, void* out, int out_dtype, long out_stride, const float* w,

@@ -315,6 +315,41 @@ def test_rope_and_causal_attention(ops, dtype, B, S, H, KVH, pad):
     assert err(got[valid], ref[valid]) < (2e-4 if dtype == torch.float32 else 4e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S,KVH,G,K,bias", [(2, 70, 1, 2, 256, False), (1, 1081, 2, 4, 512, True), (4, 300, 8, 4, 256, False)])
+def test_wqkv_gemm_with_rope_epilogue(ops, dtype, B, S, KVH, G, K, bias):
+    """wqkv projection with the head split, RoPE and the KV-cache append fused into the GEMM epilogue (modeling_internlm2.py:359-388)
+    against the two-kernel path (GEMM, then rope_split) and against numpy: covers the 128x128 and 256x256 kernels and the split tail."""
+    hd = 128
+    rng = np.random.default_rng(S + K)
+    x = rng.standard_normal((B * S, K), dtype=np.float32)
+    w = (rng.standard_normal((KVH * (G + 2) * hd, K), dtype=np.float32) / math.sqrt(K)).astype(np.float32)
+    bv = rng.standard_normal(w.shape[0], dtype=np.float32) * 0.2 if bias else None
+    pos = (np.arange(S, dtype=np.int32)[None] + np.arange(B, dtype=np.int32)[:, None] * 3) % (S + 5)   # per-sequence offsets
+    cos, sin = O.rope_tables(hd, S + 8, 1e6)
+    xd, wd = T(x, dtype), T(w, dtype)
+    cap, p0 = S + 6, 2
+    kc = torch.zeros((B, KVH, cap, hd), dtype=dtype, device=DEV); vc = torch.zeros_like(kc)
+    q = ops.gemm_qkv_rope(xd, wd, None if bv is None else T(bv), kc, vc, T(pos, torch.int32), T(cos), T(sin), B, S, KVH, G, p0)
+    kc2 = torch.zeros_like(kc); vc2 = torch.zeros_like(kc)
+    qkv = ops.gemm(xd, wd, None if bv is None else T(bv))
+    q2 = ops.rope_split(qkv, kc2, vc2, T(pos, torch.int32), T(cos), T(sin), B, S, KVH, G, hd, p0)
+    # numpy reference from the operands as the kernel sees them
+    r = (xd.float().cpu().numpy() @ wd.float().cpu().numpy().T + (0 if bv is None else bv)).reshape(B, S, KVH, G + 2, hd)
+    c, s_ = cos[pos][:, :, None, None, :], sin[pos][:, :, None, None, :]
+    rot = r * c + O._rotate_half(r) * s_
+    q_ref = rot[..., :G, :].reshape(B * S, KVH * G * hd)
+    k_ref = rot[..., G, :].transpose(0, 2, 1, 3)
+    v_ref = r[..., G + 1, :].transpose(0, 2, 1, 3)
+    tol = 2e-4 if dtype == torch.float32 else 4e-2
+    assert err(q.float().cpu().numpy(), q_ref) < tol
+    assert err(kc[:, :, p0:p0 + S].float().cpu().numpy(), k_ref) < tol and err(vc[:, :, p0:p0 + S].float().cpu().numpy(), v_ref) < tol
+    assert float(kc[:, :, :p0].abs().max()) == 0 and float(kc[:, :, p0 + S:].abs().max()) == 0      # nothing outside the appended rows
+    # the fused epilogue rotates the fp32 accumulators, the two-kernel path rotates values already rounded to the model dtype
+    assert err(q.float().cpu().numpy(), q2.float().cpu().numpy()) < (1e-5 if dtype == torch.float32 else 4e-2)
+    assert err(kc.float().cpu().numpy(), kc2.float().cpu().numpy()) < (1e-5 if dtype == torch.float32 else 4e-2)
+
+
 def test_naive_and_fewkeys_attention(ops):
     rng = np.random.default_rng(0)
     B, H, hd, Sq, Sk = 2, 8, 16, 7, 300

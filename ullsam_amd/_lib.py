@@ -17,6 +17,7 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
 # name -> argtypes, exactly mirroring include/ullsam_hip.h
 SIGNATURES = {
     "ullsam_gemm": [i32, vp, i64, vp, i64, vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, i32, vp, i64, vp],
+    "ullsam_gemm_qkv_rope": [i32, vp, i64, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, i64, vp],
     "ullsam_norm": [vp, i32, i64, vp, i32, i64, vp, vp, i64, i32, f32, i32, i32, vp, vp, vp],
     "ullsam_norm_fanout": [vp, i64, i32, vp, vp, f32, vp, vp, vp, i32, vp, i64, vp],
     "ullsam_vit_attention": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],

@@ -44,6 +44,9 @@ struct GemmArgs {
     int full_tiles, ksplit;
     float* ws;
     size_t ws_bytes;
+    // act == 4: wqkv epilogue = de-interleave + RoPE + KV-cache append (modeling_internlm2.py:361-388, 233-247) instead of a plain store
+    const int* rope_pos; const float* rope_cos; const float* rope_sin; void* rope_q; void* rope_k; void* rope_v;
+    int rope_S, rope_KVH, rope_G, rope_cap, rope_pos0, rope_rows;
     const float* row_scale;  // fp8 path: per-row scale of A (activation quantisation), per-column scale of W; null elsewhere
     const float* col_scale;
     int store_nt;    // A/B: non-temporal output stores
@@ -130,6 +133,68 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
                 dst[0] = from_f32<OutT>(o.x); dst[1] = from_f32<OutT>(o.y);
                 dst[2] = from_f32<OutT>(o.z); dst[3] = from_f32<OutT>(o.w);
             }
+        }
+        return;
+    }
+    if (p.act == 4) {
+        // wqkv: columns are (kv head, [G query heads | k | v], 128).  This thread's 8 columns sit in one 128-wide slot of the tile; the
+        // rotate_half partner of column d is d +- 64 in the same slot = the same Cs row.  q -> q_out [tok, H*128], k / v -> caches
+        // [B, KVH, cap, 128] at cache_pos0 + s; cos / sin rows by position id (clamped to the table), fp32 arithmetic as rope_split_kernel.
+        const int c0 = (tid % TPR) * 8;
+        const int gn = n0 + c0;
+        const int slot = gn >> 7, d = gn & 127;
+        const int gs = p.rope_G + 2, kv = slot / gs, g = slot - kv * gs;
+        const int pc = d < 64 ? c0 + 64 : c0 - 64;   // partner columns in the tile
+        float bx[8], bp[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bx[e] = p.bias ? p.bias[gn + e] : 0.f; bp[e] = p.bias ? p.bias[gn + (pc - c0) + e] : 0.f; }
+        T* Q = reinterpret_cast<T*>(p.rope_q);
+        T* Kc = reinterpret_cast<T*>(p.rope_k);
+        T* Vc = reinterpret_cast<T*>(p.rope_v);
+        const bool rotate = g != gs - 1;
+        // position ids of all passes first (independent loads), then the cos / sin rows one pass ahead of their use
+        int ps[PASSES];
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass) {
+            const int gm = m0 + pass * RPP + tid / TPR;
+            ps[pass] = (rotate && gm < p.M) ? min(max(p.rope_pos[gm], 0), p.rope_rows - 1) : 0;
+        }
+        float4 cn[2], sn[2];
+        auto load_cs = [&](int pass, float4 (&c)[2], float4 (&s_)[2]) {
+            const float* cp = p.rope_cos + (size_t)ps[pass] * 128 + d;
+            const float* sp = p.rope_sin + (size_t)ps[pass] * 128 + d;
+            c[0] = *reinterpret_cast<const float4*>(cp); c[1] = *reinterpret_cast<const float4*>(cp + 4);
+            s_[0] = *reinterpret_cast<const float4*>(sp); s_[1] = *reinterpret_cast<const float4*>(sp + 4);
+        };
+        if (rotate) load_cs(0, cn, sn);
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass) {
+            const int row = pass * RPP + tid / TPR;
+            const int gm = m0 + row;
+            float4 cc[2] = {cn[0], cn[1]}, ss[2] = {sn[0], sn[1]};
+            if (rotate && pass + 1 < PASSES) load_cs(pass + 1, cn, sn);
+            if (gm >= p.M || gm < m_lo) continue;
+            float x[8], y[8], o[8];
+            const float4 xa = *reinterpret_cast<const float4*>(Cs + row * BN + c0), xb = *reinterpret_cast<const float4*>(Cs + row * BN + c0 + 4);
+            const float4 ya = *reinterpret_cast<const float4*>(Cs + row * BN + pc), yb = *reinterpret_cast<const float4*>(Cs + row * BN + pc + 4);
+            x[0] = xa.x; x[1] = xa.y; x[2] = xa.z; x[3] = xa.w; x[4] = xb.x; x[5] = xb.y; x[6] = xb.z; x[7] = xb.w;
+            y[0] = ya.x; y[1] = ya.y; y[2] = ya.z; y[3] = ya.w; y[4] = yb.x; y[5] = yb.y; y[6] = yb.z; y[7] = yb.w;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { x[e] += bx[e]; y[e] += bp[e]; }
+            const int b = gm / p.rope_S, sq = gm - b * p.rope_S;
+            if (!rotate) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = x[e];
+            } else {
+                const float cv[8] = {cc[0].x, cc[0].y, cc[0].z, cc[0].w, cc[1].x, cc[1].y, cc[1].z, cc[1].w};
+                const float sv[8] = {ss[0].x, ss[0].y, ss[0].z, ss[0].w, ss[1].x, ss[1].y, ss[1].z, ss[1].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = d < 64 ? x[e] * cv[e] - y[e] * sv[e] : x[e] * cv[e] + y[e] * sv[e];
+            }
+            T* dst;
+            if (g < p.rope_G) dst = Q + (size_t)gm * ((size_t)p.rope_KVH * p.rope_G * 128) + (size_t)(kv * p.rope_G + g) * 128 + d;
+            else dst = (g == gs - 2 ? Kc : Vc) + (((size_t)b * p.rope_KVH + kv) * p.rope_cap + p.rope_pos0 + sq) * 128 + d;
+            store_row8<T>(dst, o, 8, true);
         }
         return;
     }
@@ -1600,9 +1665,11 @@ static int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     return 0;
 }
 
-extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, long ldw, void* C, long ldc, int out_f32,
-                           const float* bias, const float* residual, long ldr, int res_row_mod, int act, int M, int N,
-                           int K, void* workspace, long ws_bytes, void* stream) {
+struct RopeEpilogue { const int* pos; const float* cos; const float* sin; void* q; void* k; void* v; int S, KVH, G, cap, pos0, rows; };
+
+static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw, void* C, long ldc, int out_f32,
+                     const float* bias, const float* residual, long ldr, int res_row_mod, int act, int M, int N,
+                     int K, void* workspace, long ws_bytes, void* stream, const RopeEpilogue* rope) {
     ULLSAM_CHECK(dtype == ULLSAM_DT_F32 || dtype == ULLSAM_DT_BF16, "ullsam_gemm: bad dtype %d", dtype);
     ULLSAM_CHECK(M > 0 && N > 0 && K > 0, "ullsam_gemm: empty problem M=%d N=%d K=%d", M, N, K);
     const int esz = dtype == ULLSAM_DT_F32 ? 4 : 2;
@@ -1610,9 +1677,15 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     ULLSAM_CHECK(K % bk == 0, "ullsam_gemm: K=%d must be a multiple of %d", K, bk);
     ULLSAM_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "ullsam_gemm: A/W must be 16-byte aligned");
     ULLSAM_CHECK((lda * esz) % 16 == 0 && (ldw * esz) % 16 == 0, "ullsam_gemm: lda/ldw rows must be 16-byte multiples");
-    ULLSAM_CHECK(act >= 0 && act <= 3, "ullsam_gemm: bad act %d", act);
+    ULLSAM_CHECK(act >= 0 && act <= 4 && (act == 4) == (rope != nullptr), "ullsam_gemm: bad act %d", act);
     if (act == 3) ULLSAM_CHECK(N % 128 == 0 && !bias && !residual, "ullsam_gemm: swiglu needs N%%128==0, no bias/residual");
     GemmArgs a;
+    a.rope_pos = nullptr; a.rope_cos = a.rope_sin = nullptr; a.rope_q = a.rope_k = a.rope_v = nullptr;
+    a.rope_S = a.rope_KVH = a.rope_G = a.rope_cap = a.rope_pos0 = a.rope_rows = 0;
+    if (rope) {
+        a.rope_pos = rope->pos; a.rope_cos = rope->cos; a.rope_sin = rope->sin; a.rope_q = rope->q; a.rope_k = rope->k; a.rope_v = rope->v;
+        a.rope_S = rope->S; a.rope_KVH = rope->KVH; a.rope_G = rope->G; a.rope_cap = rope->cap; a.rope_pos0 = rope->pos0; a.rope_rows = rope->rows;
+    }
     a.A = A; a.W = W; a.C = C; a.bias = bias; a.residual = residual;
     a.M = M; a.N = N; a.K = K;
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
@@ -1638,10 +1711,10 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int variant = g_gemm_variant;
     // decode step: a handful of rows against the whole weight matrix
-    if (variant == 0 && dtype == ULLSAM_DT_BF16 && M <= 8 && K % 512 == 0 && lda % 8 == 0 && ldw % 8 == 0 &&
+    if (variant == 0 && act != 4 && dtype == ULLSAM_DT_BF16 && M <= 8 && K % 512 == 0 && lda % 8 == 0 && ldw % 8 == 0 &&
         (size_t)(M <= 4 ? 4 : 8) * K * 2 <= 144 * 1024 && (act != 3 || N % 128 == 0))
         return launch_gemm_skinny(a, s);
-    const bool v2 = variant == 2;  // the 256x128 ring is never picked automatically (slower than the 256x256 kernel on every shape)
+    const bool v2 = variant == 2 && act != 4;  // the 256x128 ring is never picked automatically (slower than the 256x256 kernel on every shape)
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     // 256x256 tiles run one per CU: use them when the last wave of tiles is >= 74 % full (measured crossover, tools/gemm_bench.py:
     // 408 / 960 / 1280 / 1904 tiles win, 272 / 320 lose to the 128x128 kernel's finer granularity)
@@ -1650,7 +1723,7 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     const bool v3_split = g_split_tail && workspace && t256 > 256 && tail256 > 0 && tail256 <= 64 && K >= 64 * bk;  // see launch_gemm_v3_impl
     const bool v3 = variant == 3 || (variant == 0 && M >= 1024 && N >= 256 && K >= 8 * bk && (fill >= 0.74 || v3_split) && (act != 3 || N % 256 == 0));  // short K / narrow N: the 256^2 tile's fixed cost or its empty half dominates
     if (act == 3 && (variant == 3) && N % 256 != 0) { ullsam_set_error("ullsam_gemm: v3 swiglu needs N%%256==0"); return -1; }
-    if (variant == 4) {
+    if (variant == 4 && act != 4) {
         if (!v4_ok(a, dtype)) { ullsam_set_error("ullsam_gemm: the persistent kernel needs bf16, N%%256==0, K%%64==0, K>=512, 16-byte aligned rows"); return -1; }
         return launch_gemm_v4(a, s);
     }
@@ -1660,4 +1733,25 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
     if (v3) return dtype == ULLSAM_DT_F32 ? launch_gemm_v3<float>(a, s) : launch_gemm_v3<bf16>(a, s);
     if (v2) return dtype == ULLSAM_DT_F32 ? launch_gemm_v2<float>(a, s) : launch_gemm_v2<bf16>(a, s);
     return dtype == ULLSAM_DT_F32 ? launch_gemm<float>(a, s) : launch_gemm<bf16>(a, s);
+}
+
+extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, long ldw, void* C, long ldc, int out_f32,
+                           const float* bias, const float* residual, long ldr, int res_row_mod, int act, int M, int N,
+                           int K, void* workspace, long ws_bytes, void* stream) {
+    ULLSAM_CHECK(act != 4, "ullsam_gemm: act 4 is ullsam_gemm_qkv_rope");
+    return gemm_impl(dtype, A, lda, W, ldw, C, ldc, out_f32, bias, residual, ldr, res_row_mod, act, M, N, K, workspace, ws_bytes, stream, nullptr);
+}
+
+// wqkv GEMM of InternLM2Attention with the head split, RoPE and the KV-cache append in its epilogue (modeling_internlm2.py:359-388):
+// x [B*S, K] . wqkv [(KVH*(G+2))*128, K]^T (+bias)  ->  q_out T [B*S, KVH*G*128] (rotated), k_cache / v_cache T [B, KVH, cap, 128]
+// rows cache_pos0 .. cache_pos0+S-1 (k rotated).  head_dim is 128 (the tile holds whole heads); the qkv tensor never exists.
+extern "C" int ullsam_gemm_qkv_rope(int dtype, const void* A, long lda, const void* W, long ldw, const float* bias, int B, int S, int K,
+                                    int KVH, int G, const int* pos, const float* cos_tab, const float* sin_tab, int tab_rows, void* q_out,
+                                    void* k_cache, void* v_cache, int cap, int cache_pos0, void* workspace, long ws_bytes, void* stream) {
+    ULLSAM_CHECK(B > 0 && S > 0 && KVH > 0 && G > 0 && tab_rows > 0, "ullsam_gemm_qkv_rope: bad dims");
+    ULLSAM_CHECK(cache_pos0 + S <= cap, "ullsam_gemm_qkv_rope: cache overflow (%d + %d > %d)", cache_pos0, S, cap);
+    ULLSAM_CHECK(((uintptr_t)q_out & 15) == 0 && ((uintptr_t)k_cache & 15) == 0 && ((uintptr_t)v_cache & 15) == 0, "ullsam_gemm_qkv_rope: 16-byte aligned outputs needed");
+    RopeEpilogue r{pos, cos_tab, sin_tab, q_out, k_cache, v_cache, S, KVH, G, cap, cache_pos0, tab_rows};
+    const int N = KVH * (G + 2) * 128;
+    return gemm_impl(dtype, A, lda, W, ldw, q_out, (long)KVH * G * 128, 0, bias, nullptr, 0, 0, 4, B * S, N, K, workspace, ws_bytes, stream, &r);
 }

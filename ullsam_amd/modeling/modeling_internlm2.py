@@ -177,9 +177,12 @@ class InternLM2Model(Packed):
                 collect.append(x.reshape(B, S, -1).to(dt))
             at, ff = layer.attention, layer.feed_forward
             xn = ops.norm(x, layer.attention_norm.w(), None, layer.attention_norm.variance_epsilon, dt, rms=True)
-            qkv = ops.gemm(xn, at.wqkv.w(dt), at.wqkv.b())
             kc, vc = (cache.k[li], cache.v[li]) if cache is not None else (tmp_k, tmp_v)
-            q = ops.rope_split(qkv, kc, vc, pos, cos, sin, B, S, KVH, G, hd, past)
+            if hd == 128 and S > 8:   # prefill: head split + RoPE + KV append in the wqkv GEMM's epilogue (no qkv round trip)
+                q = ops.gemm_qkv_rope(xn, at.wqkv.w(dt), at.wqkv.b(), kc, vc, pos, cos, sin, B, S, KVH, G, past)
+            else:
+                qkv = ops.gemm(xn, at.wqkv.w(dt), at.wqkv.b())
+                q = ops.rope_split(qkv, kc, vc, pos, cos, sin, B, S, KVH, G, hd, past)
             if S > 1:
                 a = ops.causal_attention(q, kc, vc, key_mask, B, H, KVH, hd, S, Sk, past)
             elif dt == torch.bfloat16 and hd == 128 and G <= 8:  # decode step: streaming split-K kernel over the cache

@@ -330,6 +330,23 @@ def rope_split(qkv, k_cache, v_cache, pos, cos_tab, sin_tab, B, S, KVH, G, hd, c
     return q
 
 
+def gemm_qkv_rope(x: torch.Tensor, wqkv: torch.Tensor, bias: Optional[torch.Tensor], k_cache, v_cache, pos, cos_tab, sin_tab, B, S, KVH, G,
+                  cache_pos0) -> torch.Tensor:
+    """q = rope(split(x @ wqkv^T + bias)) with k (rotated) / v appended to the caches, all in the GEMM's epilogue (head_dim 128)."""
+    _chk(x, "x"); _chk(wqkv, "wqkv", x.dtype); _chk(pos, "position_ids", torch.int32); _chk(cos_tab, "cos", torch.float32); _chk(sin_tab, "sin", torch.float32)
+    _chk(k_cache, "k_cache", x.dtype); _chk(v_cache, "v_cache", x.dtype)
+    K = x.shape[1]
+    assert wqkv.shape == (KVH * (G + 2) * 128, K) and x.shape[0] == B * S and cos_tab.shape[1] == 128
+    if bias is not None:
+        _chk(bias, "bias", torch.float32)
+    q = torch.empty((B * S, KVH * G * 128), dtype=x.dtype, device=x.device)
+    ws = _gemm_workspace(x.device)
+    _lib.call("ullsam_gemm_qkv_rope", dt_code(x.dtype), x.data_ptr(), K, wqkv.data_ptr(), K, _p(bias), B, S, K, KVH, G, pos.data_ptr(),
+              cos_tab.data_ptr(), sin_tab.data_ptr(), cos_tab.shape[0], q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_cache.shape[2],
+              cache_pos0, ws.data_ptr(), ws.numel(), _stream())
+    return q
+
+
 def argmax(logits: torch.Tensor) -> torch.Tensor:
     _chk(logits, "logits", torch.float32)
     R, V = logits.shape
