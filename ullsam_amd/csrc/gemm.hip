@@ -49,6 +49,7 @@ struct GemmArgs {
     int rope_S, rope_KVH, rope_G, rope_cap, rope_pos0, rope_rows;
     const float* row_scale;  // fp8 path: per-row scale of A (activation quantisation), per-column scale of W; null elsewhere
     const float* col_scale;
+    unsigned long long* dbg;  // diagnostic build path only (variant bit 15): s_memtime stamps of the persistent kernel's unit boundaries
     int store_nt;    // A/B: non-temporal output stores
     int late;        // v3 DMA lead (A/B): bit 0 = group 0 waits for its DMA at the end of C1 instead of L1, bit 1 = group 1 requests tile kt+2 at the end of its C1
     int skew_ticks;  // v4: start-time spread of the workgroups in s_memrealtime ticks (10 ns)
@@ -60,6 +61,8 @@ static int g_gemm_variant = 0; // bits 0-3: 0 auto, 1 = 128x128, 2 = 256x128 rin
 static int g_gemm_ablate = 0;  // timing-only ablations: bit0 no in-loop staging, bit1 no barrier (outputs are garbage)
 static int g_persistent = 1;   // ullsam_set_gemm_variant(v | 128): keep the non-persistent 256x256 kernel in auto mode (A/B)
 static int g_skew_half_us = 0;  // ullsam_set_gemm_variant bits 16-23: v4 start-time spread in units of 0.5 us (A/B)
+static int g_store_v4 = 0;     // store policy of the persistent kernel (ullsam_set_gemm_variant bits 29-31; A/B)
+static int g_dbg = 0;          // ullsam_set_gemm_variant bit 15: stamp the persistent kernel (tools/gemm_stamps.py reads them from the workspace)
 static int g_late = 0;         // ullsam_set_gemm_variant bits 24-25 (A/B of the v3 DMA lead)
 static int g_store_nt = 1;     // non-temporal bf16 output stores in the non-persistent kernels (same-process A/B: vit.qkv -3.4 %, vit.lin1 -3.6 %, llm.w13 -0.9 %);
                                // ullsam_set_gemm_variant bit 14 turns them off (A/B)
@@ -105,6 +108,18 @@ __device__ __forceinline__ void store_row8<bf16>(bf16* dst, const float* v, int 
     } else {
         for (int e = 0; e < n_valid; ++e) dst[e] = (bf16)v[e];
     }
+}
+
+
+// 16-byte global store with a cache policy (A/B of the output write path; p.store_nt carries the code):
+//   0 plain (write-back: dirty lines pile up in the XCD L2s and are flushed at the END of the kernel)   1 nt   2 sc1   3 sc0 sc1   4 sc0 sc1 nt
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
+__device__ __forceinline__ void store16_policy(void* ptr, u32x4s v, int policy) {
+    if (policy == 0) *reinterpret_cast<u32x4s*>(ptr) = v;
+    else if (policy == 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4s*>(ptr));
+    else if (policy == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+    else if (policy == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 }
 
 template <typename T, typename OutT, int BM, int NTHREADS, int BN = 128>
@@ -258,7 +273,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
             bf16x8_t o8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o8[e] = (bf16)v[e];
-            __builtin_nontemporal_store(o8, reinterpret_cast<bf16x8_t*>(C + (size_t)gm * p.ldc + gn));
+            store16_policy(C + (size_t)gm * p.ldc + gn, __builtin_bit_cast(u32x4s, o8), p.store_nt);
         } else
         store_row8<OutT>(C + (size_t)gm * p.ldc + gn, v, n_valid, p.vec_ok != 0);
     }
@@ -843,10 +858,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p) {
     const int G = gridDim.x;
     const int nk_all = p.K >> 6;
     const bool nostore = (p.ablate & 8) != 0;   // timing-only: everything but the global stores
-    const bool store_nt = p.store_nt != 0;
     auto gst = [&](void* ptr, u32x4 v) {
         if (nostore && v[0] != 0x9E3779B9u) return;
-        if (store_nt) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(ptr)); else gstore16(ptr, v);  // (nt measured slower here: the launcher leaves it off)
+        store16_policy(ptr, v, p.store_nt);
     };
     const int n_units = p.full_tiles + (p.tiles_m * p.tiles_n - p.full_tiles) * p.ksplit;
     // position inside a round of G units: workgroups b, b+8, ... share an XCD (round-robin dispatch; speed only) -> give them
@@ -943,6 +957,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p) {
         const unsigned long long wait = (unsigned long long)p.skew_ticks * (unsigned)(li * 8 + xcd) / (unsigned)G;
         while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(4);
     }
+    // diagnostic stamps (p.dbg != null only in the stamped A/B mode): [workgroup][group][unit < 4][16] shader-clock values
+    auto stamp = [&](int unit, int kk) {
+        if (p.dbg && (tid & 255) == 0 && unit < 4) p.dbg[(((size_t)blockIdx.x * 2 + grp) * 4 + unit) * 16 + kk] = __builtin_amdgcn_s_memtime();
+    };
+    if (p.dbg && (tid & 255) == 0) p.dbg[(((size_t)blockIdx.x * 2 + grp) * 4 + 0) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
     f32x4 acc[8][4];
     int round = 0;
     UnitPos cur = unit_at(0);
@@ -979,6 +998,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p) {
             for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + mm, 0, g4);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+            if (kt == cur.kt0) stamp(round, 3);
             // ---- C0
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -997,6 +1017,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p) {
             else if (wcnt == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else if (wcnt == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            if (kt == cur.kt0) stamp(round, 4); else if (kt == cur.kt0 + 1) stamp(round, 6); else if (kt == cur.kt0 + 2) stamp(round, 8);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             // ---- C1
@@ -1008,7 +1029,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p) {
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+            if (kt == cur.kt0) stamp(round, 5); else if (kt == cur.kt0 + 1) stamp(round, 7); else if (kt == cur.kt0 + 2) stamp(round, 9); else if (kt == cur.kt1 - 2) stamp(round, 10);
         }
+        stamp(round, 0);
 
         // ---- unit boundary: fetch the tile's bias from LDS (the compiler orders every LDS read behind every LDS-DMA in flight with a
         // vmcnt(0): nothing is in flight here, after the DMA below it would wait for it), request the next unit's second K-tile, then drain
@@ -1036,6 +1059,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         if (nxt.valid) stage((s + 1) & 1, nxt.m0, nxt.n0, nxt.kt0 + 1);  // s = the next unit's first step (its tile is in buffer s & 1)
         __builtin_amdgcn_sched_barrier(0);
+        stamp(round, 1);
         if ((p.ablate & 4) && acc[0][0][0] != 12345.678f) {   // timing-only: no epilogue (the accumulators stay live)
             wcnt = 0;
         } else
@@ -1161,6 +1185,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p) {
                                                                           __float_as_uint(acc[i][j][2]), __float_as_uint(acc[i][j][3])});
                 }
             wcnt = 32;
+        }
+        stamp(round, 2);
+        if (p.dbg && (tid & 255) == 0) {
+            p.dbg[(((size_t)blockIdx.x * 2 + grp) * 4 + 0) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+            p.dbg[(((size_t)blockIdx.x * 2 + grp) * 4 + 0) * 16 + 14] = (unsigned long long)(round + 1);
         }
         if (!nxt.valid) break;
         cur = nxt;
@@ -1351,7 +1380,7 @@ extern "C" int ullsam_gemm_fp8(const void* A8, long lda, const float* a_scale, c
     if (residual) vec = vec && ((uintptr_t)residual & 15) == 0 && (ldr % 4 == 0);
     a.vec_ok = vec ? 1 : 0;
     a.ablate = 0; a.ws = nullptr; a.ws_bytes = 0; a.shift_edge = 0; a.skew_ticks = 0; a.store_nt = 0; a.late = 0; a.ksplit = 1;
-    a.row_scale = a_scale; a.col_scale = w_scale;
+    a.row_scale = a_scale; a.col_scale = w_scale; a.dbg = nullptr;
     a.tiles_m = (M + 255) / 256; a.tiles_n = (N + 255) / 256; a.full_tiles = a.tiles_m * a.tiles_n;
     static PerDeviceOnce attr_set;
     if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256f8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -1380,7 +1409,7 @@ static int launch_gemm_v4_impl(GemmArgs a, hipStream_t stream) {
     }
     const int cus = num_cus();
     a.shift_edge = 1;
-    a.store_nt = 0;
+    a.store_nt = g_store_v4;
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = a.N / 256;
     const int T_ = a.tiles_m * a.tiles_n;
@@ -1426,7 +1455,7 @@ static int launch_gemm_v4(const GemmArgs& a, hipStream_t stream) {
 
 // v: bits 0-3 kernel (0 auto), +64 no split-K tail, bits 8-11 timing-only ablations (1 no staging, 2 no barrier, 4 no epilogue, 8 no stores), bits 12-13 schedule of the 256x256 kernel
 extern "C" int ullsam_set_gemm_variant(int v) {
-    g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_persistent = (v & 128) ? 0 : 1; g_skew_half_us = (v >> 16) & 255; g_store_nt = ((v >> 14) & 1) ^ 1; g_late = (v >> 24) & 3; g_gemm_ablate = (v >> 8) & 15; g_gemm_sched = (v >> 12) & 3;
+    g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_persistent = (v & 128) ? 0 : 1; g_skew_half_us = (v >> 16) & 255; g_store_nt = ((v >> 14) & 1) ? 0 : (((v >> 26) & 7) ? ((v >> 26) & 7) : 1); g_late = (v >> 24) & 3; g_dbg = (v >> 15) & 1; g_store_v4 = (int)(((unsigned)v >> 29) & 7); g_gemm_ablate = (v >> 8) & 15; g_gemm_sched = (v >> 12) & 3;
     return 0;
 }
 
@@ -1702,6 +1731,7 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     a.skew_ticks = 0;
     a.row_scale = nullptr;
     a.col_scale = nullptr;
+    a.dbg = (g_dbg && workspace && ws_bytes >= (56l << 20)) ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + (48l << 20)) : nullptr;
     a.store_nt = g_store_nt;
     a.late = g_late;
     a.ksplit = 1;
