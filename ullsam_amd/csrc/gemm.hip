@@ -122,7 +122,8 @@ __device__ __forceinline__ void store16_policy(void* ptr, u32x4s v, int policy) 
     else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 }
 
-template <typename T, typename OutT, int BM, int NTHREADS, int BN = 128>
+// EMODE (compile time, so the common epilogue carries none of the others' registers): 0 standard, 1 wqkv + RoPE (act 4), 2 fp8 scales
+template <typename T, typename OutT, int BM, int NTHREADS, int BN = 128, int EMODE = 0>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs, int m0, int n0, int tn, int tid, int m_lo = 0) {
     constexpr int TPR = BN / 8;             // threads per row (each owns 8 accumulator columns)
     constexpr int RPP = NTHREADS / TPR;     // rows per pass
@@ -151,7 +152,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
         }
         return;
     }
-    if (p.act == 4) {
+    if constexpr (EMODE == 1) {
         // wqkv: columns are (kv head, [G query heads | k | v], 128).  This thread's 8 columns sit in one 128-wide slot of the tile; the
         // rotate_half partner of column d is d +- 64 in the same slot = the same Cs row.  q -> q_out [tok, H*128], k / v -> caches
         // [B, KVH, cap, 128] at cache_pos0 + s; cos / sin rows by position id (clamped to the table), fp32 arithmetic as rope_split_kernel.
@@ -231,8 +232,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
         }
     }
     float cs[8];   // fp8 path: this thread's 8 column scales, fetched once like the bias
+    if constexpr (EMODE == 2) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) cs[e] = (p.col_scale && e < n_valid) ? p.col_scale[gn + e] : 0.f;
+        for (int e = 0; e < 8; ++e) cs[e] = e < n_valid ? p.col_scale[gn + e] : 0.f;
+    }
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
         const int row = pass * RPP + tid / TPR;
@@ -242,7 +245,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
         const float4 a = *reinterpret_cast<const float4*>(Cs + row * BN + c0);
         const float4 b = *reinterpret_cast<const float4*>(Cs + row * BN + c0 + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        if (p.row_scale) {  // fp8 operands: acc * scale_A[row] * scale_W[col]
+        if constexpr (EMODE == 2) {  // fp8 operands: acc * scale_A[row] * scale_W[col]
             const float rs = p.row_scale[gm];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= rs * cs[e];
@@ -279,7 +282,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
     }
 }
 
-template <typename T>
+template <typename T, int EMODE = 0>
 __global__ __launch_bounds__(256) void gemm128_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -386,13 +389,13 @@ __global__ __launch_bounds__(256) void gemm128_kernel(GemmArgs p) {
         return;
     }
     if (p.out_f32)
-        epilogue_rows<T, float, 128, 256>(p, Cs, m0, n0, tn, tid);
+        epilogue_rows<T, float, 128, 256, 128, EMODE>(p, Cs, m0, n0, tn, tid);
     else
-        epilogue_rows<T, T, 128, 256>(p, Cs, m0, n0, tn, tid);
+        epilogue_rows<T, T, 128, 256, 128, EMODE>(p, Cs, m0, n0, tn, tid);
 }
 
 // Sum the ksplit fp32 partials of a 32-row slab of one tail tile (same grouped tile order) and run the normal epilogue on it.
-template <typename T>
+template <typename T, int EMODE = 0>
 __global__ __launch_bounds__(256) void gemm_tail_reduce_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float Cs[32 * 128];
     const int tid = threadIdx.x;
@@ -417,9 +420,9 @@ __global__ __launch_bounds__(256) void gemm_tail_reduce_kernel(GemmArgs p) {
     }
     __syncthreads();
     if (p.out_f32)
-        epilogue_rows<T, float, 32, 256>(p, Cs, tm * 128 + slab * 32, tn * 128, tn, tid);
+        epilogue_rows<T, float, 32, 256, 128, EMODE>(p, Cs, tm * 128 + slab * 32, tn * 128, tn, tid);
     else
-        epilogue_rows<T, T, 32, 256>(p, Cs, tm * 128 + slab * 32, tn * 128, tn, tid);
+        epilogue_rows<T, T, 32, 256, 128, EMODE>(p, Cs, tm * 128 + slab * 32, tn * 128, tn, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(GemmArgs p) {
 // L2->LDS bytes per FLOP (ablation + PMC in profiles/).  Used for GEMMs whose 256x256 tile count fills the chip's
 // 256 CUs for several rounds; the epilogue is staged through LDS in two 128-row halves.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int EXP>  // EXP: 0 = production; 1 = experiment (A fragments first, one prioritised MFMA cluster)
+template <typename T, int EXP, int EMODE = 0>  // EXP: main-loop schedule (2 = production, see launch_gemm_v3); EMODE: epilogue flavour
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -611,8 +614,32 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + 32768 + (wave * 4 + i) * 1024), 16, 0, 0);
         }
     };
+    // A/B helpers: pieces [i0, i1) of this wave, or the pieces of another wave `w` (offsets recomputed: nothing kept in registers)
+    auto stage_part = [&](int buf, int kt, int i0, int i1) {
+        const size_t koff = (size_t)kt * 128;
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i >= i0 && i < i1) {
+                __builtin_amdgcn_global_load_lds(GLB_PTR(a_base + koff + a_off[i]), LDS_PTR(base + (wave * 4 + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(b_base + koff + b_off[i]), LDS_PTR(base + 32768 + (wave * 4 + i) * 1024), 16, 0, 0);
+            }
+    };
+    auto stage_for = [&](int buf, int kt, int w) {
+        const size_t koff = (size_t)kt * 128;
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (w * 4 + i) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (row & 7);
+            const unsigned int ao = (unsigned int)((size_t)(min(m0 + row, p.M - 1) - m0) * p.lda * sizeof(T)) + (c << 4);
+            const unsigned int bo = (unsigned int)((size_t)(min(n0 + row, p.N - 1) - n0) * p.ldw * sizeof(T)) + (c << 4);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_base + koff + ao), LDS_PTR(base + (w * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_base + koff + bo), LDS_PTR(base + 32768 + (w * 4 + i) * 1024), 16, 0, 0);
+        }
+    };
 
-    if constexpr (EXP == 2 && KSTEPS == 2) {
+    if constexpr (EXP >= 2 && KSTEPS == 2) {
         // Staggered two-group schedule.  Per K-tile every wave runs four segments  L0 | C0 | L1 | C1  separated by s_barrier:
         //   L0: issue the LDS-DMA of tile kt+1 (8 x 1 KiB) + ds_read the k-step-0 fragments     C0: 32 MFMAs
         //   L1: ds_read the k-step-1 fragments, then wait for this wave's DMA (vmcnt(0))         C1: 32 MFMAs
@@ -622,11 +649,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         //        tile kt+1 is at slot 4kt+4, behind the barrier that ends slot 4kt+3.
         //   WAR: buffer (kt+1)&1 was last read (tile kt-1, k-step 1) at slots 4kt-2 / 4kt-1; the DMA into it starts at slot 4kt.
         const int grp = wave >> 2;
-        // DMA lead (p.late): the DMA of tile kt+1 may start once buffer (kt+1)&1 is free = behind the barrier that ends slot 4kt-1, and must
-        // have landed by the barrier that ends slot 4kt+3.  Group 0 issues in slot 4kt (its L0) and may wait as late as the end of its C1
-        // (slot 4kt+3) instead of its L1 (bit 0); group 1 sits in its C1(kt-1) during slot 4kt and may issue there, behind its MFMAs
-        // (its own reads of that buffer are consumed by then), instead of in its L0 one slot later (bit 1).
-        const bool late0 = grp == 0 && (p.late & 1), early1 = grp == 1 && (p.late & 2);
+        // Measured and rejected on this loop (round 2, same-process A/B): group 0 waiting for its DMA at the end of C1 instead of L1 (+-0);
+        // group 1 requesting tile kt+2 behind the MFMAs of its C1 (+4..6 % slower).  Compile-time A/B variants kept:
+        //   EXP 3: the younger group (waves 4-7) issues ALL the DMA (its own pieces and those of wave - 4), the older group none
+        //   EXP 4: GROUP 0 issues 2 + 2 pieces in its L0 and the other 2 + 2 in its L1 and waits at the end of its C1 (slot 4kt+3: still ahead
+        //          of the first read in slot 4kt+4); group 1 is unchanged (its data must have landed by the end of ITS L1 = slot 4kt+3)
+        constexpr bool only1 = EXP == 3;
+        const bool split = EXP == 4 && grp == 0;
         stage(kt0 & 1, kt0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -636,7 +665,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             const char* Bb = Ab + 32768;
             Frag<T> a8[8], b[4];
             // ---- L0
-            if (kt + 1 < nk && (!early1 || kt == kt0)) stage((kt + 1) & 1, kt + 1);
+            if (only1) {
+                if (kt + 1 < nk && grp == 1) { stage((kt + 1) & 1, kt + 1); stage_for((kt + 1) & 1, kt + 1, wave - 4); }
+            } else if (split) {
+                if (kt + 1 < nk) stage_part((kt + 1) & 1, kt + 1, 0, 2);
+            } else if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), 0, lane >> 4);
 #pragma unroll
@@ -657,7 +690,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), 1, lane >> 4);
 #pragma unroll
             for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + (lane & 15), 1, lane >> 4);
-            if (!late0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (split) {
+                if (kt + 1 < nk) stage_part((kt + 1) & 1, kt + 1, 2, 4);   // second half of the request; everything is waited for at the end of C1
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             // ---- C1
@@ -668,8 +703,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 for (int j = 0; j < 4; ++j) mma16(a8[i], b[j], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (early1 && kt + 2 < nk) stage(kt & 1, kt + 2);
-            if (late0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (split) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
         }
@@ -736,9 +770,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) dst[i * 512 + tid] = src[i * 512 + tid];
         } else if (p.out_f32) {
-            epilogue_rows<T, float, 128, 512, 256>(p, Cs, m0 + half * 128, n0, tn, tid);
+            epilogue_rows<T, float, 128, 512, 256, EMODE>(p, Cs, m0 + half * 128, n0, tn, tid);
         } else {
-            epilogue_rows<T, T, 128, 512, 256>(p, Cs, m0 + half * 128, n0, tn, tid);
+            epilogue_rows<T, T, 128, 512, 256, EMODE>(p, Cs, m0 + half * 128, n0, tn, tid);
         }
     }
 }
@@ -748,7 +782,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 // pass is bandwidth-bound (ViT lin2: 64 tail tiles x 4 splits).  <4, 128>: 64 workgroups per tail tile for the LLM's 16-tile tails
 // (wo / w2, 8 splits), where the launch is latency-bound: 12.8 -> 8.9 us.  The ksplit loads of a thread are independent and
 // unrolled, so they are in flight together.
-template <typename T, int ROWS, int NT>
+template <typename T, int ROWS, int NT, int EMODE = 0>
 __global__ __launch_bounds__(NT) void gemm256_tail_reduce_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float Cs[ROWS * 256];
     constexpr int SPT = 256 / ROWS;              // slabs per tile
@@ -785,9 +819,9 @@ __global__ __launch_bounds__(NT) void gemm256_tail_reduce_kernel(GemmArgs p) {
         if (mrow + ROWS <= m_lo) return;
     }
     if (p.out_f32)
-        epilogue_rows<T, float, ROWS, NT, 256>(p, Cs, mrow, tn * 256, tn, tid, m_lo);
+        epilogue_rows<T, float, ROWS, NT, 256, EMODE>(p, Cs, mrow, tn * 256, tn, tid, m_lo);
     else
-        epilogue_rows<T, T, ROWS, NT, 256>(p, Cs, mrow, tn * 256, tn, tid, m_lo);
+        epilogue_rows<T, T, ROWS, NT, 256, EMODE>(p, Cs, mrow, tn * 256, tn, tid, m_lo);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1198,11 +1232,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();
 }
 
-template <typename T, int EXP>
+template <typename T, int EXP, int EMODE = 0>
 static int launch_gemm_v3_impl(GemmArgs a, hipStream_t stream) {
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<T, EXP>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<T, EXP, EMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     }
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (a.N + 255) / 256;
@@ -1221,12 +1255,12 @@ static int launch_gemm_v3_impl(GemmArgs a, hipStream_t stream) {
             a.ksplit = S;
         }
     }
-    gemm256_kernel<T, EXP><<<dim3(a.full_tiles + (T_ - a.full_tiles) * a.ksplit), dim3(512), 131072, stream>>>(a);
+    gemm256_kernel<T, EXP, EMODE><<<dim3(a.full_tiles + (T_ - a.full_tiles) * a.ksplit), dim3(512), 131072, stream>>>(a);
     ULLSAM_LAUNCH_CHECK();
     if (a.ksplit > 1) {
         const int tail_tiles = T_ - a.full_tiles;
-        if (tail_tiles * a.ksplit <= 128) gemm256_tail_reduce_kernel<T, 4, 128><<<dim3(tail_tiles * 64), dim3(128), 0, stream>>>(a);
-        else gemm256_tail_reduce_kernel<T, 16, 256><<<dim3(tail_tiles * 16), dim3(256), 0, stream>>>(a);
+        if (tail_tiles * a.ksplit <= 128) gemm256_tail_reduce_kernel<T, 4, 128, EMODE><<<dim3(tail_tiles * 64), dim3(128), 0, stream>>>(a);
+        else gemm256_tail_reduce_kernel<T, 16, 256, EMODE><<<dim3(tail_tiles * 16), dim3(256), 0, stream>>>(a);
         ULLSAM_LAUNCH_CHECK();
     }
     return 0;
@@ -1235,8 +1269,11 @@ template <typename T>
 static int launch_gemm_v3(GemmArgs a, hipStream_t stream) {
     // schedules (tools/gemm_bench.py codes 3 / 3+(4<<8) / 3+(6<<8)): the staggered two-group schedule measured +10..15 % on the
     // K=4096 shapes and neutral at K=1280 against both others, bit-identical results
+    if (a.act == 4) return sizeof(T) == 2 ? launch_gemm_v3_impl<T, 2, 1>(a, stream) : launch_gemm_v3_impl<T, 1, 1>(a, stream);  // wqkv + RoPE epilogue
     if (g_gemm_sched == 2) return launch_gemm_v3_impl<T, 1>(a, stream);  // fragments first + prioritised MFMA cluster, 1 barrier / K-tile
     if (g_gemm_sched == 1) return launch_gemm_v3_impl<T, 0>(a, stream);  // plain interleaved loop
+    if (sizeof(T) == 2 && g_late == 4) return launch_gemm_v3_impl<T, 3>(a, stream);  // A/B: younger group issues all DMA
+    if (sizeof(T) == 2 && g_late == 8) return launch_gemm_v3_impl<T, 4>(a, stream);  // A/B: DMA issue split over L0 / L1
     if (sizeof(T) == 2) return launch_gemm_v3_impl<T, 2>(a, stream);        // production (bf16): staggered two-group schedule
     return launch_gemm_v3_impl<T, 1>(a, stream);                            // fp32 has one k-step per K-tile: no second segment pair
 }
@@ -1358,8 +1395,8 @@ __global__ __launch_bounds__(512) void gemm256f8_kernel(GemmArgs p) {
                     for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * g4 + r) * 256 + wn * 64 + j * 16 + mm] = acc[i][j][r];
         }
         __syncthreads();
-        if (p.out_f32) epilogue_rows<bf16, float, 128, 512, 256>(p, Cs, m0 + half * 128, n0, tn, tid);
-        else epilogue_rows<bf16, bf16, 128, 512, 256>(p, Cs, m0 + half * 128, n0, tn, tid);
+        if (p.out_f32) epilogue_rows<bf16, float, 128, 512, 256, 2>(p, Cs, m0 + half * 128, n0, tn, tid);
+        else epilogue_rows<bf16, bf16, 128, 512, 256, 2>(p, Cs, m0 + half * 128, n0, tn, tid);
     }
 }
 
@@ -1455,7 +1492,7 @@ static int launch_gemm_v4(const GemmArgs& a, hipStream_t stream) {
 
 // v: bits 0-3 kernel (0 auto), +64 no split-K tail, bits 8-11 timing-only ablations (1 no staging, 2 no barrier, 4 no epilogue, 8 no stores), bits 12-13 schedule of the 256x256 kernel
 extern "C" int ullsam_set_gemm_variant(int v) {
-    g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_persistent = (v & 128) ? 0 : 1; g_skew_half_us = (v >> 16) & 255; g_store_nt = ((v >> 14) & 1) ? 0 : (((v >> 26) & 7) ? ((v >> 26) & 7) : 1); g_late = (v >> 24) & 3; g_dbg = (v >> 15) & 1; g_store_v4 = (int)(((unsigned)v >> 29) & 7); g_gemm_ablate = (v >> 8) & 15; g_gemm_sched = (v >> 12) & 3;
+    g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_persistent = (v & 128) ? 0 : 1; g_skew_half_us = (v >> 16) & 255; g_store_nt = ((v >> 14) & 1) ? 0 : (((v >> 26) & 7) ? ((v >> 26) & 7) : 1); g_late = (v >> 24) & 15; g_dbg = (v >> 15) & 1; g_store_v4 = (int)(((unsigned)v >> 29) & 7); g_gemm_ablate = (v >> 8) & 15; g_gemm_sched = (v >> 12) & 3;
     return 0;
 }
 
@@ -1471,11 +1508,11 @@ static int launch_gemm_v2(GemmArgs a, hipStream_t stream) {
     return 0;
 }
 
-template <typename T>
+template <typename T, int EMODE = 0>
 static int launch_gemm(GemmArgs a, hipStream_t stream) {
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_kernel<T, EMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     }
     // Split-K tail: with 2 workgroups per CU the chip runs 512 tiles per wave; when the last wave is at most half full, cut each
     // of its tiles into S K-ranges (fp32 partials + a reduce kernel).  Measured (tools/gemm_bench.py, variant 65 vs 1): pays only
@@ -1497,10 +1534,10 @@ static int launch_gemm(GemmArgs a, hipStream_t stream) {
         }
     }
     const int grid = a.full_tiles + (T_ - a.full_tiles) * a.ksplit;
-    gemm128_kernel<T><<<dim3(grid), dim3(256), 65536, stream>>>(a);
+    gemm128_kernel<T, EMODE><<<dim3(grid), dim3(256), 65536, stream>>>(a);
     ULLSAM_LAUNCH_CHECK();
     if (a.ksplit > 1) {
-        gemm_tail_reduce_kernel<T><<<dim3((T_ - a.full_tiles) * 4), dim3(256), 0, stream>>>(a);
+        gemm_tail_reduce_kernel<T, EMODE><<<dim3((T_ - a.full_tiles) * 4), dim3(256), 0, stream>>>(a);
         ULLSAM_LAUNCH_CHECK();
     }
     return 0;
@@ -1762,6 +1799,7 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     if (v3 && variant == 0 && g_persistent && a.act == 1 && !a.out_f32 && v4_ok(a, dtype)) return launch_gemm_v4(a, s);
     if (v3) return dtype == ULLSAM_DT_F32 ? launch_gemm_v3<float>(a, s) : launch_gemm_v3<bf16>(a, s);
     if (v2) return dtype == ULLSAM_DT_F32 ? launch_gemm_v2<float>(a, s) : launch_gemm_v2<bf16>(a, s);
+    if (a.act == 4) return dtype == ULLSAM_DT_F32 ? launch_gemm<float, 1>(a, s) : launch_gemm<bf16, 1>(a, s);
     return dtype == ULLSAM_DT_F32 ? launch_gemm<float>(a, s) : launch_gemm<bf16>(a, s);
 }
 
