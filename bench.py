@@ -125,6 +125,20 @@ class GemmTimer:
             return out
 
         ops.gemm = timed
+        orig_rope = ops.gemm_qkv_rope   # the wqkv GEMM with the RoPE epilogue is a GEMM launch like the others
+
+        def timed_rope(x, wqkv, *args, **kw):
+            if not self.on:
+                return orig_rope(x, wqkv, *args, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_rope(x, wqkv, *args, **kw)
+            e1.record()
+            self.rec.append((e0, e1, 2.0 * x.shape[0] * wqkv.shape[0] * x.shape[1]))
+            self.alg_bytes += x.numel() * x.element_size() + wqkv.numel() * wqkv.element_size() + x.shape[0] * wqkv.shape[0] * x.element_size()
+            return out
+
+        ops.gemm_qkv_rope = timed_rope
 
     def summary(self):
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec)
