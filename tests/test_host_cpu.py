@@ -369,3 +369,26 @@ def test_chat_builds_the_reference_prompt():
         assert seen["query"] == c["query"]
         assert seen["gen"]["eos_token_id"] == 92542 and me.img_context_token_id == 92546
         assert resp == "the answer" and new_hist[-1][1] == "the answer" and len(new_hist) == len(c["history"] or []) + 1
+
+
+def test_bench_host_helpers(tmp_path, monkeypatch):
+    """bench.py's host-side pieces that need no GPU: the synthetic prompt layout (one contiguous run of 1024 <IMG_CONTEXT> ids
+    bracketed by <img> / </img>, S = 1081 for the default text lengths), and the traffic record being refused when it was
+    measured on other kernel sources."""
+    import json
+    import bench
+    ids = bench.make_input_ids(20, 34, seed=1, batch=3)
+    assert ids.shape == (3, 1081) and ids.dtype == np.int64
+    for row in ids:
+        pos = np.flatnonzero(row == 92546)
+        assert len(pos) == 1024 and pos[-1] - pos[0] == 1023 and row[pos[0] - 1] == 92544 and row[pos[-1] + 1] == 92545 and row[0] == 1
+    assert np.array_equal(ids, O.make_input_ids(20, 34, seed=1, batch=3))       # same layout as the oracle's generator
+    from ullsam_amd import build as B
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    assert bench.traffic_record()[0] is None                                      # no record
+    json.dump({"csrc_digest": "0" * 64, "hbm_bytes_per_launch": 1.0}, open(tmp_path / "profiles" / "r02_pmc_bench_traffic.json", "w"))
+    val, why = bench.traffic_record()
+    assert val is None and "stale" in why
+    json.dump({"csrc_digest": B._digest(), "hbm_bytes_per_launch": 123.4}, open(tmp_path / "profiles" / "r02_pmc_bench_traffic.json", "w"))
+    assert bench.traffic_record()[0] == 123

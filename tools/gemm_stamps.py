@@ -48,6 +48,12 @@ for name in (sys.argv[1:] or ["qkv", "lin1"]):
             rows.append((grp, int(ok.sum()), d(u0[:, 1], u0[:, 0]), d(u0[:, 2], u0[:, 1]), d(u1[:, 3], u0[:, 2]), d(u1[:, 4], u1[:, 3]), d(u1[:, 5], u1[:, 4]),
                          d(u1[:, 6], u1[:, 5]), d(u1[:, 7], u1[:, 6]), d(u1[:, 8], u1[:, 7]), d(u1[:, 9], u1[:, 8]),
                          np.median(((u1[:, 10] - u1[:, 9]) / max(nk - 5, 1))[ok]) / 1e3, d(u1[:, 0], u0[:, 0])))
+        for grp in (0, 1):
+            u1 = st[:, grp, 2]
+            ok = (u1[:, 7] > 0) & (u1[:, 15] > 0)
+            md = lambda x, y: np.median((x - y)[ok]) / 1e3
+            print(f"    step 3 of a unit, group {grp}: L0 DMA issue {md(u1[:, 11], u1[:, 7]):.2f}, fragment-read issue {md(u1[:, 15], u1[:, 11]):.2f}, "
+                  f"barrier + C0 + L1 reads + DMA wait {md(u1[:, 8], u1[:, 15]):.2f}, barrier + C1 + barrier {md(u1[:, 9], u1[:, 8]):.2f} kilo-cycles")
         print(f"{name} {tag}: kilo-cycles (median over workgroups), boundary between a workgroup's 2nd and 3rd unit")
         print("  grp  n   dma-issue  epilogue  ->L0-barrier  step1:C0+L1wait  C1   step2:L0..L1wait  C1   step3:L0..L1wait  C1   steady/step  unit-period")
         for r in rows:

@@ -1026,11 +1026,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p) {
                 if (!last || nxt.valid) stage((s + 1) & 1, last ? nxt.m0 : cur.m0, last ? nxt.n0 : cur.n0, last ? nxt.kt0 : kt + 1);
                 if (last && nxt.valid) stage_bias((round + 1) & 1, nxt);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt == cur.kt0 + 2) stamp(round, 11);   // (diagnostic) L0 of the third step: after the DMA issue ...
 #pragma unroll
             for (int j = 0; j < 4; ++j) bq[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + mm, 0, g4);
 #pragma unroll
             for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + mm, 0, g4);
             __builtin_amdgcn_sched_barrier(0);
+            if (kt == cur.kt0 + 2) stamp(round, 15);   // ... and after the fragment reads were issued (before the barrier)
             __builtin_amdgcn_s_barrier();
             if (kt == cur.kt0) stamp(round, 3);
             // ---- C0
