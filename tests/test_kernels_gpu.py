@@ -140,6 +140,40 @@ def test_gemm_persistent_kernel(ops, M, N, K, mode):
         assert float((old - got).abs().max()) < 1e-2
 
 
+@pytest.mark.parametrize("M,N,K,mode", [(1500, 512, 512, "bias_gelu"), (4324, 4096, 4096, "res"), (4324, 2048, 1024, "swiglu"), (1000, 768, 320, "plain")])
+def test_gemm_ring_kernel(ops, M, N, K, mode):
+    """The half-K ring variant of the 256x256 kernel (four 32-deep LDS stages, two stages of LDS-DMA in flight, counted waits;
+    variant 6): ragged M / N, split-K tail, K not a multiple of 128, every epilogue, against the fp32 matmul of the same operands."""
+    from ullsam_amd import _lib
+    from ullsam_amd.packing import pack_w13
+    lib = _lib.load()
+    g = torch.Generator(device=DEV); g.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g)
+    ref = a.float() @ w.float().T
+    try:
+        lib.ullsam_set_gemm_variant(6)
+        if mode == "plain":
+            got, want, tol = ops.gemm(a, w).float(), ref, 3e-2
+        elif mode == "bias_gelu":
+            got, want, tol = ops.gemm(a, w, bias, act=ops.ACT_GELU).float(), torch.nn.functional.gelu(ref + bias), 3e-2
+        elif mode == "res":
+            x = torch.randn(M, N, device=DEV, generator=g)
+            want = ref + bias + x
+            ops.gemm(a, w, bias, residual=x, out_f32=True, out=x)
+            got, tol = x, 2e-3
+        else:
+            I = N // 2
+            got = ops.gemm(a, pack_w13(w[:I].contiguous(), w[I:].contiguous()), act=ops.ACT_SWIGLU).float()
+            want, tol = torch.nn.functional.silu(ref[:, :I]) * ref[:, I:], 3e-2
+        torch.cuda.synchronize()
+    finally:
+        lib.ullsam_set_gemm_variant(0)
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) < tol * max(1.0, float(want.abs().max()) / 4)
+
+
 def _e4m3_decode(u8: np.ndarray) -> np.ndarray:
     """OCP e4m3fn bytes -> float32 (the tests' own decoder: sign, 4-bit exponent bias 7, 3-bit mantissa, subnormals, 0x7f = NaN)."""
     u = u8.astype(np.int32)

@@ -1282,6 +1282,188 @@ static int launch_gemm_v3(GemmArgs a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// v6: 256x256 tile on a RING of four half-K LDS stages (bf16).  Same tile, wave layout (2 x 4, 128x64 per wave), stagger and
+// epilogue as gemm256_kernel; what changes is the grain of the pipeline.  Measured on the two-buffer loop (tools/gemm_stamps.py):
+// a wave needs 80-95 cycles to issue one 1 KiB LDS-DMA piece, so the slot in which a group requests the 8 pieces of the next
+// 64-deep K-tile (plus 12 fragment reads) takes 0.8-0.9 kilo-cycles while the partner's matrix segment it hides under takes 0.51,
+// and the other load slot is half empty; with two whole-K-tile buffers the issue cannot be moved (landing deadline).
+// Here a stage is ONE MFMA k-step (32 deep): A 256 rows x 64 B + B 256 rows x 64 B = 32 KiB, four stages = 128 KiB.
+// Per stage and wave: 4 DMA pieces (for stage s + D), 12 fragment reads, 32 MFMAs -- every load slot carries the same, smaller
+// load (4 pieces + 12 reads ~ 0.47 kilo-cycles <= one 32-MFMA segment), and the request runs D = 2 stages ahead:
+//   slot 2s   : group 0  L(s) = issue DMA(s+D), read the fragments of stage s, wait until stage s+1 has landed (counted vmcnt)
+//               group 1  C(s-1)
+//   slot 2s+1 : group 0  C(s) = 32 MFMAs          group 1  L(s)
+// RAW: a wave's pieces of stage s+D are issued in its L(s) and waited for in its L(s+D-1) (vmcnt(4(D-1)) leaves the younger stages in
+//      flight); group 1's wait is in slot 2(s+D)-1, the barrier ending that slot precedes the first read in slot 2(s+D).
+// WAR: buffer (s+D) & 3 held stage s+D-4, last read in slots 2(s+D-4) / +1: at least four slots (D <= 2) before the DMA is issued.
+// LDS image: 64-byte rows, 16-byte chunk c of row r at c ^ ((r >> 2) & 2): a ds_read_b128 lane group {rows rho, chunk g} then covers
+// all 16 sixteen-byte bank groups of the four 64 B rows sharing a 256 B bank line exactly once (conflict-free), and a DMA piece is
+// 16 rows x 64 B with the same permutation on its source chunks.
+// ---------------------------------------------------------------------------------------------------------------
+template <int EMODE, int D>
+__global__ __launch_bounds__(512) void gemm256r_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef bf16 T;
+    constexpr int STG = 32768;  // 16 KiB A + 16 KiB B per stage
+
+    const int nblk = p.full_tiles;
+    const int bid = blockIdx.x;
+    int swz, part = -1, tail_idx = 0;
+    if (bid < nblk) {
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+        swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    } else {
+        const int t = bid - nblk;
+        tail_idx = t / p.ksplit;
+        part = t - tail_idx * p.ksplit;
+        swz = nblk + tail_idx;
+    }
+    const int GM = 4;
+    const int width = GM * p.tiles_n;
+    const int group = swz / width;
+    const int first_m = group * GM;
+    const int gsize = min(p.tiles_m - first_m, GM);
+    const int tm = first_m + (swz % width) % gsize;
+    const int tn = (swz % width) / gsize;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
+    const int g4 = lane >> 4, mm = lane & 15;
+
+    // DMA pieces of this wave: A pieces 2w, 2w+1 and B pieces 2w, 2w+1 (16 rows x 64 B each); lane -> row 16 piece + lane / 4, LDS chunk lane & 3
+    const char* a_base = reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda * 2;
+    const char* b_base = reinterpret_cast<const char*>(p.W) + (size_t)n0 * p.ldw * 2;
+    unsigned int a_off[2], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 2);
+        a_off[i] = (unsigned int)((size_t)(min(m0 + row, p.M - 1) - m0) * p.lda * 2) + (c << 4);
+        b_off[i] = (unsigned int)((size_t)(min(n0 + row, p.N - 1) - n0) * p.ldw * 2) + (c << 4);
+    }
+    const int ns_all = p.K >> 5;  // stages (32-deep k-steps)
+    const int st0 = part < 0 ? 0 : (int)((long)part * ns_all / p.ksplit);
+    const int st1 = part < 0 ? ns_all : (int)((long)(part + 1) * ns_all / p.ksplit);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int s) {   // request stage s into ring slot s & 3
+        char* base = smem + (s & 3) * STG;
+        const char* ak = a_base + (size_t)s * 64;
+        const char* bk = b_base + (size_t)s * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_off[i]), LDS_PTR(base + (wave * 2 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + 16384 + (wave * 2 + i) * 1024), 16, 0, 0);
+        }
+    };
+    auto frag = [&](const char* tile, int row) -> Frag<T> {
+        return load_frag(reinterpret_cast<const T*>(tile + row * 64 + ((g4 ^ ((row >> 2) & 2)) << 4)));
+    };
+
+    // prologue: stages st0 .. st0+D-1 requested, stage st0 landed
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (st0 + d < st1) stage(st0 + d);
+    if (D == 2 && st0 + 1 < st1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int s = st0; s < st1; ++s) {
+        const char* Ab = smem + (s & 3) * STG;
+        const char* Bb = Ab + 16384;
+        Frag<T> a8[8], b[4];
+        // ---- L(s)
+        if (s + D < st1) stage(s + D);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = frag(Bb, wn * 64 + j * 16 + mm);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a8[i] = frag(Ab, wm * 128 + i * 16 + mm);
+        // stage s+1 must have landed before the barrier that lets anyone read it; younger stages stay in flight
+        if (D == 2 && s + 2 < st1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- C(s)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma16(a8[i], b[j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+
+    float* Cs = reinterpret_cast<float*>(smem);  // [128][256] fp32 = 128 KiB, one 128-row half at a time
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * g4 + r) * 256 + wn * 64 + j * 16 + mm] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (part >= 0) {
+            float4* dst = reinterpret_cast<float4*>(p.ws + ((size_t)tail_idx * p.ksplit + part) * 65536 + half * 32768);
+            const float4* src = reinterpret_cast<const float4*>(Cs);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[i * 512 + tid] = src[i * 512 + tid];
+        } else if (p.out_f32) {
+            epilogue_rows<T, float, 128, 512, 256, EMODE>(p, Cs, m0 + half * 128, n0, tn, tid);
+        } else {
+            epilogue_rows<T, T, 128, 512, 256, EMODE>(p, Cs, m0 + half * 128, n0, tn, tid);
+        }
+    }
+}
+
+template <int EMODE, int D>
+static int launch_gemm_v6_impl(GemmArgs a, hipStream_t stream) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<EMODE, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (a.N + 255) / 256;
+    const int T_ = a.tiles_m * a.tiles_n;
+    const int nk = a.K / 64;
+    const int tail = T_ % 256;
+    a.full_tiles = T_;
+    a.ksplit = 1;
+    if (g_split_tail && a.ws && T_ > 256 && tail > 0 && tail <= 64 && nk >= 64) {  // same split-K tail policy as the two-buffer kernel
+        int S = 256 / tail;
+        if (S > 8) S = 8;
+        if (S > nk / 8) S = nk / 8;
+        if (S >= 2 && (size_t)tail * S * 262144 <= a.ws_bytes) {
+            a.full_tiles = T_ - tail;
+            a.ksplit = S;
+        }
+    }
+    gemm256r_kernel<EMODE, D><<<dim3(a.full_tiles + (T_ - a.full_tiles) * a.ksplit), dim3(512), 131072, stream>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    if (a.ksplit > 1) {
+        const int tail_tiles = T_ - a.full_tiles;
+        if (tail_tiles * a.ksplit <= 128) gemm256_tail_reduce_kernel<bf16, 4, 128, EMODE><<<dim3(tail_tiles * 64), dim3(128), 0, stream>>>(a);
+        else gemm256_tail_reduce_kernel<bf16, 16, 256, EMODE><<<dim3(tail_tiles * 16), dim3(256), 0, stream>>>(a);
+        ULLSAM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+static int launch_gemm_v6(const GemmArgs& a, hipStream_t stream) {
+    if (a.act == 4) return launch_gemm_v6_impl<1, 2>(a, stream);
+    return launch_gemm_v6_impl<0, 2>(a, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) GEMM for the ViT's LayerNorm-fed linears (BASELINE configs[4], "fp8 MFMA ViT path"): the 256x256 staggered
 // kernel with v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; 2x the bf16 FLOP per clock).  A = activations quantised per
 // ROW by the preceding LayerNorm kernel (norm.hip: ullsam_norm_fp8), W = weights quantised per OUTPUT CHANNEL once; the epilogue
@@ -1793,6 +1975,10 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     const bool v3_split = g_split_tail && workspace && t256 > 256 && tail256 > 0 && tail256 <= 64 && K >= 64 * bk;  // see launch_gemm_v3_impl
     const bool v3 = variant == 3 || (variant == 0 && M >= 1024 && N >= 256 && K >= 8 * bk && (fill >= 0.74 || v3_split) && (act != 3 || N % 256 == 0));  // short K / narrow N: the 256^2 tile's fixed cost or its empty half dominates
     if (act == 3 && (variant == 3) && N % 256 != 0) { ullsam_set_error("ullsam_gemm: v3 swiglu needs N%%256==0"); return -1; }
+    if (variant == 6) {
+        if (dtype != ULLSAM_DT_BF16 || K % 64 != 0 || K < 256) { ullsam_set_error("ullsam_gemm: the ring kernel needs bf16 and K %% 64 == 0, K >= 256"); return -1; }
+        return launch_gemm_v6(a, s);
+    }
     if (variant == 4 && act != 4) {
         if (!v4_ok(a, dtype)) { ullsam_set_error("ullsam_gemm: the persistent kernel needs bf16, N%%256==0, K%%64==0, K>=512, 16-byte aligned rows"); return -1; }
         return launch_gemm_v4(a, s);
