@@ -174,6 +174,60 @@ def test_gemm_ring_kernel(ops, M, N, K, mode):
     assert float((got - want).abs().max()) < tol * max(1.0, float(want.abs().max()) / 4)
 
 
+@pytest.mark.parametrize("M,N,K,mode", [
+    (1500, 512, 512, "bias_gelu"), (1500, 512, 512, "bias_relu"), (4324, 4096, 4096, "res"), (4324, 2048, 1024, "swiglu"), (1000, 768, 384, "plain"),
+    (1001, 768, 256, "plain"),        # odd M: the LDS-staged epilogue
+    (1000, 776, 256, "bias"),         # N not a multiple of 64: ragged last line group
+    (777 * 2, 1280, 1280, "res_mod"), # broadcast residual rows (pos_embed form), fp32 out
+    (2048, 1024, 512, "f32_bias"),    # fp32 output, bias, no residual
+    (512, 256, 256, "f32_gelu"),      # activation on an fp32 output: staged epilogue
+])
+def test_gemm_four_wave_kernel(ops, M, N, K, mode):
+    """The four-wave 256x256 kernel (variant 7: one wave per SIMD, 128x128 per wave, swapped MFMA operands, stores straight from the
+    accumulators): every epilogue it implements directly and the ones it hands to the LDS-staged path, ragged M / N, the split-K
+    tail (4324 x 4096: 272 tiles), against the fp32 matmul of the same operands."""
+    from ullsam_amd import _lib
+    from ullsam_amd.packing import pack_w13
+    lib = _lib.load()
+    g = torch.Generator(device=DEV); g.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g)
+    ref = a.float() @ w.float().T
+    F = torch.nn.functional
+    try:
+        lib.ullsam_set_gemm_variant(7)
+        if mode == "plain":
+            got, want, tol = ops.gemm(a, w).float(), ref, 3e-2
+        elif mode == "bias":
+            got, want, tol = ops.gemm(a, w, bias).float(), ref + bias, 3e-2
+        elif mode == "bias_gelu":
+            got, want, tol = ops.gemm(a, w, bias, act=ops.ACT_GELU).float(), F.gelu(ref + bias), 3e-2
+        elif mode == "bias_relu":
+            got, want, tol = ops.gemm(a, w, bias, act=ops.ACT_RELU).float(), F.relu(ref + bias), 3e-2
+        elif mode == "res":
+            x = torch.randn(M, N, device=DEV, generator=g)
+            want = ref + bias + x
+            ops.gemm(a, w, bias, residual=x, out_f32=True, out=x)
+            got, tol = x, 2e-3
+        elif mode == "res_mod":
+            pe = torch.randn(777, N, device=DEV, generator=g)
+            got, want, tol = ops.gemm(a, w, bias, residual=pe, res_row_mod=777, out_f32=True), ref + bias + pe.repeat(2, 1), 2e-3
+        elif mode == "f32_bias":
+            got, want, tol = ops.gemm(a, w, bias, out_f32=True), ref + bias, 2e-3
+        elif mode == "f32_gelu":
+            got, want, tol = ops.gemm(a, w, bias, act=ops.ACT_GELU, out_f32=True), F.gelu(ref + bias), 2e-3
+        else:
+            I = N // 2
+            got = ops.gemm(a, pack_w13(w[:I].contiguous(), w[I:].contiguous()), act=ops.ACT_SWIGLU).float()
+            want, tol = F.silu(ref[:, :I]) * ref[:, I:], 3e-2
+        torch.cuda.synchronize()
+    finally:
+        lib.ullsam_set_gemm_variant(0)
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) < tol * max(1.0, float(want.abs().max()) / 4)
+
+
 def _e4m3_decode(u8: np.ndarray) -> np.ndarray:
     """OCP e4m3fn bytes -> float32 (the tests' own decoder: sign, 4-bit exponent bias 7, 3-bit mantissa, subnormals, 0x7f = NaN)."""
     u = u8.astype(np.int32)

@@ -20,6 +20,8 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "2"])]
     lib = _lib.load()
+    if os.environ.get("GEMM_GM"):   # raster group height of the 256x256 kernels (A/B)
+        lib.ullsam_set_gemm_tuning(0, int(os.environ["GEMM_GM"]))
     dev = "cuda"
     res = {}
     only = os.environ.get("GEMM_SHAPES")

@@ -56,7 +56,7 @@ SIGNATURES = {
     "ullsam_gemm_fp8": [vp, i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, vp],
 }
 PLAIN = {"ullsam_last_error_string": ([], C.c_char_p), "ullsam_abi_version": ([], i32), "ullsam_device_count": ([], i32),
-         "ullsam_set_gemm_variant": ([i32], i32), "ullsam_set_attn_variant": ([i32], i32),
+         "ullsam_set_gemm_variant": ([i32], i32), "ullsam_set_gemm_tuning": ([i32, i32], i32), "ullsam_set_attn_variant": ([i32], i32),
          "ullsam_set_norm_variant": ([i32], i32)}
 
 

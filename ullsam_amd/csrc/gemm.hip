@@ -53,6 +53,7 @@ struct GemmArgs {
     int store_nt;    // A/B: non-temporal output stores
     int late;        // v3 DMA lead (A/B): bit 0 = group 0 waits for its DMA at the end of C1 instead of L1, bit 1 = group 1 requests tile kt+2 at the end of its C1
     int skew_ticks;  // v4: start-time spread of the workgroups in s_memrealtime ticks (10 ns)
+    int group_m;     // tile rows per raster group of the 256x256 kernels (tiles of a group run column-major: group_m x tiles_n); 4 by default
     int shift_edge;  // v4: the last tile row of a ragged M starts at M-256 (rows it shares with the tile above are not stored again)
 };
 
@@ -66,6 +67,7 @@ static int g_dbg = 0;          // ullsam_set_gemm_variant bit 15: stamp the pers
 static int g_late = 0;         // ullsam_set_gemm_variant bits 24-25 (A/B of the v3 DMA lead)
 static int g_store_nt = 1;     // non-temporal bf16 output stores in the non-persistent kernels (same-process A/B: vit.qkv -3.4 %, vit.lin1 -3.6 %, llm.w13 -0.9 %);
                                // ullsam_set_gemm_variant bit 14 turns them off (A/B)
+static int g_group_m = 4;      // ullsam_set_gemm_tuning(0, gm): A/B of the raster group height
 static int g_gemm_sched = 0;   // 256x256 kernel main-loop schedule: 0 production, 1 plain interleave, 2 fragments-first / 1 barrier
 
 template <typename T>
@@ -114,6 +116,7 @@ __device__ __forceinline__ void store_row8<bf16>(bf16* dst, const float* v, int 
 // 16-byte global store with a cache policy (A/B of the output write path; p.store_nt carries the code):
 //   0 plain (write-back: dirty lines pile up in the XCD L2s and are flushed at the END of the kernel)   1 nt   2 sc1   3 sc0 sc1   4 sc0 sc1 nt
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
+typedef __attribute__((ext_vector_type(4))) int i32x4s;
 __device__ __forceinline__ void store16_policy(void* ptr, u32x4s v, int policy) {
     if (policy == 0) *reinterpret_cast<u32x4s*>(ptr) = v;
     else if (policy == 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4s*>(ptr));
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         part = t - tail_idx * p.ksplit;
         swz = nblk + tail_idx;
     }
-    const int GM = 4;
+    const int GM = p.group_m;
     const int width = GM * p.tiles_n;
     const int group = swz / width;
     const int first_m = group * GM;
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(NT) void gemm256_tail_reduce_kernel(GemmArgs p) {
     const int tid = threadIdx.x;
     const int tail_idx = blockIdx.x / SPT, slab = blockIdx.x % SPT;
     const int swz = p.full_tiles + tail_idx;
-    const int GM = 4;
+    const int GM = p.group_m;
     const int width = GM * p.tiles_n;
     const int group = swz / width;
     const int first_m = group * GM;
@@ -1318,7 +1321,7 @@ __global__ __launch_bounds__(512) void gemm256r_kernel(GemmArgs p) {
         part = t - tail_idx * p.ksplit;
         swz = nblk + tail_idx;
     }
-    const int GM = 4;
+    const int GM = p.group_m;
     const int width = GM * p.tiles_n;
     const int group = swz / width;
     const int first_m = group * GM;
@@ -1464,6 +1467,442 @@ static int launch_gemm_v6(const GemmArgs& a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// v7: 256x256 tile, FOUR waves (2 x 2, 128x128 per wave, 256 accumulator registers per lane: one wave per SIMD with the whole
+// 512-entry register file), the ring of four half-K stages of v6, and ONE software-pipelined instruction stream per wave instead of
+// two wave groups taking turns: while the 64 MFMAs of stage s run from registers, the same wave reads the 16 fragments of stage
+// s+1 and requests its 8 LDS-DMA pieces of stage s+4, spread evenly between the MFMAs (sched_group_barrier).
+// Why: (1) fragment reads per MFMA drop by a third (16 per 64 MFMAs instead of 12 per 32: LDS array time 62 % -> 50 % of the MFMA
+// time, and LDS bytes are energy on a power-bound loop); (2) the LDS-DMA requests reach the address unit one per ~128 cycles and
+// wave instead of 32 at once at the top of a load slot (where they queue at 16 cycles per KiB and hold back the fragment reads
+// behind them); (3) it is the shape the vendor library's kernels for this chip have (rocprofv3 of tools/gemm_bench.py: 256 threads,
+// MT256x256x64, 130 KiB LDS, 512 registers).
+// Per stage: wait (own pieces of stage s+1 landed: vmcnt(16) leaves s+2, s+3 in flight; fragments of stage s in registers) ->
+// s_barrier (everyone's pieces of s+1 landed; everyone has finished reading stage s = ring slot s & 3, which the DMA of s+4 reuses)
+// -> {8 DMA pieces, 16 ds_read_b128, 64 MFMAs} interleaved.  The request leads its use by three stages (~3 kilo-cycles).
+// LDS image and DMA pieces as in v6.  The number of stages per K-range is even (ranges are cut on 64-deep K-tiles), so the two
+// fragment register sets alternate statically.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mma16a(const Frag<bf16>& a, const Frag<bf16>& b, f32x4& c) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a.v), "v"(b.v));
+}
+template <int EMODE, bool STAMP = false, int ABL = 0>   // ABL (stamped diagnostic builds only; results are garbage): 1 no DMA requests, 2 no fragment reads, 4 no barrier
+__global__ __launch_bounds__(256) void gemm256w_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef bf16 T;
+    constexpr int STG = 32768;  // 16 KiB A + 16 KiB B per stage
+
+    const int nblk = p.full_tiles;
+    const int bid = blockIdx.x;
+    int swz, part = -1, tail_idx = 0;
+    if (bid < nblk) {
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+        swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    } else {
+        const int t = bid - nblk;
+        tail_idx = t / p.ksplit;
+        part = t - tail_idx * p.ksplit;
+        swz = nblk + tail_idx;
+    }
+    const int GM = p.group_m;
+    const int width = GM * p.tiles_n;
+    const int group = swz / width;
+    const int first_m = group * GM;
+    const int gsize = min(p.tiles_m - first_m, GM);
+    const int tm = first_m + (swz % width) % gsize;
+    const int tn = (swz % width) / gsize;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g4 = lane >> 4, mm = lane & 15;
+
+    // DMA pieces of this wave: A pieces 4w .. 4w+3 and B pieces 4w .. 4w+3 (16 rows x 64 B each); lane -> row 16 piece + lane / 4, LDS chunk lane & 3
+    const char* a_base = reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda * 2;
+    const char* b_base = reinterpret_cast<const char*>(p.W) + (size_t)n0 * p.ldw * 2;
+    // The MFMA operands are SWAPPED (first operand = weight fragment): a lane's four accumulator registers of a 16x16 sub-tile are four
+    // consecutive COLUMNS of one output row, so the epilogue stores straight from the accumulators.  For 2-byte outputs the weight rows
+    // of a wave are permuted on their way into the LDS so that two neighbouring sub-tiles give a lane eight consecutive columns (16 B):
+    //   LDS row R of the tile (wave half wb = R >> 7, sub-tile j = (R >> 4) & 7, r = R & 15) holds weight row
+    //   n(R) = 128 wb + 32 (j >> 1) + 8 (r >> 2) + 4 (j & 1) + (r & 3);   fp32 outputs keep n = R (four fp32 = 16 B per lane and sub-tile).
+    const bool permuted = !p.out_f32;
+    auto w_row = [&](int R) {
+        const int j = (R >> 4) & 7, r = R & 15;
+        return permuted ? (R & 128) + 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3) : R;
+    };
+    unsigned int a_off[4], b_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 2);
+        a_off[i] = (unsigned int)((size_t)(min(m0 + row, p.M - 1) - m0) * p.lda * 2) + (c << 4);
+        b_off[i] = (unsigned int)((size_t)(min(n0 + w_row(row), p.N - 1) - n0) * p.ldw * 2) + (c << 4);
+    }
+    // in-loop requests go through buffer descriptors (buffer_load_dwordx4 ... lds): the instruction offset is added to the memory AND
+    // the LDS address (tools/probes/buffer_lds.hip), so the four pieces of a matrix share one M0 (lane offsets pre-decremented by
+    // 1 KiB per piece), and an SGPR offset at or past num_records turns a request into a no-fetch (stages past the end; rows past
+    // M / N read as zeros) -- per piece ONE instruction, no compare, no branch, no address arithmetic
+    i32x4s rsrc_a, rsrc_b;
+    rsrc_a[0] = (int)(size_t)a_base; rsrc_a[1] = (int)((size_t)a_base >> 32) & 0xffff; rsrc_a[2] = (int)((long)min(p.M - m0, 256) * p.lda * 2); rsrc_a[3] = 0x00020000;
+    rsrc_b[0] = (int)(size_t)b_base; rsrc_b[1] = (int)((size_t)b_base >> 32) & 0xffff; rsrc_b[2] = (int)((long)min(p.N - n0, 256) * p.ldw * 2); rsrc_b[3] = 0x00020000;
+    unsigned int a_vo[4], b_vo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 2);
+        a_vo[i] = (unsigned int)((size_t)row * p.lda * 2) + (c << 4) - i * 1024;
+        b_vo[i] = (unsigned int)((size_t)w_row(row) * p.ldw * 2) + (c << 4) - i * 1024;
+    }
+    const int nq = p.K >> 7;   // K ranges in units of four stages (128 elements): ring slots are compile-time constants in the loop
+    const int st0 = part < 0 ? 0 : 4 * (int)((long)part * nq / p.ksplit);
+    const int st1 = part < 0 ? 4 * nq : 4 * (int)((long)(part + 1) * nq / p.ksplit);
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read addresses: row = w * 128 + i * 16 + mm, so the swizzle term (row >> 2) & 2 depends on mm only and i is a constant offset
+    const int rd_swz = ((g4 ^ ((mm >> 2) & 2)) << 4) + mm * 64;
+    const int a_rd = wm * 8192 + rd_swz;
+    const int b_rd = 16384 + wn * 8192 + rd_swz;
+
+    auto stage = [&](int s) {   // request stage s into ring slot s & 3
+        char* base = smem + (s & 3) * STG + wave * 4096;
+        const char* ak = a_base + (size_t)s * 64;
+        const char* bk = b_base + (size_t)s * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_off[i]), LDS_PTR(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + 16384 + i * 1024), 16, 0, 0);
+        }
+    };
+    auto read_frags = [&](int s, Frag<T>* fa, Frag<T>* fb) {
+        const char* Ab = smem + (s & 3) * STG + a_rd;
+        const char* Bb = smem + (s & 3) * STG + b_rd;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            fa[i] = load_frag(reinterpret_cast<const T*>(Ab + i * 1024));
+            fb[i] = load_frag(reinterpret_cast<const T*>(Bb + i * 1024));
+        }
+    };
+    // One stage.  With ONE wave per SIMD every instruction of the stream takes a ~4-cycle issue slot and a 16-cycle MFMA leaves two
+    // of them free, so the stream is written to the slot: per 8 MFMAs three ds_read_b128 and one DMA request, nothing else.
+    //  * The MFMAs are inline asm with the accumulators pinned to AGPRs ("+a"): left to itself the register allocator keeps part of
+    //    the 256 accumulators in VGPRs and shuffles them through v_accvgpr moves inside the loop.  The asm is opaque to the hazard
+    //    recogniser, so the K loop is ONE loop (a peeled tail gets a different register assignment and accumulator copies next to
+    //    the MFMAs) and branch-free: the requests of the last four stages are issued out of range (no fetch, but still counted by
+    //    vmcnt, so the counted wait at the top of a stage never changes), the reads past the end fetch stale bytes.
+    //  * A DMA request is ONE instruction (buffer_load_dwordx4 ... lds, see the descriptors above); M0 is written twice per stage.
+    //  * Four stages per loop trip (K ranges are multiples of 128): ring slots, LDS addresses and M0 values are compile-time constants.
+    //  * sched_barrier(0) after every element keeps the source order: 8 x { 2 MFMA, read, 2 MFMA, request, 2 MFMA, read, 2 MFMA, read },
+    //    the 16 reads issued by the sixth group (the top of the next stage waits for all of them: its ring slot is requested again);
+    //    the stage's first MFMA pair goes BEFORE the s_barrier (registers only) and covers part of its latency.
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
+    const unsigned wave_lds = lds0 + wave * 4096;
+    // fragment read bases for ring slots {0, 1} and {2, 3} (ds_read offsets are 16 bits); the upper pair is laundered so that it stays
+    // its own register instead of being re-derived with a VALU add in front of every read
+    int a_hi = a_rd + 65536, b_hi = b_rd + 65536;
+    asm volatile("" : "+v"(a_hi), "+v"(b_hi));
+    const char* rdA[2] = {smem + a_rd, smem + a_hi};
+    const char* rdB[2] = {smem + b_rd, smem + b_hi};
+    int kbyte = (st0 + 4) * 64;   // K byte offset of the stage requested next
+    auto iter = [&](auto slot_c, const Frag<T>* ca, const Frag<T>* cb, Frag<T>* na, Frag<T>* nb) {
+        constexpr int U = decltype(slot_c)::value;        // this stage's ring slot = the slot the request for stage s + 4 goes to
+        constexpr int R = (U + 1) & 3;                     // the slot of stage s + 1, whose fragments are read now
+        const char* Ab = rdA[R >> 1] + (R & 1) * STG;
+        const char* Bb = rdB[R >> 1] + (R & 1) * STG;
+        const int soff = kbyte < st1 * 64 ? kbyte : 0x40000000;   // past the end: out of range of either descriptor
+        auto rd = [&](int r) {   // read r of 16: the B fragments first (the next stage's first MFMAs need all of them)
+            if (ABL & 2) return;
+            if (r < 8) nb[r] = load_frag(reinterpret_cast<const T*>(Bb + r * 1024));
+            else na[r - 8] = load_frag(reinterpret_cast<const T*>(Ab + (r - 8) * 1024));
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto request = [&](int q) {
+            if (ABL & 1) return;
+            if ((ABL & 16) && wave != 0) return;   // (diagnostic) only wave 0 requests: is a request's cost its own issue or the four waves colliding?
+            const unsigned vo = q < 4 ? a_vo[q & 3] : b_vo[q & 3];
+            const i32x4s rs = q < 4 ? rsrc_a : rsrc_b;
+            switch (q & 3) {
+                case 0: asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(vo), "s"(rs), "s"(soff) : "memory"); break;
+                case 1: asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:1024 lds" :: "v"(vo), "s"(rs), "s"(soff) : "memory"); break;
+                case 2: asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:2048 lds" :: "v"(vo), "s"(rs), "s"(soff) : "memory"); break;
+                default: asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:3072 lds" :: "v"(vo), "s"(rs), "s"(soff) : "memory"); break;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // own pieces of stage s + 1 landed (the 16 of s + 2, s + 3 may stay in flight), fragments of stage s in registers
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            mma16a(cb[0], ca[q], acc[q][0]); mma16a(cb[1], ca[q], acc[q][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q == 0) {
+                // everyone's pieces of s + 1 landed; everyone has read stage s (slot U) -- its slot may be requested again
+                if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if ((q & 3) == 0 && !(ABL & 1)) {   // M0 for the next four pieces (A: q 0-3, B: q 4-7); the instructions up to the request are its wait states
+                asm volatile("s_add_i32 m0, %0, %1" :: "s"(wave_lds), "i"(U * STG + (q >> 2) * 16384));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (3 * q < 16) rd(3 * q);
+            mma16a(cb[2], ca[q], acc[q][2]); mma16a(cb[3], ca[q], acc[q][3]);
+            __builtin_amdgcn_sched_barrier(0);
+            request(q);
+            mma16a(cb[4], ca[q], acc[q][4]); mma16a(cb[5], ca[q], acc[q][5]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (3 * q + 1 < 16) rd(3 * q + 1);
+            mma16a(cb[6], ca[q], acc[q][6]); mma16a(cb[7], ca[q], acc[q][7]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (3 * q + 2 < 16) rd(3 * q + 2);
+            if (q == 6) { kbyte += 64; __builtin_amdgcn_sched_barrier(0); }
+        }
+    };
+    typedef std::integral_constant<int, 0> S0; typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, 2> S2; typedef std::integral_constant<int, 3> S3;
+
+    // (diagnostic build only) shader-clock stamps per workgroup: start, loop entry, loop exit, end
+    auto stamp = [&](int k) {
+        if (STAMP && tid == 0 && p.dbg) {
+            p.dbg[(size_t)bid * 8 + k] = __builtin_amdgcn_s_memtime();
+            if (k == 0 || k == 3) p.dbg[(size_t)bid * 8 + 4 + (k & 1)] = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock: shader clock = d(memtime) / d(realtime)
+        }
+    };
+    stamp(0);
+    // this lane's 32 output columns (permuted: 8 at 32 jp + 8 g4 for jp = 0..3; fp32: 4 at 16 j + 4 g4 for j = 0..7) keep their bias in
+    // registers across the K loop (requested first: the prologue's counted wait below covers them)
+    float bv[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) bv[e] = 0.f;
+    if (p.bias && part < 0 && EMODE == 0) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int col = n0 + wn * 128 + (permuted ? 32 * (t >> 1) + 8 * g4 + 4 * (t & 1) : 16 * t + 4 * g4);
+            if (col < p.N) {   // N % 4 == 0 on the direct path (vec_ok); the staged path fetches its own bias
+                const float4 x = *reinterpret_cast<const float4*>(p.bias + col);
+                bv[4 * t] = x.x; bv[4 * t + 1] = x.y; bv[4 * t + 2] = x.z; bv[4 * t + 3] = x.w;
+            }
+        }
+    }
+    Frag<T> fa0[8], fb0[8], fa1[8], fb1[8];
+    // prologue: the first four stages requested (st1 - st0 is a positive multiple of 4: launcher), stage st0 landed, its fragments read
+    stage(st0); stage(st0 + 1); stage(st0 + 2); stage(st0 + 3);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(st0, fa0, fb0);
+    stamp(1);
+    for (int s = st0; s < st1; s += 4) {
+        iter(S0{}, fa0, fb0, fa1, fb1);
+        iter(S1{}, fa1, fb1, fa0, fb0);
+        iter(S2{}, fa0, fb0, fa1, fb1);
+        iter(S3{}, fa1, fb1, fa0, fb0);
+    }
+    // let the last MFMAs retire before anything reads the accumulators (the asm MFMAs are opaque to the hazard recogniser); the
+    // out-of-range requests and the stale reads of the last stages must be done before the epilogue reuses the LDS
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    stamp(2);
+    if (STAMP && (p.ablate & 8)) return;   // (diagnostic) no epilogue
+
+    // ---- epilogue.  acc[i][j][r] = C[m0 + 128 wm + 16 i + mm][n0 + 128 wn + ncol(j) + r]
+    auto ncol = [&](int j) __attribute__((always_inline)) { return permuted ? 32 * (j >> 1) + 8 * g4 + 4 * (j & 1) : 16 * j + 4 * g4; };
+    const int row0 = m0 + wm * 128 + mm;            // this lane's row in sub-tile i is row0 + 16 i
+    const bool odd = mm & 1;
+    const int rowp = row0 & ~1;                     // after pair_swap the lane pair (mm, mm ^ 1) owns rows rowp + 16 i and rowp + 16 i + 1
+    auto gst = [&](void* ptr, u32x4 v) __attribute__((always_inline)) { store16_policy(ptr, __builtin_bit_cast(u32x4s, v), p.store_nt); };
+    const bool direct = EMODE == 0 && p.vec_ok && (p.N & 7) == 0 && (p.M & 1) == 0;
+    if (part >= 0) {
+        // K-range of a split tail tile: raw fp32 partial tile -> workspace [slot][256][256] (finished by gemm256_tail_reduce_kernel)
+        float* wp = p.ws + ((size_t)tail_idx * p.ksplit + part) * 65536 + (size_t)(wm * 128 + mm) * 256 + wn * 128;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *reinterpret_cast<u32x4*>(wp + (size_t)(16 * i) * 256 + ncol(j)) =
+                    (u32x4){__float_as_uint(acc[i][j][0]), __float_as_uint(acc[i][j][1]), __float_as_uint(acc[i][j][2]), __float_as_uint(acc[i][j][3])};
+    } else if (direct && !p.out_f32 && p.act != 3) {
+        // bf16 output (+bias, +GELU / ReLU): sub-tile pairs (4 lp + 2 h, + 1) are this lane's 8 columns of the 32-column group 2 lp + h;
+        // groups 2 lp and 2 lp + 1 are the two halves of a 128 B line -> pair_swap, then one instruction writes 8 rows x 128 B
+        const int colb = n0 + wn * 128 + (odd ? 32 : 0) + 8 * g4;
+        T* cp = reinterpret_cast<T*>(p.C) + (size_t)rowp * p.ldc + colb;
+        auto drain = [&](auto ACT) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int lp = 0; lp < 2; ++lp) {
+                    unsigned int o[8];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float v0 = acc[i][4 * lp + 2 * h + (q >> 1)][2 * (q & 1)] + bv[16 * lp + 8 * h + 2 * q];
+                            float v1 = acc[i][4 * lp + 2 * h + (q >> 1)][2 * (q & 1) + 1] + bv[16 * lp + 8 * h + 2 * q + 1];
+                            if constexpr (decltype(ACT)::value == 1) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); }
+                            if constexpr (decltype(ACT)::value == 2) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                            o[4 * h + q] = pack_bf16x2(v0, v1);
+                        }
+                    u32x4 s0, s1;
+                    pair_swap((u32x4){o[0], o[1], o[2], o[3]}, (u32x4){o[4], o[5], o[6], o[7]}, odd, s0, s1);
+                    if (rowp + 16 * i < p.M && colb + 64 * lp < p.N) {   // M is even: both rows of the pair or neither
+                        gst(cp + (size_t)(16 * i) * p.ldc + 64 * lp, s0);
+                        gst(cp + (size_t)(16 * i + 1) * p.ldc + 64 * lp, s1);
+                    }
+                }
+        };
+        if (p.act == 1) drain(std::integral_constant<int, 1>{});
+        else if (p.act == 2) drain(std::integral_constant<int, 2>{});
+        else drain(std::integral_constant<int, 0>{});
+    } else if (direct && !p.out_f32 && p.act == 3) {
+        // SwiGLU: the wave's 128 columns are [64 gate | 64 up] (host prepack); gate = sub-tiles 0-3, up = 4-7 of the same 8 columns:
+        // out[:, n0/2 + 64 wn + 32 jp + 8 g4 + e] = silu(gate_e) * up_e   (modeling_internlm2.py:261-264)
+        const int colb = (n0 >> 1) + wn * 64 + (odd ? 32 : 0) + 8 * g4;
+        T* cp = reinterpret_cast<T*>(p.C) + (size_t)rowp * p.ldc + colb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned int o[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float g0 = acc[i][2 * h + (q >> 1)][2 * (q & 1)], g1 = acc[i][2 * h + (q >> 1)][2 * (q & 1) + 1];
+                    const float u0 = acc[i][4 + 2 * h + (q >> 1)][2 * (q & 1)], u1 = acc[i][4 + 2 * h + (q >> 1)][2 * (q & 1) + 1];
+                    o[4 * h + q] = pack_bf16x2(silu_f(g0) * u0, silu_f(g1) * u1);
+                }
+            u32x4 s0, s1;
+            pair_swap((u32x4){o[0], o[1], o[2], o[3]}, (u32x4){o[4], o[5], o[6], o[7]}, odd, s0, s1);
+            if (rowp + 16 * i < p.M) {
+                gst(cp + (size_t)(16 * i) * p.ldc, s0);
+                gst(cp + (size_t)(16 * i + 1) * p.ldc, s1);
+            }
+        }
+    } else if (direct && p.out_f32 && p.act == 0) {
+        // fp32 residual stream: C = acc + bias + residual[row (mod res_row_mod)].  Sub-tiles (2 jp, 2 jp + 1) are the two 64 B halves of the
+        // 128 B line jp -> pair_swap; afterwards this lane owns piece (odd ? 4 : 0) + g4 of line jp in rows rowp + 16 i and + 1.
+        // Two register sets alternate: the residual rows of sub-tile i + 1 are requested before sub-tile i is stored.
+        const int colp = n0 + wn * 128 + (odd ? 16 : 0) + 4 * g4;
+        float* cp = reinterpret_cast<float*>(p.C) + (size_t)rowp * p.ldc + colp;
+        auto load_res = [&](int i, float4 (&r)[8]) {   // r[2 jp + rsel]: line jp of row rowp + 16 i + rsel
+#pragma unroll
+            for (int rsel = 0; rsel < 2; ++rsel) {
+                const int gm = min(rowp + 16 * i + rsel, p.M - 1);
+                const int rr = p.res_row_mod > 0 ? gm % p.res_row_mod : gm;
+                const float* rp = p.residual + (size_t)rr * p.ldr + colp;
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) r[2 * jp + rsel] = colp + 32 * jp < p.N ? *reinterpret_cast<const float4*>(rp + 32 * jp) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto put = [&](int i, const float4 (&r)[8]) {
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                u32x4 lo, hi, s0, s1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = __float_as_uint(acc[i][2 * jp][e] + bv[8 * jp + e]);
+                    hi[e] = __float_as_uint(acc[i][2 * jp + 1][e] + bv[8 * jp + 4 + e]);
+                }
+                pair_swap(lo, hi, odd, s0, s1);
+                const float4 r0 = r[2 * jp], r1 = r[2 * jp + 1];
+                s0 = (u32x4){__float_as_uint(__uint_as_float(s0[0]) + r0.x), __float_as_uint(__uint_as_float(s0[1]) + r0.y),
+                             __float_as_uint(__uint_as_float(s0[2]) + r0.z), __float_as_uint(__uint_as_float(s0[3]) + r0.w)};
+                s1 = (u32x4){__float_as_uint(__uint_as_float(s1[0]) + r1.x), __float_as_uint(__uint_as_float(s1[1]) + r1.y),
+                             __float_as_uint(__uint_as_float(s1[2]) + r1.z), __float_as_uint(__uint_as_float(s1[3]) + r1.w)};
+                if (rowp + 16 * i < p.M && colp + 32 * jp < p.N) {
+                    *reinterpret_cast<u32x4*>(cp + (size_t)(16 * i) * p.ldc + 32 * jp) = s0;
+                    *reinterpret_cast<u32x4*>(cp + (size_t)(16 * i + 1) * p.ldc + 32 * jp) = s1;
+                }
+            }
+        };
+        auto drain = [&](auto RES) __attribute__((always_inline)) {
+            float4 ra[8], rb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ra[j] = rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (decltype(RES)::value) load_res(0, ra);
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                if constexpr (decltype(RES)::value) { load_res(i + 1, rb); __builtin_amdgcn_sched_barrier(0); }
+                put(i, ra);
+                if constexpr (decltype(RES)::value) { if (i + 2 < 8) load_res(i + 2, ra); __builtin_amdgcn_sched_barrier(0); }
+                put(i + 1, rb);
+            }
+        };
+        if (p.residual) drain(std::true_type{}); else drain(std::false_type{});
+    } else {
+        // every other epilogue (RoPE, activations on fp32 outputs, unaligned / odd shapes): through the LDS, one 128-row half at a time
+        float* Cs = reinterpret_cast<float*>(smem);  // [128][256] fp32 = 128 KiB
+        auto staged = [&](auto half_c) __attribute__((always_inline)) {   // (a lambda called twice: as a loop the two bulky bodies are not unrolled and the accumulators land in scratch)
+            constexpr int half = decltype(half_c)::value;
+            __syncthreads();
+            if (wm == half) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        *reinterpret_cast<float4*>(Cs + (i * 16 + mm) * 256 + wn * 128 + ncol(j)) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+            __syncthreads();
+            if (p.out_f32) epilogue_rows<T, float, 128, 256, 256, EMODE>(p, Cs, m0 + half * 128, n0, tn, tid);
+            else epilogue_rows<T, T, 128, 256, 256, EMODE>(p, Cs, m0 + half * 128, n0, tn, tid);
+        };
+        staged(std::integral_constant<int, 0>{});
+        staged(std::integral_constant<int, 1>{});
+    }
+    stamp(3);
+}
+
+template <int EMODE>
+static int launch_gemm_v7_impl(GemmArgs a, hipStream_t stream) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256w_kernel<EMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (a.N + 255) / 256;
+    const int T_ = a.tiles_m * a.tiles_n;
+    const int nk = a.K / 64;
+    const int tail = T_ % 256;
+    a.full_tiles = T_;
+    a.ksplit = 1;
+    if (g_split_tail && a.ws && T_ > 256 && tail > 0 && tail <= 64 && nk >= 64) {  // same split-K tail policy as the two-buffer kernel
+        int S = 256 / tail;
+        if (S > 8) S = 8;
+        if (S > nk / 8) S = nk / 8;
+        if (S >= 2 && (size_t)tail * S * 262144 <= a.ws_bytes) {
+            a.full_tiles = T_ - tail;
+            a.ksplit = S;
+        }
+    }
+    if (a.dbg && EMODE == 0) {   // stamped diagnostic builds (tools/probes/v7_stamps.py); the ablation comes in the variant's ablate bits
+        const dim3 grid(a.full_tiles + (T_ - a.full_tiles) * a.ksplit);
+        auto go = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            kern<<<grid, dim3(256), 131072, stream>>>(a);
+        };
+        switch (a.ablate & 7) {
+            case 0: go(gemm256w_kernel<0, true, 0>); break;
+            case 1: go(gemm256w_kernel<0, true, 1>); break;
+            case 2: go(gemm256w_kernel<0, true, 2>); break;
+            case 4: go(gemm256w_kernel<0, true, 4>); break;
+            case 6: go(gemm256w_kernel<0, true, 16>); break;
+            default: go(gemm256w_kernel<0, true, 7>); break;
+        }
+    } else
+    gemm256w_kernel<EMODE><<<dim3(a.full_tiles + (T_ - a.full_tiles) * a.ksplit), dim3(256), 131072, stream>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    if (a.ksplit > 1) {
+        const int tail_tiles = T_ - a.full_tiles;
+        if (tail_tiles * a.ksplit <= 128) gemm256_tail_reduce_kernel<bf16, 4, 128, EMODE><<<dim3(tail_tiles * 64), dim3(128), 0, stream>>>(a);
+        else gemm256_tail_reduce_kernel<bf16, 16, 256, EMODE><<<dim3(tail_tiles * 16), dim3(256), 0, stream>>>(a);
+        ULLSAM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+static int launch_gemm_v7(const GemmArgs& a, hipStream_t stream) {
+    if (a.act == 4) return launch_gemm_v7_impl<1>(a, stream);
+    return launch_gemm_v7_impl<0>(a, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) GEMM for the ViT's LayerNorm-fed linears (BASELINE configs[4], "fp8 MFMA ViT path"): the 256x256 staggered
 // kernel with v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; 2x the bf16 FLOP per clock).  A = activations quantised per
 // ROW by the preceding LayerNorm kernel (norm.hip: ullsam_norm_fp8), W = weights quantised per OUTPUT CHANNEL once; the epilogue
@@ -1600,6 +2039,7 @@ extern "C" int ullsam_gemm_fp8(const void* A8, long lda, const float* a_scale, c
     const int osz = out_f32 ? 4 : 2;
     bool vec = ((uintptr_t)C & 15) == 0 && (ldc * osz) % 16 == 0 && (N % 8 == 0);
     if (residual) vec = vec && ((uintptr_t)residual & 15) == 0 && (ldr % 4 == 0);
+    a.group_m = 4;   // gemm256f8_kernel rasters with a fixed group height
     a.vec_ok = vec ? 1 : 0;
     a.ablate = 0; a.ws = nullptr; a.ws_bytes = 0; a.shift_edge = 0; a.skew_ticks = 0; a.store_nt = 0; a.late = 0; a.ksplit = 1;
     a.row_scale = a_scale; a.col_scale = w_scale; a.dbg = nullptr;
@@ -1625,6 +2065,7 @@ static int num_cus() {
 
 template <int EPI>
 static int launch_gemm_v4_impl(GemmArgs a, hipStream_t stream) {
+    a.group_m = 4;   // the persistent kernel's unit list has a fixed group height (its tail reduce must agree)
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 133120);
@@ -1676,6 +2117,11 @@ static int launch_gemm_v4(const GemmArgs& a, hipStream_t stream) {
 }
 
 // v: bits 0-3 kernel (0 auto), +64 no split-K tail, bits 8-11 timing-only ablations (1 no staging, 2 no barrier, 4 no epilogue, 8 no stores), bits 12-13 schedule of the 256x256 kernel
+extern "C" int ullsam_set_gemm_tuning(int key, int value) {
+    if (key == 0 && value >= 1 && value <= 1024) { g_group_m = value; return 0; }
+    ullsam_set_error("ullsam_set_gemm_tuning: unknown key %d / bad value %d", key, value);
+    return -1;
+}
 extern "C" int ullsam_set_gemm_variant(int v) {
     g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_persistent = (v & 128) ? 0 : 1; g_skew_half_us = (v >> 16) & 255; g_store_nt = ((v >> 14) & 1) ? 0 : (((v >> 26) & 7) ? ((v >> 26) & 7) : 1); g_late = (v >> 24) & 15; g_dbg = (v >> 15) & 1; g_store_v4 = (int)(((unsigned)v >> 29) & 7); g_gemm_ablate = (v >> 8) & 15; g_gemm_sched = (v >> 12) & 3;
     return 0;
@@ -1950,6 +2396,7 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     a.ws = reinterpret_cast<float*>(workspace);
     a.ws_bytes = workspace ? (size_t)ws_bytes : 0;
     a.shift_edge = 0;
+    a.group_m = g_group_m;
     a.skew_ticks = 0;
     a.row_scale = nullptr;
     a.col_scale = nullptr;
@@ -1975,6 +2422,10 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     const bool v3_split = g_split_tail && workspace && t256 > 256 && tail256 > 0 && tail256 <= 64 && K >= 64 * bk;  // see launch_gemm_v3_impl
     const bool v3 = variant == 3 || (variant == 0 && M >= 1024 && N >= 256 && K >= 8 * bk && (fill >= 0.74 || v3_split) && (act != 3 || N % 256 == 0));  // short K / narrow N: the 256^2 tile's fixed cost or its empty half dominates
     if (act == 3 && (variant == 3) && N % 256 != 0) { ullsam_set_error("ullsam_gemm: v3 swiglu needs N%%256==0"); return -1; }
+    if (variant == 7) {
+        if (dtype != ULLSAM_DT_BF16 || K % 128 != 0 || K < 256) { ullsam_set_error("ullsam_gemm: the four-wave kernel needs bf16 and K %% 128 == 0, K >= 256"); return -1; }
+        return launch_gemm_v7(a, s);
+    }
     if (variant == 6) {
         if (dtype != ULLSAM_DT_BF16 || K % 64 != 0 || K < 256) { ullsam_set_error("ullsam_gemm: the ring kernel needs bf16 and K %% 64 == 0, K >= 256"); return -1; }
         return launch_gemm_v6(a, s);
