@@ -12,7 +12,16 @@ kc=torch.zeros(B,KVH,S,hd,device=dev,dtype=torch.bfloat16); vc=torch.zeros_like(
 def fused(): return ops.gemm_qkv_rope(x,w,None,kc,vc,pos,cos,sin,B,S,KVH,G,0)
 def unfused():
     qkv=ops.gemm(x,w); return ops.rope_split(qkv,kc,vc,pos,cos,sin,B,S,KVH,G,hd,0)
-for name,fn in (("unfused",unfused),("fused",fused),("unfused",unfused),("fused",fused)):
+from ullsam_amd import _lib
+lib=_lib.load()
+def fused7():
+    lib.ullsam_set_gemm_variant(7)
+    try: return fused()
+    finally: lib.ullsam_set_gemm_variant(0)
+ref=fused()[0].float() if isinstance(fused(),tuple) else fused().float()
+got=fused7(); got=(got[0] if isinstance(got,tuple) else got).float()
+print("variant 7 vs auto: max |dq|", (got-ref).abs().max().item())
+for name,fn in (("unfused",unfused),("fused",fused),("fused, four-wave kernel",fused7),("unfused",unfused),("fused",fused),("fused, four-wave kernel",fused7)):
     fn(); ts=[]
     for r in range(7):
         e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)

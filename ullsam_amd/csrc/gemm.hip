@@ -67,6 +67,7 @@ static int g_dbg = 0;          // ullsam_set_gemm_variant bit 15: stamp the pers
 static int g_late = 0;         // ullsam_set_gemm_variant bits 24-25 (A/B of the v3 DMA lead)
 static int g_store_nt = 1;     // non-temporal bf16 output stores in the non-persistent kernels (same-process A/B: vit.qkv -3.4 %, vit.lin1 -3.6 %, llm.w13 -0.9 %);
                                // ullsam_set_gemm_variant bit 14 turns them off (A/B)
+static int g_auto_mask = 3;    // ullsam_set_gemm_tuning(1, mask): kernels the auto dispatch may pick besides the two-buffer one: bit 0 persistent (GELU), bit 1 four-wave
 static int g_group_m = 4;      // ullsam_set_gemm_tuning(0, gm): A/B of the raster group height
 static int g_gemm_sched = 0;   // 256x256 kernel main-loop schedule: 0 production, 1 plain interleave, 2 fragments-first / 1 barrier
 
@@ -1863,7 +1864,7 @@ static int launch_gemm_v7_impl(GemmArgs a, hipStream_t stream) {
     const int tail = T_ % 256;
     a.full_tiles = T_;
     a.ksplit = 1;
-    if (g_split_tail && a.ws && T_ > 256 && tail > 0 && tail <= 64 && nk >= 64) {  // same split-K tail policy as the two-buffer kernel
+    if (g_split_tail && a.ws && T_ > 256 && tail > 0 && tail <= 64 && nk >= 64) {  // same split-K tail policy as the two-buffer kernel (a 2-way cut of a half-full last round measured slower: 862 vs 824 us on llm.w13)
         int S = 256 / tail;
         if (S > 8) S = 8;
         if (S > nk / 8) S = nk / 8;
@@ -2119,6 +2120,7 @@ static int launch_gemm_v4(const GemmArgs& a, hipStream_t stream) {
 // v: bits 0-3 kernel (0 auto), +64 no split-K tail, bits 8-11 timing-only ablations (1 no staging, 2 no barrier, 4 no epilogue, 8 no stores), bits 12-13 schedule of the 256x256 kernel
 extern "C" int ullsam_set_gemm_tuning(int key, int value) {
     if (key == 0 && value >= 1 && value <= 1024) { g_group_m = value; return 0; }
+    if (key == 1 && value >= 0 && value <= 3) { g_auto_mask = value; return 0; }
     ullsam_set_error("ullsam_set_gemm_tuning: unknown key %d / bad value %d", key, value);
     return -1;
 }
@@ -2436,7 +2438,13 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     }
     // persistent kernel in auto mode: only where it measured faster in the same process -- bf16 output with the GELU epilogue (vit.lin1
     // 214 vs 232 us: the erf arithmetic of one wave group overlaps the other group's matrix segment); elsewhere it ties or loses 0-3 %
-    if (v3 && variant == 0 && g_persistent && a.act == 1 && !a.out_f32 && v4_ok(a, dtype)) return launch_gemm_v4(a, s);
+    if (v3 && variant == 0 && g_persistent && (g_auto_mask & 1) && a.act == 1 && !a.out_f32 && v4_ok(a, dtype)) return launch_gemm_v4(a, s);
+    // four-wave kernel in auto mode: bf16 output without residual and without GELU (its erf arithmetic has no second wave to hide under),
+    // where its direct epilogue applies -- same-process A/B: llm.w13 -2.3 ... -4.8 %, vit.qkv -1.7 %, llm.wqkv -2 %; the fp32 residual
+    // GEMMs (+2 ... +8 %) and the RoPE epilogue (+5 %) stay on the two-buffer kernel
+    if (v3 && variant == 0 && g_persistent && (g_auto_mask & 2) && dtype == ULLSAM_DT_BF16 && !a.out_f32 && !residual && (act == 0 || act == 3) && a.vec_ok && N % 8 == 0 &&
+        M % 2 == 0 && K % 128 == 0 && K >= 512)
+        return launch_gemm_v7(a, s);
     if (v3) return dtype == ULLSAM_DT_F32 ? launch_gemm_v3<float>(a, s) : launch_gemm_v3<bf16>(a, s);
     if (v2) return dtype == ULLSAM_DT_F32 ? launch_gemm_v2<float>(a, s) : launch_gemm_v2<bf16>(a, s);
     if (a.act == 4) return dtype == ULLSAM_DT_F32 ? launch_gemm<float, 1>(a, s) : launch_gemm<bf16, 1>(a, s);
