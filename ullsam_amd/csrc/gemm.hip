@@ -14,6 +14,9 @@
 //   gemm256_kernel      256x256 tile, 8 waves (2x4, 128x64 per wave), two 64 KiB stages, staggered two-group schedule (L0|C0|L1|C1),
 //                       split-K tail + gemm256_tail_reduce_kernel, LDS-staged epilogue in two 128-row halves.  The production kernel
 //                       for every large launch (and the only one for fp32).
+//   gemm256w_kernel     256x256 tile, FOUR waves (one per SIMD, 128x128 per wave, asm MFMAs on AGPR accumulators), ring of four half-K
+//                       stages, LDS-DMA through buffer descriptors, direct epilogues.  Auto mode: bf16 outputs without residual / GELU.
+//   gemm256r_kernel     the two-group kernel on the same ring (A/B only: equal).
 //   gemm256p_kernel     the same main loop made PERSISTENT (one workgroup per CU walks a unit list, DMA pipelined across units,
 //                       swapped MFMA operands + permuted W rows + lane-pair swap = direct full-line stores from the accumulators,
 //                       counted store waits).  bf16 only.  Auto mode uses it where it measured faster (GELU epilogue).
