@@ -228,6 +228,38 @@ def test_gemm_four_wave_kernel(ops, M, N, K, mode):
     assert float((got - want).abs().max()) < tol * max(1.0, float(want.abs().max()) / 4)
 
 
+@pytest.mark.parametrize("M,N,K,mode", [(4096, 1280, 1280, "res"), (2000, 960, 320, "bias_gelu"), (1234, 1000, 256, "plain"), (3000, 640, 1024, "res_mod")])
+def test_gemm_256x320_kernel(ops, M, N, K, mode):
+    """The 256x320-tile kernel (variant 8: a fifth column of sub-tiles per wave, so that widths of 1280 / 3840 give whole rounds of
+    tiles): ragged M and N (also N not a multiple of 320), each epilogue it is dispatched for, against the fp32 matmul."""
+    from ullsam_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV); g.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g)
+    ref = a.float() @ w.float().T
+    try:
+        lib.ullsam_set_gemm_variant(8)
+        if mode == "plain":
+            got, want, tol = ops.gemm(a, w).float(), ref, 3e-2
+        elif mode == "bias_gelu":
+            got, want, tol = ops.gemm(a, w, bias, act=ops.ACT_GELU).float(), torch.nn.functional.gelu(ref + bias), 3e-2
+        elif mode == "res":
+            x = torch.randn(M, N, device=DEV, generator=g)
+            want = ref + bias + x
+            ops.gemm(a, w, bias, residual=x, out_f32=True, out=x)
+            got, tol = x, 2e-3
+        else:
+            pe = torch.randn(M // 2, N, device=DEV, generator=g)
+            got, want, tol = ops.gemm(a, w, bias, residual=pe, res_row_mod=M // 2, out_f32=True), ref + bias + pe.repeat(2, 1), 2e-3
+        torch.cuda.synchronize()
+    finally:
+        lib.ullsam_set_gemm_variant(0)
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) < tol * max(1.0, float(want.abs().max()) / 4)
+
+
 def _e4m3_decode(u8: np.ndarray) -> np.ndarray:
     """OCP e4m3fn bytes -> float32 (the tests' own decoder: sign, 4-bit exponent bias 7, 3-bit mantissa, subnormals, 0x7f = NaN)."""
     u = u8.astype(np.int32)

@@ -426,6 +426,23 @@ def test_batched_greedy_generate_matches_single_and_oracle():
     assert stop.shape == (1, 6)
 
 
+def test_kv_cache_grows_like_the_reference():
+    """The reference's cache is a torch.cat per step and cannot fill up (modeling_internlm2.py:383-388): stepping a pre-allocated cache
+    past its capacity must move it to a larger allocation and give the same tokens as a cache that was large enough from the start."""
+    lm = _tiny_llm(torch.float32)
+    ids = torch.tensor([[1, 5, 9, 100, 7, 3, 11]], device=DEV)
+    want = lm.generate(input_ids=ids, max_new_tokens=10, eos_token_id=-1)[0, 7:].tolist()
+    cache = lm.model.new_cache(1, 9, DEV)                      # room for the prompt and two more tokens only
+    out = lm(input_ids=ids, past_key_values=cache, use_cache=True)
+    got = []
+    for _ in range(10):
+        tok = out.logits[:, -1].argmax(-1, keepdim=True)
+        got.append(int(tok))
+        out = lm(input_ids=tok, past_key_values=out.past_key_values, use_cache=True)
+    assert cache.cap > 9 and cache.len == 7 + 10
+    assert got == want
+
+
 def test_sampling_respects_top_k():
     lm = _tiny_llm(torch.float32)
     ids = torch.tensor([[1, 5, 9, 100, 7]], device=DEV)

@@ -70,7 +70,7 @@ static int g_dbg = 0;          // ullsam_set_gemm_variant bit 15: stamp the pers
 static int g_late = 0;         // ullsam_set_gemm_variant bits 24-25 (A/B of the v3 DMA lead)
 static int g_store_nt = 1;     // non-temporal bf16 output stores in the non-persistent kernels (same-process A/B: vit.qkv -3.4 %, vit.lin1 -3.6 %, llm.w13 -0.9 %);
                                // ullsam_set_gemm_variant bit 14 turns them off (A/B)
-static int g_auto_mask = 3;    // ullsam_set_gemm_tuning(1, mask): kernels the auto dispatch may pick besides the two-buffer one: bit 0 persistent (GELU), bit 1 four-wave
+static int g_auto_mask = 7;    // ullsam_set_gemm_tuning(1, mask): kernels the auto dispatch may pick besides the two-buffer one: bit 0 persistent (GELU), bit 1 four-wave, bit 2 256x320 tiles
 static int g_group_m = 4;      // ullsam_set_gemm_tuning(0, gm): A/B of the raster group height
 static int g_gemm_sched = 0;   // 256x256 kernel main-loop schedule: 0 production, 1 plain interleave, 2 fragments-first / 1 barrier
 
@@ -134,7 +134,10 @@ template <typename T, typename OutT, int BM, int NTHREADS, int BN = 128, int EMO
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs, int m0, int n0, int tn, int tid, int m_lo = 0) {
     constexpr int TPR = BN / 8;             // threads per row (each owns 8 accumulator columns)
     constexpr int RPP = NTHREADS / TPR;     // rows per pass
-    constexpr int PASSES = BM / RPP;        // BM = rows staged in Cs (row stride BN floats)
+    constexpr int PASSES = (BM + RPP - 1) / RPP;   // BM = rows staged in Cs (row stride BN floats)
+    constexpr bool RAGGED = BM % RPP != 0;  // 320-wide tiles: 480 of the 512 threads work, 12 rows per pass, the last pass is partial
+    static_assert(NTHREADS % TPR == 0, "threads per pass must cover whole rows");
+    if (RAGGED && tid >= NTHREADS) return;
     OutT* C = reinterpret_cast<OutT*>(p.C);
     if (p.act == 3) {
         // SwiGLU pair: tile columns [0,64) = gate rows of w1, [64,128) = up rows of w3 (host prepack);
@@ -247,7 +250,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
     for (int pass = 0; pass < PASSES; ++pass) {
         const int row = pass * RPP + tid / TPR;
         const int gm = m0 + row;
-        if (gm >= p.M || gm < m_lo) continue;
+        if (gm >= p.M || gm < m_lo || (RAGGED && row >= BM)) continue;
         float v[8];
         const float4 a = *reinterpret_cast<const float4*>(Cs + row * BN + c0);
         const float4 b = *reinterpret_cast<const float4*>(Cs + row * BN + c0 + 4);
@@ -1471,6 +1474,146 @@ static int launch_gemm_v6(const GemmArgs& a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// v8: 256 x 320 tile on the ring of four half-K stages (bf16).  Why a fifth column of sub-tiles: the ViT-H widths are multiples of 320
+// (1280 = 4 x 320, 3840 = 12 x 320), and with 64 tile rows (M = 16384) that makes the tile count a multiple of the 256 CUs --
+// `vit.proj` / `vit.lin2` (N = 1280) are 256 tiles = ONE full round instead of 320 tiles of 256x256 (1.25 rounds: the 128x128 kernel or a
+// split-K tail), `vit.qkv` 768 tiles = 3 rounds of 1.25 x the work instead of 4.  Same waves (2 x 4, now 128 x 80 per wave: 8 x 5
+// sub-tiles, 160 accumulator registers), stagger and LDS image as gemm256r_kernel; a stage is 16 KiB of A + 20 KiB of B (36 KiB, four
+// stages = 144 KiB), 16 + 20 DMA pieces: waves 0-3 (= group 0) request 5 pieces per stage, waves 4-7 request 4, so the counted wait
+// differs by group.  Per stage and wave: 4-5 pieces, 13 fragment reads, 40 MFMAs.  The epilogue stages 128 rows x 320 fp32 = the whole
+// 160 KiB of LDS at a time.
+// ---------------------------------------------------------------------------------------------------------------
+template <int EMODE>
+__global__ __launch_bounds__(512) void gemm256x320_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef bf16 T;
+    constexpr int BN = 320, NTW = 5;
+    constexpr int STG = 16384 + 20480;
+
+    const int nblk = p.full_tiles;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int GM = p.group_m;
+    const int width = GM * p.tiles_n;
+    const int group = swz / width;
+    const int first_m = group * GM;
+    const int gsize = min(p.tiles_m - first_m, GM);
+    const int tm = first_m + (swz % width) % gsize;
+    const int tn = (swz % width) / gsize;
+    const int m0 = tm * 256, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
+    const int g4 = lane >> 4, mm = lane & 15;
+
+    // DMA pieces (16 rows x 64 B): A pieces 2w, 2w+1; B pieces 2w, 2w+1 and, for waves 0-3, piece 16 + w
+    const char* a_base = reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda * 2;
+    const char* b_base = reinterpret_cast<const char*>(p.W) + (size_t)n0 * p.ldw * 2;
+    unsigned int a_off[2], b_off[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int piece = i < 2 ? wave * 2 + i : 16 + (wave & 3);
+        const int row = piece * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 2);
+        if (i < 2) a_off[i] = (unsigned int)((size_t)(min(m0 + row, p.M - 1) - m0) * p.lda * 2) + (c << 4);
+        b_off[i] = (unsigned int)((size_t)(min(n0 + row, p.N - 1) - n0) * p.ldw * 2) + (c << 4);
+    }
+    const int st1 = p.K >> 5;  // stages (32-deep k-steps)
+
+    f32x4 acc[8][NTW];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int s) {   // request stage s into ring slot s & 3
+        char* base = smem + (s & 3) * STG;
+        const char* ak = a_base + (size_t)s * 64;
+        const char* bk = b_base + (size_t)s * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_off[i]), LDS_PTR(base + (wave * 2 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + 16384 + (wave * 2 + i) * 1024), 16, 0, 0);
+        }
+        if (grp == 0) __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[2]), LDS_PTR(base + 16384 + (16 + wave) * 1024), 16, 0, 0);
+    };
+    auto frag = [&](const char* tile, int row) -> Frag<T> {
+        return load_frag(reinterpret_cast<const T*>(tile + row * 64 + ((g4 ^ ((row >> 2) & 2)) << 4)));
+    };
+    // wait until only the youngest stage's pieces (5 for group 0, 4 for group 1) are in flight / until nothing is
+    auto wait_one_left = [&]() {
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    };
+
+    // prologue: stages 0 and 1 requested, stage 0 landed
+    stage(0);
+    if (1 < st1) { stage(1); wait_one_left(); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < st1; ++s) {
+        const char* Ab = smem + (s & 3) * STG;
+        const char* Bb = Ab + 16384;
+        Frag<T> a8[8], b[NTW];
+        // ---- L(s)
+        if (s + 2 < st1) stage(s + 2);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) b[j] = frag(Bb, wn * 80 + j * 16 + mm);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a8[i] = frag(Ab, wm * 128 + i * 16 + mm);
+        // stage s+1 must have landed before the barrier that lets anyone read it; the younger stage stays in flight
+        if (s + 2 < st1) wait_one_left();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- C(s)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) mma16(a8[i], b[j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+
+    float* Cs = reinterpret_cast<float*>(smem);  // [128][320] fp32 = 160 KiB, one 128-row half at a time
+    auto staged = [&](auto half_c) __attribute__((always_inline)) {
+        constexpr int half = decltype(half_c)::value;
+        __syncthreads();
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * g4 + r) * BN + wn * 80 + j * 16 + mm] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (p.out_f32) epilogue_rows<T, float, 128, 480, BN, EMODE>(p, Cs, m0 + half * 128, n0, tn, tid);
+        else epilogue_rows<T, T, 128, 480, BN, EMODE>(p, Cs, m0 + half * 128, n0, tn, tid);
+    };
+    staged(std::integral_constant<int, 0>{});
+    staged(std::integral_constant<int, 1>{});
+}
+
+static int launch_gemm_v8(GemmArgs a, hipStream_t stream) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x320_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (a.N + 319) / 320;
+    a.full_tiles = a.tiles_m * a.tiles_n;
+    a.ksplit = 1;
+    gemm256x320_kernel<0><<<dim3(a.full_tiles), dim3(512), 163840, stream>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // v7: 256x256 tile, FOUR waves (2 x 2, 128x128 per wave, 256 accumulator registers per lane: one wave per SIMD with the whole
 // 512-entry register file), the ring of four half-K stages of v6, and ONE software-pipelined instruction stream per wave instead of
 // two wave groups taking turns: while the 64 MFMAs of stage s run from registers, the same wave reads the 16 fragments of stage
@@ -2123,7 +2266,7 @@ static int launch_gemm_v4(const GemmArgs& a, hipStream_t stream) {
 // v: bits 0-3 kernel (0 auto), +64 no split-K tail, bits 8-11 timing-only ablations (1 no staging, 2 no barrier, 4 no epilogue, 8 no stores), bits 12-13 schedule of the 256x256 kernel
 extern "C" int ullsam_set_gemm_tuning(int key, int value) {
     if (key == 0 && value >= 1 && value <= 1024) { g_group_m = value; return 0; }
-    if (key == 1 && value >= 0 && value <= 3) { g_auto_mask = value; return 0; }
+    if (key == 1 && value >= 0 && value <= 7) { g_auto_mask = value; return 0; }
     ullsam_set_error("ullsam_set_gemm_tuning: unknown key %d / bad value %d", key, value);
     return -1;
 }
@@ -2427,6 +2570,10 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     const bool v3_split = g_split_tail && workspace && t256 > 256 && tail256 > 0 && tail256 <= 64 && K >= 64 * bk;  // see launch_gemm_v3_impl
     const bool v3 = variant == 3 || (variant == 0 && M >= 1024 && N >= 256 && K >= 8 * bk && (fill >= 0.74 || v3_split) && (act != 3 || N % 256 == 0));  // short K / narrow N: the 256^2 tile's fixed cost or its empty half dominates
     if (act == 3 && (variant == 3) && N % 256 != 0) { ullsam_set_error("ullsam_gemm: v3 swiglu needs N%%256==0"); return -1; }
+    if (variant == 8) {
+        if (dtype != ULLSAM_DT_BF16 || K % 64 != 0 || K < 128 || act == 3 || act == 4) { ullsam_set_error("ullsam_gemm: the 256x320 kernel needs bf16, K %% 64 == 0, no SwiGLU / RoPE epilogue"); return -1; }
+        return launch_gemm_v8(a, s);
+    }
     if (variant == 7) {
         if (dtype != ULLSAM_DT_BF16 || K % 128 != 0 || K < 256) { ullsam_set_error("ullsam_gemm: the four-wave kernel needs bf16 and K %% 128 == 0, K >= 256"); return -1; }
         return launch_gemm_v7(a, s);
@@ -2438,6 +2585,15 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     if (variant == 4 && act != 4) {
         if (!v4_ok(a, dtype)) { ullsam_set_error("ullsam_gemm: the persistent kernel needs bf16, N%%256==0, K%%64==0, K>=512, 16-byte aligned rows"); return -1; }
         return launch_gemm_v4(a, s);
+    }
+    // 256x320 tiles in auto mode: widths that are multiples of 320 (ViT-H: 1280, 3840) when that takes fewer tile-rounds of the 256 CUs than
+    // 256x256 tiles do (a 320-wide tile is 1.25 tiles' work; a split-K tail counts as half a round) -- same-process A/B: vit.proj 58 vs 80 us,
+    // vit.proj+r 87 vs 108, vit.lin2+r 204 vs 235, vit.qkv 161 vs 173 (the shapes whose 256x256 tile count is 1.25 / 3.75 rounds)
+    if (variant == 0 && (g_auto_mask & 4) && dtype == ULLSAM_DT_BF16 && act <= 2 && N % 320 == 0 && M >= 1024 && K % 64 == 0 && K >= 256) {
+        const long t320 = (long)((M + 255) / 256) * (N / 320);
+        const double cost320 = 1.25 * (double)((t320 + 255) / 256);
+        const double cost256 = v3_split ? (double)(t256 / 256) + 0.5 : (double)((t256 + 255) / 256);
+        if (cost320 <= 0.96 * cost256) return launch_gemm_v8(a, s);
     }
     // persistent kernel in auto mode: only where it measured faster in the same process -- bf16 output with the GELU epilogue (vit.lin1
     // 214 vs 232 us: the erf arithmetic of one wave group overlaps the other group's matrix segment); elsewhere it ties or loses 0-3 %

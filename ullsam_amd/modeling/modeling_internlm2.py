@@ -103,6 +103,18 @@ class KVCache:
     def to_tuple(self):
         return tuple((k[:, :, :self.len], v[:, :, :self.len]) for k, v in zip(self.k, self.v))
 
+    def grow(self, cap: int):
+        """The reference's cache is a torch.cat per step and never fills up (modeling_internlm2.py:383-388): when the pre-allocated
+        rows run out, move the live rows into a larger allocation instead of failing."""
+        if cap <= self.cap:
+            return
+        for buf in (self.k, self.v):
+            for i, old in enumerate(buf):
+                new = torch.empty((old.shape[0], old.shape[1], cap, old.shape[3]), dtype=old.dtype, device=old.device)
+                new[:, :, :self.len].copy_(old[:, :, :self.len])
+                buf[i] = new
+        self.cap = cap
+
 
 class InternLM2Model(Packed):
     def __init__(self, config: InternLM2Config):
@@ -225,7 +237,7 @@ class InternLM2Model(Packed):
         if cache is None and use_cache:
             cache = self.new_cache(B, max(2 * S, S + 256), dev)
         if cache is not None and past + S > cache.cap:
-            raise ValueError(f"KV cache capacity {cache.cap} exceeded ({past}+{S})")
+            cache.grow(max(2 * cache.cap, past + S))
         if position_ids is None:
             position_ids = torch.arange(past, past + S, dtype=torch.long, device=dev).unsqueeze(0).expand(B, S)  # :893-898
         pos = position_ids.to(torch.int32).expand(B, S).contiguous()
