@@ -260,6 +260,42 @@ def test_gemm_256x320_kernel(ops, M, N, K, mode):
     assert float((got - want).abs().max()) < tol * max(1.0, float(want.abs().max()) / 4)
 
 
+@pytest.mark.parametrize("M,N,K,mode", [(4324, 4096, 1024, "res"), (4324, 2048, 512, "swiglu"), (1000, 700, 256, "bias_gelu"), (4352, 512, 320, "plain")])
+def test_gemm_272x256_kernel(ops, M, N, K, mode):
+    """The 272x256-tile kernel (variant 9: nine sub-tile rows in the upper wave row, eight in the lower -- 16 tile rows cover the
+    4 x 1081 = 4324 prompt rows of the bench, so the LLM's GEMMs become whole rounds of tiles): ragged M / N, the SwiGLU and the fp32
+    residual epilogues, against the fp32 matmul."""
+    from ullsam_amd import _lib
+    from ullsam_amd.packing import pack_w13
+    lib = _lib.load()
+    g = torch.Generator(device=DEV); g.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g)
+    ref = a.float() @ w.float().T
+    F = torch.nn.functional
+    try:
+        lib.ullsam_set_gemm_variant(9)
+        if mode == "plain":
+            got, want, tol = ops.gemm(a, w).float(), ref, 3e-2
+        elif mode == "bias_gelu":
+            got, want, tol = ops.gemm(a, w, bias, act=ops.ACT_GELU).float(), F.gelu(ref + bias), 3e-2
+        elif mode == "res":
+            x = torch.randn(M, N, device=DEV, generator=g)
+            want = ref + bias + x
+            ops.gemm(a, w, bias, residual=x, out_f32=True, out=x)
+            got, tol = x, 2e-3
+        else:
+            I = N // 2
+            got = ops.gemm(a, pack_w13(w[:I].contiguous(), w[I:].contiguous()), act=ops.ACT_SWIGLU).float()
+            want, tol = F.silu(ref[:, :I]) * ref[:, I:], 3e-2
+        torch.cuda.synchronize()
+    finally:
+        lib.ullsam_set_gemm_variant(0)
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) < tol * max(1.0, float(want.abs().max()) / 4)
+
+
 def _e4m3_decode(u8: np.ndarray) -> np.ndarray:
     """OCP e4m3fn bytes -> float32 (the tests' own decoder: sign, 4-bit exponent bias 7, 3-bit mantissa, subnormals, 0x7f = NaN)."""
     u = u8.astype(np.int32)

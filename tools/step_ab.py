@@ -1,7 +1,7 @@
 """Same-process A/B of the bench step (bench.py's model, inputs and step) under GEMM dispatch variants: boxes differ by up to 12 % and
 drift with load, so only interleaved rounds in one process compare two dispatch policies.
 usage: python tools/step_ab.py [rounds] [maskA,maskB,...]     auto-dispatch masks (ullsam_set_gemm_tuning key 1): 0 two-buffer kernel only,
-bit 0 persistent kernel for GELU, bit 1 four-wave kernel for bf16 outputs, bit 2 256x320 tiles for widths that are multiples of 320"""
+bit 0 persistent kernel for GELU, bit 1 four-wave kernel for bf16 outputs, bit 2 256x320 tiles, bit 3 272x256 tiles"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,7 @@ from ullsam_amd import _lib
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "3", "7"])]
+    variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "3", "7", "15"])]
     lib = _lib.load()
     dev = "cuda"
     model = bench.build_model("h", "7b", torch.bfloat16, dev)
@@ -33,7 +33,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) / 4)
-    lib.ullsam_set_gemm_tuning(1, 7)
+    lib.ullsam_set_gemm_tuning(1, 15)
     for v in variants:
         t = sorted(times[v])
         print(f"dispatch mask {v}: median {t[len(t) // 2]:.3f} ms/step  (min {t[0]:.3f}, max {t[-1]:.3f})  = {4e3 / t[len(t) // 2]:.2f} images/s")

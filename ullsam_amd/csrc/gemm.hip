@@ -70,7 +70,7 @@ static int g_dbg = 0;          // ullsam_set_gemm_variant bit 15: stamp the pers
 static int g_late = 0;         // ullsam_set_gemm_variant bits 24-25 (A/B of the v3 DMA lead)
 static int g_store_nt = 1;     // non-temporal bf16 output stores in the non-persistent kernels (same-process A/B: vit.qkv -3.4 %, vit.lin1 -3.6 %, llm.w13 -0.9 %);
                                // ullsam_set_gemm_variant bit 14 turns them off (A/B)
-static int g_auto_mask = 7;    // ullsam_set_gemm_tuning(1, mask): kernels the auto dispatch may pick besides the two-buffer one: bit 0 persistent (GELU), bit 1 four-wave, bit 2 256x320 tiles
+static int g_auto_mask = 15;   // ullsam_set_gemm_tuning(1, mask): kernels the auto dispatch may pick besides the two-buffer one: bit 0 persistent (GELU), bit 1 four-wave, bit 2 256x320 tiles, bit 3 272x256 tiles
 static int g_group_m = 4;      // ullsam_set_gemm_tuning(0, gm): A/B of the raster group height
 static int g_gemm_sched = 0;   // 256x256 kernel main-loop schedule: 0 production, 1 plain interleave, 2 fragments-first / 1 barrier
 
@@ -1483,12 +1483,14 @@ static int launch_gemm_v6(const GemmArgs& a, hipStream_t stream) {
 // differs by group.  Per stage and wave: 4-5 pieces, 13 fragment reads, 40 MFMAs.  The epilogue stages 128 rows x 320 fp32 = the whole
 // 160 KiB of LDS at a time.
 // ---------------------------------------------------------------------------------------------------------------
-template <int EMODE>
-__global__ __launch_bounds__(512) void gemm256x320_kernel(GemmArgs p) {
+template <int MI0, int MI1, int NTW, int EMODE>   // sub-tile rows of the upper / lower wave row, sub-tile columns per wave
+__global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef bf16 T;
-    constexpr int BN = 320, NTW = 5;
-    constexpr int STG = 16384 + 20480;
+    constexpr int BM = 16 * (MI0 + MI1), BN = 64 * NTW, MI = MI0 > MI1 ? MI0 : MI1;
+    constexpr int PA = BM / 16, PB = BN / 16;          // DMA pieces (16 rows x 64 B) per stage
+    constexpr int ASZ = BM * 64, STG = ASZ + BN * 64;
+    static_assert(PA >= 16 && PA <= 24 && PB >= 8 && PB <= 24, "piece assignment below: two or three pieces per wave and operand");
 
     const int nblk = p.full_tiles;
     const int bid = blockIdx.x;
@@ -1501,30 +1503,33 @@ __global__ __launch_bounds__(512) void gemm256x320_kernel(GemmArgs p) {
     const int gsize = min(p.tiles_m - first_m, GM);
     const int tm = first_m + (swz % width) % gsize;
     const int tn = (swz % width) / gsize;
-    const int m0 = tm * 256, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
     const int g4 = lane >> 4, mm = lane & 15;
 
-    // DMA pieces (16 rows x 64 B): A pieces 2w, 2w+1; B pieces 2w, 2w+1 and, for waves 0-3, piece 16 + w
+    // DMA pieces (16 rows x 64 B): piece q of an operand belongs to wave q % 8 (slots q / 8 = 0, 1, 2); a wave's piece count per stage
+    // (na + nb, wave-uniform) is what its counted wait leaves in flight
     const char* a_base = reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda * 2;
     const char* b_base = reinterpret_cast<const char*>(p.W) + (size_t)n0 * p.ldw * 2;
-    unsigned int a_off[2], b_off[3];
+    const int na = (PA - wave + 7) / 8, nb = (PB - wave + 7) / 8;
+    unsigned int a_off[3], b_off[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int piece = i < 2 ? wave * 2 + i : 16 + (wave & 3);
-        const int row = piece * 16 + (lane >> 2);
+        const int row = (wave + 8 * i) * 16 + (lane >> 2);
         const int c = (lane & 3) ^ ((row >> 2) & 2);
-        if (i < 2) a_off[i] = (unsigned int)((size_t)(min(m0 + row, p.M - 1) - m0) * p.lda * 2) + (c << 4);
+        a_off[i] = (unsigned int)((size_t)(min(m0 + row, p.M - 1) - m0) * p.lda * 2) + (c << 4);
         b_off[i] = (unsigned int)((size_t)(min(n0 + row, p.N - 1) - n0) * p.ldw * 2) + (c << 4);
     }
     const int st1 = p.K >> 5;  // stages (32-deep k-steps)
 
-    f32x4 acc[8][NTW];
+    const int mi = wm == 0 ? MI0 : MI1;            // this wave's sub-tile rows (wave-uniform)
+    const int row_w = wm == 0 ? 0 : MI0 * 16;      // first tile row of this wave
+    f32x4 acc[MI][NTW];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -1533,19 +1538,21 @@ __global__ __launch_bounds__(512) void gemm256x320_kernel(GemmArgs p) {
         const char* ak = a_base + (size_t)s * 64;
         const char* bk = b_base + (size_t)s * 64;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_off[i]), LDS_PTR(base + (wave * 2 + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + 16384 + (wave * 2 + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < 3; ++i) {
+            if (i < na) __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_off[i]), LDS_PTR(base + (wave + 8 * i) * 1024), 16, 0, 0);
+            if (i < nb) __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + ASZ + (wave + 8 * i) * 1024), 16, 0, 0);
         }
-        if (grp == 0) __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[2]), LDS_PTR(base + 16384 + (16 + wave) * 1024), 16, 0, 0);
     };
     auto frag = [&](const char* tile, int row) -> Frag<T> {
         return load_frag(reinterpret_cast<const T*>(tile + row * 64 + ((g4 ^ ((row >> 2) & 2)) << 4)));
     };
-    // wait until only the youngest stage's pieces (5 for group 0, 4 for group 1) are in flight / until nothing is
+    // wait until only the youngest stage's pieces (this wave's na + nb) are in flight
+    const int npc = na + nb;
     auto wait_one_left = [&]() {
-        if (grp == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (npc == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (npc == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (npc == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     };
 
     // prologue: stages 0 and 1 requested, stage 0 landed
@@ -1556,14 +1563,15 @@ __global__ __launch_bounds__(512) void gemm256x320_kernel(GemmArgs p) {
     if (grp == 1) __builtin_amdgcn_s_barrier();
     for (int s = 0; s < st1; ++s) {
         const char* Ab = smem + (s & 3) * STG;
-        const char* Bb = Ab + 16384;
-        Frag<T> a8[8], b[NTW];
+        const char* Bb = Ab + ASZ;
+        Frag<T> a8[MI], b[NTW];
         // ---- L(s)
         if (s + 2 < st1) stage(s + 2);
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) b[j] = frag(Bb, wn * 80 + j * 16 + mm);
+        for (int j = 0; j < NTW; ++j) b[j] = frag(Bb, wn * (16 * NTW) + j * 16 + mm);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a8[i] = frag(Ab, wm * 128 + i * 16 + mm);
+        for (int i = 0; i < MI; ++i)
+            if (i < MI1 || i < mi) a8[i] = frag(Ab, row_w + i * 16 + mm);
         // stage s+1 must have landed before the barrier that lets anyone read it; the younger stage stays in flight
         if (s + 2 < st1) wait_one_left();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1572,46 +1580,56 @@ __global__ __launch_bounds__(512) void gemm256x320_kernel(GemmArgs p) {
         // ---- C(s)
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < MI; ++i)
+            if (i < MI1 || i < mi) {
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) mma16(a8[i], b[j], acc[i][j]);
+                for (int j = 0; j < NTW; ++j) mma16(a8[i], b[j], acc[i][j]);
+            }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
 
-    float* Cs = reinterpret_cast<float*>(smem);  // [128][320] fp32 = 160 KiB, one 128-row half at a time
+    float* Cs = reinterpret_cast<float*>(smem);  // [16 MI][BN] fp32, one wave row at a time
     auto staged = [&](auto half_c) __attribute__((always_inline)) {
         constexpr int half = decltype(half_c)::value;
+        constexpr int ROWS = 16 * (half == 0 ? MI0 : MI1);
+        constexpr int NT_E = BN == 320 ? 480 : 512;   // 320 columns: 40 threads per row, 12 rows per pass
         __syncthreads();
         if (wm == half) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < (half == 0 ? MI0 : MI1); ++i)
 #pragma unroll
                 for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * g4 + r) * BN + wn * 80 + j * 16 + mm] = acc[i][j][r];
+                    for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * g4 + r) * BN + wn * (16 * NTW) + j * 16 + mm] = acc[i][j][r];
         }
         __syncthreads();
-        if (p.out_f32) epilogue_rows<T, float, 128, 480, BN, EMODE>(p, Cs, m0 + half * 128, n0, tn, tid);
-        else epilogue_rows<T, T, 128, 480, BN, EMODE>(p, Cs, m0 + half * 128, n0, tn, tid);
+        if (p.out_f32) epilogue_rows<T, float, ROWS, NT_E, BN, EMODE>(p, Cs, m0 + half * 16 * MI0, n0, tn, tid);
+        else epilogue_rows<T, T, ROWS, NT_E, BN, EMODE>(p, Cs, m0 + half * 16 * MI0, n0, tn, tid);
     };
     staged(std::integral_constant<int, 0>{});
     staged(std::integral_constant<int, 1>{});
 }
 
-static int launch_gemm_v8(GemmArgs a, hipStream_t stream) {
+template <int MI0, int MI1, int NTW>
+static int launch_gemm_ring8(GemmArgs a, hipStream_t stream) {
+    constexpr int BM = 16 * (MI0 + MI1), BN = 64 * NTW;
+    constexpr int LDS = (4 * (BM + BN) * 64 > 16 * MI0 * BN * 4) ? 4 * (BM + BN) * 64 : 16 * MI0 * BN * 4;   // the ring, or the epilogue's staging rows
+    static_assert(LDS <= 163840, "160 KiB of LDS per CU");
     static PerDeviceOnce attr_set;
-    if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x320_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-    a.tiles_m = (a.M + 255) / 256;
-    a.tiles_n = (a.N + 319) / 320;
+    if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.N + BN - 1) / BN;
     a.full_tiles = a.tiles_m * a.tiles_n;
     a.ksplit = 1;
-    gemm256x320_kernel<0><<<dim3(a.full_tiles), dim3(512), 163840, stream>>>(a);
+    gemm_ring8_kernel<MI0, MI1, NTW, 0><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
+static int launch_gemm_v8(const GemmArgs& a, hipStream_t stream) { return launch_gemm_ring8<8, 8, 5>(a, stream); }   // 256 x 320
+static int launch_gemm_v9(const GemmArgs& a, hipStream_t stream) { return launch_gemm_ring8<9, 8, 4>(a, stream); }   // 272 x 256
 
 // ---------------------------------------------------------------------------------------------------------------
 // v7: 256x256 tile, FOUR waves (2 x 2, 128x128 per wave, 256 accumulator registers per lane: one wave per SIMD with the whole
@@ -2266,7 +2284,7 @@ static int launch_gemm_v4(const GemmArgs& a, hipStream_t stream) {
 // v: bits 0-3 kernel (0 auto), +64 no split-K tail, bits 8-11 timing-only ablations (1 no staging, 2 no barrier, 4 no epilogue, 8 no stores), bits 12-13 schedule of the 256x256 kernel
 extern "C" int ullsam_set_gemm_tuning(int key, int value) {
     if (key == 0 && value >= 1 && value <= 1024) { g_group_m = value; return 0; }
-    if (key == 1 && value >= 0 && value <= 7) { g_auto_mask = value; return 0; }
+    if (key == 1 && value >= 0 && value <= 15) { g_auto_mask = value; return 0; }
     ullsam_set_error("ullsam_set_gemm_tuning: unknown key %d / bad value %d", key, value);
     return -1;
 }
@@ -2570,6 +2588,10 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     const bool v3_split = g_split_tail && workspace && t256 > 256 && tail256 > 0 && tail256 <= 64 && K >= 64 * bk;  // see launch_gemm_v3_impl
     const bool v3 = variant == 3 || (variant == 0 && M >= 1024 && N >= 256 && K >= 8 * bk && (fill >= 0.74 || v3_split) && (act != 3 || N % 256 == 0));  // short K / narrow N: the 256^2 tile's fixed cost or its empty half dominates
     if (act == 3 && (variant == 3) && N % 256 != 0) { ullsam_set_error("ullsam_gemm: v3 swiglu needs N%%256==0"); return -1; }
+    if (variant == 9) {
+        if (dtype != ULLSAM_DT_BF16 || K % 64 != 0 || K < 128 || act == 4 || (act == 3 && N % 256 != 0)) { ullsam_set_error("ullsam_gemm: the 272x256 kernel needs bf16, K %% 64 == 0, no RoPE epilogue"); return -1; }
+        return launch_gemm_v9(a, s);
+    }
     if (variant == 8) {
         if (dtype != ULLSAM_DT_BF16 || K % 64 != 0 || K < 128 || act == 3 || act == 4) { ullsam_set_error("ullsam_gemm: the 256x320 kernel needs bf16, K %% 64 == 0, no SwiGLU / RoPE epilogue"); return -1; }
         return launch_gemm_v8(a, s);
@@ -2604,6 +2626,15 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     if (v3 && variant == 0 && g_persistent && (g_auto_mask & 2) && dtype == ULLSAM_DT_BF16 && !a.out_f32 && !residual && (act == 0 || act == 3) && a.vec_ok && N % 8 == 0 &&
         M % 2 == 0 && K % 128 == 0 && K >= 512)
         return launch_gemm_v7(a, s);
+    // 272x256 tiles in auto mode: row counts that 16-row-taller tiles cover in fewer tile-rounds (the bench's 4 x 1081 = 4324 rows are 16 x 272:
+    // llm.wo / llm.w2 become ONE round of 256 tiles instead of 256 + a split-K tail of 16) -- same-process A/B: llm.wo+r 144 vs 158 us,
+    // llm.w2+r 418 vs 451, llm.wo 126 vs 154; llm.w13 stays on the four-wave kernel (828 vs 841)
+    if (variant == 0 && (g_auto_mask & 8) && dtype == ULLSAM_DT_BF16 && act <= 3 && (act != 3 || N % 256 == 0) && M >= 1024 && N >= 256 && K % 64 == 0 && K >= 256) {
+        const long t272 = (long)((M + 271) / 272) * ((N + 255) / 256);
+        const double cost272 = 1.0625 * (double)((t272 + 255) / 256);
+        const double cost256 = v3_split ? (double)(t256 / 256) + 0.5 : (double)((t256 + 255) / 256);
+        if (cost272 <= 0.96 * cost256) return launch_gemm_v9(a, s);
+    }
     if (v3) return dtype == ULLSAM_DT_F32 ? launch_gemm_v3<float>(a, s) : launch_gemm_v3<bf16>(a, s);
     if (v2) return dtype == ULLSAM_DT_F32 ? launch_gemm_v2<float>(a, s) : launch_gemm_v2<bf16>(a, s);
     if (a.act == 4) return dtype == ULLSAM_DT_F32 ? launch_gemm<float, 1>(a, s) : launch_gemm<bf16, 1>(a, s);
