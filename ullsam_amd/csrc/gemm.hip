@@ -16,7 +16,9 @@
 //                       for every large launch (and the only one for fp32).
 //   gemm256w_kernel     256x256 tile, FOUR waves (one per SIMD, 128x128 per wave, asm MFMAs on AGPR accumulators), ring of four half-K
 //                       stages, LDS-DMA through buffer descriptors, direct epilogues.  Auto mode: bf16 outputs without residual / GELU.
-//   gemm256r_kernel     the two-group kernel on the same ring (A/B only: equal).
+//   gemm_ring8_kernel   the two-group kernel on the same ring with the tile shape as template parameters: 256x320 (ViT-H widths) and 272x256
+//                       (4324 prompt rows) make the tile count a whole number of rounds of the 256 CUs; auto where that saves tile-rounds.
+//   gemm256r_kernel     the 256x256 instance of that ring (A/B only: equal to gemm256_kernel).
 //   gemm256p_kernel     the same main loop made PERSISTENT (one workgroup per CU walks a unit list, DMA pipelined across units,
 //                       swapped MFMA operands + permuted W rows + lane-pair swap = direct full-line stores from the accumulators,
 //                       counted store waits).  bf16 only.  Auto mode uses it where it measured faster (GELU epilogue).
