@@ -1597,7 +1597,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     auto staged = [&](auto half_c) __attribute__((always_inline)) {
         constexpr int half = decltype(half_c)::value;
         constexpr int ROWS = 16 * (half == 0 ? MI0 : MI1);
-        constexpr int NT_E = BN == 320 ? 480 : 512;   // 320 columns: 40 threads per row, 12 rows per pass
+        constexpr int NT_E = (512 / (BN / 8)) * (BN / 8);   // whole rows per pass: 320 columns -> 40 threads per row, 480 threads, 12 rows; 192 -> 504 threads, 21 rows
         __syncthreads();
         if (wm == half) {
 #pragma unroll
