@@ -1492,7 +1492,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     constexpr int BM = 16 * (MI0 + MI1), BN = 64 * NTW, MI = MI0 > MI1 ? MI0 : MI1;
     constexpr int PA = BM / 16, PB = BN / 16;          // DMA pieces (16 rows x 64 B) per stage
     constexpr int ASZ = BM * 64, STG = ASZ + BN * 64;
-    static_assert(PA >= 16 && PA <= 24 && PB >= 8 && PB <= 24, "piece assignment below: two or three pieces per wave and operand");
+    static_assert(PA >= 8 && PA <= 24 && PB >= 8 && PB <= 24, "piece assignment below: one to three pieces per wave and operand");
 
     const int nblk = p.full_tiles;
     const int bid = blockIdx.x;
@@ -1552,6 +1552,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     const int npc = na + nb;
     auto wait_one_left = [&]() {
         if (npc == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (npc == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else if (npc == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else if (npc == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
