@@ -63,13 +63,13 @@ struct GemmArgs {
 };
 
 static int g_split_tail = 1;   // ullsam_set_gemm_variant(v | 64) disables the split-K tail (A/B)
-static int g_gemm_variant = 0; // bits 0-3: 0 auto, 1 = 128x128, 2 = 256x128 ring, 3 = 256x256
+static int g_gemm_variant = 0; // bits 0-3 force a kernel: 0 auto, 1 128x128, 2 256x128 ring, 3 256x256 two-group, 4 persistent, 6 256x256 ring, 7 four-wave, 8 256x320 ring, 9 272x256 ring
 static int g_gemm_ablate = 0;  // timing-only ablations: bit0 no in-loop staging, bit1 no barrier (outputs are garbage)
 static int g_persistent = 1;   // ullsam_set_gemm_variant(v | 128): keep the non-persistent 256x256 kernel in auto mode (A/B)
 static int g_skew_half_us = 0;  // ullsam_set_gemm_variant bits 16-23: v4 start-time spread in units of 0.5 us (A/B)
 static int g_store_v4 = 0;     // store policy of the persistent kernel (ullsam_set_gemm_variant bits 29-31; A/B)
 static int g_dbg = 0;          // ullsam_set_gemm_variant bit 15: stamp the persistent kernel (tools/gemm_stamps.py reads them from the workspace)
-static int g_late = 0;         // ullsam_set_gemm_variant bits 24-25 (A/B of the v3 DMA lead)
+static int g_late = 0;         // ullsam_set_gemm_variant bits 24-27 (A/B of the v3 DMA issue placement: 4 / 8; they overlap the store-policy bits 26-28 -- set one or the other)
 static int g_store_nt = 1;     // non-temporal bf16 output stores in the non-persistent kernels (same-process A/B: vit.qkv -3.4 %, vit.lin1 -3.6 %, llm.w13 -0.9 %);
                                // ullsam_set_gemm_variant bit 14 turns them off (A/B)
 static int g_auto_mask = 15;   // ullsam_set_gemm_tuning(1, mask): kernels the auto dispatch may pick besides the two-buffer one: bit 0 persistent (GELU), bit 1 four-wave, bit 2 256x320 tiles, bit 3 272x256 tiles
