@@ -931,6 +931,10 @@ extern "C" int ullsam_vit_attention(int dtype, const void* qkv, void* out, const
         return dtype == 0 ? dispatch_hd<float, MODE_VIT_WINDOW, 7>(a, hd, s) : dispatch_hd<bf16, MODE_VIT_WINDOW, 4>(a, hd, s);
     }
     a.Sq = a.Sk = (int)N;
+    // bf16 on SAM's 64x64 grid: one 8-wave workgroup per 256 queries over 128-key tiles (a staged K/V tile feeds twice the queries: half the
+    // staging traffic, LDS writes and barriers per score) -- identical results, 543 vs 576 us per ViT-H layer at batch 4 (same-process A/B,
+    // tools/probes/attn8_check.py); variant 9 keeps the two 4-wave workgroups with 64-key tiles
+    if (dtype == 1 && grid_h == 64 && grid_w == 64 && g_attn_variant != 9) return dispatch_hd<bf16, MODE_VIT_GLOBAL, 8>(a, hd, s);
     return dtype == 0 ? dispatch_hd<float, MODE_VIT_GLOBAL, 4>(a, hd, s) : dispatch_hd<bf16, MODE_VIT_GLOBAL, 4>(a, hd, s);
 }
 
