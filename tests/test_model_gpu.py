@@ -74,6 +74,20 @@ def test_vit_h_d2_golden(dtype):
         assert d.mean() < 1.2 * float(g["autocast_bf16_mean_err"]), (d.mean(), float(g["autocast_bf16_mean_err"]))
 
 
+def test_vit_h_d2_golden_at_bench_batch():
+    """The same fixture at the bench's batch of 4 images (16384 token rows): the row count at which the dispatch takes the 256x320-tile GEMM
+    for qkv / proj / lin2 and the 8-wave global attention run in the bench.  Every image of the batch is the fixture's image, so every
+    one must meet the golden bound of the batch-1 test (bf16: the reference's own autocast error)."""
+    g = U.gold("vit_h_d2")
+    enc = load(make_vit(U.VIT_H_D2), U.vit_params(U.VIT_H_D2, int(g["weight_seed"])), torch.bfloat16)
+    x = torch.from_numpy(U.rand_image((1, 3, 1024, 1024), int(g["input_seed"]))).to(DEV).repeat(4, 1, 1, 1)
+    y = enc(x).float().cpu().numpy()
+    for b in range(4):
+        d = np.abs(y[b].reshape(-1)[::int(g["stride"])].astype(np.float64) - g["sample"])
+        assert d.max() < 1.5 * float(g["autocast_bf16_max_err"]), (b, d.max())
+        assert d.mean() < 1.2 * float(g["autocast_bf16_mean_err"]), (b, d.mean())
+
+
 @pytest.mark.parametrize("fixture", ["vit_h_d2", "vit_b_full"])
 def test_vit_fp8_linears_gate(fixture):
     """BASELINE configs[4] "fp8 MFMA ViT path": qkv and lin1 of every block on e4m3 operands.  The reference has no fp8 mode, so the
@@ -146,6 +160,22 @@ def test_llm_7b_l1_golden(dtype):
     else:  # reference autocast-bf16 vs its fp32 on the valid rows: max 0.030, mean 0.0037
         assert d.max() < 1.5 * float(g["autocast_bf16_max_err"]), (d.max(), float(g["autocast_bf16_max_err"]))
         assert d.mean() < 1.2 * float(g["autocast_bf16_mean_err"]), (d.mean(), float(g["autocast_bf16_mean_err"]))
+
+
+def test_llm_7b_l1_golden_at_bench_rows():
+    """The 7B-shaped layer at the bench's 4 x 1081 = 4324 prompt rows (the fixture's two samples twice): the row count at which the dispatch
+    takes the 272x256-tile GEMM for wo / w2 and the four-wave kernel for w13.  Every sample must meet the golden bound of the batch-2 test."""
+    g = U.gold("llm_7b_l1")
+    lm = _llm(U.LLM_7B_L1, torch.bfloat16)
+    emb = torch.from_numpy(U.llm_7b_l1_inputs(int(g["input_seed"]))).to(DEV).repeat(2, 1, 1)
+    mask = torch.from_numpy(g["mask"]).to(DEV).repeat(2, 1)
+    out = lm(inputs_embeds=emb, attention_mask=mask, use_cache=False, output_hidden_states=True)
+    hid = out.hidden_states[-1].float().cpu().numpy()
+    valid = g["mask"].astype(bool)[:, ::23]
+    for half in range(2):
+        d = np.abs(hid[2 * half:2 * half + 2, ::23, ::17][valid].astype(np.float64) - g["hidden_sample"][valid])
+        assert d.max() < 1.5 * float(g["autocast_bf16_max_err"]), (half, d.max())
+        assert d.mean() < 1.2 * float(g["autocast_bf16_mean_err"]), (half, d.mean())
 
 
 def test_llm_tiny_bias_and_linear_rope_golden():
