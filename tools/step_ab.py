@@ -11,7 +11,7 @@ from ullsam_amd import _lib
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "3", "7", "15"])]
+    variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "3", "7", "15"]
     lib = _lib.load()
     dev = "cuda"
     model = bench.build_model("h", "7b", torch.bfloat16, dev)
@@ -23,8 +23,10 @@ def main():
         torch.cuda.synchronize()
         times = {v: [] for v in variants}
         for r in range(rounds):
-            for v in variants:
-                lib.ullsam_set_gemm_tuning(1, v)
+            for v in (variants if r % 2 == 0 else variants[::-1]):   # ABBA: the variant measured second in a round comes out ~0.5 % faster
+                mask, _, gv = str(v).partition("v")      # "15v16384" = dispatch mask 15 with ullsam_set_gemm_variant(16384) (e.g. no nt stores)
+                lib.ullsam_set_gemm_tuning(1, int(mask))
+                lib.ullsam_set_gemm_variant(int(gv) if gv else 0)
                 step()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -34,6 +36,7 @@ def main():
                 torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) / 4)
     lib.ullsam_set_gemm_tuning(1, 15)
+    lib.ullsam_set_gemm_variant(0)
     for v in variants:
         t = sorted(times[v])
         print(f"dispatch mask {v}: median {t[len(t) // 2]:.3f} ms/step  (min {t[0]:.3f}, max {t[-1]:.3f})  = {4e3 / t[len(t) // 2]:.2f} images/s")

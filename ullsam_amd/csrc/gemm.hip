@@ -70,8 +70,10 @@ static int g_skew_half_us = 0;  // ullsam_set_gemm_variant bits 16-23: v4 start-
 static int g_store_v4 = 0;     // store policy of the persistent kernel (ullsam_set_gemm_variant bits 29-31; A/B)
 static int g_dbg = 0;          // ullsam_set_gemm_variant bit 15: stamp the persistent kernel (tools/gemm_stamps.py reads them from the workspace)
 static int g_late = 0;         // ullsam_set_gemm_variant bits 24-27 (A/B of the v3 DMA issue placement: 4 / 8; they overlap the store-policy bits 26-28 -- set one or the other)
-static int g_store_nt = 1;     // non-temporal bf16 output stores in the non-persistent kernels (same-process A/B: vit.qkv -3.4 %, vit.lin1 -3.6 %, llm.w13 -0.9 %);
-                               // ullsam_set_gemm_variant bit 14 turns them off (A/B)
+static int g_store_nt = 0;     // non-temporal bf16 output stores in the non-persistent kernels: OFF.  On cold rotating operands they measured faster
+                               // (tools/gemm_bench.py: vit.qkv -3.4 %, vit.lin1 -3.6 %, llm.w13 -0.9 %), but in the step the next kernel reads the output at
+                               // once and plain stores leave it in L2 / Infinity Cache: 84.99 vs 85.64 ms per step (tools/step_ab.py 8 15,15v16384).
+                               // ullsam_set_gemm_variant bit 14 turns them on (A/B)
 static int g_auto_mask = 15;   // ullsam_set_gemm_tuning(1, mask): kernels the auto dispatch may pick besides the two-buffer one: bit 0 persistent (GELU), bit 1 four-wave, bit 2 256x320 tiles, bit 3 272x256 tiles
 static int g_group_m = 4;      // ullsam_set_gemm_tuning(0, gm): A/B of the raster group height
 static int g_gemm_sched = 0;   // 256x256 kernel main-loop schedule: 0 production, 1 plain interleave, 2 fragments-first / 1 barrier
@@ -2292,7 +2294,7 @@ extern "C" int ullsam_set_gemm_tuning(int key, int value) {
     return -1;
 }
 extern "C" int ullsam_set_gemm_variant(int v) {
-    g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_persistent = (v & 128) ? 0 : 1; g_skew_half_us = (v >> 16) & 255; g_store_nt = ((v >> 14) & 1) ? 0 : (((v >> 26) & 7) ? ((v >> 26) & 7) : 1); g_late = (v >> 24) & 15; g_dbg = (v >> 15) & 1; g_store_v4 = (int)(((unsigned)v >> 29) & 7); g_gemm_ablate = (v >> 8) & 15; g_gemm_sched = (v >> 12) & 3;
+    g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_persistent = (v & 128) ? 0 : 1; g_skew_half_us = (v >> 16) & 255; g_store_nt = ((v >> 26) & 7) ? ((v >> 26) & 7) : ((v >> 14) & 1); g_late = (v >> 24) & 15; g_dbg = (v >> 15) & 1; g_store_v4 = (int)(((unsigned)v >> 29) & 7); g_gemm_ablate = (v >> 8) & 15; g_gemm_sched = (v >> 12) & 3;
     return 0;
 }
 
