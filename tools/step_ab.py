@@ -24,9 +24,13 @@ def main():
         times = {v: [] for v in variants}
         for r in range(rounds):
             for v in (variants if r % 2 == 0 else variants[::-1]):   # ABBA: the variant measured second in a round comes out ~0.5 % faster
-                mask, _, gv = str(v).partition("v")      # "15v16384" = dispatch mask 15 with ullsam_set_gemm_variant(16384) (e.g. no nt stores)
+                head, _, gm = str(v).partition("g")     # "15g8" = dispatch mask 15 with raster groups of 8 tile rows
+                lib.ullsam_set_gemm_tuning(0, int(gm) if gm else 4)
+                head, _, av = head.partition("a")        # "15a9" = dispatch mask 15 with ullsam_set_attn_variant(9)
+                mask, _, gv = head.partition("v")        # "15v16384" = dispatch mask 15 with ullsam_set_gemm_variant(16384) (e.g. nt stores)
                 lib.ullsam_set_gemm_tuning(1, int(mask))
                 lib.ullsam_set_gemm_variant(int(gv) if gv else 0)
+                lib.ullsam_set_attn_variant(int(av) if av else 0)
                 step()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -37,6 +41,8 @@ def main():
                 times[v].append(e0.elapsed_time(e1) / 4)
     lib.ullsam_set_gemm_tuning(1, 15)
     lib.ullsam_set_gemm_variant(0)
+    lib.ullsam_set_attn_variant(0)
+    lib.ullsam_set_gemm_tuning(0, 4)
     for v in variants:
         t = sorted(times[v])
         print(f"dispatch mask {v}: median {t[len(t) // 2]:.3f} ms/step  (min {t[0]:.3f}, max {t[-1]:.3f})  = {4e3 / t[len(t) // 2]:.2f} images/s")
