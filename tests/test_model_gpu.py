@@ -423,6 +423,21 @@ def test_checkpoint_files_load_and_run(tmp_path):
     _, low2, _, _, mk2 = _app_mask_path(dst2, x, ids, pts, lbl)
     assert torch.equal(low2, low_src) and torch.equal(mk2, mk_src)
 
+    # pre-packing after load (compute-dtype weights, [gate | up] interleave, fp8 ViT operands) changes nothing but when the packs are built,
+    # and a new load invalidates them (the packs are keyed by the parameter version)
+    dst3 = _ullsam_tiny(torch.bfloat16)
+    checkpoint.load_ullsam_checkpoint(dst3, str(tmp_path / "final_all_e24.pt"))
+    _, low_a, _, _, mk_a = _app_mask_path(dst3, x, ids, pts, lbl)
+    dst4 = _ullsam_tiny(torch.bfloat16)
+    with torch.no_grad():
+        for p_ in dst4.parameters():
+            p_.normal_()
+    assert checkpoint.prepack(dst4, fp8_vit=True) > 10          # packs of the scrambled weights ...
+    checkpoint.load_ullsam_checkpoint(dst4, str(tmp_path / "final_all_e24.pt"))
+    assert checkpoint.prepack(dst4, fp8_vit=True) > 10          # ... must not survive the load
+    _, low_b, _, _, mk_b = _app_mask_path(dst4, x, ids, pts, lbl)
+    assert torch.equal(low_a, low_b) and torch.equal(mk_a, mk_b)
+
 
 def test_missing_library_fails_loudly(monkeypatch):
     from ullsam_amd import _lib

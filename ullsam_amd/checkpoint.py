@@ -64,3 +64,25 @@ def load_llm_safetensors(model: torch.nn.Module, path_or_dir: str, prefix: str =
     have = model.state_dict()
     sd = {k: v for k, v in sd.items() if k in have and tuple(have[k].shape) == tuple(v.shape)}
     return _report(model, sd)
+
+
+def prepack(model: torch.nn.Module, fp8_vit: bool = False) -> int:
+    """Build the derived weight layouts once, right after loading, instead of inside the first forward ("into the
+    build's weight layout ... pre-packing for MFMA tiles"): the compute-dtype copies and fp32 biases of every Linear, the interleaved
+    [gate | up] rows of every InternLM2MLP (SwiGLU epilogue), and -- with fp8_vit -- the e4m3 bytes + per-channel scales of the ViT's qkv / lin1.
+    The packs live in each module's PackCache keyed by the parameter version, so an optimizer step or load_state_dict invalidates them.
+    Returns the number of packs built.  Needs the model on the GPU (the fp8 quantiser is a HIP kernel)."""
+    from .modeling.common import Linear
+    n = 0
+    for name, m in model.named_modules():
+        if isinstance(m, Linear):
+            m.w(m.weight.dtype)
+            m.b()
+            n += 1
+            if fp8_vit and m.weight.is_cuda and m.weight.dtype == torch.bfloat16 and (name.endswith("attn.qkv") or name.endswith("mlp.lin1")):
+                m.w8()
+                n += 1
+        if hasattr(m, "w13") and hasattr(m, "w1"):
+            m.w13(m.w1.weight.dtype)
+            n += 1
+    return n
