@@ -1487,7 +1487,7 @@ static int launch_gemm_v6(const GemmArgs& a, hipStream_t stream) {
 // differs by group.  Per stage and wave: 4-5 pieces, 13 fragment reads, 40 MFMAs.  The epilogue stages 128 rows x 320 fp32 = the whole
 // 160 KiB of LDS at a time.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MI0, int MI1, int NTW, int EMODE>   // sub-tile rows of the upper / lower wave row, sub-tile columns per wave
+template <int MI0, int MI1, int NTW, int EMODE, bool STAMP = false>   // sub-tile rows of the upper / lower wave row, sub-tile columns per wave
 __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef bf16 T;
@@ -1566,17 +1566,45 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();
+    // (diagnostic build only) shader-clock stamps per workgroup and wave group: loop entry, loop exit, end
+    auto stamp = [&](int kk) {
+        if (STAMP && p.dbg && (tid & 255) == 0) p.dbg[((size_t)bid * 2 + grp) * 4 + kk] = __builtin_amdgcn_s_memtime();
+    };
+    auto stamp16 = [&](int kk) {   // inside stage 10: [workgroup][group][8]
+        if (STAMP && p.dbg && (tid & 255) == 0) p.dbg[(1 << 19) + ((size_t)bid * 2 + grp) * 8 + kk] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     for (int s = 0; s < st1; ++s) {
         const char* Ab = smem + (s & 3) * STG;
         const char* Bb = Ab + ASZ;
         Frag<T> a8[MI], b[NTW];
-        // ---- L(s)
-        if (s + 2 < st1) stage(s + 2);
+        // ---- L(s): requests and fragment reads INTERLEAVED.  A wave's 4-5 requests are held back by the address unit (18 KiB per group and
+        // stage at 64 B/clk: ~400 cycles), its 12-13 reads by the LDS (52 KiB at 256 B/clk: ~250); issued one kind after the other the two
+        // times add up (650 > the partner group's 576-640 matrix cycles the slot should hide under); alternated, the LDS serves the reads
+        // while the next request waits for the address unit.
+        {
+            const bool more = s + 2 < st1;
+            char* base = smem + ((s + 2) & 3) * STG;
+            const char* ak = a_base + (size_t)(s + 2) * 64;
+            const char* bk = b_base + (size_t)(s + 2) * 64;
+            auto request = [&](int qi) __attribute__((always_inline)) {   // request qi of this wave: A0 B0 A1 B1 A2 B2
+                const int i = qi >> 1;
+                if (!(qi & 1)) { if (more && i < na) __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_off[i]), LDS_PTR(base + (wave + 8 * i) * 1024), 16, 0, 0); }
+                else { if (more && i < nb) __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + ASZ + (wave + 8 * i) * 1024), 16, 0, 0); }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            int qi = 0;
+            request(qi++);
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) b[j] = frag(Bb, wn * (16 * NTW) + j * 16 + mm);
+            for (int r = 0; r < NTW + MI; ++r) {
+                if (r < NTW) b[r] = frag(Bb, wn * (16 * NTW) + r * 16 + mm);
+                else if ((r - NTW) < MI1 || (r - NTW) < mi) a8[r - NTW] = frag(Ab, row_w + (r - NTW) * 16 + mm);
+                __builtin_amdgcn_sched_barrier(0);
+                if ((r % 3) == 2 && qi < 6) request(qi++);
+            }
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-            if (i < MI1 || i < mi) a8[i] = frag(Ab, row_w + i * 16 + mm);
+            for (; qi < 6; ++qi) request(qi);
+        }
         // stage s+1 must have landed before the barrier that lets anyone read it; the younger stage stays in flight
         if (s + 2 < st1) wait_one_left();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1595,6 +1623,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
         __builtin_amdgcn_s_barrier();
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
+    stamp(1);
 
     float* Cs = reinterpret_cast<float*>(smem);  // [16 MI][BN] fp32, one wave row at a time
     auto staged = [&](auto half_c) __attribute__((always_inline)) {
@@ -1616,6 +1645,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     };
     staged(std::integral_constant<int, 0>{});
     staged(std::integral_constant<int, 1>{});
+    stamp(2);
 }
 
 template <int MI0, int MI1, int NTW>
@@ -1629,6 +1659,10 @@ static int launch_gemm_ring8(GemmArgs a, hipStream_t stream) {
     a.tiles_n = (a.N + BN - 1) / BN;
     a.full_tiles = a.tiles_m * a.tiles_n;
     a.ksplit = 1;
+    if (a.dbg) {   // stamped diagnostic build (tools/probes/ring8_stamps.py)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        gemm_ring8_kernel<MI0, MI1, NTW, 0, true><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
+    } else
     gemm_ring8_kernel<MI0, MI1, NTW, 0><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
     ULLSAM_LAUNCH_CHECK();
     return 0;
