@@ -2659,21 +2659,22 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     // persistent kernel in auto mode: only where it measured faster in the same process -- bf16 output with the GELU epilogue (vit.lin1
     // 214 vs 232 us: the erf arithmetic of one wave group overlaps the other group's matrix segment); elsewhere it ties or loses 0-3 %
     if (v3 && variant == 0 && g_persistent && (g_auto_mask & 1) && a.act == 1 && !a.out_f32 && v4_ok(a, dtype)) return launch_gemm_v4(a, s);
-    // four-wave kernel in auto mode: bf16 output without residual and without GELU (its erf arithmetic has no second wave to hide under),
-    // where its direct epilogue applies -- same-process A/B: llm.w13 -2.3 ... -4.8 %, vit.qkv -1.7 %, llm.wqkv -2 %; the fp32 residual
-    // GEMMs (+2 ... +8 %) and the RoPE epilogue (+5 %) stay on the two-buffer kernel
-    if (v3 && variant == 0 && g_persistent && (g_auto_mask & 2) && dtype == ULLSAM_DT_BF16 && !a.out_f32 && !residual && (act == 0 || act == 3) && a.vec_ok && N % 8 == 0 &&
-        M % 2 == 0 && K % 128 == 0 && K >= 512)
-        return launch_gemm_v7(a, s);
     // 272x256 tiles in auto mode: row counts that 16-row-taller tiles cover in fewer tile-rounds (the bench's 4 x 1081 = 4324 rows are 16 x 272:
     // llm.wo / llm.w2 become ONE round of 256 tiles instead of 256 + a split-K tail of 16) -- same-process A/B: llm.wo+r 144 vs 158 us,
-    // llm.w2+r 418 vs 451, llm.wo 126 vs 154; llm.w13 stays on the four-wave kernel (828 vs 841)
+    // llm.w2+r 418 vs 451, llm.wo 126 vs 154; llm.w13 (1792 tiles = 7 whole rounds instead of 7.44) equals the four-wave kernel on cold operands
+    // (869 vs 866 us) and beats it in the step (tools/step_ab.py 6 13,15: 81.97 vs 82.74 ms), so this rule comes first
     if (variant == 0 && (g_auto_mask & 8) && dtype == ULLSAM_DT_BF16 && act <= 3 && (act != 3 || N % 256 == 0) && M >= 1024 && N >= 256 && K % 64 == 0 && K >= 256) {
         const long t272 = (long)((M + 271) / 272) * ((N + 255) / 256);
         const double cost272 = 1.0625 * (double)((t272 + 255) / 256);
         const double cost256 = v3_split ? (double)(t256 / 256) + 0.5 : (double)((t256 + 255) / 256);
         if (cost272 <= 0.96 * cost256) return launch_gemm_v9(a, s);
     }
+    // four-wave kernel in auto mode: bf16 output without residual and without GELU (its erf arithmetic has no second wave to hide under),
+    // where its direct epilogue applies -- same-process A/B: llm.w13 -2.3 ... -4.8 %, vit.qkv -1.7 %, llm.wqkv -2 %; the fp32 residual
+    // GEMMs (+2 ... +8 %) and the RoPE epilogue (+5 %) stay on the two-buffer kernel
+    if (v3 && variant == 0 && g_persistent && (g_auto_mask & 2) && dtype == ULLSAM_DT_BF16 && !a.out_f32 && !residual && (act == 0 || act == 3) && a.vec_ok && N % 8 == 0 &&
+        M % 2 == 0 && K % 128 == 0 && K >= 512)
+        return launch_gemm_v7(a, s);
     if (v3) return dtype == ULLSAM_DT_F32 ? launch_gemm_v3<float>(a, s) : launch_gemm_v3<bf16>(a, s);
     if (v2) return dtype == ULLSAM_DT_F32 ? launch_gemm_v2<float>(a, s) : launch_gemm_v2<bf16>(a, s);
     if (a.act == 4) return dtype == ULLSAM_DT_F32 ? launch_gemm<float, 1>(a, s) : launch_gemm<bf16, 1>(a, s);
