@@ -1519,17 +1519,18 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     const char* a_base = reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda * 2;
     const char* b_base = reinterpret_cast<const char*>(p.W) + (size_t)n0 * p.ldw * 2;
     const int na = (PA - wave + 7) / 8, nb = (PB - wave + 7) / 8;
-    // NTW == 4 (64 columns per wave): the MFMA operands are SWAPPED (weight fragment first), so a lane's four accumulator registers of a
-    // sub-tile are four consecutive COLUMNS of one output row and the epilogue can store straight from the accumulators; for 2-byte outputs the
-    // weight rows of a wave are permuted on their way into the LDS so that two sub-tiles give a lane eight consecutive columns (the persistent
-    // kernel's scheme): LDS row R (wave column wb = R >> 6, sub-tile j = (R >> 4) & 3, r = R & 15) holds weight row
-    //   bf16 out:  64 wb + 32 (j >> 1) + 8 (r >> 2) + 4 (j & 1) + (r & 3)          SwiGLU:  128 (wb >> 1) + 64 (j >> 1) + 32 (wb & 1) + 8 (r >> 2) + 4 (j & 1) + (r & 3)
-    //   fp32 out:  R
-    constexpr bool SWAP = NTW == 4;
-    const int perm = !SWAP || p.out_f32 ? 0 : (p.act == 3 ? 2 : 1);
+    // The MFMA operands are SWAPPED (weight fragment first), so a lane's four accumulator registers of a sub-tile are four consecutive COLUMNS
+    // of one output row and the epilogue can store straight from the accumulators; for 2-byte outputs the weight rows of a wave are permuted on
+    // their way into the LDS so that two sub-tiles give a lane eight consecutive columns (the persistent kernel's scheme).  With WW = 16 NTW
+    // columns per wave, LDS row R (wave column wb = R / WW, sub-tile j = (R % WW) >> 4, r = R & 15) holds weight row
+    //   bf16 out:  WW wb + 32 (j >> 1) + 8 (r >> 2) + 4 (j & 1) + (r & 3)  for j < 4,  WW wb + 64 + r  for the fifth sub-tile of a 320-wide tile
+    //   SwiGLU (NTW 4):  128 (wb >> 1) + 64 (j >> 1) + 32 (wb & 1) + 8 (r >> 2) + 4 (j & 1) + (r & 3)          fp32 out:  R
+    static_assert(NTW == 4 || NTW == 5, "epilogue layouts below: four sub-tiles in two pairs, optionally a fifth on its own");
+    constexpr int WW = 16 * NTW;
+    const int perm = p.out_f32 ? 0 : (p.act == 3 ? 2 : 1);
     auto w_row = [&](int R) {
-        const int wb = R >> 6, j = (R >> 4) & 3, r = R & 15;
-        if (perm == 1) return 64 * wb + 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3);
+        const int wb = R / WW, q = R - wb * WW, j = q >> 4, r = q & 15;
+        if (perm == 1) return j < 4 ? WW * wb + 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3) : WW * wb + 64 + r;
         if (perm == 2) return 128 * (wb >> 1) + 64 * (j >> 1) + 32 * (wb & 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3);
         return R;
     };
@@ -1574,14 +1575,15 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     };
 
-    // this lane's 16 output columns keep their bias in registers across the K loop (SWAP layouts: bf16 8 at 32 jp + 8 g4 for jp = 0, 1; fp32 4 at 16 j + 4 g4)
-    float bv[16];
+    // this lane's 4 NTW output columns keep their bias in registers across the K loop (sub-tile t: fp32 4 at 16 t + 4 g4; bf16 4 at
+    // 32 (t >> 1) + 8 g4 + 4 (t & 1) for t < 4 and at 64 + 4 g4 for the fifth)
+    float bv[4 * NTW];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) bv[e] = 0.f;
-    if (SWAP && p.bias && EMODE == 0 && p.act != 3) {
+    for (int e = 0; e < 4 * NTW; ++e) bv[e] = 0.f;
+    if (p.bias && EMODE == 0 && p.act != 3) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int col = n0 + wn * 64 + (p.out_f32 ? 16 * t + 4 * g4 : 32 * (t >> 1) + 8 * g4 + 4 * (t & 1));
+        for (int t = 0; t < NTW; ++t) {
+            const int col = n0 + wn * WW + ((p.out_f32 || t == 4) ? 16 * t + 4 * g4 : 32 * (t >> 1) + 8 * g4 + 4 * (t & 1));
             if (col < p.N) {
                 const float4 x = *reinterpret_cast<const float4*>(p.bias + col);
                 bv[4 * t] = x.x; bv[4 * t + 1] = x.y; bv[4 * t + 2] = x.z; bv[4 * t + 3] = x.w;
@@ -1644,10 +1646,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
         for (int i = 0; i < MI; ++i)
             if (i < MI1 || i < mi) {
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    if constexpr (SWAP) mma16(b[j], a8[i], acc[i][j]);
-                    else mma16(a8[i], b[j], acc[i][j]);
-                }
+                for (int j = 0; j < NTW; ++j) mma16(b[j], a8[i], acc[i][j]);
             }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -1656,19 +1655,26 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();
     stamp(1);
 
-    // ---- epilogue
-    if constexpr (SWAP) {
-        // acc[i][j][r] = C[m0 + row_w + 16 i + mm][n0 + 64 wn (or its SwiGLU image) + ncol(j) + r]: straight from the accumulators
+    // ---- epilogue.  acc[i][j][r] = C[m0 + row_w + 16 i + mm][n0 + ncol(j) + r]: straight from the accumulators where the layout allows
+    {
         const bool odd = mm & 1;
         const int row0 = m0 + row_w + mm;
         const int rowp = row0 & ~1;   // after pair_swap the lane pair (mm, mm ^ 1) owns rows rowp + 16 i and rowp + 16 i + 1
         const bool direct = EMODE == 0 && p.vec_ok && (p.N & 7) == 0 && (p.M & 1) == 0;
         auto gst = [&](void* ptr, u32x4 v) __attribute__((always_inline)) { store16_policy(ptr, __builtin_bit_cast(u32x4s, v), p.store_nt); };
         if (direct && !p.out_f32 && p.act != 3) {
-            // bf16 (+bias, +GELU / ReLU): sub-tiles (2 h, 2 h + 1) are this lane's 8 columns of the 32-column group h; the two groups are the halves of a 128 B line
-            const int colb = n0 + wn * 64 + (odd ? 32 : 0) + 8 * g4;
+            // bf16 (+bias, +GELU / ReLU): sub-tiles (2 h, 2 h + 1) are this lane's 8 columns of the 32-column group h; the two groups are 128 contiguous
+            // bytes of a row -> pair_swap; the fifth sub-tile of a 320-wide tile is 4 columns (8 bytes) of the lane's own row
+            const int colb = n0 + wn * WW + (odd ? 32 : 0) + 8 * g4;
             T* cp = reinterpret_cast<T*>(p.C) + (size_t)rowp * p.ldc + colb;
+            const int col5 = n0 + wn * WW + 64 + 4 * g4;
+            T* cp5 = reinterpret_cast<T*>(p.C) + (size_t)row0 * p.ldc + col5;
             auto drain = [&](auto ACT) __attribute__((always_inline)) {
+                auto actf = [&](float v) __attribute__((always_inline)) {
+                    if constexpr (decltype(ACT)::value == 1) return gelu_erf(v);
+                    else if constexpr (decltype(ACT)::value == 2) return fmaxf(v, 0.f);
+                    else return v;
+                };
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     if (!(i < MI1 || i < mi)) continue;
@@ -1676,25 +1682,29 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float v0 = acc[i][2 * h + (q >> 1)][2 * (q & 1)] + bv[8 * h + 2 * q];
-                            float v1 = acc[i][2 * h + (q >> 1)][2 * (q & 1) + 1] + bv[8 * h + 2 * q + 1];
-                            if constexpr (decltype(ACT)::value == 1) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); }
-                            if constexpr (decltype(ACT)::value == 2) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                            o[4 * h + q] = pack_bf16x2(v0, v1);
-                        }
+                        for (int q = 0; q < 4; ++q)
+                            o[4 * h + q] = pack_bf16x2(actf(acc[i][2 * h + (q >> 1)][2 * (q & 1)] + bv[8 * h + 2 * q]),
+                                                       actf(acc[i][2 * h + (q >> 1)][2 * (q & 1) + 1] + bv[8 * h + 2 * q + 1]));
                     u32x4 s0, s1;
                     pair_swap((u32x4){o[0], o[1], o[2], o[3]}, (u32x4){o[4], o[5], o[6], o[7]}, odd, s0, s1);
                     if (rowp + 16 * i < p.M && colb < p.N) {   // M is even: both rows of the pair or neither
                         gst(cp + (size_t)(16 * i) * p.ldc, s0);
                         gst(cp + (size_t)(16 * i + 1) * p.ldc, s1);
                     }
+                    if constexpr (NTW == 5) {
+                        if (row0 + 16 * i < p.M && col5 < p.N) {
+                            uint2 w;
+                            w.x = pack_bf16x2(actf(acc[i][4][0] + bv[16]), actf(acc[i][4][1] + bv[17]));
+                            w.y = pack_bf16x2(actf(acc[i][4][2] + bv[18]), actf(acc[i][4][3] + bv[19]));
+                            *reinterpret_cast<uint2*>(cp5 + (size_t)(16 * i) * p.ldc) = w;
+                        }
+                    }
                 }
             };
             if (p.act == 1) drain(std::integral_constant<int, 1>{});
             else if (p.act == 2) drain(std::integral_constant<int, 2>{});
             else drain(std::integral_constant<int, 0>{});
-        } else if (direct && !p.out_f32 && p.act == 3) {
+        } else if (NTW == 4 && direct && !p.out_f32 && p.act == 3) {
             // SwiGLU: out[:, n0/2 + 64 (wn >> 1) + 32 (wn & 1) + 8 g4 + e] = silu(gate_e) * up_e, gate = sub-tiles 0 / 1, up = 2 / 3 (modeling_internlm2.py:261-264)
             T* cp = reinterpret_cast<T*>(p.C) + (size_t)row0 * p.ldc + (n0 >> 1) + (wn >> 1) * 64 + (wn & 1) * 32 + 8 * g4;
 #pragma unroll
@@ -1710,11 +1720,14 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
                 if (row0 + 16 * i < p.M) gst(cp + (size_t)(16 * i) * p.ldc, (u32x4){o[0], o[1], o[2], o[3]});
             }
         } else if (direct && p.out_f32 && p.act == 0) {
-            // fp32 residual stream: C = acc + bias + residual[row (mod res_row_mod)]; sub-tiles (2 jp, 2 jp + 1) are the two 64 B halves of line jp
-            // -> pair_swap; two register sets alternate so that the residual rows of sub-tile i + 1 are requested before sub-tile i is stored
-            const int colp = n0 + wn * 64 + (odd ? 16 : 0) + 4 * g4;
+            // fp32 residual stream: C = acc + bias + residual[row (mod res_row_mod)]; sub-tiles (2 jp, 2 jp + 1) are 128 contiguous bytes of a row
+            // -> pair_swap; the fifth sub-tile of a 320-wide tile is 16 bytes of the lane's own row.  Two register sets alternate so that the
+            // residual rows of sub-tile i + 1 are requested before sub-tile i is stored
+            const int colp = n0 + wn * WW + (odd ? 16 : 0) + 4 * g4;
             float* cp = reinterpret_cast<float*>(p.C) + (size_t)rowp * p.ldc + colp;
-            auto load_res = [&](int i, float4 (&r)[4]) __attribute__((always_inline)) {   // r[2 jp + rsel]: line jp of row rowp + 16 i + rsel
+            const int col5 = n0 + wn * WW + 64 + 4 * g4;
+            float* cp5 = reinterpret_cast<float*>(p.C) + (size_t)row0 * p.ldc + col5;
+            auto load_res = [&](int i, float4 (&r)[5]) __attribute__((always_inline)) {   // r[2 jp + rsel]: 128 B segment jp of row rowp + 16 i + rsel; r[4]: the fifth sub-tile
 #pragma unroll
                 for (int rsel = 0; rsel < 2; ++rsel) {
                     const int gm = min(rowp + 16 * i + rsel, p.M - 1);
@@ -1723,8 +1736,13 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
 #pragma unroll
                     for (int jp = 0; jp < 2; ++jp) r[2 * jp + rsel] = colp + 32 * jp < p.N ? *reinterpret_cast<const float4*>(rp + 32 * jp) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+                if constexpr (NTW == 5) {
+                    const int gm = min(row0 + 16 * i, p.M - 1);
+                    const int rr = p.res_row_mod > 0 ? gm % p.res_row_mod : gm;
+                    r[4] = col5 < p.N ? *reinterpret_cast<const float4*>(p.residual + (size_t)rr * p.ldr + col5) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             };
-            auto put = [&](int i, const float4 (&r)[4]) __attribute__((always_inline)) {
+            auto put = [&](int i, const float4 (&r)[5]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
                     u32x4 lo, hi, s0, s1;
@@ -1744,11 +1762,16 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
                         *reinterpret_cast<u32x4*>(cp + (size_t)(16 * i + 1) * p.ldc + 32 * jp) = s1;
                     }
                 }
+                if constexpr (NTW == 5) {
+                    if (row0 + 16 * i < p.M && col5 < p.N)
+                        *reinterpret_cast<float4*>(cp5 + (size_t)(16 * i) * p.ldc) = make_float4(acc[i][4][0] + bv[16] + r[4].x, acc[i][4][1] + bv[17] + r[4].y,
+                                                                                                 acc[i][4][2] + bv[18] + r[4].z, acc[i][4][3] + bv[19] + r[4].w);
+                }
             };
             auto drain = [&](auto RES) __attribute__((always_inline)) {
-                float4 ra[4], rb[4];
+                float4 ra[5], rb[5];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ra[j] = rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int j = 0; j < 5; ++j) ra[j] = rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (decltype(RES)::value) load_res(0, ra);
 #pragma unroll
                 for (int i = 0; i < MI; i += 2) {
@@ -1763,13 +1786,14 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
             // every other epilogue (RoPE, activations on fp32 outputs, unaligned / odd shapes): through the LDS, one wave row at a time
             float* Cs = reinterpret_cast<float*>(smem);
             auto ncol = [&](int j) __attribute__((always_inline)) {   // column of sub-tile j's register 0 inside the TILE (the inverse of w_row)
-                if (perm == 1) return 64 * wn + 32 * (j >> 1) + 8 * g4 + 4 * (j & 1);
+                if (perm == 1) return j < 4 ? WW * wn + 32 * (j >> 1) + 8 * g4 + 4 * (j & 1) : WW * wn + 64 + 4 * g4;
                 if (perm == 2) return 128 * (wn >> 1) + 64 * (j >> 1) + 32 * (wn & 1) + 8 * g4 + 4 * (j & 1);
-                return 64 * wn + 16 * j + 4 * g4;
+                return WW * wn + 16 * j + 4 * g4;
             };
             auto staged = [&](auto half_c) __attribute__((always_inline)) {
                 constexpr int half = decltype(half_c)::value;
                 constexpr int ROWS = 16 * (half == 0 ? MI0 : MI1);
+                constexpr int NT_E = (512 / (BN / 8)) * (BN / 8);   // whole rows per pass: 320 columns -> 40 threads per row, 480 threads, 12 rows
                 __syncthreads();
                 if (wm == half) {
 #pragma unroll
@@ -1779,33 +1803,12 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
                             *reinterpret_cast<float4*>(Cs + (i * 16 + mm) * BN + ncol(j)) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
                 }
                 __syncthreads();
-                if (p.out_f32) epilogue_rows<T, float, ROWS, 512, BN, EMODE>(p, Cs, m0 + half * 16 * MI0, n0, tn, tid);
-                else epilogue_rows<T, T, ROWS, 512, BN, EMODE>(p, Cs, m0 + half * 16 * MI0, n0, tn, tid);
+                if (p.out_f32) epilogue_rows<T, float, ROWS, NT_E, BN, EMODE>(p, Cs, m0 + half * 16 * MI0, n0, tn, tid);
+                else epilogue_rows<T, T, ROWS, NT_E, BN, EMODE>(p, Cs, m0 + half * 16 * MI0, n0, tn, tid);
             };
             staged(std::integral_constant<int, 0>{});
             staged(std::integral_constant<int, 1>{});
         }
-    } else {
-        float* Cs = reinterpret_cast<float*>(smem);  // [16 MI][BN] fp32, one wave row at a time
-        auto staged = [&](auto half_c) __attribute__((always_inline)) {
-            constexpr int half = decltype(half_c)::value;
-            constexpr int ROWS = 16 * (half == 0 ? MI0 : MI1);
-            constexpr int NT_E = (512 / (BN / 8)) * (BN / 8);   // whole rows per pass: 320 columns -> 40 threads per row, 480 threads, 12 rows; 192 -> 504 threads, 21 rows
-            __syncthreads();
-            if (wm == half) {
-#pragma unroll
-                for (int i = 0; i < (half == 0 ? MI0 : MI1); ++i)
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * g4 + r) * BN + wn * (16 * NTW) + j * 16 + mm] = acc[i][j][r];
-            }
-            __syncthreads();
-            if (p.out_f32) epilogue_rows<T, float, ROWS, NT_E, BN, EMODE>(p, Cs, m0 + half * 16 * MI0, n0, tn, tid);
-            else epilogue_rows<T, T, ROWS, NT_E, BN, EMODE>(p, Cs, m0 + half * 16 * MI0, n0, tn, tid);
-        };
-        staged(std::integral_constant<int, 0>{});
-        staged(std::integral_constant<int, 1>{});
     }
     stamp(2);
 }
