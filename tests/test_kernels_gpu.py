@@ -506,6 +506,37 @@ def test_wqkv_gemm_with_rope_epilogue(ops, dtype, B, S, KVH, G, K, bias):
     assert err(kc.float().cpu().numpy(), kc2.float().cpu().numpy()) < (1e-5 if dtype == torch.float32 else 4e-2)
 
 
+@pytest.mark.parametrize("B,S,KVH,G,K,bias", [(1, 1081, 2, 4, 512, True), (4, 300, 8, 4, 256, False), (4, 1081, 3, 1, 256, False)])
+def test_wqkv_rope_epilogue_on_the_ring_kernel(ops, B, S, KVH, G, K, bias):
+    """The wqkv + RoPE + KV-append epilogue straight from the ring kernel's accumulators (dispatch bit 5): columns d and d + 64 of a head in one
+    lane through the weight-row permutation.  Against numpy from the operands as the kernel sees them; odd slot counts leave half a tile empty."""
+    from ullsam_amd import _lib
+    lib = _lib.load()
+    hd = 128
+    rng = np.random.default_rng(S + K)
+    x = rng.standard_normal((B * S, K), dtype=np.float32)
+    w = (rng.standard_normal((KVH * (G + 2) * hd, K), dtype=np.float32) / math.sqrt(K)).astype(np.float32)
+    bv = rng.standard_normal(w.shape[0], dtype=np.float32) * 0.2 if bias else None
+    pos = (np.arange(S, dtype=np.int32)[None] + np.arange(B, dtype=np.int32)[:, None] * 3) % (S + 5)
+    cos, sin = O.rope_tables(hd, S + 8, 1e6)
+    xd, wd = T(x, torch.bfloat16), T(w, torch.bfloat16)
+    cap, p0 = S + 6, 2
+    kc = torch.zeros((B, KVH, cap, hd), dtype=torch.bfloat16, device=DEV); vc = torch.zeros_like(kc)
+    try:
+        lib.ullsam_set_gemm_tuning(1, 63)
+        q = ops.gemm_qkv_rope(xd, wd, None if bv is None else T(bv), kc, vc, T(pos, torch.int32), T(cos), T(sin), B, S, KVH, G, p0)
+        torch.cuda.synchronize()
+    finally:
+        lib.ullsam_set_gemm_tuning(1, 31)
+    r = (xd.float().cpu().numpy() @ wd.float().cpu().numpy().T + (0 if bv is None else bv)).reshape(B, S, KVH, G + 2, hd)
+    c, s_ = cos[pos][:, :, None, None, :], sin[pos][:, :, None, None, :]
+    rot = r * c + O._rotate_half(r) * s_
+    assert err(q.float().cpu().numpy(), rot[..., :G, :].reshape(B * S, KVH * G * hd)) < 4e-2
+    assert err(kc[:, :, p0:p0 + S].float().cpu().numpy(), rot[..., G, :].transpose(0, 2, 1, 3)) < 4e-2
+    assert err(vc[:, :, p0:p0 + S].float().cpu().numpy(), r[..., G + 1, :].transpose(0, 2, 1, 3)) < 4e-2
+    assert float(kc[:, :, :p0].abs().max()) == 0 and float(kc[:, :, p0 + S:].abs().max()) == 0
+
+
 def test_naive_and_fewkeys_attention(ops):
     rng = np.random.default_rng(0)
     B, H, hd, Sq, Sk = 2, 8, 16, 7, 300

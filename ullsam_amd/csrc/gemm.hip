@@ -74,7 +74,7 @@ static int g_store_nt = 0;     // non-temporal bf16 output stores in the non-per
                                // (tools/gemm_bench.py: vit.qkv -3.4 %, vit.lin1 -3.6 %, llm.w13 -0.9 %), but in the step the next kernel reads the output at
                                // once and plain stores leave it in L2 / Infinity Cache: 84.99 vs 85.64 ms per step (tools/step_ab.py 8 15,15v16384).
                                // ullsam_set_gemm_variant bit 14 turns them on (A/B)
-static int g_auto_mask = 15;   // ullsam_set_gemm_tuning(1, mask): kernels the auto dispatch may pick besides the two-buffer one: bit 0 persistent (GELU), bit 1 four-wave, bit 2 256x320 tiles, bit 3 272x256 tiles
+static int g_auto_mask = 31;   // ullsam_set_gemm_tuning(1, mask): kernels the auto dispatch may pick besides the two-buffer one: bit 0 persistent (GELU), bit 1 four-wave, bit 2 256x320 tiles, bit 3 272x256 tiles, bit 4 GELU GEMM on the 256x320 ring when tile-rounds tie, bit 5 RoPE GEMM on the 256x256 ring
 static int g_group_m = 4;      // ullsam_set_gemm_tuning(0, gm): A/B of the raster group height
 static int g_gemm_sched = 0;   // 256x256 kernel main-loop schedule: 0 production, 1 plain interleave, 2 fragments-first / 1 barrier
 
@@ -1527,7 +1527,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     //   SwiGLU (NTW 4):  128 (wb >> 1) + 64 (j >> 1) + 32 (wb & 1) + 8 (r >> 2) + 4 (j & 1) + (r & 3)          fp32 out:  R
     static_assert(NTW == 4 || NTW == 5, "epilogue layouts below: four sub-tiles in two pairs, optionally a fifth on its own");
     constexpr int WW = 16 * NTW;
-    const int perm = p.out_f32 ? 0 : (p.act == 3 ? 2 : 1);
+    const int perm = p.out_f32 ? 0 : ((p.act == 3 || p.act == 4) ? 2 : 1);   // (RoPE pairs column d with d + 64 like SwiGLU pairs gate with up)
     auto w_row = [&](int R) {
         const int wb = R / WW, q = R - wb * WW, j = q >> 4, r = q & 15;
         if (perm == 1) return j < 4 ? WW * wb + 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3) : WW * wb + 64 + r;
@@ -1719,6 +1719,52 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
                 }
                 if (row0 + 16 * i < p.M) gst(cp + (size_t)(16 * i) * p.ldc, (u32x4){o[0], o[1], o[2], o[3]});
             }
+        } else if (NTW == 4 && EMODE == 1 && p.act == 4 && p.vec_ok) {
+            // wqkv + RoPE + KV-cache append (modeling_internlm2.py:361-388, 233-247): the tile's 256 columns are two 128-wide head slots; with the
+            // SwiGLU-style permutation this lane holds columns d .. d + 7 (sub-tiles 0 / 1) and their rotate_half partners d + 64 .. (sub-tiles 2 / 3)
+            const int slot = (n0 >> 7) + (wn >> 1), d = 32 * (wn & 1) + 8 * g4;
+            const int gs = p.rope_G + 2, kv = slot / gs, g = slot - kv * gs;
+            const bool live = slot < p.rope_KVH * gs;
+            const bool rotate = g != gs - 1;
+            float bl[8], bh[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bl[e] = (p.bias && live) ? p.bias[slot * 128 + d + e] : 0.f; bh[e] = (p.bias && live) ? p.bias[slot * 128 + d + 64 + e] : 0.f; }
+            T* Q = reinterpret_cast<T*>(p.rope_q);
+            T* Kc = reinterpret_cast<T*>(p.rope_k);
+            T* Vc = reinterpret_cast<T*>(p.rope_v);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if (!(i < MI1 || i < mi)) continue;
+                const int gm = row0 + 16 * i;
+                if (gm >= p.M || !live) continue;
+                float x[8], y[8], lo[8], hi[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { x[e] = acc[i][e >> 2][e & 3] + bl[e]; y[e] = acc[i][2 + (e >> 2)][e & 3] + bh[e]; }
+                if (rotate) {
+                    const int ps = min(max(p.rope_pos[gm], 0), p.rope_rows - 1);
+                    const float* cp = p.rope_cos + (size_t)ps * 128 + d;
+                    const float* sp = p.rope_sin + (size_t)ps * 128 + d;
+                    const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+                    const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+                    const float4 c2 = *reinterpret_cast<const float4*>(cp + 64), c3 = *reinterpret_cast<const float4*>(cp + 68);
+                    const float4 s2 = *reinterpret_cast<const float4*>(sp + 64), s3 = *reinterpret_cast<const float4*>(sp + 68);
+                    const float cl[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sl[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                    const float ch[8] = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w}, sh[8] = {s2.x, s2.y, s2.z, s2.w, s3.x, s3.y, s3.z, s3.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { lo[e] = x[e] * cl[e] - y[e] * sl[e]; hi[e] = y[e] * ch[e] + x[e] * sh[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { lo[e] = x[e]; hi[e] = y[e]; }
+                }
+                T* dst;
+                if (g < p.rope_G) dst = Q + (size_t)gm * ((size_t)p.rope_KVH * p.rope_G * 128) + (size_t)(kv * p.rope_G + g) * 128 + d;
+                else {
+                    const int bi = gm / p.rope_S, sq = gm - bi * p.rope_S;
+                    dst = (g == gs - 2 ? Kc : Vc) + (((size_t)bi * p.rope_KVH + kv) * p.rope_cap + p.rope_pos0 + sq) * 128 + d;
+                }
+                store_row8<T>(dst, lo, 8, true);
+                store_row8<T>(dst + 64, hi, 8, true);
+            }
         } else if (direct && p.out_f32 && p.act == 0) {
             // fp32 residual stream: C = acc + bias + residual[row (mod res_row_mod)]; sub-tiles (2 jp, 2 jp + 1) are 128 contiguous bytes of a row
             // -> pair_swap; the fifth sub-tile of a 320-wide tile is 16 bytes of the lane's own row.  Two register sets alternate so that the
@@ -1813,27 +1859,28 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     stamp(2);
 }
 
-template <int MI0, int MI1, int NTW>
+template <int MI0, int MI1, int NTW, int EMODE = 0>
 static int launch_gemm_ring8(GemmArgs a, hipStream_t stream) {
     constexpr int BM = 16 * (MI0 + MI1), BN = 64 * NTW;
     constexpr int LDS = (4 * (BM + BN) * 64 > 16 * MI0 * BN * 4) ? 4 * (BM + BN) * 64 : 16 * MI0 * BN * 4;   // the ring, or the epilogue's staging rows
     static_assert(LDS <= 163840, "160 KiB of LDS per CU");
     static PerDeviceOnce attr_set;
-    if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW, EMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     a.full_tiles = a.tiles_m * a.tiles_n;
     a.ksplit = 1;
-    if (a.dbg) {   // stamped diagnostic build (tools/probes/ring8_stamps.py)
+    if (a.dbg && EMODE == 0) {   // stamped diagnostic build (tools/probes/ring8_stamps.py)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         gemm_ring8_kernel<MI0, MI1, NTW, 0, true><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
     } else
-    gemm_ring8_kernel<MI0, MI1, NTW, 0><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
+    gemm_ring8_kernel<MI0, MI1, NTW, EMODE><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
 static int launch_gemm_v8(const GemmArgs& a, hipStream_t stream) { return launch_gemm_ring8<8, 8, 5>(a, stream); }   // 256 x 320
 static int launch_gemm_v9(const GemmArgs& a, hipStream_t stream) { return launch_gemm_ring8<9, 8, 4>(a, stream); }   // 272 x 256
+static int launch_gemm_ring_rope(const GemmArgs& a, hipStream_t stream) { return launch_gemm_ring8<8, 8, 4, 1>(a, stream); }   // 256 x 256, wqkv + RoPE epilogue
 
 // ---------------------------------------------------------------------------------------------------------------
 // v7: 256x256 tile, FOUR waves (2 x 2, 128x128 per wave, 256 accumulator registers per lane: one wave per SIMD with the whole
@@ -2488,7 +2535,7 @@ static int launch_gemm_v4(const GemmArgs& a, hipStream_t stream) {
 // v: bits 0-3 kernel (0 auto), +64 no split-K tail, bits 8-11 timing-only ablations (1 no staging, 2 no barrier, 4 no epilogue, 8 no stores), bits 12-13 schedule of the 256x256 kernel
 extern "C" int ullsam_set_gemm_tuning(int key, int value) {
     if (key == 0 && value >= 1 && value <= 1024) { g_group_m = value; return 0; }
-    if (key == 1 && value >= 0 && value <= 15) { g_auto_mask = value; return 0; }
+    if (key == 1 && value >= 0 && value <= 63) { g_auto_mask = value; return 0; }
     ullsam_set_error("ullsam_set_gemm_tuning: unknown key %d / bad value %d", key, value);
     return -1;
 }
@@ -2819,8 +2866,9 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
         const long t320 = (long)((M + 255) / 256) * (N / 320);
         const double cost320 = 1.25 * (double)((t320 + 255) / 256);
         const double cost256 = v3_split ? (double)(t256 / 256) + 0.5 : (double)((t256 + 255) / 256);
-        if (cost320 <= 0.96 * cost256) return launch_gemm_v8(a, s);
+        if (cost320 <= 0.96 * cost256 || (act == 1 && (g_auto_mask & 16) && cost320 <= cost256)) return launch_gemm_v8(a, s);   // (GELU: a tie in tile-rounds goes to the ring kernel: bit 4)
     }
+    if (variant == 0 && (g_auto_mask & 32) && act == 4 && dtype == ULLSAM_DT_BF16 && M >= 1024 && K % 64 == 0 && K >= 256) return launch_gemm_ring_rope(a, s);   // bit 5
     // persistent kernel in auto mode: only where it measured faster in the same process -- bf16 output with the GELU epilogue (vit.lin1
     // 214 vs 232 us: the erf arithmetic of one wave group overlaps the other group's matrix segment); elsewhere it ties or loses 0-3 %
     if (v3 && variant == 0 && g_persistent && (g_auto_mask & 1) && a.act == 1 && !a.out_f32 && v4_ok(a, dtype)) return launch_gemm_v4(a, s);
