@@ -11,7 +11,7 @@ from ullsam_amd import _lib
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "3", "7", "15"]
+    variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "15", "31"]
     lib = _lib.load()
     dev = "cuda"
     model = bench.build_model("h", "7b", torch.bfloat16, dev)
@@ -39,7 +39,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) / 4)
-    lib.ullsam_set_gemm_tuning(1, 15)
+    lib.ullsam_set_gemm_tuning(1, 31)
     lib.ullsam_set_gemm_variant(0)
     lib.ullsam_set_attn_variant(0)
     lib.ullsam_set_gemm_tuning(0, 4)
