@@ -44,6 +44,7 @@ struct AttnArgs {
     int grid_h, grid_w;     // token grid (64 x 64)
     int win, nwin_w, nwin;  // window size, windows per row, windows per image
     const void* bias_q; const void* bias_k; const void* bias_v;  // T [H*HD] slices of qkv.bias for pad tokens
+    int left_align;         // causal A/B (attn variant 10): query blocks left-aligned (the ragged block last) instead of right-aligned
 };
 
 template <typename T, int HD, int TR = 64> struct KVTile {
@@ -157,8 +158,12 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 1 : 2) void flash_attn_k
     // ---- this lane's query
     // causal: the last query blocks see the most keys -- dispatch them first so the long workgroups do not form the tail
     const int qblk = (MODE == MODE_CAUSAL) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
-    const int qi = (qblk * NWAVES + wave) * 32 + ql;  // index within sequence / window
-    bool q_valid = qi < p.Sq;
+    // causal: the query blocks are RIGHT-aligned (block b covers queries Sq - (nblk - b) * 128 ...), so the ragged block is the first one,
+    // which sees one key tile, instead of the last one, which sees them all (S = 1081: 57 of 128 rows live in the heaviest block = 11 % of
+    // the kernel's work spent on padding rows)
+    const int qbase = ((MODE == MODE_CAUSAL && !p.left_align) ? p.Sq - (int)gridDim.x * NWAVES * 32 : 0) + qblk * NWAVES * 32;
+    const int qi = qbase + wave * 32 + ql;  // index within sequence / window
+    bool q_valid = qi >= 0 && qi < p.Sq;
     long q_tok = qi;       // token index in the [B, tokens] tensors (for load and store)
     bool q_store = q_valid;
     int qh = 0, qw = 0;    // query grid coordinates (rel-pos)
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 1 : 2) void flash_attn_k
 
     int ntiles = (Sk + TR - 1) / TR;
     if (MODE == MODE_CAUSAL) {
-        const int last_q = p.q_pos0 + min(p.Sq, (qblk + 1) * NWAVES * 32) - 1;
+        const int last_q = p.q_pos0 + min(p.Sq, qbase + NWAVES * 32) - 1;
         ntiles = min(ntiles, last_q / TR + 1);
     }
     const float FMIN = -3.4028234663852886e38f;  // torch.finfo(float32).min
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 1 : 2) void flash_attn_k
     auto do_tile = [&](const int tile, const bool W14) __attribute__((always_inline)) {
         if (tile + 1 < ntiles) load_tile(tile + 1);
         const bool tile_pad = (MODE == MODE_CAUSAL && kmask_g) ? (__any(kms[lane] == 0 || (TR > 64 && kms[lane + 64] == 0)) != 0) : false;
-        const int wave_first_q = p.q_pos0 + (qblk * NWAVES + wave) * 32;
+        const int wave_first_q = p.q_pos0 + qbase + wave * 32;
         constexpr int NSUB = TR / 32;
         if (PIPE_OK && (FAST64 || W14)) {
             // block validity is a compile-time fact here: FAST64 has Sk = 4096 (every block full); W14 has Sk = 196 with the tile
@@ -514,7 +519,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 1 : 2) void flash_attn_k
                 if (kbase >= Sk) continue;
                 if (wave_first_q - p.q_pos0 >= p.Sq) continue;  // wave-uniform: no valid query in this wave
                 if (MODE == MODE_CAUSAL) {
-                    const int wave_last_q = p.q_pos0 + min(p.Sq, (qblk * NWAVES + wave + 1) * 32) - 1;
+                    const int wave_last_q = p.q_pos0 + min(p.Sq, qbase + (wave + 1) * 32) - 1;
+                    if (wave_last_q < p.q_pos0) continue;  // wave-uniform: a wave of the ragged first block that lies before query 0
                     if (kbase > wave_last_q) continue;  // wave-uniform: the whole 32-key block is in the future
                 }
                 f32x16 sc;
@@ -951,6 +957,7 @@ extern "C" int ullsam_causal_attention(int dtype, const void* q, const void* k, 
     a.o_bs = a.q_bs; a.o_ts = a.q_ts; a.o_hs = hd;
     a.B = B; a.H = H; a.groups = H / KVH; a.Sq = Sq; a.Sk = Sk; a.key_mask = key_mask; a.q_pos0 = q_pos0;
     a.scale = 1.0f / sqrtf((float)hd);
+    a.left_align = g_attn_variant == 10;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // 4 waves = 128 queries per workgroup (8 waves / 256 queries measured no faster end to end: 94.9 vs 94.5 ms per step)
     // variant 1: 8-wave workgroups (256 queries) over 128-key tiles, one per CU -- twice the matrix work per staged tile
