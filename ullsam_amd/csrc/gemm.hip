@@ -16,8 +16,10 @@
 //                       for every large launch (and the only one for fp32).
 //   gemm256w_kernel     256x256 tile, FOUR waves (one per SIMD, 128x128 per wave, asm MFMAs on AGPR accumulators), ring of four half-K
 //                       stages, LDS-DMA through buffer descriptors, direct epilogues.  Auto mode: bf16 outputs without residual / GELU.
-//   gemm_ring8_kernel   the two-group kernel on the same ring with the tile shape as template parameters: 256x320 (ViT-H widths) and 272x256
-//                       (4324 prompt rows) make the tile count a whole number of rounds of the 256 CUs; auto where that saves tile-rounds.
+//   gemm_ring8_kernel   THE production kernel of the bench step (76 % of its time): the two-group schedule on a ring of four half-K stages with the
+//                       tile shape as template parameters -- 256x320 (ViT-H widths) and 272x256 (4324 prompt rows) make the tile count a whole
+//                       number of rounds of the 256 CUs; requests and fragment reads alternated in the load slot; epilogues straight from the
+//                       accumulators (swapped operands, permuted weight rows, lane-pair swap).  Auto wherever it saves tile-rounds.
 //   gemm256r_kernel     the 256x256 instance of that ring (A/B only: equal to gemm256_kernel).
 //   gemm256p_kernel     the same main loop made PERSISTENT (one workgroup per CU walks a unit list, DMA pipelined across units,
 //                       swapped MFMA operands + permuted W rows + lane-pair swap = direct full-line stores from the accumulators,
