@@ -19,7 +19,7 @@ def t(fn, n=4, reps=5):
 rh14, rw14 = (torch.randn(27, hd, device=dev) * 0.1).bfloat16(), (torch.randn(27, hd, device=dev) * 0.1).bfloat16()
 rh64, rw64 = (torch.randn(127, hd, device=dev) * 0.1).bfloat16(), (torch.randn(127, hd, device=dev) * 0.1).bfloat16()
 H, KVH, S = 32, 8, 1081
-q = torch.randn(B * S, H * 128, device=dev).bfloat16()
+q = (torch.randn(B * S, H * 128, device=dev) * float(os.environ.get("ATTN_QSCALE", "1"))).bfloat16()
 kc = torch.randn(B, KVH, S, 128, device=dev).bfloat16(); vc = torch.randn(B, KVH, S, 128, device=dev).bfloat16()
 ops.vit_attention(qkv[0], rh64, rw64, bias, B, heads, hd, 64, 64, 0); torch.cuda.synchronize()  # clocks / caches warm
 for _ in range(3): ops.vit_attention(qkv[0], rh64, rw64, bias, B, heads, hd, 64, 64, 0)

@@ -45,7 +45,6 @@ struct AttnArgs {
     int win, nwin_w, nwin;  // window size, windows per row, windows per image
     const void* bias_q; const void* bias_k; const void* bias_v;  // T [H*HD] slices of qkv.bias for pad tokens
     int left_align;         // causal A/B (attn variant 10): query blocks left-aligned (the ragged block last) instead of right-aligned
-    int serial_blocks;      // causal A/B (attn variant 11): the two 32-key blocks of a tile one after the other (no QK of block 1 under block 0's softmax)
 };
 
 template <typename T, int HD, int TR = 64> struct KVTile {
@@ -513,24 +512,6 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 1 : 2) void flash_attn_k
                     if (sub + 1 == NSUB || !valid(sub + 1)) pv_block(sub, p0, p1);  // drain before the tile buffer is recycled
                 }
             }
-        } else if (MODE == MODE_CAUSAL && sizeof(T) == 2 && !p.serial_blocks && wave_first_q - p.q_pos0 < p.Sq && tile * TR + (NSUB - 1) * 32 < Sk &&
-                   tile * TR + (NSUB - 1) * 32 <= p.q_pos0 + min(p.Sq, qbase + (wave + 1) * 32) - 1 && qbase + (wave + 1) * 32 > 0) {
-            // causal prefill, every 32-key block of the tile live for this wave (wave-uniform): the scores of block j + 1 are issued before
-            // block j's softmax and the PV product of block j - 1 with them, so the matrix pipe works under the wave's own VALU stretches.
-            // Same operations in the same order on every register as the loop below (the O rescale by alpha = 1 is exact).
-            f32x16 sc[2];
-            Frag<T> p0, p1;
-            qk_block(0, sc[0]);
-#pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub) {
-                if (sub + 1 < NSUB) qk_block(sub + 1, sc[(sub + 1) & 1]);
-                if (sub > 0) pv_block(sub - 1, p0, p1);
-                const float alpha = soft_block(tile, sub, W14, tile_pad, wave_first_q, sc[sub & 1]);
-                scale_o(alpha);
-                p0 = pack_p(sc[sub & 1], 0, (const T*)nullptr);
-                p1 = pack_p(sc[sub & 1], 1, (const T*)nullptr);
-                if (sub + 1 == NSUB) pv_block(sub, p0, p1);  // drain before the tile buffer is recycled
-            }
         } else {
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
@@ -949,7 +930,7 @@ extern "C" int ullsam_vit_attention(int dtype, const void* qkv, void* out, const
         a.nwin = a.nwin_w * ((grid_h + window - 1) / window);
         a.Sq = a.Sk = window * window;
         // SAM's own shape (14x14 windows, head_dim 80, bf16): the whole-window kernel; variant 2 forces the tiled kernel for A/B
-        a.q_pos0 = g_attn_variant >= 3 ? g_attn_variant - 3 : 2;  // stagger of the second resident workgroup, units of s_sleep(127) = 3.4 us (A/B: variant 3 + n)
+        a.q_pos0 = (g_attn_variant >= 3 && g_attn_variant <= 8) ? g_attn_variant - 3 : 2;  // stagger of the second resident workgroup, units of s_sleep(127) = 3.4 us (A/B: variant 3 + n)
         if (dtype == 1 && window == 14 && hd == 80 && g_attn_variant != 1 && g_attn_variant != 2) return launch_win14(a, s);
         // window = 196 queries: one 7-wave workgroup (128-key tiles) or two 4-wave workgroups (64-key tiles, 3 resident per CU)
         if (g_attn_variant == 1) return dtype == 0 ? dispatch_hd<float, MODE_VIT_WINDOW, 7>(a, hd, s) : dispatch_hd<bf16, MODE_VIT_WINDOW, 7>(a, hd, s);
@@ -977,7 +958,6 @@ extern "C" int ullsam_causal_attention(int dtype, const void* q, const void* k, 
     a.B = B; a.H = H; a.groups = H / KVH; a.Sq = Sq; a.Sk = Sk; a.key_mask = key_mask; a.q_pos0 = q_pos0;
     a.scale = 1.0f / sqrtf((float)hd);
     a.left_align = g_attn_variant == 10;
-    a.serial_blocks = g_attn_variant == 11;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // 4 waves = 128 queries per workgroup (8 waves / 256 queries measured no faster end to end: 94.9 vs 94.5 ms per step)
     // variant 1: 8-wave workgroups (256 queries) over 128-key tiles, one per CU -- twice the matrix work per staged tile
