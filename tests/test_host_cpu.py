@@ -395,3 +395,7 @@ def test_bench_host_helpers(tmp_path, monkeypatch):
     assert val is None and "stale" in why
     json.dump({"csrc_digest": B._digest(), "hbm_bytes_per_launch": 123.4}, open(tmp_path / "profiles" / "r02_pmc_bench_traffic.json", "w"))
     assert bench.traffic_record()[0] == 123
+    # the digest names the kernel sources and flags, not the directory the tree is checked out in (the GPU box runs from a scratch path)
+    d0 = B._digest()
+    monkeypatch.setattr(B, "FLAGS", B.FLAGS[:-1] + ["/somewhere/else/include"])
+    assert B._digest() == d0

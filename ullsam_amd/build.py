@@ -28,7 +28,7 @@ def _digest():
         if f.endswith((".hip", ".h")):
             h.update(f.encode())
             h.update(open(os.path.join(CSRC, f), "rb").read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS[:-1] + ["include"]).encode())   # (the include directory by name: the digest must not depend on where the tree is checked out)
     return h.hexdigest()
 
 
