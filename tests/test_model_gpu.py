@@ -358,6 +358,35 @@ def test_batched_forward_equals_per_sample():
         assert (mk2[b] != mk1[0]).float().mean().item() < 1e-5
 
 
+def test_mask_path_replays_from_a_hip_graph():
+    """The whole mask path (ViT -> projector -> LLM prefill -> prompt encoder -> mask decoder -> upsample) is plain kernel launches on the
+    current stream, so it can be captured once in a HIP graph and replayed: same logits and masks, bit for bit, also after the input
+    buffers are overwritten with another image.  (Under capture `forward` skips its host-side image-token span check, which needs a D2H copy
+    and an event wait; the un-captured warm-up call on the same ids has made it.)"""
+    m = _ullsam_tiny(torch.bfloat16)
+    x = torch.from_numpy(U.rand_image((1, 3, 1024, 1024), 11)).to(DEV).to(torch.bfloat16)
+    x2 = torch.from_numpy(U.rand_image((1, 3, 1024, 1024), 12)).to(DEV).to(torch.bfloat16)
+    ids = torch.from_numpy(O.make_input_ids(20, 34, seed=5, batch=1)).to(DEV)
+    pts = torch.tensor([[[300.0, 700.0]]], device=DEV)
+    lbl = torch.ones((1, 1), dtype=torch.int32, device=DEV)
+    xin = x.clone()
+    eager = [_app_mask_path(m, xi, ids, pts, lbl) for xi in (x, x2)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _app_mask_path(m, xin, ids, pts, lbl)     # warm-up on a side stream, as torch's capture protocol asks
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        _, low, _, _, mk = _app_mask_path(m, xin, ids, pts, lbl)
+    for xi, ref in ((x, eager[0]), (x2, eager[1]), (x, eager[0])):
+        xin.copy_(xi)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(low, ref[1]) and torch.equal(mk, ref[4])
+    assert not torch.equal(eager[0][1], eager[1][1])
+
+
 def test_sam_forward_golden():
     g = U.gold("sam_forward")
     from ullsam_amd.build_sam import _build_sam

@@ -127,10 +127,14 @@ class InternVLSAMModel(Packed):
         ids = input_ids.contiguous()
         # image-token scan first, so its tiny D2H copy is long finished when it is checked at the end (no pipeline bubble)
         rank, rng = ops.scan_image_tokens(ids, self.img_context_token_id)  # id is hard-coded, the kwarg is ignored (:102,136)
-        rng_host = torch.empty((B, 2), dtype=torch.int32, pin_memory=True)
-        rng_host.copy_(rng, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        # (under HIP-graph capture no host copy / event wait is allowed: the span check below then belongs to the un-captured warm-up
+        # call the capturing code has to make on the same ids anyway)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            rng_host = torch.empty((B, 2), dtype=torch.int32, pin_memory=True)
+            rng_host.copy_(rng, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
         img_tok = self.vision_model.forward_tokens(pixel_values)                    # [B, 4096, 256] fp32
         vit_embeds = self._mlp1_tokens(img_tok, B)                                    # [B*1024, Dl] fp32
         x = ops.embed_tokens(lm.model.tok_embeddings.weight.detach(), ids, rank, vit_embeds)
@@ -146,13 +150,14 @@ class InternVLSAMModel(Packed):
             rows = ops.gather_rows(out.hidden_states[-1].reshape(B * S, -1), rng, B, S, n_img)   # hidden[:, start:end] (:198-200)
             dense_tok = self._mlp2_tokens(rows, B)
             hidden_states = ops.transpose(dense_tok, B, g * g, 256).reshape(B, 256, g, g)
-            ev.synchronize()
-            r = rng_host.numpy()
-            if (r[:, 1] <= r[:, 0]).any():
-                raise ValueError("Can not find vision token!")  # (:202-203)
-            if ((r[:, 1] - r[:, 0]) != n_img).any():
-                raise RuntimeError(f"image-token span {(r[:, 1] - r[:, 0]).tolist()} != {n_img}: text_aware_dense_feature needs a "
-                                   "32x32 token grid (the reference's reshape fails the same way)")
+            if not capturing:
+                ev.synchronize()
+                r = rng_host.numpy()
+                if (r[:, 1] <= r[:, 0]).any():
+                    raise ValueError("Can not find vision token!")  # (:202-203)
+                if ((r[:, 1] - r[:, 0]) != n_img).any():
+                    raise RuntimeError(f"image-token span {(r[:, 1] - r[:, 0]).tolist()} != {n_img}: text_aware_dense_feature needs a "
+                                       "32x32 token grid (the reference's reshape fails the same way)")
         ret = CausalLMOutputWithPast(loss=out.loss, logits=out._logits, logits_fn=out._logits_fn, past_key_values=out.past_key_values,
                                      hidden_states=hidden_states, attentions=None)
         ret.image_embeddings = image_embeddings
