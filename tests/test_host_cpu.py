@@ -399,3 +399,15 @@ def test_bench_host_helpers(tmp_path, monkeypatch):
     d0 = B._digest()
     monkeypatch.setattr(B, "FLAGS", B.FLAGS[:-1] + ["/somewhere/else/include"])
     assert B._digest() == d0
+
+
+def test_library_binds_the_hip_runtime_torch_ships():
+    """`_lib.load()` before `import torch` (what `__graft_entry__.build()` followed by `smoke()` does in one process) must still leave ONE
+    HIP runtime in the process -- torch's: with /opt/rocm's libamdhip64 bound first, the first kernel launch on a GPU box fails with
+    "no ROCm-capable device is detected"."""
+    import subprocess, sys
+    code = ("from ullsam_amd import _lib; _lib.load(); import sys; assert 'torch' in sys.modules; "
+            "hip = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}); print(hip); "
+            "assert len(hip) == 1 and '/torch/lib/' in hip[0], hip")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -70,6 +70,10 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise UllsamError(f"{LIB_PATH} not found -- run `python -m ullsam_amd.build` (there is no CPU fallback)")
+    # torch first: it ships its own libamdhip64 / libhsa-runtime64, and the process must hold ONE HIP runtime -- the one whose device
+    # pointers and streams this library is handed.  Loaded before torch, the library would bind /opt/rocm's runtime instead, and the
+    # second runtime in the process finds no device ("no ROCm-capable device is detected" on the first launch).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
