@@ -1717,7 +1717,10 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
                 for (int q = 0; q < 4; ++q) {
                     const float g0 = acc[i][q >> 1][2 * (q & 1)], g1 = acc[i][q >> 1][2 * (q & 1) + 1];
                     const float u0 = acc[i][2 + (q >> 1)][2 * (q & 1)], u1 = acc[i][2 + (q >> 1)][2 * (q & 1) + 1];
-                    o[q] = pack_bf16x2(silu_f(g0) * u0, silu_f(g1) * u1);
+                    // silu = g * rcp(1 + exp(-g)) with the hardware reciprocal (1 ulp) instead of the correctly rounded division (ten instructions): the
+                    // result is rounded to bf16 two lines below.  (ablate bit 0 = the division, for A/B)
+                    if (p.ablate & 1) o[q] = pack_bf16x2(silu_f(g0) * u0, silu_f(g1) * u1);
+                    else o[q] = pack_bf16x2(g0 * __builtin_amdgcn_rcpf(1.0f + __expf(-g0)) * u0, g1 * __builtin_amdgcn_rcpf(1.0f + __expf(-g1)) * u1);
                 }
                 if (row0 + 16 * i < p.M) gst(cp + (size_t)(16 * i) * p.ldc, (u32x4){o[0], o[1], o[2], o[3]});
             }
