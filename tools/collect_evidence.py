@@ -128,7 +128,7 @@ def main():
     ktcsv = find(kt, "*kernel_trace.csv")
     name = "kernel_summary_HEAD" if a.mode == "mask" else "decode_summary"
     kernel_summary(ktcsv, 6 if a.mode == "mask" else 1, os.path.join(prof, f"r{a.round}_{name}.txt"),
-                   stamp + (" -- rocprofv3 --kernel-trace -- python3 bench.py --steps 4 --warmup 2 (all 6 steps counted)" if a.mode == "mask"
+                   stamp + (" -- rocprofv3 --kernel-trace -- python3 bench.py --steps 4 --warmup 2 (6 steps traced, the 5 after the first counted)" if a.mode == "mask"
                             else " -- rocprofv3 --kernel-trace -- python3 tools/decode_bench.py"))
     if a.skip_pmc or a.mode != "mask":
         return
