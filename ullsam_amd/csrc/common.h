@@ -123,6 +123,19 @@ __device__ __forceinline__ float erf_as(float x) {
     return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+// GELU for results that are rounded to bf16 (the ring GEMM's epilogue: 160 evaluations per thread of a 256x320 tile): Phi(x) = 0.5 erfc(-x / sqrt2)
+// with erfc(z) = exp(z P5(z)) on 0 <= z <= 4 (least-squares fit of log erfc weighted for the absolute error; |erf| error <= 1.0e-6, GELU within
+// 1.9e-6 abs of the erf form over [-12, 12] in fp32 arithmetic: tools/check_erf.py).  ONE quarter-rate transcendental (v_exp_f32) per value
+// instead of erf_as's two (v_rcp_f32 + v_exp_f32), and the negative tail keeps its relative accuracy (no 1 - erf cancellation).
+__device__ __forceinline__ float gelu_erfc5(float x) {
+    const float z = fminf(fabsf(x) * 0.70710678118654752440f, 4.0f);
+    float p = fmaf(-0.00303853428f, z, 0.0299264971f);   // log2(erfc(z)) / z
+    p = fmaf(p, z, -0.149057642f);
+    p = fmaf(p, z, -0.918339764f);
+    p = fmaf(p, z, -1.62791028f);
+    const float q = __builtin_amdgcn_exp2f(fmaf(p, z, -1.0f));   // 0.5 erfc(z)
+    return x * (x > 0.f ? 1.0f - q : q);
+}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // row of a 32x32 accumulator register for lane-half h

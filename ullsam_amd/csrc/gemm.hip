@@ -1673,7 +1673,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
             T* cp5 = reinterpret_cast<T*>(p.C) + (size_t)row0 * p.ldc + col5;
             auto drain = [&](auto ACT) __attribute__((always_inline)) {
                 auto actf = [&](float v) __attribute__((always_inline)) {
-                    if constexpr (decltype(ACT)::value == 1) return gelu_erf(v);
+                    if constexpr (decltype(ACT)::value == 1) return (p.ablate & 2) ? gelu_erf(v) : gelu_erfc5(v);   // (ablate bit 1: the two-transcendental erf form, A/B)
                     else if constexpr (decltype(ACT)::value == 2) return fmaxf(v, 0.f);
                     else return v;
                 };
