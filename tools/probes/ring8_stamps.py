@@ -23,3 +23,7 @@ for name in (sys.argv[1:] or ["w13", "w2", "qkv", "lin2"]):
     ns = K // 32
     loop = np.median(st[:, :, 1] - st[:, :, 0]); epi = np.median(st[:, :, 2] - st[:, :, 1])
     print(f"{name}: {tiles} tiles of {BM}x{BN}; loop {loop:.0f} = {loop / ns:.0f} cycles/stage ({mf} MFMAs per SIMD and stage = {16 * mf} matrix cycles)  epilogue {epi:.0f}  launch {e0.elapsed_time(e1) * 100:.0f} us")
+    pro = np.median(st[:, 0, 0] - st[:, 0, 3])   # first instruction of the workgroup -> loop entry (setup, two stages requested, the first landed)
+    per_wg = pro + loop + epi
+    rounds = (tiles + 255) // 256
+    print(f"   prologue {pro:.0f} cycles; prologue + loop + epilogue = {per_wg:.0f} cycles per workgroup, x {rounds} rounds = {per_wg * rounds:.0f}")

@@ -1492,6 +1492,7 @@ static int launch_gemm_v6(const GemmArgs& a, hipStream_t stream) {
 template <int MI0, int MI1, int NTW, int EMODE, bool STAMP = false>   // sub-tile rows of the upper / lower wave row, sub-tile columns per wave
 __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned long long t_entry = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;   // (diagnostic build) the workgroup's first instruction
     typedef bf16 T;
     constexpr int BM = 16 * (MI0 + MI1), BN = 64 * NTW, MI = MI0 > MI1 ? MI0 : MI1;
     constexpr int PA = BM / 16, PB = BN / 16;          // DMA pieces (16 rows x 64 B) per stage
@@ -1862,6 +1863,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
         }
     }
     stamp(2);
+    if (STAMP && p.dbg && (tid & 255) == 0) p.dbg[((size_t)bid * 2 + grp) * 4 + 3] = t_entry;
 }
 
 template <int MI0, int MI1, int NTW, int EMODE = 0>
