@@ -25,8 +25,12 @@ extern "C" {
 #define ULLSAM_ACT_RELU 2
 #define ULLSAM_ACT_SWIGLU 3 /* paired 64-column gate/up blocks -> silu(gate)*up */
 
+/* Bumped whenever an entry point is added or a signature changes.  The Python binding refuses a library that reports another
+   version (a stale libullsam_hip.so would otherwise receive shifted arguments, e.g. a row count where the stream is expected). */
+#define ULLSAM_ABI_VERSION 2
+
 const char* ullsam_last_error_string(void);
-int ullsam_abi_version(void);
+int ullsam_abi_version(void); /* == ULLSAM_ABI_VERSION of the header the library was built from */
 int ullsam_device_count(void);
 /* GEMM kernel selection for A/B measurements: 0 = auto (by shape), 1 = 128x128 tile, 2 = 256x128 tile / 3-stage ring, 3 = 256x256 tile; +64 = no split-K tail; +256/+512/+1024 = timing-only ablations (outputs are garbage); +4096/+8192 = alternative main-loop schedules of the 256x256 kernel. */
 int ullsam_set_gemm_variant(int variant);

@@ -36,7 +36,9 @@ def test_c_abi_exports_every_declared_symbol(lib):
         assert hasattr(lib, s), f"{s} declared in include/ullsam_hip.h but not exported"
     bound = set(_lib.SIGNATURES) | set(_lib.PLAIN)
     assert bound == set(syms), (bound ^ set(syms))
-    assert lib.ullsam_abi_version() == 1
+    from ullsam_amd import _lib
+    hdr_v = int(re.search(r'#define ULLSAM_ABI_VERSION (\d+)', open(os.path.join(ROOT, "include", "ullsam_hip.h")).read()).group(1))
+    assert lib.ullsam_abi_version() == _lib.ABI_VERSION == hdr_v
     assert lib.ullsam_last_error_string() is not None
     # the measurement knobs are host-side state: settable without a GPU, and an unknown key is an error with a message, not a crash
     assert lib.ullsam_set_gemm_tuning(1, 31) == 0 and lib.ullsam_set_gemm_tuning(0, 4) == 0
@@ -153,9 +155,9 @@ def test_shard_range_partitions():
 def _fake_step(images: torch.Tensor):
     """Stand-in for the per-image path (images are independent units): a deterministic per-image function with the real
     output shapes' structure (fp32 logits, u8 masks, int64 token ids)."""
-    low = torch.stack([torch.sin(im * 3.0 + im.flip(-1)).reshape(1, 8, 8) for im in images])
+    low = torch.sin(images * 3.0 + images.flip(-1)).reshape(-1, 1, 8, 8)          # per-image, also for a shard of zero images
     mk = (low > 0.1).to(torch.uint8).repeat(1, 1, 2, 2)
-    tok = torch.stack([(im.reshape(-1)[:5] * 1000).long() for im in images])
+    tok = (images.reshape(images.shape[0], 64)[:, :5] * 1000).long()
     return low, mk, tok
 
 
@@ -177,8 +179,9 @@ def _gloo_worker(rank, world, port, q):
         eq = parallel.all_gather_rows(torch.full((2, 2), float(rank)), counts=[2, 2])  # equal shards: single collective
         ok = ok and eq[:, 0].tolist() == [0.0, 0.0, 1.0, 1.0]
         # DP equivalence (distributed level): sharded run + gather == the unsharded run, bit for bit,
-        # for an even and a ragged split, through the blocking and the overlapped (async) exchange
-        for n_img in (4, 7):
+        # for an even and a ragged split and for fewer images than ranks (n_img = 1: rank 1 holds ZERO rows and must still take
+        # part in the collective instead of raising before it), through the blocking and the overlapped (async) exchange
+        for n_img in (4, 7, 1):
             imgs = torch.from_numpy(np.random.default_rng(n_img).random((n_img, 8, 8), dtype=np.float32))
             full = _fake_step(imgs)
             a, b = parallel.shard_range(n_img, rank, world)

@@ -10,6 +10,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ULLSAM_HIP_LIB") or os.path.join(_HERE, "lib", "libullsam_hip.so")  # env: A/B a side build (developer switch)
 
+ABI_VERSION = 2  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
+
 _lib = None
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -83,6 +85,9 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = res
+    got = lib.ullsam_abi_version()
+    if got != ABI_VERSION:
+        raise UllsamError(f"{LIB_PATH} reports ABI version {got}, this binding is version {ABI_VERSION}: stale build -- run `python -m ullsam_amd.build --force`")
     _lib = lib
     return lib
 

@@ -174,6 +174,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
         // [B, KVH, cap, 128] at cache_pos0 + s; cos / sin rows by position id (clamped to the table), fp32 arithmetic as rope_split_kernel.
         const int c0 = (tid % TPR) * 8;
         const int gn = n0 + c0;
+        if (gn >= p.N) return;   // N = KVH*(G+2)*128 is a multiple of 128 only: the upper half of a 256-wide tile may lie past it
         const int slot = gn >> 7, d = gn & 127;
         const int gs = p.rope_G + 2, kv = slot / gs, g = slot - kv * gs;
         const int pc = d < 64 ? c0 + 64 : c0 - 64;   // partner columns in the tile
@@ -2846,12 +2847,14 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     const bool v3_split = g_split_tail && workspace && t256 > 256 && tail256 > 0 && tail256 <= 64 && K >= 64 * bk;  // see launch_gemm_v3_impl
     const bool v3 = variant == 3 || (variant == 0 && M >= 1024 && N >= 256 && K >= 8 * bk && (fill >= 0.74 || v3_split) && (act != 3 || N % 256 == 0));  // short K / narrow N: the 256^2 tile's fixed cost or its empty half dominates
     if (act == 3 && (variant == 3) && N % 256 != 0) { ullsam_set_error("ullsam_gemm: v3 swiglu needs N%%256==0"); return -1; }
+    // the ring kernels keep a lane's bias columns in registers, fetched as float4 at 4-column offsets: whole, aligned groups only
+    const bool bias_v4 = !bias || (N % 4 == 0 && ((uintptr_t)bias & 15) == 0);
     if (variant == 9) {
-        if (dtype != ULLSAM_DT_BF16 || K % 64 != 0 || K < 128 || act == 4 || (act == 3 && N % 256 != 0)) { ullsam_set_error("ullsam_gemm: the 272x256 kernel needs bf16, K %% 64 == 0, no RoPE epilogue"); return -1; }
+        if (dtype != ULLSAM_DT_BF16 || K % 64 != 0 || K < 128 || act == 4 || (act == 3 && N % 256 != 0) || !bias_v4) { ullsam_set_error("ullsam_gemm: the 272x256 kernel needs bf16, K %% 64 == 0, no RoPE epilogue"); return -1; }
         return launch_gemm_v9(a, s);
     }
     if (variant == 8) {
-        if (dtype != ULLSAM_DT_BF16 || K % 64 != 0 || K < 128 || act == 3 || act == 4) { ullsam_set_error("ullsam_gemm: the 256x320 kernel needs bf16, K %% 64 == 0, no SwiGLU / RoPE epilogue"); return -1; }
+        if (dtype != ULLSAM_DT_BF16 || K % 64 != 0 || K < 128 || act == 3 || act == 4 || !bias_v4) { ullsam_set_error("ullsam_gemm: the 256x320 kernel needs bf16, K %% 64 == 0, no SwiGLU / RoPE epilogue"); return -1; }
         return launch_gemm_v8(a, s);
     }
     if (variant == 7) {
@@ -2869,7 +2872,7 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     // 256x320 tiles in auto mode: widths that are multiples of 320 (ViT-H: 1280, 3840) when that takes fewer tile-rounds of the 256 CUs than
     // 256x256 tiles do (a 320-wide tile is 1.25 tiles' work; a split-K tail counts as half a round) -- same-process A/B: vit.proj 58 vs 80 us,
     // vit.proj+r 87 vs 108, vit.lin2+r 204 vs 235, vit.qkv 161 vs 173 (the shapes whose 256x256 tile count is 1.25 / 3.75 rounds)
-    if (variant == 0 && (g_auto_mask & 4) && dtype == ULLSAM_DT_BF16 && act <= 2 && N % 320 == 0 && M >= 1024 && K % 64 == 0 && K >= 256) {
+    if (variant == 0 && (g_auto_mask & 4) && dtype == ULLSAM_DT_BF16 && act <= 2 && N % 320 == 0 && M >= 1024 && K % 64 == 0 && K >= 256 && bias_v4) {
         const long t320 = (long)((M + 255) / 256) * (N / 320);
         const double cost320 = 1.25 * (double)((t320 + 255) / 256);
         const double cost256 = v3_split ? (double)(t256 / 256) + 0.5 : (double)((t256 + 255) / 256);
@@ -2883,7 +2886,7 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     // llm.wo / llm.w2 become ONE round of 256 tiles instead of 256 + a split-K tail of 16) -- same-process A/B: llm.wo+r 144 vs 158 us,
     // llm.w2+r 418 vs 451, llm.wo 126 vs 154; llm.w13 (1792 tiles = 7 whole rounds instead of 7.44) equals the four-wave kernel on cold operands
     // (869 vs 866 us) and beats it in the step (tools/step_ab.py 6 13,15: 81.97 vs 82.74 ms), so this rule comes first
-    if (variant == 0 && (g_auto_mask & 8) && dtype == ULLSAM_DT_BF16 && act <= 3 && (act != 3 || N % 256 == 0) && M >= 1024 && N >= 256 && K % 64 == 0 && K >= 256) {
+    if (variant == 0 && (g_auto_mask & 8) && dtype == ULLSAM_DT_BF16 && act <= 3 && (act != 3 || N % 256 == 0) && M >= 1024 && N >= 256 && K % 64 == 0 && K >= 256 && bias_v4) {
         const long t272 = (long)((M + 271) / 272) * ((N + 255) / 256);
         const double cost272 = 1.0625 * (double)((t272 + 255) / 256);
         const double cost256 = v3_split ? (double)(t256 / 256) + 0.5 : (double)((t256 + 255) / 256);

@@ -1,5 +1,6 @@
 // C-ABI runtime helpers: error string, version, device probe.  See include/ullsam_hip.h.
 #include "common.h"
+#include "ullsam_hip.h"
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -13,7 +14,7 @@ void ullsam_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ullsam_last_error_string(void) { return g_err; }
-extern "C" int ullsam_abi_version(void) { return 1; }
+extern "C" int ullsam_abi_version(void) { return ULLSAM_ABI_VERSION; }
 
 // Returns the number of visible HIP devices (0 when none); never throws.
 extern "C" int ullsam_device_count(void) {

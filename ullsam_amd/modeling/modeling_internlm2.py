@@ -330,8 +330,11 @@ class InternLM2ForCausalLM(Packed):
         # `eos_check_every` steps earlier (pinned buffer + event, no stream sync): the host keeps enqueueing steps while the GPU works,
         # and at most that many surplus steps run after the last eos; their tokens are `pad` and are trimmed below, so the returned
         # ids are exactly those of a loop that tests every step.
-        every = max(1, int(kwargs.get("eos_check_every", 8)))
-        pending = []  # (step index, pinned flag, event)
+        # With do_sample the test is made every step (blocking): a surplus step would draw from the global torch RNG and leave its state
+        # different from a loop that stops at once, so later sampled calls would not reproduce against the reference loop.
+        every = 0 if do_sample else max(1, int(kwargs.get("eos_check_every", 8)))
+        flags = torch.empty((max_new_tokens,), dtype=torch.bool, pin_memory=True) if eos_set != {-1} else None  # one pinned buffer per call
+        pending = []  # (step index, event)
         stop_at = None
         mask_full = torch.ones((B, S + max_new_tokens), dtype=torch.long, device=dev)
         mask_full[:, :S] = mask
@@ -347,15 +350,14 @@ class InternLM2ForCausalLM(Packed):
             for e in eos_set:
                 done = done | (tok == e)
             if eos_set != {-1}:
-                flag = torch.empty((1,), dtype=torch.bool, pin_memory=True)
-                flag.copy_(done.all().reshape(1), non_blocking=True)
+                flags[step:step + 1].copy_(done.all().reshape(1), non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
-                pending.append((step, flag, ev))
-                while pending and (pending[0][2].query() or len(pending) > every):
-                    st, fl, ev0 = pending.pop(0)
+                pending.append((step, ev))
+                while pending and (pending[0][1].query() or len(pending) > every):
+                    st, ev0 = pending.pop(0)
                     ev0.synchronize()
-                    if bool(fl[0]):
+                    if bool(flags[st]):
                         stop_at = st
                         break
             if stop_at is not None or step == max_new_tokens - 1:
@@ -366,9 +368,9 @@ class InternLM2ForCausalLM(Packed):
             pos_next = pos_next + 1
             h_last = out.last_hidden_state[:, -1]
         if stop_at is None:
-            for st, fl, ev0 in pending:  # the loop ran out: the earliest step at which everything was done, if any
+            for st, ev0 in pending:  # the loop ran out: the earliest step at which everything was done, if any
                 ev0.synchronize()
-                if bool(fl[0]):
+                if bool(flags[st]):
                     stop_at = st
                     break
         if stop_at is not None:

@@ -13,6 +13,7 @@ exchange of step k with the compute of step k+1.
 """
 from __future__ import annotations
 
+import math
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -46,12 +47,14 @@ def exchange_counts(n_local: int, device, group=None) -> List[int]:
 class _Pending:
     """Handle of an in-flight packed all-gather: wait() -> the gathered tensors, rows in rank order."""
 
-    def __init__(self, work, out, specs, counts, mx):
-        self.work, self.out, self.specs, self.counts, self.mx = work, out, specs, counts, mx
+    def __init__(self, work, out, specs, counts, mx, rec=None):
+        # `rec` (the local send buffer) is held until wait(): the collective reads it asynchronously
+        self.work, self.out, self.specs, self.counts, self.mx, self.rec = work, out, specs, counts, mx, rec
 
     def wait(self):
         if self.work is not None:
             self.work.wait()  # the current stream waits for the collective (nccl) / the call blocks (gloo)
+        self.rec = None
         ws = len(self.counts)
         rec = self.out.reshape(ws, self.mx, -1)
         if any(n != self.mx for n in self.counts):
@@ -86,20 +89,25 @@ def packed_all_gather(tensors: Sequence[Optional[torch.Tensor]], counts: Optiona
             specs.append((None, None, 0))
             continue
         assert t.shape[0] == n
-        b = t.contiguous().reshape(n, -1).view(torch.uint8)
-        specs.append((tuple(t.shape[1:]), t.dtype, b.shape[1]))
+        # bytes per row from the shape, not from reshape(n, -1): a rank may hold zero rows (n_items < world size)
+        row_bytes = math.prod(t.shape[1:]) * t.element_size()
+        b = t.contiguous().view(torch.uint8).reshape(n, row_bytes)
+        specs.append((tuple(t.shape[1:]), t.dtype, row_bytes))
         parts.append(b)
-    rec = parts[0] if len(parts) == 1 else torch.cat(parts, 1)
-    if n != mx:
-        pad = torch.zeros((mx, rec.shape[1]), dtype=torch.uint8, device=dev)
-        pad[:n] = rec
-        rec = pad
+    width = sum(s[2] for s in specs)
+    # one send buffer of the padded shard size, filled in place (no zero-fill + copy of the whole record for ragged shards:
+    # the pad rows are trimmed on arrival and never read)
+    rec = torch.empty((mx, width), dtype=torch.uint8, device=dev)
+    off = 0
+    for b in parts:
+        rec[:n, off:off + b.shape[1]] = b
+        off += b.shape[1]
     if not (dist.is_available() and dist.is_initialized()):
         p = _Pending(None, rec, specs, counts, mx)
         return p if async_op else p.wait()
-    out = torch.empty((ws * mx, rec.shape[1]), dtype=torch.uint8, device=dev)
-    work = dist.all_gather_into_tensor(out, rec.contiguous(), group=group, async_op=async_op)
-    p = _Pending(work if async_op else None, out, specs, counts, mx)
+    out = torch.empty((ws * mx, width), dtype=torch.uint8, device=dev)
+    work = dist.all_gather_into_tensor(out, rec, group=group, async_op=async_op)
+    p = _Pending(work if async_op else None, out, specs, counts, mx, rec)
     return p if async_op else p.wait()
 
 
