@@ -38,6 +38,7 @@ VIT = {"h": dict(dim=1280, depth=32, heads=16, glob=[7, 15, 23, 31]), "l": dict(
 LLM = {"7b": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8),
        "2b": dict(hidden_size=2048, intermediate_size=8192, num_hidden_layers=24, num_attention_heads=16, num_key_value_heads=8),
        "none": None}
+DATA_NOTE = "synthetic (uniform random 1024x1024 tiles, random-init weights, synthetic token ids)"
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
@@ -158,10 +159,10 @@ def make_inputs(B, S, device, full: bool):
     return x, pts, lbl, ids
 
 
-def make_step(model, inputs, dtype, world, gather: bool = True):
+def mask_path_compute(model, inputs, dtype):
     """One pass of the hot path over the batch (app.py:580-645's call sequence; prompt encoder / mask decoder / upsample run once
-    over the B images -- one image per prompt)."""
-    from ullsam_amd import ops, parallel
+    over the B images -- one image per prompt) -> (low-res logits, thresholded masks)."""
+    from ullsam_amd import ops
     x32, pts, lbl, ids = inputs
     B = x32.shape[0]
     x = x32.to(dtype)  # pixel values as the model dtype sees them (app.py:522 moves pixels to the GPU in the model dtype)
@@ -169,9 +170,8 @@ def make_step(model, inputs, dtype, world, gather: bool = True):
     if full:
         am = torch.ones_like(ids)
         flags = (ids == 92546)[..., None].long()
-    pending = [None]
 
-    def step():
+    def compute():
         if full:
             out = model(pixel_values=x, input_ids=ids, attention_mask=am, image_flags=flags, return_dict=True, use_cache=False,
                         output_hidden_states=True)
@@ -186,11 +186,36 @@ def make_step(model, inputs, dtype, world, gather: bool = True):
             outs = model(recs, multimask_output=False)
             low = torch.cat([o["low_res_logits"] for o in outs])
             mk = torch.cat([o["masks"] for o in outs]).to(torch.uint8)
+        return low, mk
+
+    return compute
+
+
+def stub_compute(batch: int, rank: int):
+    """`--stub` (control-path self-test, no GPU): a deterministic per-image CPU function with the real outputs' structure (fp32 low-res
+    logits, u8 masks).  It exists so that the launcher / world assertion / barrier / max-over-ranks / gather / rank-0 JSON path of this
+    file runs under gloo in the CPU tests; it measures nothing."""
+    imgs = torch.from_numpy(np.random.default_rng(100 + rank).random((batch, 16, 16), dtype=np.float32))
+
+    def compute():
+        low = torch.sin(imgs * 3.0 + imgs.flip(-1)).reshape(batch, 1, 16, 16)
+        return low, (low > 0.0).to(torch.uint8).repeat(1, 1, 4, 4)
+
+    return compute
+
+
+def make_step(compute, batch: int, world: int, gather: bool = True):
+    """step() = compute() + (N > 1) the RCCL all-gather of its results, overlapped with the next step's compute."""
+    from ullsam_amd import parallel
+    pending = [None]
+
+    def step():
+        low, mk = compute()
         if world > 1 and gather:
             # the exchange of step k overlaps the compute of step k+1: at most one gather in flight
             if pending[0] is not None:
                 pending[0].wait()
-            pending[0] = parallel.gather_mask_results_async(low, mk, None, counts=[B] * world)
+            pending[0] = parallel.gather_mask_results_async(low, mk, None, counts=[batch] * world)
         return low, mk
 
     def drain():
@@ -210,14 +235,14 @@ def mask_iou_vs_fp32(model, vit, llm, inputs, device):
     bench configuration itself.  Outside the timed region."""
     from ullsam_amd import ops
     with torch.no_grad():
-        low_b, mk_b = make_step(model, inputs, torch.bfloat16, 1, gather=False)()
+        low_b, mk_b = mask_path_compute(model, inputs, torch.bfloat16)()
         m32 = build_model(vit, llm, torch.float32, device, init=False)
         sd = {k: v.float() for k, v in model.state_dict().items()}
         missing, unexpected = m32.load_state_dict(sd, strict=False)
         assert not missing and not unexpected, (missing[:3], unexpected[:3])
         del sd
         x32, pts, lbl, ids = inputs
-        low_f, mk_f = make_step(m32, (x32.to(torch.bfloat16).float(), pts, lbl, ids), torch.float32, 1, gather=False)()
+        low_f, mk_f = mask_path_compute(m32, (x32.to(torch.bfloat16).float(), pts, lbl, ids), torch.float32)()
         iou = ops.mask_iou(mk_b.contiguous(), mk_f.contiguous()).cpu().numpy()
         d = (low_b.float() - low_f.float()).abs().max().item()
         dm = (low_b.float() - low_f.float()).abs().mean().item()
@@ -371,6 +396,78 @@ def traffic_record():
     return round(rec["hbm_bytes_per_launch"]), f"rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per GEMM launch, profiles/{os.path.basename(tpath)} (same kernel sources)"
 
 
+def dist_setup(gpus: int, stub: bool):
+    """Rank / world from the launcher's environment, the world-size assertion, the process group (RCCL; gloo in --stub) and every rank's
+    device name.  -> (rank, world, device, ranks_seen)"""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} but WORLD_SIZE={world}; launch one rank per GPU (or leave WORLD_SIZE unset)")
+    if stub:
+        device, me = "cpu", f"rank {rank}: cpu (stub)"
+    else:
+        torch.cuda.set_device(local)
+        device = f"cuda:{local}"
+        me = f"rank {rank}: cuda:{local} {torch.cuda.get_device_name(local)}"
+    ranks_seen = [me]
+    if world > 1:
+        import torch.distributed as dist
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        assert dist.get_world_size() == gpus
+        names = [None] * world
+        dist.all_gather_object(names, me)
+        ranks_seen = names
+    return rank, world, device, ranks_seen
+
+
+def timed_steps(step, warmup: int, steps: int, world: int, device: str, on_timed=None):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; the last step's exchange is inside the
+    timed region; -> (seconds = MAX over ranks, the last gathered result)."""
+    gpu = device != "cpu"
+
+    def barrier():
+        if gpu:
+            torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        if gpu:
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(warmup):
+            step()
+        step.drain()
+        barrier()
+        if on_timed:
+            on_timed(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        gathered = step.drain()
+        barrier()
+        dt = time.perf_counter() - t0
+        if on_timed:
+            on_timed(False)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, gathered
+
+
+def dist_teardown(world: int):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -384,25 +481,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-iou", action="store_true", help="skip the fp32 run that gives mask_iou_vs_fp32")
     ap.add_argument("--mode", default="mask", choices=["mask", "decode"], help="mask: the headline images/s path; decode: greedy tokens/s of the caption path")
+    ap.add_argument("--stub", action="store_true", help="control-path self-test without a GPU (gloo, a stub step): measures nothing")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(_spawn_ranks(a.gpus, sys.argv[1:]))
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch one rank per GPU (or leave WORLD_SIZE unset)")
-    torch.cuda.set_device(local)
-    device = f"cuda:{local}"
-    ranks_seen = [torch.cuda.get_device_name(local)]
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(device))
-        assert dist.get_world_size() == a.gpus
-        names = [None] * world
-        dist.all_gather_object(names, f"rank {rank}: cuda:{local} {torch.cuda.get_device_name(local)}")
-        ranks_seen = names
+    rank, world, device, ranks_seen = dist_setup(a.gpus, a.stub)
+    if a.stub:
+        step = make_step(stub_compute(a.batch, rank), a.batch, world)
+        dt, gathered = timed_steps(step, a.warmup, a.steps, world, device)
+        if world > 1:
+            assert gathered is not None and gathered[0].shape[0] == a.batch * world and gathered[1].shape[0] == a.batch * world
+        if rank == 0:
+            print(json.dumps({"metric": "STUB (bench.py control path self-test; not a measurement)", "value": round(a.batch * world * a.steps / dt, 2),
+                              "unit": "stub steps", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+                              "stub": True, "data": "stub", "config": {"workload": "stub", "global_batch": a.batch * world, "ranks": ranks_seen},
+                              "gathered_rows": None if gathered is None else int(gathered[0].shape[0])}), flush=True)
+        dist_teardown(world)
+        return
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     if a.mode == "decode":
         if world != 1:
@@ -418,34 +514,10 @@ def main():
     timer = GemmTimer()
     full = LLM[a.llm] is not None
     inputs = make_inputs(a.batch, a.seq, device, full)
-    step = make_step(model, inputs, dtype, world)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    with torch.no_grad():
-        for _ in range(a.warmup):
-            step()
-        step.drain()
-        barrier()
-        timer.on = True
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step()
-        gathered = step.drain()  # the last step's exchange is inside the timed region
-        barrier()
-        dt = time.perf_counter() - t0
-        timer.on = False
+    step = make_step(mask_path_compute(model, inputs, dtype), a.batch, world)
+    dt, gathered = timed_steps(step, a.warmup, a.steps, world, device, on_timed=lambda on: setattr(timer, "on", on))
     if world > 1:
-        import torch.distributed as dist
         assert gathered is not None and gathered[0].shape[0] == a.batch * world and gathered[1].shape[0] == a.batch * world
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     n_launch, gemm_ms, gemm_flops = timer.summary()
     traffic, traffic_note = (None, "not the default workload")
     if a.vit == "h" and a.llm == "7b" and a.batch == 4 and a.dtype == "bf16":
@@ -457,7 +529,7 @@ def main():
     line = {
         "metric": "images/s end-to-end (ViT+LLM+mask) 1024^2", "value": round(value, 4), "unit": "images/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (uniform random 1024x1024 tiles, random-init weights, synthetic token ids)",
+        "vs_baseline": None, "dtype": a.dtype, "data": DATA_NOTE,
         "config": {"workload": (f"uLLSAM mask path (app.py:580-645): SAM ViT-{a.vit.upper()} + "
                                 + (f"InternLM2-{a.llm}-shaped prefill S={a.seq} + " if full else "")
                                 + f"prompt encoder + mask decoder + x4 upsample/threshold, 1 point prompt/image, batch {a.batch}/GPU"),
@@ -476,10 +548,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.vit, a.llm, a.seq)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    dist_teardown(world)
 
 
 if __name__ == "__main__":

@@ -401,10 +401,126 @@ def case_llm_tiny_bias_linear():
          logits_last_argmax=o.logits[:, -1].numpy().argmax(-1))
 
 
+
+VIT_H_FULL = dict(img_size=1024, patch_size=16, embed_dim=1280, depth=32, num_heads=16, mlp_ratio=4, out_chans=256,
+                  qkv_bias=True, use_rel_pos=True, window_size=14, global_attn_indexes=[7, 15, 23, 31])   # build_sam.py:14-21
+LLM_7B_FULL = dict(LLM_7B_L1, num_hidden_layers=32)
+FULL_STAGES_VIT = (7, 15, 23, 31)     # block indices whose OUTPUT is sampled (after 8 / 16 / 24 / 32 blocks)
+FULL_STAGES_LLM = (7, 15, 23, 31)     # decoder layers whose OUTPUT is sampled
+FULL_STRIDE = 997
+
+
+def fill_module_inplace(mod: torch.nn.Module, seed: int, prefix: str = "", workers: int = 8):
+    """fill_module without a second copy of the weights (the 7B-shaped model is 31 GB in fp32): parameters and persistent buffers are
+    overwritten one by one, generated on a thread pool (numpy's generators release the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    sd = mod.state_dict()
+
+    def one(kv):
+        k, v = kv
+        v.copy_(torch.from_numpy(O.fill_param(prefix + k, tuple(v.shape), seed)).to(v.dtype))
+
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(one, sd.items()))
+
+
+def _build_full_depth():
+    """The bench configuration as the reference builds it (build_sam.py:14-21 + train_joint_v2.py:1424-1461), parameters left
+    uninitialised (31 GB of kaiming draws would take minutes and are overwritten anyway)."""
+    from modeling import ImageEncoderViT
+    from modeling.configuration_internvl_chat import InternVLChatConfig
+    from modeling.modeling_internvl_sam import InternVLSAMModel
+    saved = (torch.nn.Linear.reset_parameters, torch.nn.Embedding.reset_parameters, torch.nn.init.normal_, torch.nn.init.trunc_normal_)
+    torch.nn.Linear.reset_parameters = lambda self: None
+    torch.nn.Embedding.reset_parameters = lambda self: None
+    torch.nn.init.normal_ = lambda t, *a, **k: t
+    torch.nn.init.trunc_normal_ = lambda t, *a, **k: t
+    try:
+        sam = _sam_small()
+        vit = ImageEncoderViT(norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), **VIT_H_FULL)
+        cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-H-16"]}, llm_config=dict(LLM_7B_FULL),
+                                 downsample_ratio=0.5, template="internlm2-chat", ps_version="v2", force_image_size=1024)
+        cfg.llm_config.rope_scaling = None
+        m = InternVLSAMModel(cfg, vision_model=vit, prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder).eval()
+    finally:
+        torch.nn.Linear.reset_parameters, torch.nn.Embedding.reset_parameters, torch.nn.init.normal_, torch.nn.init.trunc_normal_ = saved
+    return m
+
+
+def case_full_depth():
+    """The bench configuration at FULL depth through the reference (app.py:580-645 call sequence): ViT-H x 32 blocks + a 7B-shaped
+    InternLM2 x 32 layers at S = 1081 + prompt encoder + mask decoder + x4 upsample, on a synthetic microscopy tile
+    (ullsam_amd/utils/synthetic.py), in fp32 and under torch.autocast("cpu", bfloat16).  Stores strided samples after ViT block
+    8 / 16 / 24 / 32 and LLM layer 8 / 16 / 24 / 32, the image embedding, the dense feature, the low-res logits, the mask, and
+    the reference's own autocast-vs-fp32 error at every one of those stages (the bound our bf16 mode is held to)."""
+    from ullsam_amd.utils.synthetic import microscopy_batch
+    tile_seed = int(os.environ.get("FULL_DEPTH_TILE_SEED", "3"))
+    t = time.time()
+    m = _build_full_depth()
+    fill_module_inplace(m, seed=0)
+    print(f"  built + filled in {time.time() - t:.0f}s")
+    x_np, pts = microscopy_batch([tile_seed])
+    lbl = np.array([[1]], np.int32)
+    ids = O.make_input_ids(n_text_pre=20, n_text_post=34, seed=1)
+    assert ids.shape[1] == 1081
+    tids = torch.from_numpy(ids)
+    x = torch.from_numpy(x_np)
+
+    def run():
+        st = {}
+        hooks = []
+        for i in FULL_STAGES_VIT:
+            hooks.append(m.vision_model.blocks[i].register_forward_hook(
+                lambda mod, inp, out, i=i: st.__setitem__(f"vit{i + 1}", out.detach().float().numpy().reshape(-1)[::FULL_STRIDE].copy())))
+        for i in FULL_STAGES_LLM:
+            hooks.append(m.language_model.model.layers[i].register_forward_hook(
+                lambda mod, inp, out, i=i: st.__setitem__(f"llm{i + 1}", out[0].detach().float().numpy().reshape(-1)[::FULL_STRIDE].copy())))
+        out = m(pixel_values=x, input_ids=tids, attention_mask=torch.ones_like(tids), image_flags=(tids == 92546)[..., None].long(),
+                return_dict=True, use_cache=False, output_hidden_states=True)
+        for h in hooks:
+            h.remove()
+        sp, de = m.prompt_encoder(points=(torch.from_numpy(pts), torch.from_numpy(lbl)), boxes=None, masks=None,
+                                  llm_hidden_states=out.hidden_states)
+        low, iou = m.mask_decoder(image_embeddings=out.image_embeddings, image_pe=m.prompt_encoder.get_dense_pe(),
+                                  sparse_prompt_embeddings=sp, dense_prompt_embeddings=de, multimask_output=False)
+        up = torch.nn.functional.interpolate(low.float(), (1024, 1024), mode="bilinear", align_corners=False)
+        st["img_emb"] = out.image_embeddings.float().numpy().reshape(-1)[::37].copy()
+        st["dense_feat"] = out.hidden_states.float().numpy().reshape(-1)[::37].copy()
+        st["low"] = low.float().numpy()
+        st["iou_pred"] = iou.float().numpy()
+        st["mask"] = (up[0, 0].sigmoid() > 0.5).numpy()     # app.py:640-645
+        return st
+
+    t = time.time()
+    f = run()
+    print(f"  reference fp32 full-depth forward {time.time() - t:.0f}s")
+    t = time.time()
+    with torch.autocast("cpu", dtype=torch.bfloat16, cache_enabled=False):
+        b = run()
+    print(f"  reference autocast-bf16 full-depth forward {time.time() - t:.0f}s")
+    out = {}
+    print("  stage            mean|x|    autocast mean|d|  max|d|   rel")
+    for k in [f"vit{i + 1}" for i in FULL_STAGES_VIT] + ["img_emb"] + [f"llm{i + 1}" for i in FULL_STAGES_LLM] + ["dense_feat", "low"]:
+        d = np.abs(b[k].astype(np.float64) - f[k])
+        out[k] = f[k]
+        out[k + "_ac_mean_err"] = np.float64(d.mean())
+        out[k + "_ac_max_err"] = np.float64(d.max())
+        out[k + "_mean_abs"] = np.float64(np.abs(f[k]).mean())
+        print(f"  {k:14s} {np.abs(f[k]).mean():10.4f} {d.mean():14.5f} {d.max():10.4f} {d.mean() / np.abs(f[k]).mean():8.4f}")
+    ac_iou = O.calc_iou(b["mask"], f["mask"])
+    lo = f["low"].reshape(-1)
+    print(f"  mask fill {f['mask'].mean():.4f}; autocast mask IoU vs fp32 {ac_iou:.6f}; low-res logits mean|x| {np.abs(lo).mean():.3f}, "
+          f"share within the autocast mean error of 0: {(np.abs(lo) < out['low_ac_mean_err']).mean():.5f}; "
+          f"percentiles {np.percentile(lo, [1, 10, 25, 50, 75, 90, 99]).round(2)}")
+    save("full_depth", weight_seed=0, tile_seed=tile_seed, ids_seed=1, stride=FULL_STRIDE, pts=pts, lbl=lbl,
+         mask_bits=np.packbits(f["mask"]), mask_fill=np.float64(f["mask"].mean()), iou_pred=f["iou_pred"],
+         ac_mask_iou=np.float64(ac_iou), ac_iou_pred=b["iou_pred"], **out)
+
 CASES = {"chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
          "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full,
          "vit_h_d2": case_vit_h_d2, "llm_7b_l1": case_llm_7b_l1,
-         "rope_variants": case_rope_variants, "llm_tiny_bias_linear": case_llm_tiny_bias_linear}
+         "rope_variants": case_rope_variants, "llm_tiny_bias_linear": case_llm_tiny_bias_linear,
+         "full_depth": case_full_depth}
 
 if __name__ == "__main__":
     for n in (sys.argv[1:] or list(CASES)):

@@ -414,3 +414,26 @@ def test_library_binds_the_hip_runtime_torch_ships():
             "assert len(hip) == 1 and '/torch/lib/' in hip[0], hip")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_bench_gpus2_control_path_runs_end_to_end_in_stub_mode():
+    """`python bench.py --gpus 2 --stub`: the parent (WORLD_SIZE unset) spawns `torch.distributed.run` with two ranks through the same
+    `_spawn_ranks` route the real bench takes and never touches a GPU; the ranks assert the world size, run warm-up + timed steps between
+    barriers with the one-in-flight packed gather, take the max over ranks, and rank 0 prints ONE JSON line.  (What cannot be run without
+    GPUs -- RCCL itself -- is the only difference from the real N > 1 launch.)"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--steps", "3", "--warmup", "1", "--batch", "3"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["stub"] is True
+    assert len(rec["config"]["ranks"]) == 2 and rec["config"]["ranks"][1].startswith("rank 1")
+    assert rec["config"]["global_batch"] == 6 and rec["gathered_rows"] == 6
+    # a launcher that sets WORLD_SIZE to something else than --gpus is refused before any work
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)

@@ -472,7 +472,8 @@ def test_rope_and_causal_attention(ops, dtype, B, S, H, KVH, pad):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,S,KVH,G,K,bias", [(2, 70, 1, 2, 256, False), (1, 1081, 2, 4, 512, True), (4, 300, 8, 4, 256, False)])
+@pytest.mark.parametrize("B,S,KVH,G,K,bias", [(2, 70, 1, 2, 256, False), (1, 1081, 2, 4, 512, True), (4, 300, 8, 4, 256, False),
+                                              (4, 1081, 5, 3, 256, True)])   # 25 head slots = N 3200 = 12.5 tiles of 256: the last tile's upper half lies past N (221 tiles -> the 256x256 kernel)
 def test_wqkv_gemm_with_rope_epilogue(ops, dtype, B, S, KVH, G, K, bias):
     """wqkv projection with the head split, RoPE and the KV-cache append fused into the GEMM epilogue (modeling_internlm2.py:359-388)
     against the two-kernel path (GEMM, then rope_split) and against numpy: covers the 128x128 and 256x256 kernels and the split tail."""

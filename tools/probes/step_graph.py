@@ -9,7 +9,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = "cuda"
 model = bench.build_model("h", "7b", torch.bfloat16, dev)
 inputs = bench.make_inputs(4, 1081, dev, True)
-step = bench.make_step(model, inputs, torch.bfloat16, 1)
+step = bench.mask_path_compute(model, inputs, torch.bfloat16)
 
 
 def timed(fn, n=10):

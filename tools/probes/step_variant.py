@@ -10,7 +10,7 @@ lib = _lib.load()
 lib.ullsam_set_attn_variant(int(sys.argv[1]))
 model = bench.build_model("h", "7b", torch.bfloat16, "cuda")
 inputs = bench.make_inputs(4, 1081, "cuda", True)
-step = bench.make_step(model, inputs, torch.bfloat16, 1)
+step = bench.mask_path_compute(model, inputs, torch.bfloat16)
 with torch.no_grad():
     for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
         step()

@@ -16,7 +16,7 @@ def main():
     dev = "cuda"
     model = bench.build_model("h", "7b", torch.bfloat16, dev)
     inputs = bench.make_inputs(4, 1081, dev, True)
-    step = bench.make_step(model, inputs, torch.bfloat16, 1)
+    step = bench.mask_path_compute(model, inputs, torch.bfloat16)
     with torch.no_grad():
         for _ in range(3):
             step()

@@ -1,0 +1,43 @@
+"""Synthetic 1024x1024 "microscopy" tiles (BASELINE.json north_star: "throughput on synthetic 1024x1024 microscopy tiles").
+
+No datasets exist offline, so the bench, the full-depth parity fixture and the tests share this numpy generator: flat-intensity
+discs ("cells") on a dark background with a little sensor noise.  Why this and not uniform noise: a tile of i.i.d. pixels gives
+every token an unrelated embedding and mask logits with a Gaussian marginal centred on the threshold, so the share of pixels
+within the bf16 error of zero is ~0.8 * (error / sigma) whatever the weights are -- an IoU computed on such a mask measures the
+input, not the arithmetic.  Cells give two populations of tokens (inside / outside), hence two modes of logits with a margin
+between them, which is what a mask of a real microscopy image looks like.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+
+
+def microscopy_tile(seed: int, size: int = 1024, n_cells: int = 14, r_range: Tuple[float, float] = (70.0, 150.0),
+                    bg: float = 0.1, fg: float = 0.8, noise: float = 0.02) -> Tuple[np.ndarray, np.ndarray]:
+    """-> (image float32 [3, size, size] in [0, 1], cell centres float32 [n_cells, 2] as (x, y) pixel coordinates).
+    Deterministic in `seed` (numpy default_rng: the same tile on the GPU box and in the build container)."""
+    rng = np.random.default_rng([int(seed), 0x5EED])
+    cx = rng.uniform(0, size, n_cells)
+    cy = rng.uniform(0, size, n_cells)
+    r = rng.uniform(r_range[0], r_range[1], n_cells)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    inside = np.zeros((size, size), bool)
+    for i in range(n_cells):
+        inside |= (xx - np.float32(cx[i])) ** 2 + (yy - np.float32(cy[i])) ** 2 < np.float32(r[i]) ** 2
+    img = np.where(inside, np.float32(fg), np.float32(bg)) + np.float32(noise) * rng.standard_normal((size, size), dtype=np.float32)
+    img = np.clip(img, 0.0, 1.0).astype(np.float32)
+    centres = np.stack([cx, cy], 1).astype(np.float32)
+    return np.repeat(img[None], 3, 0), centres
+
+
+def microscopy_batch(seeds, size: int = 1024, **kw) -> Tuple[np.ndarray, np.ndarray]:
+    """-> (images [B, 3, size, size], one positive click per image [B, 1, 2]: the centre of the cell nearest the tile's middle)."""
+    imgs, pts = [], []
+    for s in seeds:
+        im, c = microscopy_tile(int(s), size, **kw)
+        k = int(np.argmin(((c - size / 2) ** 2).sum(1)))
+        imgs.append(im)
+        pts.append(np.clip(c[k], 0, size - 1))
+    return np.stack(imgs), np.stack(pts)[:, None, :].astype(np.float32)
