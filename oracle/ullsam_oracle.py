@@ -81,6 +81,23 @@ def fill_param(name: str, shape: Sequence[int], seed: int = 0) -> np.ndarray:
     return (x / math.sqrt(max(fan_in, 1))).astype(F32)
 
 
+def fill_rule(name: str, shape: Sequence[int]) -> Tuple[float, float]:
+    """(mean, std) of the normal distribution fill_param draws parameter `name` from -- the same table, stated as numbers, for
+    the agreement check with bench.py's random init (ullsam_amd/utils/synthetic.py::param_init_rule; tests/test_host_cpu.py)."""
+    shape = tuple(int(s) for s in shape)
+    if int(np.prod(shape)) > (1 << 22) and len(shape) > 1:
+        shape = (max(1, (1 << 22) // int(np.prod(shape[1:]))),) + shape[1:]   # big matrices: fewer rows (no rule depends on dim 0 of a big one)
+    if int(np.prod(shape)) < 64:
+        shape = (64,) + shape[1:]   # one-element parameters (llm_scale_factor, llm_bias): a line needs more than one point
+    v = fill_param(name, shape, 0).astype(np.float64)
+    z = np.random.default_rng([0, zlib.crc32(name.encode())]).standard_normal(v.shape, dtype=np.float32).astype(np.float64)
+    # fill_param is affine in its N(0, 1) draw: recover (mean, std) exactly by a least-squares line through (z, v)
+    zz, vv = z.reshape(-1), v.reshape(-1)
+    std = float(((zz - zz.mean()) * (vv - vv.mean())).sum() / ((zz - zz.mean()) ** 2).sum())
+    mean = float(vv.mean() - std * zz.mean())
+    return float(mean), float(std)
+
+
 def fill_state(shapes: Dict[str, Sequence[int]], seed: int = 0) -> Params:
     return {k: fill_param(k, s, seed) for k, s in shapes.items()}
 

@@ -437,3 +437,26 @@ def test_bench_gpus2_control_path_runs_end_to_end_in_stub_mode():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)
+
+
+def test_bench_init_rule_is_the_fixture_filler_rule():
+    """bench.py draws its random weights by ullsam_amd.utils.synthetic.param_init_rule; the reference-generated fixtures (incl. the
+    full-depth one) were filled by oracle.fill_param.  Same (mean, std) for every parameter of the composite model, so the bench's
+    `mask_iou_vs_fp32` is measured on the weight statistics the full-depth parity fixture pins."""
+    from ullsam_amd.utils.synthetic import microscopy_batch, param_init_rule
+    P = {}
+    P.update(O.vit_shapes(embed_dim=128, depth=2, num_heads=2, global_attn_indexes=(1,), prefix="vision_model."))
+    P.update(O.prompt_encoder_shapes(prefix="prompt_encoder."))
+    P.update(O.mask_decoder_shapes(prefix="mask_decoder."))
+    P.update(O.internlm2_shapes(256, 2, 2, 1, 512, 1000, prefix="language_model."))
+    P.update(O.projector_shapes(256))
+    for k, shp in P.items():
+        (m0, s0), (m1, s1) = O.fill_rule(k, shp), param_init_rule(k, shp)
+        assert abs(m0 - m1) < 1e-6 and abs(s0 - s1) < 1e-6 * max(1.0, s1), (k, shp, (m0, s0), (m1, s1))
+    # the synthetic tile: deterministic, two intensity populations, the click lies inside a cell
+    a, pa = microscopy_batch([3])
+    b, pb = microscopy_batch([3])
+    assert np.array_equal(a, b) and np.array_equal(pa, pb) and a.shape == (1, 3, 1024, 1024) and a.dtype == np.float32
+    assert 0.2 < float((a[0, 0] > 0.45).mean()) < 0.7
+    x, y = int(pa[0, 0, 0]), int(pa[0, 0, 1])
+    assert a[0, 0, y, x] > 0.45

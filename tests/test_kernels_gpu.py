@@ -799,3 +799,76 @@ def test_gemm256_split_k_tail_matches_unsplit(ops):
     rows = np.r_[0:32, 4200:4324]
     ref = a.float().cpu().numpy()[rows] @ w.float().cpu().numpy().T + res.cpu().numpy()[rows]
     assert err(y1.cpu().numpy()[rows], ref) < 2e-2
+
+
+def _implied_abs_error(got_bf16: torch.Tensor, exact64: torch.Tensor):
+    """A bf16 output cannot show a 1e-5 error directly (its ulp is 2^-8 relative), but it shows it statistically: an approximation error e
+    moves a value across a rounding boundary with probability 2 e / ulp.  Per binade of the exact result: mismatch share x ulp / 2 = the
+    implied mean absolute error of the function BEFORE rounding; also returns the largest mismatch in ulps (must be 1)."""
+    want = exact64.to(torch.float32).to(torch.bfloat16)
+    neq = got_bf16 != want
+    mag = exact64.abs()
+    worst, worst_ulps = 0.0, 0
+    for e in range(-9, 3):
+        sel = (mag >= 2.0 ** e) & (mag < 2.0 ** (e + 1))
+        n = int(sel.sum())
+        if n < 20000:
+            continue
+        ulp = 2.0 ** (e - 7)
+        worst = max(worst, float(neq[sel].float().mean()) * ulp / 2)
+        if bool(neq[sel].any()):
+            worst_ulps = max(worst_ulps, int(((got_bf16[sel].float() - want[sel].float()).abs() / ulp).max().round()))
+    return worst, worst_ulps
+
+
+@pytest.mark.parametrize("variant,M,N", [(8, 2048, 640), (9, 2176, 512)])
+def test_ring_kernel_gelu_epilogue_to_1e5_of_exact_erf(ops, variant, M, N):
+    """The production bf16 ring kernels evaluate GELU with a degree-5 erfc fit (`gelu_erfc5`) that the fp32 parity mode never executes.  Drive
+    that epilogue with pre-activations known exactly (one-hot operands: acc = x_m * c_n exactly, + an fp32 bias) and compare with the exact erf
+    form in float64: implied absolute error < 1e-5 in every binade, never more than one bf16 ulp off."""
+    from ullsam_amd import _lib
+    lib = _lib.load()
+    K = 128
+    g = torch.Generator(device=DEV); g.manual_seed(variant)
+    xm = (torch.rand(M, device=DEV, generator=g) * 12 - 6).bfloat16()              # pre-activations over [-6.5, 6.5]
+    cn = torch.tensor([0.25, 0.5, 1.0], device=DEV)[torch.randint(0, 3, (N,), device=DEV, generator=g)]
+    bias = (torch.rand(N, device=DEV, generator=g) - 0.5)
+    a = torch.zeros(M, K, device=DEV, dtype=torch.bfloat16); a[:, 0] = xm
+    w = torch.zeros(N, K, device=DEV, dtype=torch.bfloat16); w[:, 0] = cn.bfloat16()
+    try:
+        lib.ullsam_set_gemm_variant(variant)
+        got = ops.gemm(a, w, bias, act=ops.ACT_GELU)
+        torch.cuda.synchronize()
+    finally:
+        lib.ullsam_set_gemm_variant(0)
+    pre = (xm.float()[:, None] * cn[None, :] + bias[None, :]).double()              # the kernel's fp32 pre-activation, exactly
+    exact = 0.5 * pre * (1.0 + torch.erf(pre / math.sqrt(2.0)))
+    e, ulps = _implied_abs_error(got, exact)
+    print(f"ring variant {variant}: GELU epilogue implied |error| {e:.2e}, worst mismatch {ulps} ulp")
+    assert e < 1e-5 and ulps <= 1, (e, ulps)
+
+
+def test_ring_kernel_swiglu_epilogue_to_1e5_of_exact_division(ops):
+    """The 272x256 ring kernel's SwiGLU epilogue multiplies by v_rcp_f32 instead of dividing (bf16 only: the fp32 parity mode keeps the
+    division).  gate = x_m * c_n exactly, up = 1 exactly: the output must be bf16(silu(gate)) up to the implied-error bound."""
+    from ullsam_amd import _lib
+    from ullsam_amd.packing import pack_w13
+    lib = _lib.load()
+    M, I, K = 2176, 512, 128
+    g = torch.Generator(device=DEV); g.manual_seed(3)
+    xm = (torch.rand(M, device=DEV, generator=g) * 16 - 8).bfloat16()
+    cn = torch.tensor([0.25, 0.5, 1.0, 2.0], device=DEV)[torch.randint(0, 4, (I,), device=DEV, generator=g)]
+    a = torch.zeros(M, K, device=DEV, dtype=torch.bfloat16); a[:, 0] = xm; a[:, 1] = 1.0
+    w1 = torch.zeros(I, K, device=DEV, dtype=torch.bfloat16); w1[:, 0] = cn.bfloat16()
+    w3 = torch.zeros(I, K, device=DEV, dtype=torch.bfloat16); w3[:, 1] = 1.0
+    try:
+        lib.ullsam_set_gemm_variant(9)
+        got = ops.gemm(a, pack_w13(w1, w3), act=ops.ACT_SWIGLU)
+        torch.cuda.synchronize()
+    finally:
+        lib.ullsam_set_gemm_variant(0)
+    gate = (xm.float()[:, None] * cn[None, :]).double()
+    exact = gate / (1.0 + torch.exp(-gate))
+    e, ulps = _implied_abs_error(got, exact)
+    print(f"272x256 ring: SwiGLU epilogue implied |error| {e:.2e}, worst mismatch {ulps} ulp")
+    assert e < 1e-5 and ulps <= 1, (e, ulps)

@@ -164,7 +164,7 @@ def test_llm_7b_l1_golden(dtype):
 
 def test_llm_7b_l1_golden_at_bench_rows():
     """The 7B-shaped layer at the bench's 4 x 1081 = 4324 prompt rows (the fixture's two samples twice): the row count at which the dispatch
-    takes the 272x256-tile GEMM for wo / w2 and the four-wave kernel for w13.  Every sample must meet the golden bound of the batch-2 test."""
+    takes the 272x256-tile ring GEMM for wo / w2 / w13.  Every sample must meet the golden bound of the batch-2 test."""
     g = U.gold("llm_7b_l1")
     lm = _llm(U.LLM_7B_L1, torch.bfloat16)
     emb = torch.from_numpy(U.llm_7b_l1_inputs(int(g["input_seed"]))).to(DEV).repeat(2, 1, 1)
@@ -534,3 +534,85 @@ def test_mask_iou_op_matches_calc_iou():
     got = ops.mask_iou(torch.from_numpy(a.astype(np.uint8)).to(DEV), torch.from_numpy(b.astype(np.uint8)).to(DEV)).cpu().numpy()
     for i in range(3):
         assert abs(got[i] - O.calc_iou(a[i], b[i])) < 1e-9
+
+
+# ---- the bench configuration at FULL depth (ViT-H x 32 blocks + 7B-shaped InternLM2 x 32 layers) against the reference ----------------
+FULL_STAGES = (7, 15, 23, 31)
+
+
+def _fill_model_from_rule(model, seed=0, workers=16):
+    """Every parameter / persistent buffer <- oracle.fill_param(name) (the filler the fixtures were generated with), produced on a
+    thread pool (numpy generators release the GIL) and copied straight into the device tensors: no second 31 GB copy on the host."""
+    from concurrent.futures import ThreadPoolExecutor
+    sd = model.state_dict()
+
+    def one(kv):
+        k, v = kv
+        v.copy_(torch.from_numpy(O.fill_param(k, tuple(v.shape), seed)).to(v.dtype))
+
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(one, sd.items()))
+    return model
+
+
+def _full_depth_run(m, g, dtype):
+    """app.py:580-645 on the fixture's tile with stage taps -> dict of strided samples named like the fixture's entries."""
+    from ullsam_amd.utils.synthetic import microscopy_batch
+    st, stride = {}, int(g["stride"])
+    x_np, pts = microscopy_batch([int(g["tile_seed"])])
+    assert np.array_equal(pts, g["pts"])
+    m.vision_model.stage_probe = lambda i, t: st.__setitem__(f"vit{i + 1}", t.float().reshape(-1)[::stride].cpu().numpy()) if i in FULL_STAGES else None
+    m.language_model.model.stage_probe = lambda i, t: st.__setitem__(f"llm{i + 1}", t.float().reshape(-1)[::stride].cpu().numpy()) if i in FULL_STAGES else None
+    ids = torch.from_numpy(O.make_input_ids(n_text_pre=20, n_text_post=34, seed=int(g["ids_seed"]))).to(DEV)
+    out, low, iou, up, mk = _app_mask_path(m, torch.from_numpy(x_np).to(DEV).to(dtype), ids, torch.from_numpy(pts).to(DEV),
+                                           torch.from_numpy(g["lbl"]).to(DEV))
+    torch.cuda.synchronize()
+    m.vision_model.stage_probe = m.language_model.model.stage_probe = None
+    st["img_emb"] = out.image_embeddings.float().cpu().numpy().reshape(-1)[::37]
+    st["dense_feat"] = out.hidden_states.float().cpu().numpy().reshape(-1)[::37]
+    st["low"] = low.float().cpu().numpy()
+    st["mask"] = mk[0, 0].cpu().numpy().astype(bool)
+    st["iou_pred"] = iou.float().cpu().numpy()
+    return st
+
+
+FULL_KEYS = [f"vit{i + 1}" for i in FULL_STAGES] + ["img_emb"] + [f"llm{i + 1}" for i in FULL_STAGES] + ["dense_feat", "low"]
+
+
+def test_full_depth_golden_fp32_and_bf16():
+    """BASELINE configs[2] at its real depth against the reference run at that depth (tests/golden/full_depth.npz: fp32 outputs + the
+    reference's own torch.autocast(bf16) error at every stage), on a synthetic microscopy tile.
+      fp32 mode: every stage within 1e-3 * max(1, |stage|_max-ish scale) of the reference, low-res logits within 1e-3 * scale, mask IoU delta < 1e-4;
+      bf16 mode: mean error of every stage <= 1.5 x the reference's autocast mean error, logits max error <= 1.5 x its max error, and mask IoU
+      vs the reference's fp32 mask >= the reference's autocast IoU - 0.01.
+    Prints the per-stage error table DESIGN.md section 2 quotes."""
+    import bench
+    g = U.gold("full_depth")
+    ref_mask = np.unpackbits(g["mask_bits"])[:1024 * 1024].reshape(1024, 1024).astype(bool)
+    m32 = _fill_model_from_rule(bench.build_model("h", "7b", torch.float32, DEV, init=False), int(g["weight_seed"]))
+    f = _full_depth_run(m32, g, torch.float32)
+    mb = bench.build_model("h", "7b", torch.bfloat16, DEV, init=False)
+    missing, unexpected = mb.load_state_dict({k: v.to(torch.bfloat16) for k, v in m32.state_dict().items()}, strict=False)
+    assert not missing and not unexpected
+    del m32
+    torch.cuda.empty_cache()
+    b = _full_depth_run(mb, g, torch.bfloat16)
+    print("\nstage        mean|x|   fp32: max|d|  rel(max)   bf16: mean|d|  (reference autocast)   max|d|  (reference autocast)")
+    rows = {}
+    for k in FULL_KEYS:
+        ref = g[k].astype(np.float64)
+        d32, d16 = np.abs(f[k] - ref), np.abs(b[k] - ref)
+        scale = max(1.0, float(np.abs(ref).max()))
+        rows[k] = (d32.max(), scale, d16.mean(), float(g[k + "_ac_mean_err"]), d16.max(), float(g[k + "_ac_max_err"]))
+        print(f"{k:11s} {np.abs(ref).mean():8.4f}   {d32.max():10.2e}  {d32.max() / scale:8.1e}   {d16.mean():10.5f}  ({float(g[k + '_ac_mean_err']):.5f})"
+              f"          {d16.max():8.4f}  ({float(g[k + '_ac_max_err']):.4f})")
+    iou32, iou16 = O.calc_iou(f["mask"], ref_mask), O.calc_iou(b["mask"], ref_mask)
+    print(f"mask IoU vs the reference's fp32 mask: fp32 mode {iou32:.6f}, bf16 mode {iou16:.6f} (the reference's own autocast: {float(g['ac_mask_iou']):.6f}); "
+          f"mask fill {float(g['mask_fill']):.3f}")
+    for k, (e32, scale, m16, acm, x16, acx) in rows.items():
+        assert e32 < 1e-3 * scale, (k, e32, scale)
+        assert m16 < 1.5 * acm, (k, m16, acm)
+    assert rows["low"][4] < 1.5 * rows["low"][5], rows["low"]
+    assert err(f["iou_pred"], g["iou_pred"]) < 1e-3
+    assert 1.0 - iou32 < 1e-4, iou32
+    assert iou16 >= float(g["ac_mask_iou"]) - 0.01, (iou16, float(g["ac_mask_iou"]))

@@ -109,6 +109,9 @@ class ImageEncoderViT(Packed):
         # Off by default (the headline metric is bf16); not part of the state_dict.  proj / lin2 stay bf16: their inputs are not
         # row-normalised, a per-row scale would have to be found in the producing kernel's epilogue.
         self.fp8_linears = False
+        # diagnostic tap (the reference's blocks are nn.Modules that take forward hooks; here the blocks are fused into forward_tokens):
+        # when set, called as stage_probe(block_index, x) with the fp32 residual stream [B*N, D] after every block.  Not part of the state_dict.
+        self.stage_probe = None
 
     @property
     def compute_dtype(self) -> torch.dtype:
@@ -131,7 +134,7 @@ class ImageEncoderViT(Packed):
         pos = None if self.pos_embed is None else self.f32("pos", self.pos_embed).reshape(N, D)
         xres = ops.gemm(cols, wp, None if pe.bias is None else self.f32("patch_b", pe.bias), residual=pos, res_row_mod=N, out_f32=True)
         fp8 = bool(self.fp8_linears) and dt == torch.bfloat16 and D % 128 == 0
-        for blk in self.blocks:
+        for bi, blk in enumerate(self.blocks):
             at = blk.attn
             if fp8:
                 q8, sa = ops.rows_fp8(xres, *blk.norm1.wb(), blk.norm1.eps)
@@ -150,6 +153,8 @@ class ImageEncoderViT(Packed):
                 xn = ops.norm(xres, *blk.norm2.wb(), blk.norm2.eps, dt)
                 h = ops.gemm(xn, blk.mlp.lin1.w(dt), blk.mlp.lin1.b(), act=blk.mlp.act_code)
             ops.gemm(h, blk.mlp.lin2.w(dt), blk.mlp.lin2.b(), residual=xres, out_f32=True, out=xres)
+            if self.stage_probe is not None:
+                self.stage_probe(bi, xres)
         n0, n1, n2, n3 = self.neck[0], self.neck[1], self.neck[2], self.neck[3]
         C = self.out_chans
         w0 = self.pk("neck0", n0.weight, lambda: n0.weight.detach().reshape(C, D).to(dt).contiguous())

@@ -127,6 +127,7 @@ class InternLM2Model(Packed):
         self.norm = InternLM2RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self._rope = None
         self.collect_all_hidden_states = False
+        self.stage_probe = None   # diagnostic tap: stage_probe(layer_index, x) with the fp32 residual stream [B*S, D] after every layer
 
     def get_input_embeddings(self):
         return self.tok_embeddings
@@ -207,6 +208,8 @@ class InternLM2Model(Packed):
             xn = ops.norm(x, layer.ffn_norm.w(), None, layer.ffn_norm.variance_epsilon, dt, rms=True)
             hmid = ops.gemm(xn, ff.w13(dt), act=ops.ACT_SWIGLU)
             ops.gemm(hmid, ff.w2.w(dt), None, residual=x, out_f32=True, out=x)
+            if self.stage_probe is not None:
+                self.stage_probe(li, x)
         if cache is not None:
             cache.len = Sk
         return ops.norm(x, self.norm.w(), None, self.norm.variance_epsilon, dt, rms=True)
