@@ -272,3 +272,82 @@ def test_generator_min_mask_region_area_and_coco_rle():
     for rc, rp in zip(coco, plain):
         assert isinstance(rc["segmentation"]["counts"], str)
         assert np.array_equal(A.rle_to_mask(A.coco_decode_rle(rc["segmentation"])), rp["segmentation"])
+
+
+# ---- BASELINE configs[4] at its real size: 64x64 points on a 2048^2 tile, SAM ViT-H encoder, bf16 and fp8 ViT linears --------------------
+REAL_AMG = dict(points_per_side=64, points_per_batch=64, pred_iou_thresh=0.2, stability_score_thresh=0.9, stability_score_offset=0.1,
+                box_nms_thresh=0.7, output_mode="uncompressed_rle")   # random-init decoder: thresholds at the ~85th / ~70th percentile of its scores
+
+
+def _box_iou_matrix(kb):
+    x0 = np.maximum(kb[:, None, 0], kb[None, :, 0]); y0 = np.maximum(kb[:, None, 1], kb[None, :, 1])
+    x1 = np.minimum(kb[:, None, 2], kb[None, :, 2]); y1 = np.minimum(kb[:, None, 3], kb[None, :, 3])
+    inter = np.maximum(x1 - x0, 0) * np.maximum(y1 - y0, 0)
+    area = (kb[:, 2] - kb[:, 0]) * (kb[:, 3] - kb[:, 1])
+    return inter / np.maximum(area[:, None] + area[None, :] - inter, 1e-9)
+
+
+def test_generator_real_size_vit_h_2048_tile_bf16_and_fp8():
+    """`SamAutomaticMaskGenerator` exactly as configs[4] names it -- ViT-H encoder, one 2048^2 microscopy tile, 64 x 64 = 4096 point prompts
+    in batches of 64 with multimask output (12288 candidate masks) -- in bf16 and with `fp8_linears=True`:
+      * the fused post-processing kernel and the helper chain (postprocess_masks -> calculate_stability_score -> threshold ->
+        batched_mask_to_box -> mask_to_rle_pytorch, utils/amg.py:107-176,303-346) return the SAME records at full size;
+      * masks survive the filters (`masks_kept > 0`) and every record is consistent: area = RLE foreground, bbox = box of the decoded mask,
+        scores above their thresholds, no two kept boxes above the NMS threshold;
+      * fp8 vs bf16: the kept sets overlap (>= 80 % of the bf16 records have an fp8 record from the same click with box IoU >= 0.9) and matched
+        masks agree (mask IoU >= 0.97 on a sample)."""
+    import bench
+    from ullsam_amd.automatic_mask_generator import SamAutomaticMaskGenerator
+    from ullsam_amd.utils.synthetic import microscopy_tile
+    sam = bench.build_model("h", "none", torch.bfloat16, DEV)
+    img_np, _ = microscopy_tile(7, size=2048, n_cells=40, r_range=(90.0, 260.0))
+    img = torch.from_numpy(img_np * 255.0).to(DEV)
+    fused = SamAutomaticMaskGenerator(sam, fused_postprocess=True, **REAL_AMG).generate(img)
+    chain = SamAutomaticMaskGenerator(sam, fused_postprocess=False, **REAL_AMG).generate(img)
+    print(f"configs[4] real size: {len(fused)} records kept of 12288 candidates (bf16)")
+    assert len(fused) == len(chain) and len(fused) >= 20, (len(fused), len(chain))
+    for ra, rb in zip(fused, chain):
+        assert ra["segmentation"] == rb["segmentation"] and ra["bbox"] == rb["bbox"] and ra["area"] == rb["area"]
+        assert ra["point_coords"] == rb["point_coords"] and ra["stability_score"] == rb["stability_score"] and ra["predicted_iou"] == rb["predicted_iou"]
+    boxes = []
+    for i, r in enumerate(fused):
+        assert r["predicted_iou"] > REAL_AMG["pred_iou_thresh"] and r["stability_score"] >= REAL_AMG["stability_score_thresh"]
+        assert r["segmentation"]["size"] == [2048, 2048] and sum(r["segmentation"]["counts"]) == 2048 * 2048
+        assert r["area"] == sum(r["segmentation"]["counts"][1::2]) and r["crop_box"] == [0, 0, 2048, 2048]
+        x, y, w, h = r["bbox"]
+        boxes.append([x, y, x + w, y + h])
+        if i % max(1, len(fused) // 16) == 0:       # decode a sample of the masks (4 MiB each) and re-derive the box
+            seg = AO.rle_to_mask(r["segmentation"])
+            b = AO.batched_mask_to_box(seg[None])[0]
+            assert [int(b[0]), int(b[1]), int(b[2] - b[0]), int(b[3] - b[1])] == r["bbox"] and int(seg.sum()) == r["area"]
+    kb = np.asarray(boxes, np.float32)
+    iou = _box_iou_matrix(kb)
+    np.fill_diagonal(iou, 0)
+    assert float(iou.max()) <= REAL_AMG["box_nms_thresh"] + 1e-6
+    # ---- fp8 (e4m3) qkv / lin1 in the encoder: BASELINE configs[4] "fp8 MFMA ViT path"
+    sam.image_encoder.fp8_linears = True
+    f8 = SamAutomaticMaskGenerator(sam, fused_postprocess=True, **REAL_AMG).generate(img)
+    sam.image_encoder.fp8_linears = False
+    assert len(f8) >= 20
+    by_pt = {}
+    for r in f8:
+        by_pt.setdefault(tuple(r["point_coords"][0]), []).append(r)
+    matched, pairs = 0, []
+    for r in fused:
+        x, y, w, h = r["bbox"]
+        a = np.asarray([[x, y, x + w, y + h]], np.float32)
+        best, best_r = 0.0, None
+        for c in by_pt.get(tuple(r["point_coords"][0]), []):
+            cx, cy, cw, ch = c["bbox"]
+            v = float(_box_iou_matrix(np.concatenate([a, np.asarray([[cx, cy, cx + cw, cy + ch]], np.float32)]))[0, 1])
+            if v > best:
+                best, best_r = v, c
+        if best >= 0.9:
+            matched += 1
+            pairs.append((r, best_r))
+    share = matched / len(fused)
+    ious = [O.calc_iou(AO.rle_to_mask(a["segmentation"]), AO.rle_to_mask(b["segmentation"])) for a, b in pairs[::max(1, len(pairs) // 12)]]
+    print(f"fp8 vs bf16: {len(f8)} vs {len(fused)} records, {share:.3f} of the bf16 records matched by an fp8 record of the same click; "
+          f"mask IoU of matched pairs min {min(ious):.4f} mean {float(np.mean(ious)):.4f}")
+    assert share >= 0.8, share
+    assert min(ious) >= 0.97, ious

@@ -850,7 +850,7 @@ def test_ring_kernel_gelu_epilogue_to_1e5_of_exact_erf(ops, variant, M, N):
 
 def test_ring_kernel_swiglu_epilogue_to_1e5_of_exact_division(ops):
     """The 272x256 ring kernel's SwiGLU epilogue multiplies by v_rcp_f32 instead of dividing (bf16 only: the fp32 parity mode keeps the
-    division).  gate = x_m * c_n exactly, up = 1 exactly: the output must be bf16(silu(gate)) up to the implied-error bound."""
+    division).  gate = x_m * c_n and up = y_m * d_n exactly (one-hot operands): the output must be bf16(silu(gate) * up) up to the implied-error bound."""
     from ullsam_amd import _lib
     from ullsam_amd.packing import pack_w13
     lib = _lib.load()
@@ -858,9 +858,11 @@ def test_ring_kernel_swiglu_epilogue_to_1e5_of_exact_division(ops):
     g = torch.Generator(device=DEV); g.manual_seed(3)
     xm = (torch.rand(M, device=DEV, generator=g) * 16 - 8).bfloat16()
     cn = torch.tensor([0.25, 0.5, 1.0, 2.0], device=DEV)[torch.randint(0, 4, (I,), device=DEV, generator=g)]
-    a = torch.zeros(M, K, device=DEV, dtype=torch.bfloat16); a[:, 0] = xm; a[:, 1] = 1.0
+    ym = (torch.rand(M, device=DEV, generator=g) + 1.0).bfloat16()                 # up = y_m * d_n exactly: many distinct products, so that the
+    dn = torch.tensor([0.5, 1.0, 2.0], device=DEV)[torch.randint(0, 3, (I,), device=DEV, generator=g)]   # mismatch share is a probability, not a count of a few values
+    a = torch.zeros(M, K, device=DEV, dtype=torch.bfloat16); a[:, 0] = xm; a[:, 1] = ym
     w1 = torch.zeros(I, K, device=DEV, dtype=torch.bfloat16); w1[:, 0] = cn.bfloat16()
-    w3 = torch.zeros(I, K, device=DEV, dtype=torch.bfloat16); w3[:, 1] = 1.0
+    w3 = torch.zeros(I, K, device=DEV, dtype=torch.bfloat16); w3[:, 1] = dn.bfloat16()
     try:
         lib.ullsam_set_gemm_variant(9)
         got = ops.gemm(a, pack_w13(w1, w3), act=ops.ACT_SWIGLU)
@@ -868,7 +870,7 @@ def test_ring_kernel_swiglu_epilogue_to_1e5_of_exact_division(ops):
     finally:
         lib.ullsam_set_gemm_variant(0)
     gate = (xm.float()[:, None] * cn[None, :]).double()
-    exact = gate / (1.0 + torch.exp(-gate))
+    exact = gate / (1.0 + torch.exp(-gate)) * (ym.float()[:, None] * dn[None, :]).double()
     e, ulps = _implied_abs_error(got, exact)
     print(f"272x256 ring: SwiGLU epilogue implied |error| {e:.2e}, worst mismatch {ulps} ulp")
     assert e < 1e-5 and ulps <= 1, (e, ulps)

@@ -15,7 +15,7 @@ RUNS = [
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="02")
+    ap.add_argument("--round", default="03")
     ap.add_argument("--head", default="unknown")
     a = ap.parse_args()
     out = {"git_head": a.head, "note": "one call of tools/other_configs.py, default steps/warmup; raw lines of bench.py / tools/amg_bench.py"}
