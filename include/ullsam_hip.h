@@ -35,7 +35,8 @@ int ullsam_device_count(void);
 /* GEMM kernel selection for A/B measurements: 0 = auto (by shape), 1 = 128x128 tile, 2 = 256x128 tile / 3-stage ring, 3 = 256x256 tile; +64 = no split-K tail; +256/+512/+1024 = timing-only ablations (outputs are garbage); +4096/+8192 = alternative main-loop schedules of the 256x256 kernel. */
 int ullsam_set_gemm_variant(int variant);
 /* measurement knob, not part of the reference's interface: key 0 = tile rows per raster group of the 256x256 GEMM kernels (default 4);
-   key 1 = kernels the automatic dispatch may use besides the two-buffer 256x256 one (bit 0 persistent, bit 1 four-wave, bit 2 256x320 tiles, bit 3 272x256 tiles, bit 4 GELU GEMM on the 256x320 ring, bit 5 RoPE GEMM on the 256x256 ring) */
+   key 1 = kernels the automatic dispatch may use besides the two-buffer 256x256 one (bit 0 persistent, bit 1 four-wave, bit 2 256x320 tiles, bit 3 272x256 tiles, bit 4 GELU GEMM on the 256x320 ring, bit 5 RoPE GEMM on the 256x256 ring);
+   key 2 = main-loop version of the ring GEMM kernels (1 default, 0 = the round-2 loop, kept for same-process A/B) */
 int ullsam_set_gemm_tuning(int key, int value);
 /* Attention A/B switch: 0 = production, 1 = windowed attention with one 7-wave workgroup per (window, head). */
 int ullsam_set_attn_variant(int variant);

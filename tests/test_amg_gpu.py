@@ -275,8 +275,12 @@ def test_generator_min_mask_region_area_and_coco_rle():
 
 
 # ---- BASELINE configs[4] at its real size: 64x64 points on a 2048^2 tile, SAM ViT-H encoder, bf16 and fp8 ViT linears --------------------
-REAL_AMG = dict(points_per_side=64, points_per_batch=64, pred_iou_thresh=0.2, stability_score_thresh=0.9, stability_score_offset=0.1,
-                box_nms_thresh=0.7, output_mode="uncompressed_rle")   # random-init decoder: thresholds at the ~85th / ~70th percentile of its scores
+# A random-init decoder draws full-frame textures, not objects: every box is (nearly) the whole tile, so box NMS at SAM's 0.7 would keep ONE
+# record.  The score thresholds sit at the ~90th / ~87th percentile of this decoder's predicted-IoU / stability distributions (measured with
+# tools/probes/amg_full_probe.py) so that on the order of a hundred masks survive, and box NMS runs with threshold 1.0 (keeps all; the NMS
+# kernel itself is pinned at scale by test_box_nms_matches_oracle).
+REAL_AMG = dict(points_per_side=64, points_per_batch=64, pred_iou_thresh=0.4, stability_score_thresh=0.95, stability_score_offset=0.1,
+                box_nms_thresh=1.0, output_mode="uncompressed_rle")
 
 
 def _box_iou_matrix(kb):
@@ -293,7 +297,7 @@ def test_generator_real_size_vit_h_2048_tile_bf16_and_fp8():
       * the fused post-processing kernel and the helper chain (postprocess_masks -> calculate_stability_score -> threshold ->
         batched_mask_to_box -> mask_to_rle_pytorch, utils/amg.py:107-176,303-346) return the SAME records at full size;
       * masks survive the filters (`masks_kept > 0`) and every record is consistent: area = RLE foreground, bbox = box of the decoded mask,
-        scores above their thresholds, no two kept boxes above the NMS threshold;
+        scores above their thresholds;
       * fp8 vs bf16: the kept sets overlap (>= 80 % of the bf16 records have an fp8 record from the same click with box IoU >= 0.9) and matched
         masks agree (mask IoU >= 0.97 on a sample)."""
     import bench
@@ -320,10 +324,6 @@ def test_generator_real_size_vit_h_2048_tile_bf16_and_fp8():
             seg = AO.rle_to_mask(r["segmentation"])
             b = AO.batched_mask_to_box(seg[None])[0]
             assert [int(b[0]), int(b[1]), int(b[2] - b[0]), int(b[3] - b[1])] == r["bbox"] and int(seg.sum()) == r["area"]
-    kb = np.asarray(boxes, np.float32)
-    iou = _box_iou_matrix(kb)
-    np.fill_diagonal(iou, 0)
-    assert float(iou.max()) <= REAL_AMG["box_nms_thresh"] + 1e-6
     # ---- fp8 (e4m3) qkv / lin1 in the encoder: BASELINE configs[4] "fp8 MFMA ViT path"
     sam.image_encoder.fp8_linears = True
     f8 = SamAutomaticMaskGenerator(sam, fused_postprocess=True, **REAL_AMG).generate(img)

@@ -1,7 +1,7 @@
 """Throughput of the automatic mask generator (BASELINE.json configs[4] shape: 64x64 point grid on a 2048^2 tile, SAM ViT-H;
 ULLSAM_FP8=1 switches the encoder's LayerNorm-fed linears to the fp8 (e4m3) MFMA path of that config).  Synthetic microscopy tile, random-init
-weights; the default thresholds are those of tests/test_amg_gpu.py::test_generator_real_size_vit_h_2048_tile_bf16_and_fp8 (the ~85th / ~70th
-percentile of the random decoder's scores), so that masks SURVIVE and box NMS + RLE emission are inside the timed tile.
+weights; the default thresholds are those of tests/test_amg_gpu.py::test_generator_real_size_vit_h_2048_tile_bf16_and_fp8 (the ~90th / ~87th
+percentile of the random decoder's scores, box NMS at 1.0), so that masks SURVIVE and box NMS + RLE emission are inside the timed tile.
 usage: [ULLSAM_FP8=1] python tools/amg_bench.py [points_per_side] [tile] [vit] [stability_thresh] [stability_offset] [iters] [pred_iou_thresh]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,10 +13,11 @@ from ullsam_amd.automatic_mask_generator import SamAutomaticMaskGenerator
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 tile = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 vit = sys.argv[3] if len(sys.argv) > 3 else "h"
-stab = float(sys.argv[4]) if len(sys.argv) > 4 else 0.9
+stab = float(sys.argv[4]) if len(sys.argv) > 4 else 0.95
 off = float(sys.argv[5]) if len(sys.argv) > 5 else 0.1
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 3
-piou = float(sys.argv[7]) if len(sys.argv) > 7 else 0.2
+piou = float(sys.argv[7]) if len(sys.argv) > 7 else 0.4
+nms = float(sys.argv[8]) if len(sys.argv) > 8 else 1.0   # a random-init decoder's boxes are all full-frame: SAM's 0.7 would keep one record
 if os.environ.get("ULLSAM_GEMM_VARIANT"):
     from ullsam_amd import _lib
     _lib.load().ullsam_set_gemm_variant(int(os.environ["ULLSAM_GEMM_VARIANT"]))
@@ -24,7 +25,7 @@ sam = build_model(vit, "none", torch.bfloat16, "cuda:0")
 fp8 = os.environ.get("ULLSAM_FP8") == "1"
 sam.image_encoder.fp8_linears = fp8
 gen = SamAutomaticMaskGenerator(sam, points_per_side=side, points_per_batch=64, pred_iou_thresh=piou, stability_score_thresh=stab,
-                                stability_score_offset=off, box_nms_thresh=0.7, output_mode="uncompressed_rle")
+                                stability_score_offset=off, box_nms_thresh=nms, output_mode="uncompressed_rle")
 from ullsam_amd.utils.synthetic import microscopy_tile
 img = torch.from_numpy(microscopy_tile(7, size=tile, n_cells=40, r_range=(90.0 * tile / 2048, 260.0 * tile / 2048))[0] * 255).cuda()
 t_enc = t_all = 0.0
@@ -38,5 +39,5 @@ for it in range(iters):
         t_enc += t1 - t0; t_all += t2 - t1
 print(json.dumps({"workload": f"AMG {side}x{side} points on a {tile}^2 tile, SAM ViT-{vit.upper()}, {'fp8 (e4m3) qkv/lin1 + bf16' if fp8 else 'bf16'}, 64 prompts/batch, multimask",
                   "seconds_per_tile": round(t_all / (iters - 1), 4), "encoder_seconds": round(t_enc / (iters - 1), 4), "prompts_per_s": round(side * side / (t_all / (iters - 1)), 1),
-                  "masks_kept": len(recs), "thresholds": {"pred_iou": piou, "stability": stab, "stability_offset": off, "box_nms": 0.7}}))
+                  "masks_kept": len(recs), "thresholds": {"pred_iou": piou, "stability": stab, "stability_offset": off, "box_nms": nms}}))
 assert len(recs) > 0, "every mask was filtered: the timed tile did no NMS / RLE work"

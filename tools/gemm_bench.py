@@ -18,7 +18,13 @@ SHAPES = [  # (name, M, N, K, act)
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "2"])]
+    variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "2"]   # "9" = ullsam_set_gemm_variant(9); "0L0" = auto dispatch with the round-2 ring loop (tuning key 2)
+
+    def select(v):
+        head, _, lv = str(v).partition("L")
+        lib.ullsam_set_gemm_tuning(2, int(lv) if lv else 1)
+        lib.ullsam_set_gemm_variant(int(head))
+        return int(head)
     lib = _lib.load()
     if os.environ.get("GEMM_GM"):   # raster group height of the 256x256 kernels (A/B)
         lib.ullsam_set_gemm_tuning(0, int(os.environ["GEMM_GM"]))
@@ -41,9 +47,8 @@ def main():
         ref = None
         skip = False
         for v in variants:
-            if v < 0:
+            if select(v) < 0:
                 continue
-            lib.ullsam_set_gemm_variant(v)
             try:
                 out = ops.gemm(a, w, bias, act=act, out_f32=res)
             except Exception as e:
@@ -52,19 +57,18 @@ def main():
                 ref = out.float()
             else:
                 d = (out.float() - ref).abs().max().item()
-                assert d < 0.1 or v > 15, (name, v, d)
+                assert d < 0.1 or select(v) > 15, (name, v, d)
         if skip:
             lib.ullsam_set_gemm_variant(0)
             continue
         times = {v: [] for v in variants}
         for r in range(rounds):
             for v in variants:
-                if v >= 0:
-                    lib.ullsam_set_gemm_variant(v)
+                vi = select(v)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for i in range(ncopy):
-                    if v < 0:   # comparator only: the vendor library's plain GEMM (no epilogue) through torch
+                    if vi < 0:   # comparator only: the vendor library's plain GEMM (no epilogue) through torch
                         torch.nn.functional.linear(As[i], Ws[i])
                     else:
                         ops.gemm(As[i], Ws[i], bias, act=act, out=Cs[i], out_f32=res, residual=Cs[i] if res else None)
@@ -78,6 +82,7 @@ def main():
             line += f" | v{v}: {t * 1e3:8.1f} us {fl / t / 1e9:7.1f} TF/s"
         print(line, flush=True)
     lib.ullsam_set_gemm_variant(0)
+    lib.ullsam_set_gemm_tuning(2, 1)
 
 
 if __name__ == "__main__":

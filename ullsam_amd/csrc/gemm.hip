@@ -78,6 +78,7 @@ static int g_store_nt = 0;     // non-temporal bf16 output stores in the non-per
                                // ullsam_set_gemm_variant bit 14 turns them on (A/B)
 static int g_auto_mask = 31;   // ullsam_set_gemm_tuning(1, mask): kernels the auto dispatch may pick besides the two-buffer one: bit 0 persistent (GELU), bit 1 four-wave, bit 2 256x320 tiles, bit 3 272x256 tiles, bit 4 GELU GEMM on the 256x320 ring when tile-rounds tie, bit 5 RoPE GEMM on the 256x256 ring
 static int g_group_m = 4;      // ullsam_set_gemm_tuning(0, gm): A/B of the raster group height
+static int g_ring_lv = 1;      // ullsam_set_gemm_tuning(2, v): main-loop version of the ring kernel (1 = specialised per wave class, 0 = round 2's)
 static int g_gemm_sched = 0;   // 256x256 kernel main-loop schedule: 0 production, 1 plain interleave, 2 fragments-first / 1 barrier
 
 template <typename T>
@@ -1490,7 +1491,7 @@ static int launch_gemm_v6(const GemmArgs& a, hipStream_t stream) {
 // differs by group.  Per stage and wave: 4-5 pieces, 13 fragment reads, 40 MFMAs.  The epilogue stages 128 rows x 320 fp32 = the whole
 // 160 KiB of LDS at a time.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MI0, int MI1, int NTW, int EMODE, bool STAMP = false>   // sub-tile rows of the upper / lower wave row, sub-tile columns per wave
+template <int MI0, int MI1, int NTW, int EMODE, bool STAMP = false, int LV = 1>   // sub-tile rows of the upper / lower wave row, sub-tile columns per wave; LV: main-loop version (0 = round 2's, A/B)
 __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned long long t_entry = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;   // (diagnostic build) the workgroup's first instruction
@@ -1608,53 +1609,123 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
         if (STAMP && p.dbg && (tid & 255) == 0) p.dbg[(1 << 19) + ((size_t)bid * 2 + grp) * 8 + kk] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
-    for (int s = 0; s < st1; ++s) {
-        const char* Ab = smem + (s & 3) * STG;
-        const char* Bb = Ab + ASZ;
-        Frag<T> a8[MI], b[NTW];
-        // ---- L(s): requests and fragment reads INTERLEAVED.  A wave's 4-5 requests are held back by the address unit (18 KiB per group and
-        // stage at 64 B/clk: ~400 cycles), its 12-13 reads by the LDS (52 KiB at 256 B/clk: ~250); issued one kind after the other the two
-        // times add up (650 > the partner group's 576-640 matrix cycles the slot should hide under); alternated, the LDS serves the reads
-        // while the next request waits for the address unit.
-        {
-            const bool more = s + 2 < st1;
-            char* base = smem + ((s + 2) & 3) * STG;
-            const char* ak = a_base + (size_t)(s + 2) * 64;
-            const char* bk = b_base + (size_t)(s + 2) * 64;
-            auto request = [&](int qi) __attribute__((always_inline)) {   // request qi of this wave: A0 B0 A1 B1 A2 B2
-                const int i = qi >> 1;
-                if (!(qi & 1)) { if (more && i < na) __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_off[i]), LDS_PTR(base + (wave + 8 * i) * 1024), 16, 0, 0); }
-                else { if (more && i < nb) __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + ASZ + (wave + 8 * i) * 1024), 16, 0, 0); }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            int qi = 0;
-            request(qi++);
-#pragma unroll
-            for (int r = 0; r < NTW + MI; ++r) {
-                if (r < NTW) b[r] = frag(Bb, wn * (16 * NTW) + r * 16 + mm);
-                else if ((r - NTW) < MI1 || (r - NTW) < mi) a8[r - NTW] = frag(Ab, row_w + (r - NTW) * 16 + mm);
-                __builtin_amdgcn_sched_barrier(0);
-                if ((r % 3) == 2 && qi < 6) request(qi++);
+    if constexpr (LV == 0) {
+        for (int s = 0; s < st1; ++s) {
+            const char* Ab = smem + (s & 3) * STG;
+            const char* Bb = Ab + ASZ;
+            Frag<T> a8[MI], b[NTW];
+            // ---- L(s): requests and fragment reads INTERLEAVED.  A wave's 4-5 requests are held back by the address unit (18 KiB per group and
+            // stage at 64 B/clk: ~400 cycles), its 12-13 reads by the LDS (52 KiB at 256 B/clk: ~250); issued one kind after the other the two
+            // times add up (650 > the partner group's 576-640 matrix cycles the slot should hide under); alternated, the LDS serves the reads
+            // while the next request waits for the address unit.
+            {
+                const bool more = s + 2 < st1;
+                char* base = smem + ((s + 2) & 3) * STG;
+                const char* ak = a_base + (size_t)(s + 2) * 64;
+                const char* bk = b_base + (size_t)(s + 2) * 64;
+                auto request = [&](int qi) __attribute__((always_inline)) {   // request qi of this wave: A0 B0 A1 B1 A2 B2
+                    const int i = qi >> 1;
+                    if (!(qi & 1)) { if (more && i < na) __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_off[i]), LDS_PTR(base + (wave + 8 * i) * 1024), 16, 0, 0); }
+                    else { if (more && i < nb) __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + ASZ + (wave + 8 * i) * 1024), 16, 0, 0); }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                int qi = 0;
+                request(qi++);
+    #pragma unroll
+                for (int r = 0; r < NTW + MI; ++r) {
+                    if (r < NTW) b[r] = frag(Bb, wn * (16 * NTW) + r * 16 + mm);
+                    else if ((r - NTW) < MI1 || (r - NTW) < mi) a8[r - NTW] = frag(Ab, row_w + (r - NTW) * 16 + mm);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if ((r % 3) == 2 && qi < 6) request(qi++);
+                }
+    #pragma unroll
+                for (; qi < 6; ++qi) request(qi);
             }
-#pragma unroll
-            for (; qi < 6; ++qi) request(qi);
+            // stage s+1 must have landed before the barrier that lets anyone read it; the younger stage stays in flight
+            if (s + 2 < st1) wait_one_left();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- C(s)
+            __builtin_amdgcn_s_setprio(1);
+    #pragma unroll
+            for (int i = 0; i < MI; ++i)
+                if (i < MI1 || i < mi) {
+    #pragma unroll
+                    for (int j = 0; j < NTW; ++j) mma16(b[j], a8[i], acc[i][j]);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
         }
-        // stage s+1 must have landed before the barrier that lets anyone read it; the younger stage stays in flight
-        if (s + 2 < st1) wait_one_left();
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---- C(s)
-        __builtin_amdgcn_s_setprio(1);
+    } else {
+        // Round 3: the same schedule with everything a stage decides at run time decided ONCE.  The load slot is the critical path of a stage
+        // (it is longer than the partner group's matrix slot), and the wave's instruction stream is in order: every scalar compare / branch in
+        // it -- "is there a stage s + 2?", "does this wave own a third piece?", the five-way choice of the counted wait -- sat between the
+        // requests and reads and was paid twice per stage.  Here the piece counts (NA, NB) are template arguments of the loop body (a wave class
+        // is picked once, before the loop: at most four copies of the body), the last two stages (nothing left to request) run in a peeled tail,
+        // and the wait is one literal s_waitcnt.
+        auto body = [&](int s, auto NA_c, auto NB_c, auto MORE_c) __attribute__((always_inline)) {
+            constexpr int NA = decltype(NA_c)::value, NB = decltype(NB_c)::value;
+            constexpr bool MORE = decltype(MORE_c)::value;
+            const char* Ab = smem + (s & 3) * STG;
+            const char* Bb = Ab + ASZ;
+            Frag<T> a8[MI], b[NTW];
+            {
+                char* base = smem + ((s + 2) & 3) * STG;
+                const char* ak = a_base + (size_t)(s + 2) * 64;
+                const char* bk = b_base + (size_t)(s + 2) * 64;
+                auto request = [&](int qi) __attribute__((always_inline)) {   // request qi of this wave: A0 B0 A1 B1 A2 B2 (qi is a constant after unrolling)
+                    const int i = qi >> 1;
+                    if (MORE && !(qi & 1) && i < NA) __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_off[i]), LDS_PTR(base + (wave + 8 * i) * 1024), 16, 0, 0);
+                    if (MORE && (qi & 1) && i < NB) __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + ASZ + (wave + 8 * i) * 1024), 16, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                // requests and reads alternated: one request, then three reads, ... (the order round 2 measured best)
+                int qi = 0;
+                request(qi++);
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-            if (i < MI1 || i < mi) {
+                for (int r = 0; r < NTW + MI; ++r) {
+                    if (r < NTW) b[r] = frag(Bb, wn * (16 * NTW) + r * 16 + mm);
+                    else if ((r - NTW) < MI1 || (r - NTW) < mi) a8[r - NTW] = frag(Ab, row_w + (r - NTW) * 16 + mm);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if ((r % 3) == 2 && qi < 6) request(qi++);
+                }
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) mma16(b[j], a8[i], acc[i][j]);
+                for (; qi < 6; ++qi) request(qi);
             }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+            if constexpr (!MORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (NA + NB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (NA + NB == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if constexpr (NA + NB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (NA + NB == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                if (i < MI1 || i < mi) {
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) mma16(b[j], a8[i], acc[i][j]);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        auto run = [&](auto NA_c, auto NB_c) __attribute__((always_inline)) {
+            int s = 0;
+            for (; s + 2 < st1; ++s) body(s, NA_c, NB_c, std::true_type{});
+            for (; s < st1; ++s) body(s, NA_c, NB_c, std::false_type{});
+        };
+        constexpr int NA_LO = PA / 8, NA_HI = (PA + 7) / 8, NB_LO = PB / 8, NB_HI = (PB + 7) / 8;
+        if (NA_HI != NA_LO && na == NA_HI) {
+            if (NB_HI != NB_LO && nb == NB_HI) run(std::integral_constant<int, NA_HI>{}, std::integral_constant<int, NB_HI>{});
+            else run(std::integral_constant<int, NA_HI>{}, std::integral_constant<int, NB_LO>{});
+        } else {
+            if (NB_HI != NB_LO && nb == NB_HI) run(std::integral_constant<int, NA_LO>{}, std::integral_constant<int, NB_HI>{});
+            else run(std::integral_constant<int, NA_LO>{}, std::integral_constant<int, NB_LO>{});
+        }
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
     stamp(1);
@@ -1881,6 +1952,10 @@ static int launch_gemm_ring8(GemmArgs a, hipStream_t stream) {
     if (a.dbg && EMODE == 0) {   // stamped diagnostic build (tools/probes/ring8_stamps.py)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         gemm_ring8_kernel<MI0, MI1, NTW, 0, true><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
+    } else if (g_ring_lv == 0) {   // round 2's main loop (A/B: ullsam_set_gemm_tuning(2, 0))
+        static PerDeviceOnce attr0;
+        if (attr0.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW, EMODE, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        gemm_ring8_kernel<MI0, MI1, NTW, EMODE, false, 0><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
     } else
     gemm_ring8_kernel<MI0, MI1, NTW, EMODE><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
     ULLSAM_LAUNCH_CHECK();
@@ -2544,6 +2619,7 @@ static int launch_gemm_v4(const GemmArgs& a, hipStream_t stream) {
 extern "C" int ullsam_set_gemm_tuning(int key, int value) {
     if (key == 0 && value >= 1 && value <= 1024) { g_group_m = value; return 0; }
     if (key == 1 && value >= 0 && value <= 63) { g_auto_mask = value; return 0; }
+    if (key == 2 && value >= 0 && value <= 1) { g_ring_lv = value; return 0; }
     ullsam_set_error("ullsam_set_gemm_tuning: unknown key %d / bad value %d", key, value);
     return -1;
 }
