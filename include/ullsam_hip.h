@@ -27,16 +27,16 @@ extern "C" {
 
 /* Bumped whenever an entry point is added or a signature changes.  The Python binding refuses a library that reports another
    version (a stale libullsam_hip.so would otherwise receive shifted arguments, e.g. a row count where the stream is expected). */
-#define ULLSAM_ABI_VERSION 2
+#define ULLSAM_ABI_VERSION 3
 
 const char* ullsam_last_error_string(void);
 int ullsam_abi_version(void); /* == ULLSAM_ABI_VERSION of the header the library was built from */
 int ullsam_device_count(void);
-/* GEMM kernel selection for A/B measurements: 0 = auto (by shape), 1 = 128x128 tile, 2 = 256x128 tile / 3-stage ring, 3 = 256x256 tile; +64 = no split-K tail; +256/+512/+1024 = timing-only ablations (outputs are garbage); +4096/+8192 = alternative main-loop schedules of the 256x256 kernel. */
+/* GEMM kernel selection for A/B measurements and the kernel tests: 0 = auto (by shape), 1 = 128x128 tile, 3 = 256x256 two-buffer kernel,
+   6 / 8 / 9 = ring kernel with 256x256 / 256x320 / 272x256 tiles; +64 = no split-K tail; +32768 = stamped diagnostic launch of the ring kernel. */
 int ullsam_set_gemm_variant(int variant);
-/* measurement knob, not part of the reference's interface: key 0 = tile rows per raster group of the 256x256 GEMM kernels (default 4);
-   key 1 = kernels the automatic dispatch may use besides the two-buffer 256x256 one (bit 0 persistent, bit 1 four-wave, bit 2 256x320 tiles, bit 3 272x256 tiles, bit 4 GELU GEMM on the 256x320 ring, bit 5 RoPE GEMM on the 256x256 ring);
-   key 2 = main-loop version of the ring GEMM kernels (1 default, 0 = the round-2 loop, kept for same-process A/B) */
+/* measurement knob, not part of the reference's interface: key 0 = tile rows per raster group of the 256-row-tile GEMM kernels (default 4);
+   key 1 = ring tile shapes the automatic dispatch may use (bit 0 256x256, bit 1 256x320, bit 2 272x256; default 7) */
 int ullsam_set_gemm_tuning(int key, int value);
 /* Attention A/B switch: 0 = production, 1 = windowed attention with one 7-wave workgroup per (window, head). */
 int ullsam_set_attn_variant(int variant);

@@ -41,7 +41,7 @@ def test_c_abi_exports_every_declared_symbol(lib):
     assert lib.ullsam_abi_version() == _lib.ABI_VERSION == hdr_v
     assert lib.ullsam_last_error_string() is not None
     # the measurement knobs are host-side state: settable without a GPU, and an unknown key is an error with a message, not a crash
-    assert lib.ullsam_set_gemm_tuning(1, 31) == 0 and lib.ullsam_set_gemm_tuning(0, 4) == 0
+    assert lib.ullsam_set_gemm_tuning(1, 7) == 0 and lib.ullsam_set_gemm_tuning(0, 4) == 0
     assert lib.ullsam_set_gemm_tuning(99, 0) != 0 and b"unknown key" in lib.ullsam_last_error_string()
 
 

@@ -7,7 +7,7 @@ from ullsam_amd import ops, _lib
 
 SHAPES = [  # (name, M, N, K, act)
     ("llm.wqkv", 4324, 6144, 4096, 0), ("llm.wo", 4324, 4096, 4096, 0), ("llm.w13", 4324, 28672, 4096, 3),
-    ("llm.w2", 4324, 4096, 14336, 0), ("vit.qkv", 16384, 3840, 1280, 0), ("vit.proj", 16384, 1280, 1280, 0),
+    ("llm.w2", 4324, 4096, 14336, 0), ("vitb.qkv", 16384, 2304, 768, 0), ("2b.wo", 4324, 2048, 2048, 0), ("mlp1.fc2", 4096, 4096, 4096, 0), ("vit.qkv", 16384, 3840, 1280, 0), ("vit.proj", 16384, 1280, 1280, 0),
     ("vit.lin1", 16384, 5120, 1280, 1), ("vit.lin2", 16384, 1280, 5120, 0), ("2b.w13", 4324, 16384, 2048, 3),
     ("vitb.lin1", 4096, 3072, 768, 1),
     # act code + 16: fp32 output with an fp32 residual updated in place (the residual-stream GEMMs of both transformers)
@@ -18,12 +18,13 @@ SHAPES = [  # (name, M, N, K, act)
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "2"]   # "9" = ullsam_set_gemm_variant(9); "0L0" = auto dispatch with the round-2 ring loop (tuning key 2)
+    variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "3"]   # "9" = ullsam_set_gemm_variant(9); "0m3" = auto dispatch with ring-shape mask 3 (tuning key 1)
 
     def select(v):
-        head, _, lv = str(v).partition("L")
-        lib.ullsam_set_gemm_tuning(2, int(lv) if lv else 1)
-        lib.ullsam_set_gemm_variant(int(head))
+        head, _, mk = str(v).partition("m")
+        lib.ullsam_set_gemm_tuning(1, int(mk) if mk else 7)
+        if int(head) >= 0:
+            lib.ullsam_set_gemm_variant(int(head))
         return int(head)
     lib = _lib.load()
     if os.environ.get("GEMM_GM"):   # raster group height of the 256x256 kernels (A/B)
@@ -82,7 +83,7 @@ def main():
             line += f" | v{v}: {t * 1e3:8.1f} us {fl / t / 1e9:7.1f} TF/s"
         print(line, flush=True)
     lib.ullsam_set_gemm_variant(0)
-    lib.ullsam_set_gemm_tuning(2, 1)
+    lib.ullsam_set_gemm_tuning(1, 7)
 
 
 if __name__ == "__main__":

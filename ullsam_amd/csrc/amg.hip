@@ -281,16 +281,6 @@ extern "C" int ullsam_rle_emit(const unsigned long long* words, const int* selec
 // so the 4 B/pixel logits and 1 B/pixel masks of the separate helpers (12288 masks x 16 MiB per 2048^2 tile) are replaced by
 // 1 bit/pixel of change words.  The row taps are wave-uniform, so the x-interpolated low-res rows and intermediate rows are
 // memoised in registers (two slots each) while a wave walks down its 64 rows.
-struct Tap { int i0, i1; float l; };
-__device__ inline Tap tap_of(int o, float scale, int n_in) {
-    float f = ((float)o + 0.5f) * scale - 0.5f;
-    if (f < 0.f) f = 0.f;
-    Tap t;
-    t.i0 = min((int)f, n_in - 1);
-    t.i1 = min(t.i0 + 1, n_in - 1);
-    t.l = f - (float)t.i0;
-    return t;
-}
 __device__ inline Tap utap_of(int o, float scale, int n_in) {  // wave-uniform argument -> scalar indices
     Tap t = tap_of(o, scale, n_in);
     t.i0 = __builtin_amdgcn_readfirstlane(t.i0);
@@ -310,13 +300,13 @@ __device__ inline float post_eval(const float* __restrict__ lowp, const PostGeom
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const Tap c = tap_of(b ? tx.i1 : tx.i0, g.s1x, g.LW);
-            const float top = lowp[(long)r.i0 * g.LW + c.i0] * (1.f - c.l) + lowp[(long)r.i0 * g.LW + c.i1] * c.l;
-            const float bot = lowp[(long)r.i1 * g.LW + c.i0] * (1.f - c.l) + lowp[(long)r.i1 * g.LW + c.i1] * c.l;
-            iv[b] = top * (1.f - r.l) + bot * r.l;
+            const float top = lerp_rn(lowp[(long)r.i0 * g.LW + c.i0], lowp[(long)r.i0 * g.LW + c.i1], c.l);
+            const float bot = lerp_rn(lowp[(long)r.i1 * g.LW + c.i0], lowp[(long)r.i1 * g.LW + c.i1], c.l);
+            iv[b] = lerp_rn(top, bot, r.l);
         }
-        h[a] = iv[0] * (1.f - tx.l) + iv[1] * tx.l;
+        h[a] = lerp_rn(iv[0], iv[1], tx.l);
     }
-    return h[0] * (1.f - ty.l) + h[1] * ty.l;
+    return lerp_rn(h[0], h[1], ty.l);
 }
 
 // acc = 2*acc + (v > thr): compare + add-with-carry, exact `>` semantics (false for NaN).  Rows are pushed top first, so after
@@ -413,8 +403,8 @@ __global__ __launch_bounds__(256) void amg_postprocess_kernel(const float* __res
             const float* row = lowp + (long)lr * g.LW;
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
-                o0[j] = row[t0[j].i0] * (1.f - t0[j].l) + row[t0[j].i1] * t0[j].l;
-                o1[j] = row[t1[j].i0] * (1.f - t1[j].l) + row[t1[j].i1] * t1[j].l;
+                o0[j] = lerp_rn(row[t0[j].i0], row[t0[j].i1], t0[j].l);
+                o1[j] = lerp_rn(row[t1[j].i0], row[t1[j].i1], t1[j].l);
             }
             if (gka <= gkb) {
                 gka = lr;
@@ -443,8 +433,8 @@ __global__ __launch_bounds__(256) void amg_postprocess_kernel(const float* __res
             get_g(rr.i1, q0, q1);
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
-                const float i0 = p0[j] * (1.f - rr.l) + q0[j] * rr.l, i1 = p1[j] * (1.f - rr.l) + q1[j] * rr.l;
-                h[j] = i0 * (1.f - tx[j].l) + i1 * tx[j].l;
+                const float i0 = lerp_rn(p0[j], q0[j], rr.l), i1 = lerp_rn(p1[j], q1[j], rr.l);
+                h[j] = lerp_rn(i0, i1, tx[j].l);
             }
             if (hka <= hkb) {
                 hka = iy;
@@ -462,7 +452,7 @@ __global__ __launch_bounds__(256) void amg_postprocess_kernel(const float* __res
             get_h(ty.i0, h0);
             get_h(ty.i1, h1);
 #pragma unroll
-            for (int j = 0; j < NC; ++j) v[j] = h0[j] * (1.f - ty.l) + h1[j] * ty.l;
+            for (int j = 0; j < NC; ++j) v[j] = lerp_rn(h0[j], h1[j], ty.l);
         };
 #pragma unroll
         for (int j = 0; j < NC; ++j) wm[j] = whi[j] = wlo[j] = 0;

@@ -141,6 +141,26 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 // row of a 32x32 accumulator register for lane-half h
 __device__ __forceinline__ int crow32(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
+// Bilinear resampling (F.interpolate(mode="bilinear", align_corners=False); sam.py:154-162, app.py:635-640) shared by the resize kernel
+// (decoder.hip) and the fused mask post-processing kernel (amg.hip).  Both must produce the SAME bits for the same tap -- the generator's
+// fused path is checked for equality with the helper chain over 12288 masks x 4 M pixels, where a single a*b+c contracted to an fma in one
+// kernel and not in the other flips a pixel that sits on the threshold -- so the arithmetic is written once, with contraction off.
+struct Tap { int i0, i1; float l; };
+__device__ __forceinline__ Tap tap_of(int o, float scale, int n_in) {
+#pragma clang fp contract(off)
+    float f = ((float)o + 0.5f) * scale - 0.5f;
+    if (f < 0.f) f = 0.f;
+    Tap t;
+    t.i0 = min((int)f, n_in - 1);
+    t.i1 = min(t.i0 + 1, n_in - 1);
+    t.l = f - (float)t.i0;
+    return t;
+}
+__device__ __forceinline__ float lerp_rn(float a, float b, float l) {   // a (1 - l) + b l: two products and a sum, each rounded once
+#pragma clang fp contract(off)
+    return a * (1.f - l) + b * l;
+}
+
 // hipFuncSetAttribute applies to the function object of the CURRENT device: one "done" flag per device (a process may drive
 // several GPUs).  A benign race (two host threads setting the same attribute) is possible and harmless.
 struct PerDeviceOnce {

@@ -296,15 +296,11 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
         const long n = i / ((long)OW * OH);
-        float fy = ((float)oy + 0.5f) * sy - 0.5f; if (fy < 0.f) fy = 0.f;
-        float fx = ((float)ox + 0.5f) * sx - 0.5f; if (fx < 0.f) fx = 0.f;
-        const int y0 = min((int)fy, IH - 1), x0 = min((int)fx, IW - 1);
-        const int y1 = min(y0 + 1, IH - 1), x1 = min(x0 + 1, IW - 1);
-        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const Tap ty = tap_of(oy, sy, IH), tx = tap_of(ox, sx, IW);
         const float* p = in + n * in_ps;
-        const float top = p[(long)y0 * in_ld + x0] * (1.f - lx) + p[(long)y0 * in_ld + x1] * lx;
-        const float bot = p[(long)y1 * in_ld + x0] * (1.f - lx) + p[(long)y1 * in_ld + x1] * lx;
-        const float v = top * (1.f - ly) + bot * ly;
+        const float top = lerp_rn(p[(long)ty.i0 * in_ld + tx.i0], p[(long)ty.i0 * in_ld + tx.i1], tx.l);
+        const float bot = lerp_rn(p[(long)ty.i1 * in_ld + tx.i0], p[(long)ty.i1 * in_ld + tx.i1], tx.l);
+        const float v = lerp_rn(top, bot, ty.l);
         if (out) out[i] = v;
         if (mask) mask[i] = v > thr ? 1 : 0;
     }

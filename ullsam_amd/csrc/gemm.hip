@@ -11,23 +11,20 @@
 // wave instruction = 8 rows).  LDS image: 128-byte rows, 16-byte chunk index XOR (row & 7): the DMA writes lane-linear, so the
 // swizzle is applied to the per-lane SOURCE address and again on the ds_read_b128 (cdna guide 5.4 rule 21) -> conflict-free reads.
 // Kernels in this file (dispatch at the bottom, ullsam_gemm):
-//   gemm256_kernel      256x256 tile, 8 waves (2x4, 128x64 per wave), two 64 KiB stages, staggered two-group schedule (L0|C0|L1|C1),
-//                       split-K tail + gemm256_tail_reduce_kernel, LDS-staged epilogue in two 128-row halves.  The production kernel
-//                       for every large launch (and the only one for fp32).
-//   gemm256w_kernel     256x256 tile, FOUR waves (one per SIMD, 128x128 per wave, asm MFMAs on AGPR accumulators), ring of four half-K
-//                       stages, LDS-DMA through buffer descriptors, direct epilogues.  Auto mode: bf16 outputs without residual / GELU.
-//   gemm_ring8_kernel   THE production kernel of the bench step (76 % of its time): the two-group schedule on a ring of four half-K stages with the
-//                       tile shape as template parameters -- 256x320 (ViT-H widths) and 272x256 (4324 prompt rows) make the tile count a whole
-//                       number of rounds of the 256 CUs; requests and fragment reads alternated in the load slot; epilogues straight from the
-//                       accumulators (swapped operands, permuted weight rows, lane-pair swap).  Auto wherever it saves tile-rounds.
-//   gemm256r_kernel     the 256x256 instance of that ring (A/B only: equal to gemm256_kernel).
-//   gemm256p_kernel     the same main loop made PERSISTENT (one workgroup per CU walks a unit list, DMA pipelined across units,
-//                       swapped MFMA operands + permuted W rows + lane-pair swap = direct full-line stores from the accumulators,
-//                       counted store waits).  bf16 only.  Auto mode uses it where it measured faster (GELU epilogue).
-//   gemm128_kernel      128x128 tile, 4 waves, 2 workgroups per CU, one barrier per K-tile: small M / narrow N / short K and
-//                       launches whose 256x256 tile count would leave the last round < 74 % full.
-//   gemm256x128_kernel  3-stage ring; never faster than the above in the pipeline, kept selectable for A/B only.
+//   gemm_ring8_kernel   THE production kernel of bf16 launches with >= 1024 rows (85 % of the bench step): 8 waves in two staggered groups on a
+//                       ring of four half-K LDS stages, tile shape as template parameters -- 256x256, 256x320 (ViT-H widths) and 272x256 (the
+//                       4324 prompt rows) so that the tile count is a whole number of rounds of the 256 CUs; requests and fragment reads
+//                       alternated in the load slot, the slot's control flow resolved at compile time per wave class; epilogues straight
+//                       from the accumulators (swapped operands, permuted weight rows, lane-pair swap).
+//   gemm256_kernel      256x256 tile, two 64 KiB stages, staggered two-group schedule (L0|C0|L1|C1), split-K tail + gemm256_tail_reduce_kernel,
+//                       LDS-staged epilogue.  fp32 (parity mode), the wqkv GEMM with its RoPE epilogue, and bf16 launches whose 256x256
+//                       tile count leaves a sliver that a split-K tail absorbs.
+//   gemm128_kernel      128x128 tile, 4 waves, 2 workgroups per CU, one barrier per K-tile: small M / narrow N / short K and launches whose
+//                       256-row tile count would leave the last round mostly empty.
+//   gemm256f8_kernel    the 256x256 two-buffer loop on v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 ViT linears, BASELINE configs[4]).
 //   gemm_skinny_*       M <= 8 (decode step): weight-streaming, no tiles.
+// Variants that were built, measured and removed (a 256x128 three-stage ring, a persistent two-buffer kernel, a four-wave 512-register
+// kernel, a stream-K tail, the RoPE epilogue on the ring): DESIGN.md section 7 keeps their numbers.
 // Epilogues: bias / GELU(erf) / ReLU / SwiGLU pair / fp32 residual (optionally row-broadcast, for pos_embed), fused.
 #include "common.h"
 #include <type_traits>
@@ -44,7 +41,6 @@ struct GemmArgs {
     int act;      // 0 none, 1 gelu(erf), 2 relu, 3 swiglu pair (tile = [64 gate | 64 up])
     int out_f32;  // C element type: 1 -> float, 0 -> T
     int vec_ok;   // stores / residual loads may be 16-byte vectors
-    int ablate;   // timing-only ablations of the v2 main loop (bit0: no in-loop staging, bit1: no barrier); results are garbage
     int tiles_m, tiles_n;
     // split-K tail (v1 only): tiles [0, full_tiles) run whole; each remaining tile is cut into ksplit K-ranges whose fp32 partial
     // tiles go to `ws` ([tail][ksplit][128*128]) and are summed + finished by gemm_tail_reduce_kernel
@@ -56,30 +52,15 @@ struct GemmArgs {
     int rope_S, rope_KVH, rope_G, rope_cap, rope_pos0, rope_rows;
     const float* row_scale;  // fp8 path: per-row scale of A (activation quantisation), per-column scale of W; null elsewhere
     const float* col_scale;
-    unsigned long long* dbg;  // diagnostic build path only (variant bit 15): s_memtime stamps of the persistent kernel's unit boundaries
-    int store_nt;    // A/B: non-temporal output stores
-    int late;        // v3 DMA lead (A/B): bit 0 = group 0 waits for its DMA at the end of C1 instead of L1, bit 1 = group 1 requests tile kt+2 at the end of its C1
-    int skew_ticks;  // v4: start-time spread of the workgroups in s_memrealtime ticks (10 ns)
-    int group_m;     // tile rows per raster group of the 256x256 kernels (tiles of a group run column-major: group_m x tiles_n); 4 by default
-    int shift_edge;  // v4: the last tile row of a ragged M starts at M-256 (rows it shares with the tile above are not stored again)
+    unsigned long long* dbg;  // diagnostic launches only (ullsam_set_gemm_variant bit 15): s_memtime stamps of the ring kernel (tools/probes/ring8_stamps.py)
+    int group_m;     // tile rows per raster group of the 256-row-tile kernels (tiles of a group run column-major: group_m x tiles_n); 4 by default
 };
 
-static int g_split_tail = 1;   // ullsam_set_gemm_variant(v | 64) disables the split-K tail (A/B)
-static int g_gemm_variant = 0; // bits 0-3 force a kernel: 0 auto, 1 128x128, 2 256x128 ring, 3 256x256 two-group, 4 persistent, 6 256x256 ring, 7 four-wave, 8 256x320 ring, 9 272x256 ring
-static int g_gemm_ablate = 0;  // timing-only ablations: bit0 no in-loop staging, bit1 no barrier (outputs are garbage)
-static int g_persistent = 1;   // ullsam_set_gemm_variant(v | 128): keep the non-persistent 256x256 kernel in auto mode (A/B)
-static int g_skew_half_us = 0;  // ullsam_set_gemm_variant bits 16-23: v4 start-time spread in units of 0.5 us (A/B)
-static int g_store_v4 = 0;     // store policy of the persistent kernel (ullsam_set_gemm_variant bits 29-31; A/B)
-static int g_dbg = 0;          // ullsam_set_gemm_variant bit 15: stamp the persistent kernel (tools/gemm_stamps.py reads them from the workspace)
-static int g_late = 0;         // ullsam_set_gemm_variant bits 24-27 (A/B of the v3 DMA issue placement: 4 / 8; they overlap the store-policy bits 26-28 -- set one or the other)
-static int g_store_nt = 0;     // non-temporal bf16 output stores in the non-persistent kernels: OFF.  On cold rotating operands they measured faster
-                               // (tools/gemm_bench.py: vit.qkv -3.4 %, vit.lin1 -3.6 %, llm.w13 -0.9 %), but in the step the next kernel reads the output at
-                               // once and plain stores leave it in L2 / Infinity Cache: 84.99 vs 85.64 ms per step (tools/step_ab.py 8 15,15v16384).
-                               // ullsam_set_gemm_variant bit 14 turns them on (A/B)
-static int g_auto_mask = 31;   // ullsam_set_gemm_tuning(1, mask): kernels the auto dispatch may pick besides the two-buffer one: bit 0 persistent (GELU), bit 1 four-wave, bit 2 256x320 tiles, bit 3 272x256 tiles, bit 4 GELU GEMM on the 256x320 ring when tile-rounds tie, bit 5 RoPE GEMM on the 256x256 ring
-static int g_group_m = 4;      // ullsam_set_gemm_tuning(0, gm): A/B of the raster group height
-static int g_ring_lv = 1;      // ullsam_set_gemm_tuning(2, v): main-loop version of the ring kernel (1 = specialised per wave class, 0 = round 2's)
-static int g_gemm_sched = 0;   // 256x256 kernel main-loop schedule: 0 production, 1 plain interleave, 2 fragments-first / 1 barrier
+static int g_split_tail = 1;   // ullsam_set_gemm_variant(v | 64) disables the split-K tails (A/B)
+static int g_gemm_variant = 0; // bits 0-3 force a kernel: 0 auto, 1 128x128, 3 256x256 two-buffer, 6 256x256 ring, 8 256x320 ring, 9 272x256 ring
+static int g_dbg = 0;          // ullsam_set_gemm_variant bit 15: stamp the ring kernel (tools/probes/ring8_stamps.py reads the stamps from the workspace)
+static int g_auto_mask = 7;    // ullsam_set_gemm_tuning(1, mask): ring tile shapes the auto dispatch may pick: bit 0 256x256, bit 1 256x320, bit 2 272x256
+static int g_group_m = 4;      // ullsam_set_gemm_tuning(0, gm): raster group height (measured: 4 -> 83.26 ms per step, 8 -> 83.73, 2 -> 84.35)
 
 template <typename T>
 __device__ __forceinline__ Frag<T> lds_frag(const char* tile, int row, int ks, int g);
@@ -124,21 +105,9 @@ __device__ __forceinline__ void store_row8<bf16>(bf16* dst, const float* v, int 
 }
 
 
-// 16-byte global store with a cache policy (A/B of the output write path; p.store_nt carries the code):
-//   0 plain (write-back: dirty lines pile up in the XCD L2s and are flushed at the END of the kernel)   1 nt   2 sc1   3 sc0 sc1   4 sc0 sc1 nt
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
-typedef __attribute__((ext_vector_type(4))) int i32x4s;
-__device__ __forceinline__ void store16_policy(void* ptr, u32x4s v, int policy) {
-    if (policy == 0) *reinterpret_cast<u32x4s*>(ptr) = v;
-    else if (policy == 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4s*>(ptr));
-    else if (policy == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
-    else if (policy == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
-}
-
 // EMODE (compile time, so the common epilogue carries none of the others' registers): 0 standard, 1 wqkv + RoPE (act 4), 2 fp8 scales
 template <typename T, typename OutT, int BM, int NTHREADS, int BN = 128, int EMODE = 0>
-__device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs, int m0, int n0, int tn, int tid, int m_lo = 0) {
+__device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs, int m0, int n0, int tn, int tid) {
     constexpr int TPR = BN / 8;             // threads per row (each owns 8 accumulator columns)
     constexpr int RPP = NTHREADS / TPR;     // rows per pass
     constexpr int PASSES = (BM + RPP - 1) / RPP;   // BM = rows staged in Cs (row stride BN floats)
@@ -155,7 +124,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
             const int t = tid % TPR;
             const int grp = t >> 4, j0 = (t & 15) * 4;  // every 128 accumulator columns = [64 gate | 64 up]
             const int gm = m0 + row;
-            if (gm >= p.M || gm < m_lo) continue;
+            if (gm >= p.M) continue;
             const float4 g = *reinterpret_cast<const float4*>(Cs + row * BN + grp * 128 + j0);
             const float4 u = *reinterpret_cast<const float4*>(Cs + row * BN + grp * 128 + 64 + j0);
             float4 o = make_float4(silu_f(g.x) * u.x, silu_f(g.y) * u.y, silu_f(g.z) * u.z, silu_f(g.w) * u.w);
@@ -207,7 +176,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
             const int gm = m0 + row;
             float4 cc[2] = {cn[0], cn[1]}, ss[2] = {sn[0], sn[1]};
             if (rotate && pass + 1 < PASSES) load_cs(pass + 1, cn, sn);
-            if (gm >= p.M || gm < m_lo) continue;
+            if (gm >= p.M) continue;
             float x[8], y[8], o[8];
             const float4 xa = *reinterpret_cast<const float4*>(Cs + row * BN + c0), xb = *reinterpret_cast<const float4*>(Cs + row * BN + c0 + 4);
             const float4 ya = *reinterpret_cast<const float4*>(Cs + row * BN + pc), yb = *reinterpret_cast<const float4*>(Cs + row * BN + pc + 4);
@@ -258,7 +227,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
     for (int pass = 0; pass < PASSES; ++pass) {
         const int row = pass * RPP + tid / TPR;
         const int gm = m0 + row;
-        if (gm >= p.M || gm < m_lo || (RAGGED && row >= BM)) continue;
+        if (gm >= p.M || (RAGGED && row >= BM)) continue;
         float v[8];
         const float4 a = *reinterpret_cast<const float4*>(Cs + row * BN + c0);
         const float4 b = *reinterpret_cast<const float4*>(Cs + row * BN + c0 + 4);
@@ -289,13 +258,6 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, const float* Cs
                 for (int e = 0; e < n_valid; ++e) v[e] += rp[e];
             }
         }
-        if ((p.ablate & 8) && v[0] != 12345.678f) continue;  // timing-only: everything but the global stores
-        if (p.store_nt && p.vec_ok && n_valid == 8 && sizeof(OutT) == 2) {
-            bf16x8_t o8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o8[e] = (bf16)v[e];
-            store16_policy(C + (size_t)gm * p.ldc + gn, __builtin_bit_cast(u32x4s, o8), p.store_nt);
-        } else
         store_row8<OutT>(C + (size_t)gm * p.ldc + gn, v, n_valid, p.vec_ok != 0);
     }
 }
@@ -444,127 +406,13 @@ __global__ __launch_bounds__(256) void gemm_tail_reduce_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// v2: 256x128 tile, 8 waves (4 x 2, each 64x64), 3-stage LDS-DMA ring.  One barrier per K-tile; the DMA of tiles kt+1
-// and kt+2 stays in flight across it (counted s_waitcnt vmcnt, raw s_barrier -- a __syncthreads() would drain vmcnt(0),
-// cdna guide section 5 "Pipelining across barriers").  LDS: 3 x (32 KiB A + 16 KiB B) = 144 KiB, one workgroup per CU.
-// RAW: a wave waits for its own DMA pieces of tile kt, then the barrier => every piece of tile kt has landed before any
-// ds_read of it.  WAR: the stage issued after the barrier of iteration kt overwrites the buffer of tile kt-1, whose
-// fragment reads were consumed by MFMAs (data dependence) before their wave reached this barrier.
-// ---------------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(512) void gemm256x128_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int EPC = 16 / (int)sizeof(T);
-    constexpr int BK = 8 * EPC;
-    constexpr int KSTEPS = BK / 32;
-    constexpr int STAGE = 49152;  // 32 KiB A + 16 KiB B
-
-    const int nblk = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x;
-    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int GM = 4;
-    const int width = GM * p.tiles_n;
-    const int group = swz / width;
-    const int first_m = group * GM;
-    const int gsize = min(p.tiles_m - first_m, GM);
-    const int tm = first_m + (swz % width) % gsize;
-    const int tn = (swz % width) / gsize;
-    const int m0 = tm * 256, n0 = tn * 128;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const char* a_src[4];
-    const char* b_src[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ (row & 7);
-        const int gm = min(m0 + row, p.M - 1);
-        a_src[i] = reinterpret_cast<const char*>(p.A) + (size_t)gm * p.lda * sizeof(T) + (c << 4);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ (row & 7);
-        const int gn = min(n0 + row, p.N - 1);
-        b_src[i] = reinterpret_cast<const char*>(p.W) + (size_t)gn * p.ldw * sizeof(T) + (c << 4);
-    }
-    const int nk = p.K / BK;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    auto stage = [&](int buf, int kt) {
-        const size_t koff = (size_t)kt * 128;
-        char* base = smem + buf * STAGE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[i] + koff), LDS_PTR(base + (wave * 4 + i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[i] + koff), LDS_PTR(base + 32768 + (wave * 2 + i) * 1024), 16, 0, 0);
-    };
-
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk && !(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(p.ablate & 2)) __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk && !(p.ablate & 1)) stage(buf == 0 ? 2 : buf - 1, kt + 2);
-        const char* Ab = smem + buf * STAGE;
-        const char* Bb = Ab + 32768;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            Frag<T> a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = lds_frag<T>(Ab, wm * 64 + i * 16 + (lane & 15), ks, lane >> 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), ks, lane >> 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mma16(a[i], b[j], acc[i][j]);
-        }
-        buf = buf == 2 ? 0 : buf + 1;
-    }
-
-    __syncthreads();
-    float* Cs = reinterpret_cast<float*>(smem);  // [256][128] fp32 = 128 KiB
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm * 64 + i * 16 + 4 * (lane >> 4) + r;
-                const int col = wn * 64 + j * 16 + (lane & 15);
-                Cs[row * 128 + col] = acc[i][j][r];
-            }
-    __syncthreads();
-    if (p.out_f32)
-        epilogue_rows<T, float, 256, 512>(p, Cs, m0, n0, tn, tid);
-    else
-        epilogue_rows<T, T, 256, 512>(p, Cs, m0, n0, tn, tid);
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
 // v3: 256x256 tile, 8 waves (2 x 4), 128x64 per wave (8x4 MFMA 16x16 tiles, 128 accumulator registers), two 64 KiB
 // LDS stages, LDS-DMA double buffer with one barrier per K-tile (the v1 loop).  Versus the 64x64 per-wave tile this
 // issues 12 instead of 16 ds_read_b128 per 32 MFMAs and half the LDS-DMA instructions per MFMA, and halves the
 // L2->LDS bytes per FLOP (ablation + PMC in profiles/).  Used for GEMMs whose 256x256 tile count fills the chip's
 // 256 CUs for several rounds; the epilogue is staged through LDS in two 128-row halves.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int EXP, int EMODE = 0>  // EXP: main-loop schedule (2 = production, see launch_gemm_v3); EMODE: epilogue flavour
+template <typename T, int EMODE = 0>  // EMODE: epilogue flavour
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -632,32 +480,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + 32768 + (wave * 4 + i) * 1024), 16, 0, 0);
         }
     };
-    // A/B helpers: pieces [i0, i1) of this wave, or the pieces of another wave `w` (offsets recomputed: nothing kept in registers)
-    auto stage_part = [&](int buf, int kt, int i0, int i1) {
-        const size_t koff = (size_t)kt * 128;
-        char* base = smem + buf * STAGE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i >= i0 && i < i1) {
-                __builtin_amdgcn_global_load_lds(GLB_PTR(a_base + koff + a_off[i]), LDS_PTR(base + (wave * 4 + i) * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(GLB_PTR(b_base + koff + b_off[i]), LDS_PTR(base + 32768 + (wave * 4 + i) * 1024), 16, 0, 0);
-            }
-    };
-    auto stage_for = [&](int buf, int kt, int w) {
-        const size_t koff = (size_t)kt * 128;
-        char* base = smem + buf * STAGE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (w * 4 + i) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ (row & 7);
-            const unsigned int ao = (unsigned int)((size_t)(min(m0 + row, p.M - 1) - m0) * p.lda * sizeof(T)) + (c << 4);
-            const unsigned int bo = (unsigned int)((size_t)(min(n0 + row, p.N - 1) - n0) * p.ldw * sizeof(T)) + (c << 4);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(a_base + koff + ao), LDS_PTR(base + (w * 4 + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(b_base + koff + bo), LDS_PTR(base + 32768 + (w * 4 + i) * 1024), 16, 0, 0);
-        }
-    };
-
-    if constexpr (EXP >= 2 && KSTEPS == 2) {
+    if constexpr (KSTEPS == 2) {   // bf16
         // Staggered two-group schedule.  Per K-tile every wave runs four segments  L0 | C0 | L1 | C1  separated by s_barrier:
         //   L0: issue the LDS-DMA of tile kt+1 (8 x 1 KiB) + ds_read the k-step-0 fragments     C0: 32 MFMAs
         //   L1: ds_read the k-step-1 fragments, then wait for this wave's DMA (vmcnt(0))         C1: 32 MFMAs
@@ -667,13 +490,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         //        tile kt+1 is at slot 4kt+4, behind the barrier that ends slot 4kt+3.
         //   WAR: buffer (kt+1)&1 was last read (tile kt-1, k-step 1) at slots 4kt-2 / 4kt-1; the DMA into it starts at slot 4kt.
         const int grp = wave >> 2;
-        // Measured and rejected on this loop (round 2, same-process A/B): group 0 waiting for its DMA at the end of C1 instead of L1 (+-0);
-        // group 1 requesting tile kt+2 behind the MFMAs of its C1 (+4..6 % slower).  Compile-time A/B variants kept:
-        //   EXP 3: the younger group (waves 4-7) issues ALL the DMA (its own pieces and those of wave - 4), the older group none
-        //   EXP 4: GROUP 0 issues 2 + 2 pieces in its L0 and the other 2 + 2 in its L1 and waits at the end of its C1 (slot 4kt+3: still ahead
-        //          of the first read in slot 4kt+4); group 1 is unchanged (its data must have landed by the end of ITS L1 = slot 4kt+3)
-        constexpr bool only1 = EXP == 3;
-        const bool split = EXP == 4 && grp == 0;
+        // (Measured and rejected on this loop in round 2: other placements of the DMA issue / wait -- DESIGN.md section 7.)
         stage(kt0 & 1, kt0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -683,11 +500,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             const char* Bb = Ab + 32768;
             Frag<T> a8[8], b[4];
             // ---- L0
-            if (only1) {
-                if (kt + 1 < nk && grp == 1) { stage((kt + 1) & 1, kt + 1); stage_for((kt + 1) & 1, kt + 1, wave - 4); }
-            } else if (split) {
-                if (kt + 1 < nk) stage_part((kt + 1) & 1, kt + 1, 0, 2);
-            } else if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), 0, lane >> 4);
 #pragma unroll
@@ -708,9 +521,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), 1, lane >> 4);
 #pragma unroll
             for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + (lane & 15), 1, lane >> 4);
-            if (split) {
-                if (kt + 1 < nk) stage_part((kt + 1) & 1, kt + 1, 2, 4);   // second half of the request; everything is waited for at the end of C1
-            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             // ---- C1
@@ -721,51 +532,34 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 for (int j = 0; j < 4; ++j) mma16(a8[i], b[j], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (split) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();
-    } else {
+    } else {   // fp32: one k-step per K-tile, one barrier per K-tile
         stage(kt0 & 1, kt0);
         for (int kt = kt0; kt < nk; ++kt) {
-            if (!(p.ablate & 2)) __syncthreads();  // tile kt landed (vmcnt(0) + barrier); every wave is done reading buffer (kt+1)&1
-            if (kt + 1 < nk && !(p.ablate & 1)) stage((kt + 1) & 1, kt + 1);
+            __syncthreads();  // tile kt landed (vmcnt(0) + barrier); every wave is done reading buffer (kt+1)&1
+            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
             const char* Ab = smem + (kt & 1) * STAGE;
             const char* Bb = Ab + 32768;
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
-                Frag<T> b[4];
+                Frag<T> b[4], a8[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) b[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + (lane & 15), ks, lane >> 4);
-                if (EXP == 1) {  // experiment: all 8 A fragments first, then one prioritised MFMA cluster
-                    Frag<T> a8[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + (lane & 15), ks, lane >> 4);
-                    __builtin_amdgcn_s_setprio(1);
+                for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + (lane & 15), ks, lane >> 4);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < 8; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) mma16(a8[i], b[j], acc[i][j]);
-                    __builtin_amdgcn_s_setprio(0);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const Frag<T> a = lds_frag<T>(Ab, wm * 128 + i * 16 + (lane & 15), ks, lane >> 4);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) mma16(a, b[j], acc[i][j]);
-                    }
-                }
+                    for (int j = 0; j < 4; ++j) mma16(a8[i], b[j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
             }
         }
-
     }
 
     float* Cs = reinterpret_cast<float*>(smem);  // [128][256] fp32 = 128 KiB, one 128-row half at a time
-    if (p.ablate & 4) {  // timing-only: no epilogue at all (keeps the accumulators live)
-        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[7][3][3];
-        return;
-    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         __syncthreads();
@@ -830,40 +624,14 @@ __global__ __launch_bounds__(NT) void gemm256_tail_reduce_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < VPT; ++i) reinterpret_cast<float4*>(Cs)[i * NT + tid] = acc[i];
     __syncthreads();
-    int mrow = tm * 256 + slab * ROWS, m_lo = 0;
-    if (p.shift_edge && tm * 256 + 256 > p.M) {  // v4 partials of the shifted last tile row: local row l is global row M - 256 + l;
-        mrow = p.M - 256 + slab * ROWS;          // rows below tm * 256 belong to the tile above
-        m_lo = tm * 256;
-        if (mrow + ROWS <= m_lo) return;
-    }
+    const int mrow = tm * 256 + slab * ROWS;
     if (p.out_f32)
-        epilogue_rows<T, float, ROWS, NT, 256, EMODE>(p, Cs, mrow, tn * 256, tn, tid, m_lo);
+        epilogue_rows<T, float, ROWS, NT, 256, EMODE>(p, Cs, mrow, tn * 256, tn, tid);
     else
-        epilogue_rows<T, T, ROWS, NT, 256, EMODE>(p, Cs, mrow, tn * 256, tn, tid, m_lo);
+        epilogue_rows<T, T, ROWS, NT, 256, EMODE>(p, Cs, mrow, tn * 256, tn, tid);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// v4: PERSISTENT 256x256 kernel (bf16).  One workgroup per CU walks a list of units (whole tiles, then the K-ranges of the
-// split tail); the main loop is v3's staggered four-slot schedule and runs CONTINUOUSLY across units:
-//   * the LDS-DMA of the next unit's first K-tile is issued in the last K-step of the current unit, the DMA of its second
-//     K-tile right after the last MFMA, BEFORE the epilogue -- no unit starts with an empty pipeline;
-//   * the epilogue goes straight from the accumulators to memory (no LDS round trip, no barrier): the MFMA operands are
-//     swapped (D^T = W . A^T), so a lane owns 4 consecutive output columns per 16x16 tile, and the DMA places the rows of W
-//     in LDS in a permuted order so that a lane's registers form runs of 8 consecutive bf16 columns: every store instruction
-//     writes 64 contiguous bytes per row (fp32 output: identity order, 4 fp32 = 16 B per lane and tile, also 64 B per row);
-//   * the stores are fire-and-forget: they are YOUNGER than the next unit's second-K-tile DMA, whose wait is a counted
-//     vmcnt(#stores), so a wave first waits for a store acknowledgement one and a half K-steps later.  HBM writes of unit i
-//     drain under the main loop of unit i+1 instead of in a chip-wide burst at the end of every round of tiles;
-//   * the bias of a tile (256 floats) arrives by one extra 1 KiB LDS-DMA with the tile's first K-tile: no register is held
-//     across the K loop for the epilogue and the epilogue has no vector-memory load to wait for.
-// Ragged M: the last tile row starts at M - 256 (all loads in bounds, no clamping); the rows it shares with the tile above
-// are computed twice and stored once (by the tile above).
-// Hazards (slot numbering of v3, s = global K-step count of the workgroup, buffer = s & 1):
-//   RAW  DMA for step s+1 is issued in slot 4s (or between slots 4s+3 and 4s+4 at a unit boundary, for step s+2) and waited for by
-//        the issuing wave in its L1 slot, before the barrier that precedes the first read (slot 4s+4 / 4s+8).
-//   WAR  the boundary DMA overwrites the buffer of the unit's last step s, last read in slots 4s+2 / 4s+3: it is issued behind the barrier that ends 4s+3
-//        (group 0; group 1 one slot later) -- the same distance as v3's regular in-loop DMA.
-// ---------------------------------------------------------------------------------------------------------------
+// Helpers of the direct (accumulator -> memory) epilogues of the ring kernel.
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 __device__ __forceinline__ void gstore16(void* ptr, u32x4 v) {   // exactly one global_store_dwordx4 (the counted vmcnt waits rely on it)
@@ -894,370 +662,11 @@ __device__ __forceinline__ void pair_swap(const u32x4& lo, const u32x4& hi, bool
     for (int e = 0; e < 4; ++e) { first[e] = odd ? recv[e] : lo[e]; second[e] = odd ? hi[e] : recv[e]; }
 }
 
-struct UnitPos { int m0, mfirst, n0, kt0, kt1, part, slot; bool valid; };
-
-// EPI: 0 = bf16 output (+bias, +GELU/ReLU)   1 = SwiGLU pair, bf16 output   2 = fp32 output (+bias, +act, +fp32 residual)
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STAGE = 65536;  // 32 KiB A + 32 KiB B; behind the two stages: 2 x 1 KiB of bias
-    typedef bf16 T;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
-    const int g4 = lane >> 4, mm = lane & 15;
-    const int G = gridDim.x;
-    const int nk_all = p.K >> 6;
-    const bool nostore = (p.ablate & 8) != 0;   // timing-only: everything but the global stores
-    auto gst = [&](void* ptr, u32x4 v) {
-        if (nostore && v[0] != 0x9E3779B9u) return;
-        store16_policy(ptr, v, p.store_nt);
-    };
-    const int n_units = p.full_tiles + (p.tiles_m * p.tiles_n - p.full_tiles) * p.ksplit;
-    // position inside a round of G units: workgroups b, b+8, ... share an XCD (round-robin dispatch; speed only) -> give them
-    // neighbouring tiles.  A round of c = min(G, units left) units is dealt to the 8 XCDs in 8 equal runs of consecutive units
-    // (4 tile rows x 8 tile columns per XCD in a full round at G = 256; a partial last round still loads every XCD's L2 and
-    // fabric port equally instead of filling XCD 0, 1, ... first)
-    const int b = blockIdx.x;
-    const int xcd = b & 7, li = b >> 3;
-
-    auto unit_at = [&](int round) -> UnitPos {
-        UnitPos u;
-        const int left = n_units - round * G;
-        int s_ = n_units;  // invalid
-        if ((G & 7) == 0) {
-            const int c = min(left, G);
-            const int q = c >> 3, rem = c & 7;
-            if (c > 0 && li < q + (xcd < rem ? 1 : 0)) s_ = round * G + xcd * q + min(xcd, rem) + li;
-        } else if (b < left) {
-            s_ = round * G + b;
-        }
-        u.valid = s_ < n_units;
-        int swz = s_;
-        u.part = -1; u.slot = 0; u.kt0 = 0; u.kt1 = nk_all;
-        if (s_ >= p.full_tiles) {
-            const int t = s_ - p.full_tiles;
-            const int tail_idx = t / p.ksplit;
-            u.part = t - tail_idx * p.ksplit;
-            u.slot = t;
-            swz = p.full_tiles + tail_idx;
-            u.kt0 = (int)((long)u.part * nk_all / p.ksplit);
-            u.kt1 = (int)((long)(u.part + 1) * nk_all / p.ksplit);
-        }
-        const int GM = 4;
-        const int width = GM * p.tiles_n;
-        const int group = swz / width;
-        const int first_m = group * GM;
-        const int gsize = min(p.tiles_m - first_m, GM);
-        u.mfirst = (first_m + (swz % width) % gsize) * 256;
-        u.m0 = min(u.mfirst, p.M - 256);       // rows [m0, mfirst) belong to the tile above and are not stored by this one
-        u.n0 = ((swz % width) / gsize) * 256;
-        return u;
-    };
-
-    // DMA sources: LDS row R = 8 (4 wave + i) + lane/8 takes 16-byte chunk (lane & 7) ^ (R & 7) of a source row.  R & 7 = lane / 8 does not
-    // depend on i, and the source row splits into a wave-uniform part (SGPR arithmetic, per i) plus a lane part (one VGPR per operand):
-    //   A: source row = R.   W: the wave's 64 LDS rows (tile j = (R >> 4) & 3, row r = R & 15) are a permutation of its 64 weight rows:
-    //   EPI 0 (bf16 out)   n = 64 wb + 32 (j >> 1) + 8 (r >> 2) + 4 (j & 1) + (r & 3)      -> runs of 8 consecutive columns per lane
-    //   EPI 1 (SwiGLU)     n = 128 (wb >> 1) + 64 (j >> 1) + 32 (wb & 1) + 8 (r >> 2) + 4 (j & 1) + (r & 3)   -> [gate | up] of the same 8 columns
-    //   EPI 2 (fp32 out)   n = R                                                         -> 4 fp32 = 16 B per lane and tile
-    const long lda2 = p.lda * 2, ldw2 = p.ldw * 2;
-    const int lr = lane >> 3;                                   // R & 7
-    const int chunk = ((lane & 7) ^ lr) << 4;
-    const unsigned int a_lane = (unsigned int)(lr * lda2) + chunk;
-    const unsigned int b_lane = (unsigned int)((EPI == 2 ? lr : 8 * (lr >> 2) + (lr & 3)) * ldw2) + chunk;
-    unsigned int a_uni[4], b_uni[4];          // wave-uniform byte offsets of DMA piece i (SGPRs; < 2^31, checked by the launcher)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = wave * 4 + i;           // R >> 3
-        const int wb = q >> 3, j = (q >> 1) & 3, rh = q & 1;  // r >> 2 = 2 rh + (lr >> 2)
-        int wr;
-        if (EPI == 2) wr = q * 8;
-        else if (EPI == 0) wr = wb * 64 + 32 * (j >> 1) + 16 * rh + 4 * (j & 1);
-        else wr = (wb >> 1) * 128 + 64 * (j >> 1) + (wb & 1) * 32 + 16 * rh + 4 * (j & 1);
-        a_uni[i] = __builtin_amdgcn_readfirstlane((unsigned int)(q * 8 * lda2));
-        b_uni[i] = __builtin_amdgcn_readfirstlane((unsigned int)(wr * ldw2));
-    }
-    const char* Abase = reinterpret_cast<const char*>(p.A);
-    const char* Wbase = reinterpret_cast<const char*>(p.W);
-
-    auto stage = [&](int buf, int m0, int n0, int kt) {
-        char* base = smem + buf * STAGE;
-        const char* ak = Abase + (size_t)m0 * lda2 + (size_t)kt * 128;   // wave-uniform (SGPR) base + 32-bit offset (uniform part + lane part)
-        const char* bk = Wbase + (size_t)n0 * ldw2 + (size_t)kt * 128;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned int ao = a_lane + a_uni[i], bo = b_lane + b_uni[i];
-            asm volatile("" : "+v"(ao), "+v"(bo));  // keep base + offset apart: no hoisted 64-bit per-lane pointers (register pressure)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(ak + ao), LDS_PTR(base + (wave * 4 + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(bk + bo), LDS_PTR(base + 32768 + (wave * 4 + i) * 1024), 16, 0, 0);
-        }
-    };
-    auto stage_bias = [&](int slot, const UnitPos& u) {
-        if (p.bias && wave == 0 && u.part < 0)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(reinterpret_cast<const char*>(p.bias + u.n0) + lane * 16), LDS_PTR(smem + 2 * STAGE + slot * 1024), 16, 0, 0);
-    };
-
-    // Desynchronise the CUs: every tile costs every CU the same time, so without this all 256 workgroups reach their epilogues together
-    // and each round of tiles ends in a chip-wide store burst (32 MiB of bf16 at the HBM write rate = ~10 us with every matrix pipe idle:
-    // the queued stores hold back the next tile's DMA).  Workgroup b starts p.skew_ticks * (position of b among the G workgroups) / G
-    // late (s_memrealtime ticks, 100 MHz); the offsets persist, the bursts become a steady stream under the other CUs' main loops.
-    // Workgroups with the lowest in-XCD index start first and are the ones that get a unit of a partial last round.
-    if (p.skew_ticks > 0) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long wait = (unsigned long long)p.skew_ticks * (unsigned)(li * 8 + xcd) / (unsigned)G;
-        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(4);
-    }
-    // diagnostic stamps (p.dbg != null only in the stamped A/B mode): [workgroup][group][unit < 4][16] shader-clock values
-    auto stamp = [&](int unit, int kk) {
-        if (p.dbg && (tid & 255) == 0 && unit < 4) p.dbg[(((size_t)blockIdx.x * 2 + grp) * 4 + unit) * 16 + kk] = __builtin_amdgcn_s_memtime();
-    };
-    if (p.dbg && (tid & 255) == 0) p.dbg[(((size_t)blockIdx.x * 2 + grp) * 4 + 0) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
-    f32x4 acc[8][4];
-    int round = 0;
-    UnitPos cur = unit_at(0);
-    if (!cur.valid) return;
-    int s = 0;          // global K-step counter: buffer = s & 1
-    int wcnt = 0;       // stores this wave has in flight behind the boundary DMA (0: wait for everything)
-    stage(0, cur.m0, cur.n0, cur.kt0);
-    stage_bias(0, cur);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    stage(1, cur.m0, cur.n0, cur.kt0 + 1);
-
-    for (;;) {
-        const UnitPos nxt = unit_at(round + 1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-        for (int kt = cur.kt0; kt < cur.kt1; ++kt, ++s) {
-            const char* Ab = smem + (s & 1) * STAGE;
-            const char* Bb = Ab + 32768;
-            Frag<T> a8[8], bq[4];
-            // ---- L0
-            if (kt != cur.kt0) {  // (the first step's successor was requested at the unit boundary)
-                const bool last = kt + 1 >= cur.kt1;
-                if (!last || nxt.valid) stage((s + 1) & 1, last ? nxt.m0 : cur.m0, last ? nxt.n0 : cur.n0, last ? nxt.kt0 : kt + 1);
-                if (last && nxt.valid) stage_bias((round + 1) & 1, nxt);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt == cur.kt0 + 2) stamp(round, 11);   // (diagnostic) L0 of the third step: after the DMA issue ...
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bq[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + mm, 0, g4);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + mm, 0, g4);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt == cur.kt0 + 2) stamp(round, 15);   // ... and after the fragment reads were issued (before the barrier)
-            __builtin_amdgcn_s_barrier();
-            if (kt == cur.kt0) stamp(round, 3);
-            // ---- C0
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mma16(bq[j], a8[i], acc[i][j]);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // ---- L1
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bq[j] = lds_frag<T>(Bb, wn * 64 + j * 16 + mm, 1, g4);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a8[i] = lds_frag<T>(Ab, wm * 128 + i * 16 + mm, 1, g4);
-            if (kt != cur.kt0 || wcnt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (wcnt == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (wcnt == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            if (kt == cur.kt0) stamp(round, 4); else if (kt == cur.kt0 + 1) stamp(round, 6); else if (kt == cur.kt0 + 2) stamp(round, 8);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // ---- C1
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mma16(bq[j], a8[i], acc[i][j]);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            if (kt == cur.kt0) stamp(round, 5); else if (kt == cur.kt0 + 1) stamp(round, 7); else if (kt == cur.kt0 + 2) stamp(round, 9); else if (kt == cur.kt1 - 2) stamp(round, 10);
-        }
-        stamp(round, 0);
-
-        // ---- unit boundary: fetch the tile's bias from LDS (the compiler orders every LDS read behind every LDS-DMA in flight with a
-        // vmcnt(0): nothing is in flight here, after the DMA below it would wait for it), request the next unit's second K-tile, then drain
-        // the accumulators (stores only: nothing to wait for)
-        const bool full_rows = cur.m0 == cur.mfirst;   // false only for the shifted last tile row of a ragged M
-        // (the epilogue's per-lane address pieces are recomputed from an opaque copy of the lane id, so that nothing but `lane` itself stays
-        // live across the K loop for them: the loop runs at the register limit)
-        int lane_e = lane;
-        asm volatile("" : "+v"(lane_e));
-        const int g4 = lane_e >> 4, mm = lane_e & 15;
-        const int row0 = cur.m0 + wm * 128 + mm;       // this lane's row in sub-tile i is row0 + 16 i
-        float bv[16];
-        if (EPI != 1) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) bv[e] = 0.f;
-            if (p.bias && cur.part < 0) {
-                const float* bl = reinterpret_cast<const float*>(smem + 2 * STAGE + (round & 1) * 1024) + wn * 64;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {  // EPI 0: columns 32 (q >> 1) + 8 g4 + 4 (q & 1) .. +3;  EPI 2: 16 q + 4 g4 .. +3
-                    const float4 x0 = *reinterpret_cast<const float4*>(bl + (EPI == 0 ? 32 * (q >> 1) + 8 * g4 + 4 * (q & 1) : 16 * q + 4 * g4));
-                    bv[4 * q + 0] = x0.x; bv[4 * q + 1] = x0.y; bv[4 * q + 2] = x0.z; bv[4 * q + 3] = x0.w;
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (nxt.valid) stage((s + 1) & 1, nxt.m0, nxt.n0, nxt.kt0 + 1);  // s = the next unit's first step (its tile is in buffer s & 1)
-        __builtin_amdgcn_sched_barrier(0);
-        stamp(round, 1);
-        if ((p.ablate & 4) && acc[0][0][0] != 12345.678f) {   // timing-only: no epilogue (the accumulators stay live)
-            wcnt = 0;
-        } else
-        if (EPI == 0 && cur.part < 0) {
-            const bool odd = mm & 1;
-            const int rowp = row0 & ~1;   // the lane pair's first row (sub-tile i: + 16 i); this lane writes 16 B piece (odd ? 4 : 0) + g4 of both rows
-            T* cp = reinterpret_cast<T*>(p.C) + (size_t)rowp * p.ldc + cur.n0 + wn * 64 + (odd ? 32 : 0) + 8 * g4;
-            auto drain = [&](auto ACT, auto FULL) {   // compile-time activation / row predicate: straight-line code per variant
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    unsigned int o[8];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float v0 = acc[i][2 * h + (q >> 1)][2 * (q & 1)] + bv[8 * h + 2 * q];
-                            float v1 = acc[i][2 * h + (q >> 1)][2 * (q & 1) + 1] + bv[8 * h + 2 * q + 1];
-                            if constexpr (decltype(ACT)::value == 1) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); }
-                            if constexpr (decltype(ACT)::value == 2) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                            o[4 * h + q] = pack_bf16x2(v0, v1);
-                        }
-                    u32x4 s0, s1;
-                    pair_swap((u32x4){o[0], o[1], o[2], o[3]}, (u32x4){o[4], o[5], o[6], o[7]}, odd, s0, s1);
-                    if (decltype(FULL)::value || rowp + 16 * i >= cur.mfirst) gst(cp + (size_t)(16 * i) * p.ldc, s0);
-                    if (decltype(FULL)::value || rowp + 16 * i + 1 >= cur.mfirst) gst(cp + (size_t)(16 * i + 1) * p.ldc, s1);
-                }
-            };
-            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-            if (full_rows) {
-                if (p.act == 1) drain(I1{}, std::true_type{});
-                else if (p.act == 2) drain(I2{}, std::true_type{});
-                else drain(I0{}, std::true_type{});
-            } else {
-                if (p.act == 1) drain(I1{}, std::false_type{});
-                else if (p.act == 2) drain(I2{}, std::false_type{});
-                else drain(I0{}, std::false_type{});
-            }
-            wcnt = full_rows ? 16 : 0;
-        } else if (EPI == 1 && cur.part < 0) {
-            // out[:, n0/2 + 64 (wn>>1) + 32 (wn&1) + 8 g4 + e] = silu(gate_e) * up_e, gate = tiles 0/1, up = tiles 2/3   (modeling_internlm2.py:261-264)
-            T* cp = reinterpret_cast<T*>(p.C) + (size_t)row0 * p.ldc + (cur.n0 >> 1) + (wn >> 1) * 64 + (wn & 1) * 32 + 8 * g4;
-            auto drain = [&](auto FULL) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    unsigned int o[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float g0 = acc[i][q >> 1][2 * (q & 1)], g1 = acc[i][q >> 1][2 * (q & 1) + 1];
-                        const float u0 = acc[i][2 + (q >> 1)][2 * (q & 1)], u1 = acc[i][2 + (q >> 1)][2 * (q & 1) + 1];
-                        o[q] = pack_bf16x2(silu_f(g0) * u0, silu_f(g1) * u1);
-                    }
-                    if (decltype(FULL)::value || row0 + 16 * i >= cur.mfirst) gst(cp + (size_t)(16 * i) * p.ldc, (u32x4){o[0], o[1], o[2], o[3]});
-                }
-            };
-            if (full_rows) drain(std::true_type{}); else drain(std::false_type{});
-            wcnt = full_rows ? 8 : 0;
-        } else if (EPI == 2 && cur.part < 0) {
-            // fp32 residual stream: C = acc + bias + residual[row (mod res_row_mod)]  (no activation on this path: checked by the launcher).
-            // Two register sets alternate: the residual rows of sub-tile i+1 are requested before sub-tile i is stored (counted waits).
-            // whole-line accesses: tiles (0, 1) and (2, 3) of a sub-tile are the two 64 B halves of a 128 B line -> pair_swap per tile pair;
-            // afterwards this lane owns piece (odd ? 4 : 0) + g4 of line jp = 0, 1 in the rows rowp + 16 i and rowp + 16 i + 1
-            const bool odd = mm & 1;
-            const int rowp = row0 & ~1;
-            const int colp = cur.n0 + wn * 64 + (odd ? 16 : 0) + 4 * g4;
-            float* cp = reinterpret_cast<float*>(p.C) + (size_t)rowp * p.ldc + colp;
-            auto load_res = [&](int i, float4 (&r)[4]) {   // r[2 jp + rsel]: line jp of row rowp + 16 i + rsel
-#pragma unroll
-                for (int rsel = 0; rsel < 2; ++rsel) {
-                    const int gm = rowp + 16 * i + rsel;
-                    const int rr = p.res_row_mod > 0 ? gm % p.res_row_mod : gm;
-                    const float* rp = p.residual + (size_t)rr * p.ldr + colp;
-#pragma unroll
-                    for (int jp = 0; jp < 2; ++jp) r[2 * jp + rsel] = *reinterpret_cast<const float4*>(rp + 32 * jp);
-                }
-            };
-            auto put = [&](int i, const float4 (&r)[4], auto FULL) {
-#pragma unroll
-                for (int jp = 0; jp < 2; ++jp) {
-                    u32x4 lo, hi, s0, s1;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        lo[e] = __float_as_uint(acc[i][2 * jp][e] + bv[8 * jp + e]);
-                        hi[e] = __float_as_uint(acc[i][2 * jp + 1][e] + bv[8 * jp + 4 + e]);
-                    }
-                    pair_swap(lo, hi, odd, s0, s1);
-                    const float4 r0 = r[2 * jp], r1 = r[2 * jp + 1];
-                    s0 = (u32x4){__float_as_uint(__uint_as_float(s0[0]) + r0.x), __float_as_uint(__uint_as_float(s0[1]) + r0.y),
-                                 __float_as_uint(__uint_as_float(s0[2]) + r0.z), __float_as_uint(__uint_as_float(s0[3]) + r0.w)};
-                    s1 = (u32x4){__float_as_uint(__uint_as_float(s1[0]) + r1.x), __float_as_uint(__uint_as_float(s1[1]) + r1.y),
-                                 __float_as_uint(__uint_as_float(s1[2]) + r1.z), __float_as_uint(__uint_as_float(s1[3]) + r1.w)};
-                    if (decltype(FULL)::value || rowp + 16 * i >= cur.mfirst) gst(cp + (size_t)(16 * i) * p.ldc + 32 * jp, s0);
-                    if (decltype(FULL)::value || rowp + 16 * i + 1 >= cur.mfirst) gst(cp + (size_t)(16 * i + 1) * p.ldc + 32 * jp, s1);
-                }
-            };
-            auto drain = [&](auto RES, auto FULL) {
-                float4 ra[4], rb[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ra[j] = rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (decltype(RES)::value) load_res(0, ra);
-#pragma unroll
-                for (int i = 0; i < 8; i += 2) {
-                    if constexpr (decltype(RES)::value) { load_res(i + 1, rb); __builtin_amdgcn_sched_barrier(0); }
-                    put(i, ra, FULL);
-                    if constexpr (decltype(RES)::value) { if (i + 2 < 8) load_res(i + 2, ra); __builtin_amdgcn_sched_barrier(0); }
-                    put(i + 1, rb, FULL);
-                }
-            };
-            if (p.residual) { if (full_rows) drain(std::true_type{}, std::true_type{}); else drain(std::true_type{}, std::false_type{}); }
-            else { if (full_rows) drain(std::false_type{}, std::true_type{}); else drain(std::false_type{}, std::false_type{}); }
-            wcnt = (full_rows && !p.residual) ? 32 : 0;  // with a residual the loads' waits have drained the queue anyway
-        } else {
-            // K-range of a split tail tile: raw fp32 partial tile -> workspace [slot][256][256] (finished by gemm256_tail_reduce_kernel)
-            float* wp = p.ws + (size_t)cur.slot * 65536 + (size_t)(wm * 128 + mm) * 256;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int nl;
-                    if (EPI == 2) nl = wn * 64 + 16 * j + 4 * g4;
-                    else if (EPI == 0) nl = wn * 64 + 32 * (j >> 1) + 8 * g4 + 4 * (j & 1);
-                    else nl = (wn >> 1) * 128 + 64 * (j >> 1) + (wn & 1) * 32 + 8 * g4 + 4 * (j & 1);
-                    gst(wp + (size_t)(16 * i) * 256 + nl, (u32x4){__float_as_uint(acc[i][j][0]), __float_as_uint(acc[i][j][1]),
-                                                                          __float_as_uint(acc[i][j][2]), __float_as_uint(acc[i][j][3])});
-                }
-            wcnt = 32;
-        }
-        stamp(round, 2);
-        if (p.dbg && (tid & 255) == 0) {
-            p.dbg[(((size_t)blockIdx.x * 2 + grp) * 4 + 0) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
-            p.dbg[(((size_t)blockIdx.x * 2 + grp) * 4 + 0) * 16 + 14] = (unsigned long long)(round + 1);
-        }
-        if (!nxt.valid) break;
-        cur = nxt;
-        ++round;
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-}
-
-template <typename T, int EXP, int EMODE = 0>
+template <typename T, int EMODE = 0>
 static int launch_gemm_v3_impl(GemmArgs a, hipStream_t stream) {
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<T, EXP, EMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<T, EMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     }
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (a.N + 255) / 256;
@@ -1276,7 +685,7 @@ static int launch_gemm_v3_impl(GemmArgs a, hipStream_t stream) {
             a.ksplit = S;
         }
     }
-    gemm256_kernel<T, EXP, EMODE><<<dim3(a.full_tiles + (T_ - a.full_tiles) * a.ksplit), dim3(512), 131072, stream>>>(a);
+    gemm256_kernel<T, EMODE><<<dim3(a.full_tiles + (T_ - a.full_tiles) * a.ksplit), dim3(512), 131072, stream>>>(a);
     ULLSAM_LAUNCH_CHECK();
     if (a.ksplit > 1) {
         const int tail_tiles = T_ - a.full_tiles;
@@ -1288,210 +697,30 @@ static int launch_gemm_v3_impl(GemmArgs a, hipStream_t stream) {
 }
 template <typename T>
 static int launch_gemm_v3(GemmArgs a, hipStream_t stream) {
-    // schedules (tools/gemm_bench.py codes 3 / 3+(4<<8) / 3+(6<<8)): the staggered two-group schedule measured +10..15 % on the
-    // K=4096 shapes and neutral at K=1280 against both others, bit-identical results
-    if (a.act == 4) return sizeof(T) == 2 ? launch_gemm_v3_impl<T, 2, 1>(a, stream) : launch_gemm_v3_impl<T, 1, 1>(a, stream);  // wqkv + RoPE epilogue
-    if (g_gemm_sched == 2) return launch_gemm_v3_impl<T, 1>(a, stream);  // fragments first + prioritised MFMA cluster, 1 barrier / K-tile
-    if (g_gemm_sched == 1) return launch_gemm_v3_impl<T, 0>(a, stream);  // plain interleaved loop
-    if (sizeof(T) == 2 && g_late == 4) return launch_gemm_v3_impl<T, 3>(a, stream);  // A/B: younger group issues all DMA
-    if (sizeof(T) == 2 && g_late == 8) return launch_gemm_v3_impl<T, 4>(a, stream);  // A/B: DMA issue split over L0 / L1
-    if (sizeof(T) == 2) return launch_gemm_v3_impl<T, 2>(a, stream);        // production (bf16): staggered two-group schedule
-    return launch_gemm_v3_impl<T, 1>(a, stream);                            // fp32 has one k-step per K-tile: no second segment pair
+    if (a.act == 4) return launch_gemm_v3_impl<T, 1>(a, stream);   // wqkv + RoPE epilogue
+    return launch_gemm_v3_impl<T, 0>(a, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// v6: 256x256 tile on a RING of four half-K LDS stages (bf16).  Same tile, wave layout (2 x 4, 128x64 per wave), stagger and
-// epilogue as gemm256_kernel; what changes is the grain of the pipeline.  Measured on the two-buffer loop (tools/gemm_stamps.py):
-// a wave needs 80-95 cycles to issue one 1 KiB LDS-DMA piece, so the slot in which a group requests the 8 pieces of the next
-// 64-deep K-tile (plus 12 fragment reads) takes 0.8-0.9 kilo-cycles while the partner's matrix segment it hides under takes 0.51,
-// and the other load slot is half empty; with two whole-K-tile buffers the issue cannot be moved (landing deadline).
-// Here a stage is ONE MFMA k-step (32 deep): A 256 rows x 64 B + B 256 rows x 64 B = 32 KiB, four stages = 128 KiB.
-// Per stage and wave: 4 DMA pieces (for stage s + D), 12 fragment reads, 32 MFMAs -- every load slot carries the same, smaller
-// load (4 pieces + 12 reads ~ 0.47 kilo-cycles <= one 32-MFMA segment), and the request runs D = 2 stages ahead:
-//   slot 2s   : group 0  L(s) = issue DMA(s+D), read the fragments of stage s, wait until stage s+1 has landed (counted vmcnt)
+// The ring kernel (bf16): BM x BN tile, 8 waves (2 x 4; a wave owns MI0 or MI1 sub-tile rows x NTW sub-tile columns of 16x16), two wave groups
+// (waves 0-3 / 4-7 = upper / lower wave row) staggered by one slot on a ring of FOUR half-K LDS stages.  A stage is ONE MFMA k-step (32 deep):
+// A BM rows x 64 B + B BN rows x 64 B; per stage and wave: 4-5 LDS-DMA pieces (1 KiB = 16 rows x 64 B; piece q of an operand belongs to wave
+// q % 8), 12-13 fragment reads, 32-40 MFMAs; the request runs two stages ahead:
+//   slot 2s   : group 0  L(s) = request stage s+2 + read the fragments of stage s, wait until stage s+1 has landed (counted vmcnt)
 //               group 1  C(s-1)
-//   slot 2s+1 : group 0  C(s) = 32 MFMAs          group 1  L(s)
-// RAW: a wave's pieces of stage s+D are issued in its L(s) and waited for in its L(s+D-1) (vmcnt(4(D-1)) leaves the younger stages in
-//      flight); group 1's wait is in slot 2(s+D)-1, the barrier ending that slot precedes the first read in slot 2(s+D).
-// WAR: buffer (s+D) & 3 held stage s+D-4, last read in slots 2(s+D-4) / +1: at least four slots (D <= 2) before the DMA is issued.
-// LDS image: 64-byte rows, 16-byte chunk c of row r at c ^ ((r >> 2) & 2): a ds_read_b128 lane group {rows rho, chunk g} then covers
-// all 16 sixteen-byte bank groups of the four 64 B rows sharing a 256 B bank line exactly once (conflict-free), and a DMA piece is
-// 16 rows x 64 B with the same permutation on its source chunks.
+//   slot 2s+1 : group 0  C(s) = the MFMAs          group 1  L(s)
+// RAW: a wave's pieces of stage s+2 are issued in its L(s) and waited for in its L(s+1) (the counted wait leaves only the youngest stage in
+//      flight); group 1's wait is in slot 2(s+2)-1, the barrier ending that slot precedes the first read in slot 2(s+2).
+// WAR: buffer (s+2) & 3 held stage s-2, last read in slots 2(s-2) / +1: four slots before the DMA is issued.
+// LDS image: 64-byte rows, 16-byte chunk c of row r at c ^ ((r >> 2) & 2): a ds_read_b128 lane group {rows rho, chunk g} covers all 16
+// sixteen-byte bank groups of the four 64 B rows sharing a 256 B bank line exactly once (conflict-free); the DMA applies the same
+// permutation to its source chunks (the LDS-DMA writes lane-linear).
+// Tile shapes (template arguments): 256x256 <8,8,4>; 256x320 <8,8,5> -- the ViT-H widths are multiples of 320 (1280 = 4 x 320, 3840 = 12 x 320,
+// 5120 = 16 x 320), and with 64 tile rows (M = 16384) the tile count becomes a multiple of the 256 CUs: vit.proj / lin2 are ONE round instead of
+// 1.25, vit.qkv 3 rounds of 1.25 x the work instead of 4; 272x256 <9,8,4> -- the bench's 4 x 1081 = 4324 prompt rows are 16 x 272: llm.wo / w2
+// one round of 256 tiles, llm.w13 7 whole rounds instead of 7.44.  The LDS-staged epilogue (odd shapes) uses up to 128 rows x 320 fp32 = 160 KiB.
 // ---------------------------------------------------------------------------------------------------------------
-template <int EMODE, int D>
-__global__ __launch_bounds__(512) void gemm256r_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef bf16 T;
-    constexpr int STG = 32768;  // 16 KiB A + 16 KiB B per stage
-
-    const int nblk = p.full_tiles;
-    const int bid = blockIdx.x;
-    int swz, part = -1, tail_idx = 0;
-    if (bid < nblk) {
-        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-        swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    } else {
-        const int t = bid - nblk;
-        tail_idx = t / p.ksplit;
-        part = t - tail_idx * p.ksplit;
-        swz = nblk + tail_idx;
-    }
-    const int GM = p.group_m;
-    const int width = GM * p.tiles_n;
-    const int group = swz / width;
-    const int first_m = group * GM;
-    const int gsize = min(p.tiles_m - first_m, GM);
-    const int tm = first_m + (swz % width) % gsize;
-    const int tn = (swz % width) / gsize;
-    const int m0 = tm * 256, n0 = tn * 256;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
-    const int g4 = lane >> 4, mm = lane & 15;
-
-    // DMA pieces of this wave: A pieces 2w, 2w+1 and B pieces 2w, 2w+1 (16 rows x 64 B each); lane -> row 16 piece + lane / 4, LDS chunk lane & 3
-    const char* a_base = reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda * 2;
-    const char* b_base = reinterpret_cast<const char*>(p.W) + (size_t)n0 * p.ldw * 2;
-    unsigned int a_off[2], b_off[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((row >> 2) & 2);
-        a_off[i] = (unsigned int)((size_t)(min(m0 + row, p.M - 1) - m0) * p.lda * 2) + (c << 4);
-        b_off[i] = (unsigned int)((size_t)(min(n0 + row, p.N - 1) - n0) * p.ldw * 2) + (c << 4);
-    }
-    const int ns_all = p.K >> 5;  // stages (32-deep k-steps)
-    const int st0 = part < 0 ? 0 : (int)((long)part * ns_all / p.ksplit);
-    const int st1 = part < 0 ? ns_all : (int)((long)(part + 1) * ns_all / p.ksplit);
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    auto stage = [&](int s) {   // request stage s into ring slot s & 3
-        char* base = smem + (s & 3) * STG;
-        const char* ak = a_base + (size_t)s * 64;
-        const char* bk = b_base + (size_t)s * 64;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_off[i]), LDS_PTR(base + (wave * 2 + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + 16384 + (wave * 2 + i) * 1024), 16, 0, 0);
-        }
-    };
-    auto frag = [&](const char* tile, int row) -> Frag<T> {
-        return load_frag(reinterpret_cast<const T*>(tile + row * 64 + ((g4 ^ ((row >> 2) & 2)) << 4)));
-    };
-
-    // prologue: stages st0 .. st0+D-1 requested, stage st0 landed
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (st0 + d < st1) stage(st0 + d);
-    if (D == 2 && st0 + 1 < st1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    for (int s = st0; s < st1; ++s) {
-        const char* Ab = smem + (s & 3) * STG;
-        const char* Bb = Ab + 16384;
-        Frag<T> a8[8], b[4];
-        // ---- L(s)
-        if (s + D < st1) stage(s + D);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = frag(Bb, wn * 64 + j * 16 + mm);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a8[i] = frag(Ab, wm * 128 + i * 16 + mm);
-        // stage s+1 must have landed before the barrier that lets anyone read it; younger stages stay in flight
-        if (D == 2 && s + 2 < st1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---- C(s)
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mma16(a8[i], b[j], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-
-    float* Cs = reinterpret_cast<float*>(smem);  // [128][256] fp32 = 128 KiB, one 128-row half at a time
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        __syncthreads();
-        if (wm == half) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * g4 + r) * 256 + wn * 64 + j * 16 + mm] = acc[i][j][r];
-        }
-        __syncthreads();
-        if (part >= 0) {
-            float4* dst = reinterpret_cast<float4*>(p.ws + ((size_t)tail_idx * p.ksplit + part) * 65536 + half * 32768);
-            const float4* src = reinterpret_cast<const float4*>(Cs);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) dst[i * 512 + tid] = src[i * 512 + tid];
-        } else if (p.out_f32) {
-            epilogue_rows<T, float, 128, 512, 256, EMODE>(p, Cs, m0 + half * 128, n0, tn, tid);
-        } else {
-            epilogue_rows<T, T, 128, 512, 256, EMODE>(p, Cs, m0 + half * 128, n0, tn, tid);
-        }
-    }
-}
-
-template <int EMODE, int D>
-static int launch_gemm_v6_impl(GemmArgs a, hipStream_t stream) {
-    static PerDeviceOnce attr_set;
-    if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256r_kernel<EMODE, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    a.tiles_m = (a.M + 255) / 256;
-    a.tiles_n = (a.N + 255) / 256;
-    const int T_ = a.tiles_m * a.tiles_n;
-    const int nk = a.K / 64;
-    const int tail = T_ % 256;
-    a.full_tiles = T_;
-    a.ksplit = 1;
-    if (g_split_tail && a.ws && T_ > 256 && tail > 0 && tail <= 64 && nk >= 64) {  // same split-K tail policy as the two-buffer kernel
-        int S = 256 / tail;
-        if (S > 8) S = 8;
-        if (S > nk / 8) S = nk / 8;
-        if (S >= 2 && (size_t)tail * S * 262144 <= a.ws_bytes) {
-            a.full_tiles = T_ - tail;
-            a.ksplit = S;
-        }
-    }
-    gemm256r_kernel<EMODE, D><<<dim3(a.full_tiles + (T_ - a.full_tiles) * a.ksplit), dim3(512), 131072, stream>>>(a);
-    ULLSAM_LAUNCH_CHECK();
-    if (a.ksplit > 1) {
-        const int tail_tiles = T_ - a.full_tiles;
-        if (tail_tiles * a.ksplit <= 128) gemm256_tail_reduce_kernel<bf16, 4, 128, EMODE><<<dim3(tail_tiles * 64), dim3(128), 0, stream>>>(a);
-        else gemm256_tail_reduce_kernel<bf16, 16, 256, EMODE><<<dim3(tail_tiles * 16), dim3(256), 0, stream>>>(a);
-        ULLSAM_LAUNCH_CHECK();
-    }
-    return 0;
-}
-static int launch_gemm_v6(const GemmArgs& a, hipStream_t stream) {
-    if (a.act == 4) return launch_gemm_v6_impl<1, 2>(a, stream);
-    return launch_gemm_v6_impl<0, 2>(a, stream);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// v8: 256 x 320 tile on the ring of four half-K stages (bf16).  Why a fifth column of sub-tiles: the ViT-H widths are multiples of 320
-// (1280 = 4 x 320, 3840 = 12 x 320), and with 64 tile rows (M = 16384) that makes the tile count a multiple of the 256 CUs --
-// `vit.proj` / `vit.lin2` (N = 1280) are 256 tiles = ONE full round instead of 320 tiles of 256x256 (1.25 rounds: the 128x128 kernel or a
-// split-K tail), `vit.qkv` 768 tiles = 3 rounds of 1.25 x the work instead of 4.  Same waves (2 x 4, now 128 x 80 per wave: 8 x 5
-// sub-tiles, 160 accumulator registers), stagger and LDS image as gemm256r_kernel; a stage is 16 KiB of A + 20 KiB of B (36 KiB, four
-// stages = 144 KiB), 16 + 20 DMA pieces: waves 0-3 (= group 0) request 5 pieces per stage, waves 4-7 request 4, so the counted wait
-// differs by group.  Per stage and wave: 4-5 pieces, 13 fragment reads, 40 MFMAs.  The epilogue stages 128 rows x 320 fp32 = the whole
-// 160 KiB of LDS at a time.
-// ---------------------------------------------------------------------------------------------------------------
-template <int MI0, int MI1, int NTW, int EMODE, bool STAMP = false, int LV = 1>   // sub-tile rows of the upper / lower wave row, sub-tile columns per wave; LV: main-loop version (0 = round 2's, A/B)
+template <int MI0, int MI1, int NTW, bool STAMP = false>   // sub-tile rows of the upper / lower wave row, sub-tile columns per wave
 __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned long long t_entry = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;   // (diagnostic build) the workgroup's first instruction
@@ -1532,7 +761,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     //   SwiGLU (NTW 4):  128 (wb >> 1) + 64 (j >> 1) + 32 (wb & 1) + 8 (r >> 2) + 4 (j & 1) + (r & 3)          fp32 out:  R
     static_assert(NTW == 4 || NTW == 5, "epilogue layouts below: four sub-tiles in two pairs, optionally a fifth on its own");
     constexpr int WW = 16 * NTW;
-    const int perm = p.out_f32 ? 0 : ((p.act == 3 || p.act == 4) ? 2 : 1);   // (RoPE pairs column d with d + 64 like SwiGLU pairs gate with up)
+    const int perm = p.out_f32 ? 0 : (p.act == 3 ? 2 : 1);
     auto w_row = [&](int R) {
         const int wb = R / WW, q = R - wb * WW, j = q >> 4, r = q & 15;
         if (perm == 1) return j < 4 ? WW * wb + 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3) : WW * wb + 64 + r;
@@ -1585,7 +814,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     float bv[4 * NTW];
 #pragma unroll
     for (int e = 0; e < 4 * NTW; ++e) bv[e] = 0.f;
-    if (p.bias && EMODE == 0 && p.act != 3) {
+    if (p.bias && p.act != 3) {
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             const int col = n0 + wn * WW + ((p.out_f32 || t == 4) ? 16 * t + 4 * g4 : 32 * (t >> 1) + 8 * g4 + 4 * (t & 1));
@@ -1609,56 +838,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
         if (STAMP && p.dbg && (tid & 255) == 0) p.dbg[(1 << 19) + ((size_t)bid * 2 + grp) * 8 + kk] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
-    if constexpr (LV == 0) {
-        for (int s = 0; s < st1; ++s) {
-            const char* Ab = smem + (s & 3) * STG;
-            const char* Bb = Ab + ASZ;
-            Frag<T> a8[MI], b[NTW];
-            // ---- L(s): requests and fragment reads INTERLEAVED.  A wave's 4-5 requests are held back by the address unit (18 KiB per group and
-            // stage at 64 B/clk: ~400 cycles), its 12-13 reads by the LDS (52 KiB at 256 B/clk: ~250); issued one kind after the other the two
-            // times add up (650 > the partner group's 576-640 matrix cycles the slot should hide under); alternated, the LDS serves the reads
-            // while the next request waits for the address unit.
-            {
-                const bool more = s + 2 < st1;
-                char* base = smem + ((s + 2) & 3) * STG;
-                const char* ak = a_base + (size_t)(s + 2) * 64;
-                const char* bk = b_base + (size_t)(s + 2) * 64;
-                auto request = [&](int qi) __attribute__((always_inline)) {   // request qi of this wave: A0 B0 A1 B1 A2 B2
-                    const int i = qi >> 1;
-                    if (!(qi & 1)) { if (more && i < na) __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_off[i]), LDS_PTR(base + (wave + 8 * i) * 1024), 16, 0, 0); }
-                    else { if (more && i < nb) __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + ASZ + (wave + 8 * i) * 1024), 16, 0, 0); }
-                    __builtin_amdgcn_sched_barrier(0);
-                };
-                int qi = 0;
-                request(qi++);
-    #pragma unroll
-                for (int r = 0; r < NTW + MI; ++r) {
-                    if (r < NTW) b[r] = frag(Bb, wn * (16 * NTW) + r * 16 + mm);
-                    else if ((r - NTW) < MI1 || (r - NTW) < mi) a8[r - NTW] = frag(Ab, row_w + (r - NTW) * 16 + mm);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if ((r % 3) == 2 && qi < 6) request(qi++);
-                }
-    #pragma unroll
-                for (; qi < 6; ++qi) request(qi);
-            }
-            // stage s+1 must have landed before the barrier that lets anyone read it; the younger stage stays in flight
-            if (s + 2 < st1) wait_one_left();
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // ---- C(s)
-            __builtin_amdgcn_s_setprio(1);
-    #pragma unroll
-            for (int i = 0; i < MI; ++i)
-                if (i < MI1 || i < mi) {
-    #pragma unroll
-                    for (int j = 0; j < NTW; ++j) mma16(b[j], a8[i], acc[i][j]);
-                }
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-        }
-    } else {
+    {
         // Round 3: the same schedule with everything a stage decides at run time decided ONCE.  The load slot is the critical path of a stage
         // (it is longer than the partner group's matrix slot), and the wave's instruction stream is in order: every scalar compare / branch in
         // it -- "is there a stage s + 2?", "does this wave own a third piece?", the five-way choice of the counted wait -- sat between the
@@ -1735,8 +915,8 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
         const bool odd = mm & 1;
         const int row0 = m0 + row_w + mm;
         const int rowp = row0 & ~1;   // after pair_swap the lane pair (mm, mm ^ 1) owns rows rowp + 16 i and rowp + 16 i + 1
-        const bool direct = EMODE == 0 && p.vec_ok && (p.N & 7) == 0 && (p.M & 1) == 0;
-        auto gst = [&](void* ptr, u32x4 v) __attribute__((always_inline)) { store16_policy(ptr, __builtin_bit_cast(u32x4s, v), p.store_nt); };
+        const bool direct = p.vec_ok && (p.N & 7) == 0 && (p.M & 1) == 0;
+        auto gst = [&](void* ptr, u32x4 v) __attribute__((always_inline)) { *reinterpret_cast<u32x4*>(ptr) = v; };
         if (direct && !p.out_f32 && p.act != 3) {
             // bf16 (+bias, +GELU / ReLU): sub-tiles (2 h, 2 h + 1) are this lane's 8 columns of the 32-column group h; the two groups are 128 contiguous
             // bytes of a row -> pair_swap; the fifth sub-tile of a 320-wide tile is 4 columns (8 bytes) of the lane's own row
@@ -1746,7 +926,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
             T* cp5 = reinterpret_cast<T*>(p.C) + (size_t)row0 * p.ldc + col5;
             auto drain = [&](auto ACT) __attribute__((always_inline)) {
                 auto actf = [&](float v) __attribute__((always_inline)) {
-                    if constexpr (decltype(ACT)::value == 1) return (p.ablate & 2) ? gelu_erf(v) : gelu_erfc5(v);   // (ablate bit 1: the two-transcendental erf form, A/B)
+                    if constexpr (decltype(ACT)::value == 1) return gelu_erfc5(v);   // results are rounded to bf16: the one-transcendental form (common.h), gated by tests/test_kernels_gpu.py
                     else if constexpr (decltype(ACT)::value == 2) return fmaxf(v, 0.f);
                     else return v;
                 };
@@ -1791,57 +971,10 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
                     const float g0 = acc[i][q >> 1][2 * (q & 1)], g1 = acc[i][q >> 1][2 * (q & 1) + 1];
                     const float u0 = acc[i][2 + (q >> 1)][2 * (q & 1)], u1 = acc[i][2 + (q >> 1)][2 * (q & 1) + 1];
                     // silu = g * rcp(1 + exp(-g)) with the hardware reciprocal (1 ulp) instead of the correctly rounded division (ten instructions): the
-                    // result is rounded to bf16 two lines below.  (ablate bit 0 = the division, for A/B)
-                    if (p.ablate & 1) o[q] = pack_bf16x2(silu_f(g0) * u0, silu_f(g1) * u1);
-                    else o[q] = pack_bf16x2(g0 * __builtin_amdgcn_rcpf(1.0f + __expf(-g0)) * u0, g1 * __builtin_amdgcn_rcpf(1.0f + __expf(-g1)) * u1);
+                    // result is rounded to bf16 two lines below (gated to 1e-5 of the exact form by tests/test_kernels_gpu.py)
+                    o[q] = pack_bf16x2(g0 * __builtin_amdgcn_rcpf(1.0f + __expf(-g0)) * u0, g1 * __builtin_amdgcn_rcpf(1.0f + __expf(-g1)) * u1);
                 }
                 if (row0 + 16 * i < p.M) gst(cp + (size_t)(16 * i) * p.ldc, (u32x4){o[0], o[1], o[2], o[3]});
-            }
-        } else if (NTW == 4 && EMODE == 1 && p.act == 4 && p.vec_ok) {
-            // wqkv + RoPE + KV-cache append (modeling_internlm2.py:361-388, 233-247): the tile's 256 columns are two 128-wide head slots; with the
-            // SwiGLU-style permutation this lane holds columns d .. d + 7 (sub-tiles 0 / 1) and their rotate_half partners d + 64 .. (sub-tiles 2 / 3)
-            const int slot = (n0 >> 7) + (wn >> 1), d = 32 * (wn & 1) + 8 * g4;
-            const int gs = p.rope_G + 2, kv = slot / gs, g = slot - kv * gs;
-            const bool live = slot < p.rope_KVH * gs;
-            const bool rotate = g != gs - 1;
-            float bl[8], bh[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { bl[e] = (p.bias && live) ? p.bias[slot * 128 + d + e] : 0.f; bh[e] = (p.bias && live) ? p.bias[slot * 128 + d + 64 + e] : 0.f; }
-            T* Q = reinterpret_cast<T*>(p.rope_q);
-            T* Kc = reinterpret_cast<T*>(p.rope_k);
-            T* Vc = reinterpret_cast<T*>(p.rope_v);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                if (!(i < MI1 || i < mi)) continue;
-                const int gm = row0 + 16 * i;
-                if (gm >= p.M || !live) continue;
-                float x[8], y[8], lo[8], hi[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { x[e] = acc[i][e >> 2][e & 3] + bl[e]; y[e] = acc[i][2 + (e >> 2)][e & 3] + bh[e]; }
-                if (rotate) {
-                    const int ps = min(max(p.rope_pos[gm], 0), p.rope_rows - 1);
-                    const float* cp = p.rope_cos + (size_t)ps * 128 + d;
-                    const float* sp = p.rope_sin + (size_t)ps * 128 + d;
-                    const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
-                    const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
-                    const float4 c2 = *reinterpret_cast<const float4*>(cp + 64), c3 = *reinterpret_cast<const float4*>(cp + 68);
-                    const float4 s2 = *reinterpret_cast<const float4*>(sp + 64), s3 = *reinterpret_cast<const float4*>(sp + 68);
-                    const float cl[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sl[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-                    const float ch[8] = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w}, sh[8] = {s2.x, s2.y, s2.z, s2.w, s3.x, s3.y, s3.z, s3.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { lo[e] = x[e] * cl[e] - y[e] * sl[e]; hi[e] = y[e] * ch[e] + x[e] * sh[e]; }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { lo[e] = x[e]; hi[e] = y[e]; }
-                }
-                T* dst;
-                if (g < p.rope_G) dst = Q + (size_t)gm * ((size_t)p.rope_KVH * p.rope_G * 128) + (size_t)(kv * p.rope_G + g) * 128 + d;
-                else {
-                    const int bi = gm / p.rope_S, sq = gm - bi * p.rope_S;
-                    dst = (g == gs - 2 ? Kc : Vc) + (((size_t)bi * p.rope_KVH + kv) * p.rope_cap + p.rope_pos0 + sq) * 128 + d;
-                }
-                store_row8<T>(dst, lo, 8, true);
-                store_row8<T>(dst + 64, hi, 8, true);
             }
         } else if (direct && p.out_f32 && p.act == 0) {
             // fp32 residual stream: C = acc + bias + residual[row (mod res_row_mod)]; sub-tiles (2 jp, 2 jp + 1) are 128 contiguous bytes of a row
@@ -1927,8 +1060,8 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
                             *reinterpret_cast<float4*>(Cs + (i * 16 + mm) * BN + ncol(j)) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
                 }
                 __syncthreads();
-                if (p.out_f32) epilogue_rows<T, float, ROWS, NT_E, BN, EMODE>(p, Cs, m0 + half * 16 * MI0, n0, tn, tid);
-                else epilogue_rows<T, T, ROWS, NT_E, BN, EMODE>(p, Cs, m0 + half * 16 * MI0, n0, tn, tid);
+                if (p.out_f32) epilogue_rows<T, float, ROWS, NT_E, BN>(p, Cs, m0 + half * 16 * MI0, n0, tn, tid);
+                else epilogue_rows<T, T, ROWS, NT_E, BN>(p, Cs, m0 + half * 16 * MI0, n0, tn, tid);
             };
             staged(std::integral_constant<int, 0>{});
             staged(std::integral_constant<int, 1>{});
@@ -1938,468 +1071,28 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     if (STAMP && p.dbg && (tid & 255) == 0) p.dbg[((size_t)bid * 2 + grp) * 4 + 3] = t_entry;
 }
 
-template <int MI0, int MI1, int NTW, int EMODE = 0>
+template <int MI0, int MI1, int NTW>
 static int launch_gemm_ring8(GemmArgs a, hipStream_t stream) {
     constexpr int BM = 16 * (MI0 + MI1), BN = 64 * NTW;
     constexpr int LDS = (4 * (BM + BN) * 64 > 16 * MI0 * BN * 4) ? 4 * (BM + BN) * 64 : 16 * MI0 * BN * 4;   // the ring, or the epilogue's staging rows
     static_assert(LDS <= 163840, "160 KiB of LDS per CU");
     static PerDeviceOnce attr_set;
-    if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW, EMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (attr_set.first()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    }
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     a.full_tiles = a.tiles_m * a.tiles_n;
     a.ksplit = 1;
-    if (a.dbg && EMODE == 0) {   // stamped diagnostic build (tools/probes/ring8_stamps.py)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        gemm_ring8_kernel<MI0, MI1, NTW, 0, true><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
-    } else if (g_ring_lv == 0) {   // round 2's main loop (A/B: ullsam_set_gemm_tuning(2, 0))
-        static PerDeviceOnce attr0;
-        if (attr0.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW, EMODE, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        gemm_ring8_kernel<MI0, MI1, NTW, EMODE, false, 0><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
-    } else
-    gemm_ring8_kernel<MI0, MI1, NTW, EMODE><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
+    if (a.dbg) gemm_ring8_kernel<MI0, MI1, NTW, true><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);   // stamped diagnostic build (tools/probes/ring8_stamps.py)
+    else gemm_ring8_kernel<MI0, MI1, NTW><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
+static int launch_gemm_v6(const GemmArgs& a, hipStream_t stream) { return launch_gemm_ring8<8, 8, 4>(a, stream); }   // 256 x 256
 static int launch_gemm_v8(const GemmArgs& a, hipStream_t stream) { return launch_gemm_ring8<8, 8, 5>(a, stream); }   // 256 x 320
 static int launch_gemm_v9(const GemmArgs& a, hipStream_t stream) { return launch_gemm_ring8<9, 8, 4>(a, stream); }   // 272 x 256
-static int launch_gemm_ring_rope(const GemmArgs& a, hipStream_t stream) { return launch_gemm_ring8<8, 8, 4, 1>(a, stream); }   // 256 x 256, wqkv + RoPE epilogue
-
-// ---------------------------------------------------------------------------------------------------------------
-// v7: 256x256 tile, FOUR waves (2 x 2, 128x128 per wave, 256 accumulator registers per lane: one wave per SIMD with the whole
-// 512-entry register file), the ring of four half-K stages of v6, and ONE software-pipelined instruction stream per wave instead of
-// two wave groups taking turns: while the 64 MFMAs of stage s run from registers, the same wave reads the 16 fragments of stage
-// s+1 and requests its 8 LDS-DMA pieces of stage s+4, spread evenly between the MFMAs (sched_group_barrier).
-// Why: (1) fragment reads per MFMA drop by a third (16 per 64 MFMAs instead of 12 per 32: LDS array time 62 % -> 50 % of the MFMA
-// time, and LDS bytes are energy on a power-bound loop); (2) the LDS-DMA requests reach the address unit one per ~128 cycles and
-// wave instead of 32 at once at the top of a load slot (where they queue at 16 cycles per KiB and hold back the fragment reads
-// behind them); (3) it is the shape the vendor library's kernels for this chip have (rocprofv3 of tools/gemm_bench.py: 256 threads,
-// MT256x256x64, 130 KiB LDS, 512 registers).
-// Per stage: wait (own pieces of stage s+1 landed: vmcnt(16) leaves s+2, s+3 in flight; fragments of stage s in registers) ->
-// s_barrier (everyone's pieces of s+1 landed; everyone has finished reading stage s = ring slot s & 3, which the DMA of s+4 reuses)
-// -> {8 DMA pieces, 16 ds_read_b128, 64 MFMAs} interleaved.  The request leads its use by three stages (~3 kilo-cycles).
-// LDS image and DMA pieces as in v6.  The number of stages per K-range is even (ranges are cut on 64-deep K-tiles), so the two
-// fragment register sets alternate statically.
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void mma16a(const Frag<bf16>& a, const Frag<bf16>& b, f32x4& c) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a.v), "v"(b.v));
-}
-template <int EMODE, bool STAMP = false, int ABL = 0>   // ABL (stamped diagnostic builds only; results are garbage): 1 no DMA requests, 2 no fragment reads, 4 no barrier
-__global__ __launch_bounds__(256) void gemm256w_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef bf16 T;
-    constexpr int STG = 32768;  // 16 KiB A + 16 KiB B per stage
-
-    const int nblk = p.full_tiles;
-    const int bid = blockIdx.x;
-    int swz, part = -1, tail_idx = 0;
-    if (bid < nblk) {
-        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-        swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    } else {
-        const int t = bid - nblk;
-        tail_idx = t / p.ksplit;
-        part = t - tail_idx * p.ksplit;
-        swz = nblk + tail_idx;
-    }
-    const int GM = p.group_m;
-    const int width = GM * p.tiles_n;
-    const int group = swz / width;
-    const int first_m = group * GM;
-    const int gsize = min(p.tiles_m - first_m, GM);
-    const int tm = first_m + (swz % width) % gsize;
-    const int tn = (swz % width) / gsize;
-    const int m0 = tm * 256, n0 = tn * 256;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int g4 = lane >> 4, mm = lane & 15;
-
-    // DMA pieces of this wave: A pieces 4w .. 4w+3 and B pieces 4w .. 4w+3 (16 rows x 64 B each); lane -> row 16 piece + lane / 4, LDS chunk lane & 3
-    const char* a_base = reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda * 2;
-    const char* b_base = reinterpret_cast<const char*>(p.W) + (size_t)n0 * p.ldw * 2;
-    // The MFMA operands are SWAPPED (first operand = weight fragment): a lane's four accumulator registers of a 16x16 sub-tile are four
-    // consecutive COLUMNS of one output row, so the epilogue stores straight from the accumulators.  For 2-byte outputs the weight rows
-    // of a wave are permuted on their way into the LDS so that two neighbouring sub-tiles give a lane eight consecutive columns (16 B):
-    //   LDS row R of the tile (wave half wb = R >> 7, sub-tile j = (R >> 4) & 7, r = R & 15) holds weight row
-    //   n(R) = 128 wb + 32 (j >> 1) + 8 (r >> 2) + 4 (j & 1) + (r & 3);   fp32 outputs keep n = R (four fp32 = 16 B per lane and sub-tile).
-    const bool permuted = !p.out_f32;
-    auto w_row = [&](int R) {
-        const int j = (R >> 4) & 7, r = R & 15;
-        return permuted ? (R & 128) + 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3) : R;
-    };
-    unsigned int a_off[4], b_off[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((row >> 2) & 2);
-        a_off[i] = (unsigned int)((size_t)(min(m0 + row, p.M - 1) - m0) * p.lda * 2) + (c << 4);
-        b_off[i] = (unsigned int)((size_t)(min(n0 + w_row(row), p.N - 1) - n0) * p.ldw * 2) + (c << 4);
-    }
-    // in-loop requests go through buffer descriptors (buffer_load_dwordx4 ... lds): the instruction offset is added to the memory AND
-    // the LDS address (tools/probes/buffer_lds.hip), so the four pieces of a matrix share one M0 (lane offsets pre-decremented by
-    // 1 KiB per piece), and an SGPR offset at or past num_records turns a request into a no-fetch (stages past the end; rows past
-    // M / N read as zeros) -- per piece ONE instruction, no compare, no branch, no address arithmetic
-    i32x4s rsrc_a, rsrc_b;
-    rsrc_a[0] = (int)(size_t)a_base; rsrc_a[1] = (int)((size_t)a_base >> 32) & 0xffff; rsrc_a[2] = (int)((long)min(p.M - m0, 256) * p.lda * 2); rsrc_a[3] = 0x00020000;
-    rsrc_b[0] = (int)(size_t)b_base; rsrc_b[1] = (int)((size_t)b_base >> 32) & 0xffff; rsrc_b[2] = (int)((long)min(p.N - n0, 256) * p.ldw * 2); rsrc_b[3] = 0x00020000;
-    unsigned int a_vo[4], b_vo[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((row >> 2) & 2);
-        a_vo[i] = (unsigned int)((size_t)row * p.lda * 2) + (c << 4) - i * 1024;
-        b_vo[i] = (unsigned int)((size_t)w_row(row) * p.ldw * 2) + (c << 4) - i * 1024;
-    }
-    const int nq = p.K >> 7;   // K ranges in units of four stages (128 elements): ring slots are compile-time constants in the loop
-    const int st0 = part < 0 ? 0 : 4 * (int)((long)part * nq / p.ksplit);
-    const int st1 = part < 0 ? 4 * nq : 4 * (int)((long)(part + 1) * nq / p.ksplit);
-
-    f32x4 acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // fragment read addresses: row = w * 128 + i * 16 + mm, so the swizzle term (row >> 2) & 2 depends on mm only and i is a constant offset
-    const int rd_swz = ((g4 ^ ((mm >> 2) & 2)) << 4) + mm * 64;
-    const int a_rd = wm * 8192 + rd_swz;
-    const int b_rd = 16384 + wn * 8192 + rd_swz;
-
-    auto stage = [&](int s) {   // request stage s into ring slot s & 3
-        char* base = smem + (s & 3) * STG + wave * 4096;
-        const char* ak = a_base + (size_t)s * 64;
-        const char* bk = b_base + (size_t)s * 64;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_off[i]), LDS_PTR(base + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + 16384 + i * 1024), 16, 0, 0);
-        }
-    };
-    auto read_frags = [&](int s, Frag<T>* fa, Frag<T>* fb) {
-        const char* Ab = smem + (s & 3) * STG + a_rd;
-        const char* Bb = smem + (s & 3) * STG + b_rd;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            fa[i] = load_frag(reinterpret_cast<const T*>(Ab + i * 1024));
-            fb[i] = load_frag(reinterpret_cast<const T*>(Bb + i * 1024));
-        }
-    };
-    // One stage.  With ONE wave per SIMD every instruction of the stream takes a ~4-cycle issue slot and a 16-cycle MFMA leaves two
-    // of them free, so the stream is written to the slot: per 8 MFMAs three ds_read_b128 and one DMA request, nothing else.
-    //  * The MFMAs are inline asm with the accumulators pinned to AGPRs ("+a"): left to itself the register allocator keeps part of
-    //    the 256 accumulators in VGPRs and shuffles them through v_accvgpr moves inside the loop.  The asm is opaque to the hazard
-    //    recogniser, so the K loop is ONE loop (a peeled tail gets a different register assignment and accumulator copies next to
-    //    the MFMAs) and branch-free: the requests of the last four stages are issued out of range (no fetch, but still counted by
-    //    vmcnt, so the counted wait at the top of a stage never changes), the reads past the end fetch stale bytes.
-    //  * A DMA request is ONE instruction (buffer_load_dwordx4 ... lds, see the descriptors above); M0 is written twice per stage.
-    //  * Four stages per loop trip (K ranges are multiples of 128): ring slots, LDS addresses and M0 values are compile-time constants.
-    //  * sched_barrier(0) after every element keeps the source order: 8 x { 2 MFMA, read, 2 MFMA, request, 2 MFMA, read, 2 MFMA, read },
-    //    the 16 reads issued by the sixth group (the top of the next stage waits for all of them: its ring slot is requested again);
-    //    the stage's first MFMA pair goes BEFORE the s_barrier (registers only) and covers part of its latency.
-    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
-    const unsigned wave_lds = lds0 + wave * 4096;
-    // fragment read bases for ring slots {0, 1} and {2, 3} (ds_read offsets are 16 bits); the upper pair is laundered so that it stays
-    // its own register instead of being re-derived with a VALU add in front of every read
-    int a_hi = a_rd + 65536, b_hi = b_rd + 65536;
-    asm volatile("" : "+v"(a_hi), "+v"(b_hi));
-    const char* rdA[2] = {smem + a_rd, smem + a_hi};
-    const char* rdB[2] = {smem + b_rd, smem + b_hi};
-    int kbyte = (st0 + 4) * 64;   // K byte offset of the stage requested next
-    auto iter = [&](auto slot_c, const Frag<T>* ca, const Frag<T>* cb, Frag<T>* na, Frag<T>* nb) {
-        constexpr int U = decltype(slot_c)::value;        // this stage's ring slot = the slot the request for stage s + 4 goes to
-        constexpr int R = (U + 1) & 3;                     // the slot of stage s + 1, whose fragments are read now
-        const char* Ab = rdA[R >> 1] + (R & 1) * STG;
-        const char* Bb = rdB[R >> 1] + (R & 1) * STG;
-        const int soff = kbyte < st1 * 64 ? kbyte : 0x40000000;   // past the end: out of range of either descriptor
-        auto rd = [&](int r) {   // read r of 16: the B fragments first (the next stage's first MFMAs need all of them)
-            if (ABL & 2) return;
-            if (r < 8) nb[r] = load_frag(reinterpret_cast<const T*>(Bb + r * 1024));
-            else na[r - 8] = load_frag(reinterpret_cast<const T*>(Ab + (r - 8) * 1024));
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto request = [&](int q) {
-            if (ABL & 1) return;
-            if ((ABL & 16) && wave != 0) return;   // (diagnostic) only wave 0 requests: is a request's cost its own issue or the four waves colliding?
-            const unsigned vo = q < 4 ? a_vo[q & 3] : b_vo[q & 3];
-            const i32x4s rs = q < 4 ? rsrc_a : rsrc_b;
-            switch (q & 3) {
-                case 0: asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(vo), "s"(rs), "s"(soff) : "memory"); break;
-                case 1: asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:1024 lds" :: "v"(vo), "s"(rs), "s"(soff) : "memory"); break;
-                case 2: asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:2048 lds" :: "v"(vo), "s"(rs), "s"(soff) : "memory"); break;
-                default: asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:3072 lds" :: "v"(vo), "s"(rs), "s"(soff) : "memory"); break;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        // own pieces of stage s + 1 landed (the 16 of s + 2, s + 3 may stay in flight), fragments of stage s in registers
-        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            mma16a(cb[0], ca[q], acc[q][0]); mma16a(cb[1], ca[q], acc[q][1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (q == 0) {
-                // everyone's pieces of s + 1 landed; everyone has read stage s (slot U) -- its slot may be requested again
-                if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if ((q & 3) == 0 && !(ABL & 1)) {   // M0 for the next four pieces (A: q 0-3, B: q 4-7); the instructions up to the request are its wait states
-                asm volatile("s_add_i32 m0, %0, %1" :: "s"(wave_lds), "i"(U * STG + (q >> 2) * 16384));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (3 * q < 16) rd(3 * q);
-            mma16a(cb[2], ca[q], acc[q][2]); mma16a(cb[3], ca[q], acc[q][3]);
-            __builtin_amdgcn_sched_barrier(0);
-            request(q);
-            mma16a(cb[4], ca[q], acc[q][4]); mma16a(cb[5], ca[q], acc[q][5]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (3 * q + 1 < 16) rd(3 * q + 1);
-            mma16a(cb[6], ca[q], acc[q][6]); mma16a(cb[7], ca[q], acc[q][7]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (3 * q + 2 < 16) rd(3 * q + 2);
-            if (q == 6) { kbyte += 64; __builtin_amdgcn_sched_barrier(0); }
-        }
-    };
-    typedef std::integral_constant<int, 0> S0; typedef std::integral_constant<int, 1> S1;
-    typedef std::integral_constant<int, 2> S2; typedef std::integral_constant<int, 3> S3;
-
-    // (diagnostic build only) shader-clock stamps per workgroup: start, loop entry, loop exit, end
-    auto stamp = [&](int k) {
-        if (STAMP && tid == 0 && p.dbg) {
-            p.dbg[(size_t)bid * 8 + k] = __builtin_amdgcn_s_memtime();
-            if (k == 0 || k == 3) p.dbg[(size_t)bid * 8 + 4 + (k & 1)] = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock: shader clock = d(memtime) / d(realtime)
-        }
-    };
-    stamp(0);
-    // this lane's 32 output columns (permuted: 8 at 32 jp + 8 g4 for jp = 0..3; fp32: 4 at 16 j + 4 g4 for j = 0..7) keep their bias in
-    // registers across the K loop (requested first: the prologue's counted wait below covers them)
-    float bv[32];
-#pragma unroll
-    for (int e = 0; e < 32; ++e) bv[e] = 0.f;
-    if (p.bias && part < 0 && EMODE == 0) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int col = n0 + wn * 128 + (permuted ? 32 * (t >> 1) + 8 * g4 + 4 * (t & 1) : 16 * t + 4 * g4);
-            if (col < p.N) {   // N % 4 == 0 on the direct path (vec_ok); the staged path fetches its own bias
-                const float4 x = *reinterpret_cast<const float4*>(p.bias + col);
-                bv[4 * t] = x.x; bv[4 * t + 1] = x.y; bv[4 * t + 2] = x.z; bv[4 * t + 3] = x.w;
-            }
-        }
-    }
-    Frag<T> fa0[8], fb0[8], fa1[8], fb1[8];
-    // prologue: the first four stages requested (st1 - st0 is a positive multiple of 4: launcher), stage st0 landed, its fragments read
-    stage(st0); stage(st0 + 1); stage(st0 + 2); stage(st0 + 3);
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    read_frags(st0, fa0, fb0);
-    stamp(1);
-    for (int s = st0; s < st1; s += 4) {
-        iter(S0{}, fa0, fb0, fa1, fb1);
-        iter(S1{}, fa1, fb1, fa0, fb0);
-        iter(S2{}, fa0, fb0, fa1, fb1);
-        iter(S3{}, fa1, fb1, fa0, fb0);
-    }
-    // let the last MFMAs retire before anything reads the accumulators (the asm MFMAs are opaque to the hazard recogniser); the
-    // out-of-range requests and the stale reads of the last stages must be done before the epilogue reuses the LDS
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    stamp(2);
-    if (STAMP && (p.ablate & 8)) return;   // (diagnostic) no epilogue
-
-    // ---- epilogue.  acc[i][j][r] = C[m0 + 128 wm + 16 i + mm][n0 + 128 wn + ncol(j) + r]
-    auto ncol = [&](int j) __attribute__((always_inline)) { return permuted ? 32 * (j >> 1) + 8 * g4 + 4 * (j & 1) : 16 * j + 4 * g4; };
-    const int row0 = m0 + wm * 128 + mm;            // this lane's row in sub-tile i is row0 + 16 i
-    const bool odd = mm & 1;
-    const int rowp = row0 & ~1;                     // after pair_swap the lane pair (mm, mm ^ 1) owns rows rowp + 16 i and rowp + 16 i + 1
-    auto gst = [&](void* ptr, u32x4 v) __attribute__((always_inline)) { store16_policy(ptr, __builtin_bit_cast(u32x4s, v), p.store_nt); };
-    const bool direct = EMODE == 0 && p.vec_ok && (p.N & 7) == 0 && (p.M & 1) == 0;
-    if (part >= 0) {
-        // K-range of a split tail tile: raw fp32 partial tile -> workspace [slot][256][256] (finished by gemm256_tail_reduce_kernel)
-        float* wp = p.ws + ((size_t)tail_idx * p.ksplit + part) * 65536 + (size_t)(wm * 128 + mm) * 256 + wn * 128;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                *reinterpret_cast<u32x4*>(wp + (size_t)(16 * i) * 256 + ncol(j)) =
-                    (u32x4){__float_as_uint(acc[i][j][0]), __float_as_uint(acc[i][j][1]), __float_as_uint(acc[i][j][2]), __float_as_uint(acc[i][j][3])};
-    } else if (direct && !p.out_f32 && p.act != 3) {
-        // bf16 output (+bias, +GELU / ReLU): sub-tile pairs (4 lp + 2 h, + 1) are this lane's 8 columns of the 32-column group 2 lp + h;
-        // groups 2 lp and 2 lp + 1 are the two halves of a 128 B line -> pair_swap, then one instruction writes 8 rows x 128 B
-        const int colb = n0 + wn * 128 + (odd ? 32 : 0) + 8 * g4;
-        T* cp = reinterpret_cast<T*>(p.C) + (size_t)rowp * p.ldc + colb;
-        auto drain = [&](auto ACT) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int lp = 0; lp < 2; ++lp) {
-                    unsigned int o[8];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float v0 = acc[i][4 * lp + 2 * h + (q >> 1)][2 * (q & 1)] + bv[16 * lp + 8 * h + 2 * q];
-                            float v1 = acc[i][4 * lp + 2 * h + (q >> 1)][2 * (q & 1) + 1] + bv[16 * lp + 8 * h + 2 * q + 1];
-                            if constexpr (decltype(ACT)::value == 1) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); }
-                            if constexpr (decltype(ACT)::value == 2) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                            o[4 * h + q] = pack_bf16x2(v0, v1);
-                        }
-                    u32x4 s0, s1;
-                    pair_swap((u32x4){o[0], o[1], o[2], o[3]}, (u32x4){o[4], o[5], o[6], o[7]}, odd, s0, s1);
-                    if (rowp + 16 * i < p.M && colb + 64 * lp < p.N) {   // M is even: both rows of the pair or neither
-                        gst(cp + (size_t)(16 * i) * p.ldc + 64 * lp, s0);
-                        gst(cp + (size_t)(16 * i + 1) * p.ldc + 64 * lp, s1);
-                    }
-                }
-        };
-        if (p.act == 1) drain(std::integral_constant<int, 1>{});
-        else if (p.act == 2) drain(std::integral_constant<int, 2>{});
-        else drain(std::integral_constant<int, 0>{});
-    } else if (direct && !p.out_f32 && p.act == 3) {
-        // SwiGLU: the wave's 128 columns are [64 gate | 64 up] (host prepack); gate = sub-tiles 0-3, up = 4-7 of the same 8 columns:
-        // out[:, n0/2 + 64 wn + 32 jp + 8 g4 + e] = silu(gate_e) * up_e   (modeling_internlm2.py:261-264)
-        const int colb = (n0 >> 1) + wn * 64 + (odd ? 32 : 0) + 8 * g4;
-        T* cp = reinterpret_cast<T*>(p.C) + (size_t)rowp * p.ldc + colb;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            unsigned int o[8];
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float g0 = acc[i][2 * h + (q >> 1)][2 * (q & 1)], g1 = acc[i][2 * h + (q >> 1)][2 * (q & 1) + 1];
-                    const float u0 = acc[i][4 + 2 * h + (q >> 1)][2 * (q & 1)], u1 = acc[i][4 + 2 * h + (q >> 1)][2 * (q & 1) + 1];
-                    o[4 * h + q] = pack_bf16x2(silu_f(g0) * u0, silu_f(g1) * u1);
-                }
-            u32x4 s0, s1;
-            pair_swap((u32x4){o[0], o[1], o[2], o[3]}, (u32x4){o[4], o[5], o[6], o[7]}, odd, s0, s1);
-            if (rowp + 16 * i < p.M) {
-                gst(cp + (size_t)(16 * i) * p.ldc, s0);
-                gst(cp + (size_t)(16 * i + 1) * p.ldc, s1);
-            }
-        }
-    } else if (direct && p.out_f32 && p.act == 0) {
-        // fp32 residual stream: C = acc + bias + residual[row (mod res_row_mod)].  Sub-tiles (2 jp, 2 jp + 1) are the two 64 B halves of the
-        // 128 B line jp -> pair_swap; afterwards this lane owns piece (odd ? 4 : 0) + g4 of line jp in rows rowp + 16 i and + 1.
-        // Two register sets alternate: the residual rows of sub-tile i + 1 are requested before sub-tile i is stored.
-        const int colp = n0 + wn * 128 + (odd ? 16 : 0) + 4 * g4;
-        float* cp = reinterpret_cast<float*>(p.C) + (size_t)rowp * p.ldc + colp;
-        auto load_res = [&](int i, float4 (&r)[8]) {   // r[2 jp + rsel]: line jp of row rowp + 16 i + rsel
-#pragma unroll
-            for (int rsel = 0; rsel < 2; ++rsel) {
-                const int gm = min(rowp + 16 * i + rsel, p.M - 1);
-                const int rr = p.res_row_mod > 0 ? gm % p.res_row_mod : gm;
-                const float* rp = p.residual + (size_t)rr * p.ldr + colp;
-#pragma unroll
-                for (int jp = 0; jp < 4; ++jp) r[2 * jp + rsel] = colp + 32 * jp < p.N ? *reinterpret_cast<const float4*>(rp + 32 * jp) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        };
-        auto put = [&](int i, const float4 (&r)[8]) {
-#pragma unroll
-            for (int jp = 0; jp < 4; ++jp) {
-                u32x4 lo, hi, s0, s1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    lo[e] = __float_as_uint(acc[i][2 * jp][e] + bv[8 * jp + e]);
-                    hi[e] = __float_as_uint(acc[i][2 * jp + 1][e] + bv[8 * jp + 4 + e]);
-                }
-                pair_swap(lo, hi, odd, s0, s1);
-                const float4 r0 = r[2 * jp], r1 = r[2 * jp + 1];
-                s0 = (u32x4){__float_as_uint(__uint_as_float(s0[0]) + r0.x), __float_as_uint(__uint_as_float(s0[1]) + r0.y),
-                             __float_as_uint(__uint_as_float(s0[2]) + r0.z), __float_as_uint(__uint_as_float(s0[3]) + r0.w)};
-                s1 = (u32x4){__float_as_uint(__uint_as_float(s1[0]) + r1.x), __float_as_uint(__uint_as_float(s1[1]) + r1.y),
-                             __float_as_uint(__uint_as_float(s1[2]) + r1.z), __float_as_uint(__uint_as_float(s1[3]) + r1.w)};
-                if (rowp + 16 * i < p.M && colp + 32 * jp < p.N) {
-                    *reinterpret_cast<u32x4*>(cp + (size_t)(16 * i) * p.ldc + 32 * jp) = s0;
-                    *reinterpret_cast<u32x4*>(cp + (size_t)(16 * i + 1) * p.ldc + 32 * jp) = s1;
-                }
-            }
-        };
-        auto drain = [&](auto RES) __attribute__((always_inline)) {
-            float4 ra[8], rb[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ra[j] = rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (decltype(RES)::value) load_res(0, ra);
-#pragma unroll
-            for (int i = 0; i < 8; i += 2) {
-                if constexpr (decltype(RES)::value) { load_res(i + 1, rb); __builtin_amdgcn_sched_barrier(0); }
-                put(i, ra);
-                if constexpr (decltype(RES)::value) { if (i + 2 < 8) load_res(i + 2, ra); __builtin_amdgcn_sched_barrier(0); }
-                put(i + 1, rb);
-            }
-        };
-        if (p.residual) drain(std::true_type{}); else drain(std::false_type{});
-    } else {
-        // every other epilogue (RoPE, activations on fp32 outputs, unaligned / odd shapes): through the LDS, one 128-row half at a time
-        float* Cs = reinterpret_cast<float*>(smem);  // [128][256] fp32 = 128 KiB
-        auto staged = [&](auto half_c) __attribute__((always_inline)) {   // (a lambda called twice: as a loop the two bulky bodies are not unrolled and the accumulators land in scratch)
-            constexpr int half = decltype(half_c)::value;
-            __syncthreads();
-            if (wm == half) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        *reinterpret_cast<float4*>(Cs + (i * 16 + mm) * 256 + wn * 128 + ncol(j)) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            }
-            __syncthreads();
-            if (p.out_f32) epilogue_rows<T, float, 128, 256, 256, EMODE>(p, Cs, m0 + half * 128, n0, tn, tid);
-            else epilogue_rows<T, T, 128, 256, 256, EMODE>(p, Cs, m0 + half * 128, n0, tn, tid);
-        };
-        staged(std::integral_constant<int, 0>{});
-        staged(std::integral_constant<int, 1>{});
-    }
-    stamp(3);
-}
-
-template <int EMODE>
-static int launch_gemm_v7_impl(GemmArgs a, hipStream_t stream) {
-    static PerDeviceOnce attr_set;
-    if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256w_kernel<EMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    a.tiles_m = (a.M + 255) / 256;
-    a.tiles_n = (a.N + 255) / 256;
-    const int T_ = a.tiles_m * a.tiles_n;
-    const int nk = a.K / 64;
-    const int tail = T_ % 256;
-    a.full_tiles = T_;
-    a.ksplit = 1;
-    if (g_split_tail && a.ws && T_ > 256 && tail > 0 && tail <= 64 && nk >= 64) {  // same split-K tail policy as the two-buffer kernel (a 2-way cut of a half-full last round measured slower: 862 vs 824 us on llm.w13)
-        int S = 256 / tail;
-        if (S > 8) S = 8;
-        if (S > nk / 8) S = nk / 8;
-        if (S >= 2 && (size_t)tail * S * 262144 <= a.ws_bytes) {
-            a.full_tiles = T_ - tail;
-            a.ksplit = S;
-        }
-    }
-    if (a.dbg && EMODE == 0) {   // stamped diagnostic builds (tools/probes/v7_stamps.py); the ablation comes in the variant's ablate bits
-        const dim3 grid(a.full_tiles + (T_ - a.full_tiles) * a.ksplit);
-        auto go = [&](auto kern) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-            kern<<<grid, dim3(256), 131072, stream>>>(a);
-        };
-        switch (a.ablate & 7) {
-            case 0: go(gemm256w_kernel<0, true, 0>); break;
-            case 1: go(gemm256w_kernel<0, true, 1>); break;
-            case 2: go(gemm256w_kernel<0, true, 2>); break;
-            case 4: go(gemm256w_kernel<0, true, 4>); break;
-            case 6: go(gemm256w_kernel<0, true, 16>); break;
-            default: go(gemm256w_kernel<0, true, 7>); break;
-        }
-    } else
-    gemm256w_kernel<EMODE><<<dim3(a.full_tiles + (T_ - a.full_tiles) * a.ksplit), dim3(256), 131072, stream>>>(a);
-    ULLSAM_LAUNCH_CHECK();
-    if (a.ksplit > 1) {
-        const int tail_tiles = T_ - a.full_tiles;
-        if (tail_tiles * a.ksplit <= 128) gemm256_tail_reduce_kernel<bf16, 4, 128, EMODE><<<dim3(tail_tiles * 64), dim3(128), 0, stream>>>(a);
-        else gemm256_tail_reduce_kernel<bf16, 16, 256, EMODE><<<dim3(tail_tiles * 16), dim3(256), 0, stream>>>(a);
-        ULLSAM_LAUNCH_CHECK();
-    }
-    return 0;
-}
-static int launch_gemm_v7(const GemmArgs& a, hipStream_t stream) {
-    if (a.act == 4) return launch_gemm_v7_impl<1>(a, stream);
-    return launch_gemm_v7_impl<0>(a, stream);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) GEMM for the ViT's LayerNorm-fed linears (BASELINE configs[4], "fp8 MFMA ViT path"): the 256x256 staggered
@@ -2540,7 +1233,7 @@ extern "C" int ullsam_gemm_fp8(const void* A8, long lda, const float* a_scale, c
     if (residual) vec = vec && ((uintptr_t)residual & 15) == 0 && (ldr % 4 == 0);
     a.group_m = 4;   // gemm256f8_kernel rasters with a fixed group height
     a.vec_ok = vec ? 1 : 0;
-    a.ablate = 0; a.ws = nullptr; a.ws_bytes = 0; a.shift_edge = 0; a.skew_ticks = 0; a.store_nt = 0; a.late = 0; a.ksplit = 1;
+    a.ws = nullptr; a.ws_bytes = 0; a.ksplit = 1;
     a.row_scale = a_scale; a.col_scale = w_scale; a.dbg = nullptr;
     a.tiles_m = (M + 255) / 256; a.tiles_n = (N + 255) / 256; a.full_tiles = a.tiles_m * a.tiles_n;
     static PerDeviceOnce attr_set;
@@ -2550,93 +1243,15 @@ extern "C" int ullsam_gemm_fp8(const void* A8, long lda, const float* a_scale, c
     return 0;
 }
 
-static int num_cus() {
-    static int n[32] = {};
-    int d = 0;
-    (void)hipGetDevice(&d);
-    d &= 31;
-    if (n[d] == 0) {
-        hipDeviceProp_t prop;
-        n[d] = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
-    return n[d];
-}
-
-template <int EPI>
-static int launch_gemm_v4_impl(GemmArgs a, hipStream_t stream) {
-    a.group_m = 4;   // the persistent kernel's unit list has a fixed group height (its tail reduce must agree)
-    static PerDeviceOnce attr_set;
-    if (attr_set.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 133120);
-    }
-    const int cus = num_cus();
-    a.shift_edge = 1;
-    a.store_nt = g_store_v4;
-    a.tiles_m = (a.M + 255) / 256;
-    a.tiles_n = a.N / 256;
-    const int T_ = a.tiles_m * a.tiles_n;
-    const int nk = a.K / 64;
-    // the tiles left over after the last full round of `cus` tiles are cut along K so that they fill the chip once more
-    const int tail = T_ % cus;
-    a.full_tiles = T_;
-    a.ksplit = 1;
-    if (g_split_tail && a.ws && T_ > cus && tail > 0 && tail <= cus / 4 && nk >= 64) {
-        int S = cus / tail;
-        if (S > 8) S = 8;
-        if (S > nk / 8) S = nk / 8;
-        if (S >= 2 && (size_t)tail * S * 262144 <= a.ws_bytes) {
-            a.full_tiles = T_ - tail;
-            a.ksplit = S;
-        }
-    }
-    const int n_units = a.full_tiles + (T_ - a.full_tiles) * a.ksplit;
-    // start-time spread of the workgroups (see the kernel): measured neutral at 5 / 10 / 20 us on every shape (the per-CU store path, not
-    // the chip-wide burst, bounds the epilogue: tools/store_probe.hip), so it is off unless the A/B switch sets it
-    a.skew_ticks = 0;
-    if (g_skew_half_us > 0) a.skew_ticks = g_skew_half_us * 50;
-    gemm256p_kernel<EPI><<<dim3(n_units < cus ? n_units : cus), dim3(512), 133120, stream>>>(a);
-    ULLSAM_LAUNCH_CHECK();
-    if (a.ksplit > 1) {
-        const int tail_tiles = T_ - a.full_tiles;
-        if (tail_tiles * a.ksplit <= 128) gemm256_tail_reduce_kernel<bf16, 4, 128><<<dim3(tail_tiles * 64), dim3(128), 0, stream>>>(a);
-        else gemm256_tail_reduce_kernel<bf16, 16, 256><<<dim3(tail_tiles * 16), dim3(256), 0, stream>>>(a);
-        ULLSAM_LAUNCH_CHECK();
-    }
-    return 0;
-}
-static bool v4_ok(const GemmArgs& a, int dtype) {
-    return dtype == ULLSAM_DT_BF16 && a.vec_ok && a.M >= 256 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 512 && (a.lda % 8 == 0) && (a.ldw % 8 == 0) &&
-           (!a.bias || ((uintptr_t)a.bias & 15) == 0) && (!a.out_f32 || a.act == 0) &&
-           (size_t)a.lda * 2 * 256 < (1ull << 31) && (size_t)a.ldw * 2 * 256 < (1ull << 31);
-}
-static int launch_gemm_v4(const GemmArgs& a, hipStream_t stream) {
-    if (a.act == 3) return launch_gemm_v4_impl<1>(a, stream);
-    if (a.out_f32) return launch_gemm_v4_impl<2>(a, stream);
-    return launch_gemm_v4_impl<0>(a, stream);
-}
-
-// v: bits 0-3 kernel (0 auto), +64 no split-K tail, bits 8-11 timing-only ablations (1 no staging, 2 no barrier, 4 no epilogue, 8 no stores), bits 12-13 schedule of the 256x256 kernel
+// measurement knobs (not part of the reference's interface)
 extern "C" int ullsam_set_gemm_tuning(int key, int value) {
     if (key == 0 && value >= 1 && value <= 1024) { g_group_m = value; return 0; }
-    if (key == 1 && value >= 0 && value <= 63) { g_auto_mask = value; return 0; }
-    if (key == 2 && value >= 0 && value <= 1) { g_ring_lv = value; return 0; }
+    if (key == 1 && value >= 0 && value <= 7) { g_auto_mask = value; return 0; }
     ullsam_set_error("ullsam_set_gemm_tuning: unknown key %d / bad value %d", key, value);
     return -1;
 }
 extern "C" int ullsam_set_gemm_variant(int v) {
-    g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_persistent = (v & 128) ? 0 : 1; g_skew_half_us = (v >> 16) & 255; g_store_nt = ((v >> 26) & 7) ? ((v >> 26) & 7) : ((v >> 14) & 1); g_late = (v >> 24) & 15; g_dbg = (v >> 15) & 1; g_store_v4 = (int)(((unsigned)v >> 29) & 7); g_gemm_ablate = (v >> 8) & 15; g_gemm_sched = (v >> 12) & 3;
-    return 0;
-}
-
-template <typename T>
-static int launch_gemm_v2(GemmArgs a, hipStream_t stream) {
-    static PerDeviceOnce attr_set;
-    if (attr_set.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
-    }
-    a.tiles_m = (a.M + 255) / 256;
-    gemm256x128_kernel<T><<<dim3(a.tiles_m * a.tiles_n), dim3(512), 147456, stream>>>(a);
-    ULLSAM_LAUNCH_CHECK();
+    g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_dbg = (v >> 15) & 1;
     return 0;
 }
 
@@ -2840,7 +1455,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_ksplit_kernel(GemmArgs p) {
 }
 
 static int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
-    if (a.act != 3 && a.N <= 8192 && a.K % 2048 == 0 && g_gemm_sched != 1) {  // narrow: K split over the waves of a workgroup (A/B: sched bits = 1)
+    if (a.act != 3 && a.N <= 8192 && a.K % 2048 == 0) {  // narrow: K split over the waves of a workgroup
         const dim3 g((unsigned)((a.N + 3) / 4));
         if (a.M <= 4) gemm_skinny_ksplit_kernel<4><<<g, 256, 0, stream>>>(a);
         else gemm_skinny_ksplit_kernel<8><<<g, 256, 0, stream>>>(a);
@@ -2893,17 +1508,12 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     bool vec = ((uintptr_t)C & 15) == 0 && (ldc * osz) % 16 == 0 && (n_out % 8 == 0);
     if (residual) vec = vec && ((uintptr_t)residual & 15) == 0 && (ldr % 4 == 0);
     a.vec_ok = vec ? 1 : 0;
-    a.ablate = g_gemm_ablate;
     a.ws = reinterpret_cast<float*>(workspace);
     a.ws_bytes = workspace ? (size_t)ws_bytes : 0;
-    a.shift_edge = 0;
     a.group_m = g_group_m;
-    a.skew_ticks = 0;
     a.row_scale = nullptr;
     a.col_scale = nullptr;
     a.dbg = (g_dbg && workspace && ws_bytes >= (56l << 20)) ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + (48l << 20)) : nullptr;
-    a.store_nt = g_store_nt;
-    a.late = g_late;
     a.ksplit = 1;
     a.tiles_m = (M + 127) / 128;
     a.tiles_n = (N + 127) / 128;
@@ -2914,68 +1524,41 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     if (variant == 0 && act != 4 && dtype == ULLSAM_DT_BF16 && M <= 8 && K % 512 == 0 && lda % 8 == 0 && ldw % 8 == 0 &&
         (size_t)(M <= 4 ? 4 : 8) * K * 2 <= 144 * 1024 && (act != 3 || N % 128 == 0))
         return launch_gemm_skinny(a, s);
-    const bool v2 = variant == 2 && act != 4;  // the 256x128 ring is never picked automatically (slower than the 256x256 kernel on every shape)
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-    // 256x256 tiles run one per CU: use them when the last wave of tiles is >= 74 % full (measured crossover, tools/gemm_bench.py:
-    // 408 / 960 / 1280 / 1904 tiles win, 272 / 320 lose to the 128x128 kernel's finer granularity)
+    // 256-row tiles run one per CU: use them when the last round of tiles is >= 74 % full (measured crossover, tools/gemm_bench.py:
+    // 408 / 960 / 1280 / 1904 tiles win, 272 / 320 lose to the 128x128 kernel's finer granularity) or a split-K tail absorbs the sliver
     const double fill = (double)t256 / (double)(((t256 + 255) / 256) * 256);
     const long tail256 = t256 % 256;
     const bool v3_split = g_split_tail && workspace && t256 > 256 && tail256 > 0 && tail256 <= 64 && K >= 64 * bk;  // see launch_gemm_v3_impl
-    const bool v3 = variant == 3 || (variant == 0 && M >= 1024 && N >= 256 && K >= 8 * bk && (fill >= 0.74 || v3_split) && (act != 3 || N % 256 == 0));  // short K / narrow N: the 256^2 tile's fixed cost or its empty half dominates
-    if (act == 3 && (variant == 3) && N % 256 != 0) { ullsam_set_error("ullsam_gemm: v3 swiglu needs N%%256==0"); return -1; }
+    const bool big = M >= 1024 && N >= 256 && K >= 8 * bk && (act != 3 || N % 256 == 0);  // short K / narrow N: a 256^2 tile's fixed cost or its empty half dominates
     // the ring kernels keep a lane's bias columns in registers, fetched as float4 at 4-column offsets: whole, aligned groups only
     const bool bias_v4 = !bias || (N % 4 == 0 && ((uintptr_t)bias & 15) == 0);
-    if (variant == 9) {
-        if (dtype != ULLSAM_DT_BF16 || K % 64 != 0 || K < 128 || act == 4 || (act == 3 && N % 256 != 0) || !bias_v4) { ullsam_set_error("ullsam_gemm: the 272x256 kernel needs bf16, K %% 64 == 0, no RoPE epilogue"); return -1; }
-        return launch_gemm_v9(a, s);
+    const bool ring_ok = dtype == ULLSAM_DT_BF16 && act <= 3 && K % 64 == 0 && K >= 128 && bias_v4 && (act != 3 || N % 256 == 0);
+    if (variant == 6 || variant == 8 || variant == 9) {
+        if (!ring_ok || (variant == 8 && act == 3)) { ullsam_set_error("ullsam_gemm: the ring kernels need bf16, K %% 64 == 0, K >= 128, no RoPE epilogue (256x320: no SwiGLU)"); return -1; }
+        return variant == 6 ? launch_gemm_v6(a, s) : variant == 8 ? launch_gemm_v8(a, s) : launch_gemm_v9(a, s);
     }
-    if (variant == 8) {
-        if (dtype != ULLSAM_DT_BF16 || K % 64 != 0 || K < 128 || act == 3 || act == 4 || !bias_v4) { ullsam_set_error("ullsam_gemm: the 256x320 kernel needs bf16, K %% 64 == 0, no SwiGLU / RoPE epilogue"); return -1; }
-        return launch_gemm_v8(a, s);
+    if (variant == 1) return a.act == 4 ? (dtype == ULLSAM_DT_F32 ? launch_gemm<float, 1>(a, s) : launch_gemm<bf16, 1>(a, s))
+                                        : (dtype == ULLSAM_DT_F32 ? launch_gemm<float>(a, s) : launch_gemm<bf16>(a, s));
+    if (variant == 3) {
+        if (act == 3 && N % 256 != 0) { ullsam_set_error("ullsam_gemm: the 256x256 kernel's SwiGLU epilogue needs N %% 256 == 0"); return -1; }
+        return dtype == ULLSAM_DT_F32 ? launch_gemm_v3<float>(a, s) : launch_gemm_v3<bf16>(a, s);
     }
-    if (variant == 7) {
-        if (dtype != ULLSAM_DT_BF16 || K % 128 != 0 || K < 256) { ullsam_set_error("ullsam_gemm: the four-wave kernel needs bf16 and K %% 128 == 0, K >= 256"); return -1; }
-        return launch_gemm_v7(a, s);
+    // Auto, bf16, >= 1024 rows: the ring tile shape that covers the problem in the fewest tile-rounds of the 256 CUs (a tile's cost = its
+    // area in units of 256x256; a split-K tail of the two-buffer kernel counts as half a round).  256x320 needs N % 320 == 0 (ViT-H: 1280,
+    // 3840, 5120 -- vit.proj / lin2 become ONE round instead of 1.25, vit.qkv 3 x 1.25 instead of 4); 272x256 makes the bench's 4 x 1081 =
+    // 4324 prompt rows 16 tile rows (llm.wo / w2: one round instead of 256 tiles + a tail; llm.w13: 7 whole rounds instead of 7.44).
+    if (ring_ok && M >= 1024 && N >= 256 && K >= 256) {
+        const double c256 = v3_split ? (double)(t256 / 256) + 0.5 : (double)((t256 + 255) / 256);   // 256x256 tiles (with the two-buffer kernel's split-K tail)
+        const long t320 = (long)((M + 255) / 256) * (N / 320), t272 = (long)((M + 271) / 272) * ((N + 255) / 256);
+        const double c320 = (N % 320 == 0 && act != 3 && (g_auto_mask & 2)) ? 1.25 * (double)((t320 + 255) / 256) : 1e9;
+        const double c272 = (g_auto_mask & 4) ? 1.0625 * (double)((t272 + 255) / 256) : 1e9;
+        if (c320 <= 0.96 * c256 || (act == 1 && c320 <= c256)) return launch_gemm_v8(a, s);   // (GELU: a tie in tile-rounds goes to 256x320, measured in round 2)
+        if (c272 <= 0.96 * c256) return launch_gemm_v9(a, s);
+        if ((g_auto_mask & 1) && big && fill >= 0.74 && !v3_split) return launch_gemm_v6(a, s);
     }
-    if (variant == 6) {
-        if (dtype != ULLSAM_DT_BF16 || K % 64 != 0 || K < 256) { ullsam_set_error("ullsam_gemm: the ring kernel needs bf16 and K %% 64 == 0, K >= 256"); return -1; }
-        return launch_gemm_v6(a, s);
-    }
-    if (variant == 4 && act != 4) {
-        if (!v4_ok(a, dtype)) { ullsam_set_error("ullsam_gemm: the persistent kernel needs bf16, N%%256==0, K%%64==0, K>=512, 16-byte aligned rows"); return -1; }
-        return launch_gemm_v4(a, s);
-    }
-    // 256x320 tiles in auto mode: widths that are multiples of 320 (ViT-H: 1280, 3840) when that takes fewer tile-rounds of the 256 CUs than
-    // 256x256 tiles do (a 320-wide tile is 1.25 tiles' work; a split-K tail counts as half a round) -- same-process A/B: vit.proj 58 vs 80 us,
-    // vit.proj+r 87 vs 108, vit.lin2+r 204 vs 235, vit.qkv 161 vs 173 (the shapes whose 256x256 tile count is 1.25 / 3.75 rounds)
-    if (variant == 0 && (g_auto_mask & 4) && dtype == ULLSAM_DT_BF16 && act <= 2 && N % 320 == 0 && M >= 1024 && K % 64 == 0 && K >= 256 && bias_v4) {
-        const long t320 = (long)((M + 255) / 256) * (N / 320);
-        const double cost320 = 1.25 * (double)((t320 + 255) / 256);
-        const double cost256 = v3_split ? (double)(t256 / 256) + 0.5 : (double)((t256 + 255) / 256);
-        if (cost320 <= 0.96 * cost256 || (act == 1 && (g_auto_mask & 16) && cost320 <= cost256)) return launch_gemm_v8(a, s);   // (GELU: a tie in tile-rounds goes to the ring kernel: bit 4)
-    }
-    if (variant == 0 && (g_auto_mask & 32) && act == 4 && dtype == ULLSAM_DT_BF16 && M >= 1024 && K % 64 == 0 && K >= 256) return launch_gemm_ring_rope(a, s);   // bit 5
-    // persistent kernel in auto mode: only where it measured faster in the same process -- bf16 output with the GELU epilogue (vit.lin1
-    // 214 vs 232 us: the erf arithmetic of one wave group overlaps the other group's matrix segment); elsewhere it ties or loses 0-3 %
-    if (v3 && variant == 0 && g_persistent && (g_auto_mask & 1) && a.act == 1 && !a.out_f32 && v4_ok(a, dtype)) return launch_gemm_v4(a, s);
-    // 272x256 tiles in auto mode: row counts that 16-row-taller tiles cover in fewer tile-rounds (the bench's 4 x 1081 = 4324 rows are 16 x 272:
-    // llm.wo / llm.w2 become ONE round of 256 tiles instead of 256 + a split-K tail of 16) -- same-process A/B: llm.wo+r 144 vs 158 us,
-    // llm.w2+r 418 vs 451, llm.wo 126 vs 154; llm.w13 (1792 tiles = 7 whole rounds instead of 7.44) equals the four-wave kernel on cold operands
-    // (869 vs 866 us) and beats it in the step (tools/step_ab.py 6 13,15: 81.97 vs 82.74 ms), so this rule comes first
-    if (variant == 0 && (g_auto_mask & 8) && dtype == ULLSAM_DT_BF16 && act <= 3 && (act != 3 || N % 256 == 0) && M >= 1024 && N >= 256 && K % 64 == 0 && K >= 256 && bias_v4) {
-        const long t272 = (long)((M + 271) / 272) * ((N + 255) / 256);
-        const double cost272 = 1.0625 * (double)((t272 + 255) / 256);
-        const double cost256 = v3_split ? (double)(t256 / 256) + 0.5 : (double)((t256 + 255) / 256);
-        if (cost272 <= 0.96 * cost256) return launch_gemm_v9(a, s);
-    }
-    // four-wave kernel in auto mode: bf16 output without residual and without GELU (its erf arithmetic has no second wave to hide under),
-    // where its direct epilogue applies -- same-process A/B: llm.w13 -2.3 ... -4.8 %, vit.qkv -1.7 %, llm.wqkv -2 %; the fp32 residual
-    // GEMMs (+2 ... +8 %) and the RoPE epilogue (+5 %) stay on the two-buffer kernel
-    if (v3 && variant == 0 && g_persistent && (g_auto_mask & 2) && dtype == ULLSAM_DT_BF16 && !a.out_f32 && !residual && (act == 0 || act == 3) && a.vec_ok && N % 8 == 0 &&
-        M % 2 == 0 && K % 128 == 0 && K >= 512)
-        return launch_gemm_v7(a, s);
-    if (v3) return dtype == ULLSAM_DT_F32 ? launch_gemm_v3<float>(a, s) : launch_gemm_v3<bf16>(a, s);
-    if (v2) return dtype == ULLSAM_DT_F32 ? launch_gemm_v2<float>(a, s) : launch_gemm_v2<bf16>(a, s);
+    const bool v3 = big && (fill >= 0.74 || v3_split);
+    if (v3) return dtype == ULLSAM_DT_F32 ? launch_gemm_v3<float>(a, s) : launch_gemm_v3<bf16>(a, s);   // fp32, the RoPE epilogue, bf16 shapes no ring takes
     if (a.act == 4) return dtype == ULLSAM_DT_F32 ? launch_gemm<float, 1>(a, s) : launch_gemm<bf16, 1>(a, s);
     return dtype == ULLSAM_DT_F32 ? launch_gemm<float>(a, s) : launch_gemm<bf16>(a, s);
 }
