@@ -391,6 +391,46 @@ def test_rope_and_causal_attention(ops, dtype, B, S, H, KVH, pad):
     assert err(got[valid], ref[valid]) < (2e-4 if dtype == torch.float32 else 4e-2)
 
 
+@pytest.mark.parametrize("B,Sq,past,H,KVH,pad", [(4, 1081, 0, 32, 8, 13), (2, 70, 0, 2, 1, 9), (1, 200, 0, 4, 2, 0), (1, 129, 0, 2, 2, 0),
+                                                  (3, 64, 0, 4, 4, 5), (2, 300, 77, 8, 2, 20), (1, 1, 500, 4, 4, 0)])
+def test_causal_attention_dma_kernel_is_bit_identical_to_the_tiled_kernel(ops, B, Sq, past, H, KVH, pad):
+    """causal128_attn_kernel (bf16, head_dim 128: K/V tiles by LDS-DMA into a double-buffered, XOR-swizzled LDS image) against the tiled
+    flash_attn_kernel (attention variant 11) on the same operands: same MFMA order, same mask arithmetic, so the outputs must be equal bit for
+    bit -- ragged query blocks, left padding, cached keys before the first query (q_pos0 > 0), a single query, the bench's shape -- and both
+    agree with a float64 softmax of the reference's additive finfo.min masks (modeling_internlm2.py:96-125)."""
+    from ullsam_amd import _lib
+    lib = _lib.load()
+    hd, G, Sk = 128, H // KVH, past + Sq
+    g = torch.Generator(device=DEV); g.manual_seed(Sq + past + H)
+    q = torch.randn(B * Sq, H * hd, device=DEV, generator=g).bfloat16()
+    cap = Sk + 5
+    kc = torch.randn(B, KVH, cap, hd, device=DEV, generator=g).bfloat16()
+    vc = torch.randn(B, KVH, cap, hd, device=DEV, generator=g).bfloat16()
+    mask = torch.ones(B, Sk, dtype=torch.int32, device=DEV)
+    if pad:
+        mask[-1, :pad] = 0
+    km = mask if pad else None
+    new = ops.causal_attention(q, kc, vc, km, B, H, KVH, hd, Sq, Sk, past)
+    try:
+        lib.ullsam_set_attn_variant(11)
+        old = ops.causal_attention(q, kc, vc, km, B, H, KVH, hd, Sq, Sk, past)
+    finally:
+        lib.ullsam_set_attn_variant(0)
+    torch.cuda.synchronize()
+    assert torch.equal(new, old), float((new.float() - old.float()).abs().max())
+    # float64 reference on the operands as the kernel sees them
+    qf = q.double().reshape(B, Sq, H, hd).permute(0, 2, 1, 3)
+    kf = kc[:, :, :Sk].double().repeat_interleave(G, 1)
+    vf = vc[:, :, :Sk].double().repeat_interleave(G, 1)
+    sc = qf @ kf.transpose(-1, -2) / math.sqrt(hd)
+    fmin = float(torch.finfo(torch.float32).min)
+    qpos = past + torch.arange(Sq, device=DEV)[:, None]
+    add = torch.where(torch.arange(Sk, device=DEV)[None, :] > qpos, fmin, 0.0)[None, None] + torch.where(mask[:, None, None, :] == 0, fmin, 0.0)
+    ref = (torch.softmax((sc + add).float(), -1).double() @ vf).permute(0, 2, 1, 3).reshape(B * Sq, H * hd)
+    valid = (mask[:, past:] != 0).reshape(-1)
+    assert float((new.double() - ref)[valid].abs().max()) < 4e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,S,KVH,G,K,bias", [(2, 70, 1, 2, 256, False), (1, 1081, 2, 4, 512, True), (4, 300, 8, 4, 256, False),
                                               (4, 1081, 5, 3, 256, True)])   # 25 head slots = N 3200 = 12.5 tiles of 256: the last tile's upper half lies past N (221 tiles -> the 256x256 kernel)

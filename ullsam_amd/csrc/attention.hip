@@ -26,6 +26,7 @@
 //  naive_attn_kernel / fewkeys_attn_kernel: small-shape attention for the two-way mask decoder
 //  (transformer.py:220-242) and the fp32 / odd-shape q_len==1 decode step.
 #include "common.h"
+#include <type_traits>
 
 enum { MODE_PLAIN = 0, MODE_CAUSAL = 1, MODE_VIT_GLOBAL = 2, MODE_VIT_WINDOW = 3 };
 
@@ -405,11 +406,11 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 1 : 2) void flash_attn_k
             float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(s[r] * scale2 - m_new);
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale2, -m_new));   // (explicit: the LDS-DMA kernel must round the same way)
                 s[r] = pv;
                 psum += pv;
             }
-            l_run = l_run * alpha + psum;
+            l_run = __builtin_fmaf(l_run, alpha, psum);
             m_run = m_new;
             return alpha;
         }
@@ -440,9 +441,10 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 1 : 2) void flash_attn_k
                 if (kms[sub * 32 + crow32(r, h)] == 0) add += FMIN;
                 // = finfo.min (score absorbed) or -inf; deliberately NOT rescaled by log2(e): a row whose
                 // keys are all single-masked must stay uniform over them, as in the reference's eager softmax
-                if (add != 0.f) v = s[r] * p.scale + add;
+                if (add != 0.f) v = __builtin_fmaf(s[r], p.scale, add);
             }
             if (!FAST64 && !interior && !(MODE == MODE_VIT_WINDOW && W14) && kt >= Sk) v = -INFINITY;
+            if (MODE == MODE_CAUSAL) asm volatile("" : "+v"(v));   // the product is rounded here, not contracted into the exponent's subtraction below (as in causal128_attn_kernel)
             s[r] = v;
             mx = fmaxf(mx, v);
         }
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 1 : 2) void flash_attn_k
             s[r] = pv;
             if (!LSUM_MFMA) psum += pv;
         }
-        l_run = l_run * alpha + psum;
+        l_run = (MODE == MODE_CAUSAL) ? __builtin_fmaf(l_run, alpha, psum) : l_run * alpha + psum;
         m_run = m_new;
         return alpha;
     };
@@ -898,6 +900,284 @@ static int launch_win14(const AttnArgs& a, hipStream_t s) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------
+//  causal128_attn_kernel: InternLM2 GQA prefill (modeling_internlm2.py:383-419, masks of :96-125,830-851) for bf16, head_dim 128 -- the
+//  production path of the LLM's 32 layers.  Same mathematics, mask semantics and MFMA order as flash_attn_kernel<bf16, 128, MODE_CAUSAL, 4>
+//  (the results are bit-identical: tests/test_kernels_gpu.py), different data movement.  The tiled kernel stages every 64-key K/V tile
+//  global -> registers -> LDS with two barriers per tile and one tile of lead: with two 32-key blocks of work per wave and tile the fetch
+//  latency is exposed (4.0 kilo-cycles per block and wave against 0.5 of MFMA + 0.7 of softmax arithmetic: rocprofv3, round 2).  Here
+//    * K and V tiles arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 4 key rows per wave instruction) into a DOUBLE-buffered image,
+//      requested a whole tile ahead, no staging registers (32 VGPRs less), ONE barrier per tile;
+//    * the image has plain 256-byte rows with 16-byte chunk ch of row r stored at slot ch ^ (((r & 3) << 2) | ((r >> 2) & 3)) (cdna guide
+//      T10, "one image for row reads AND transposed reads", layout (b)): the K fragments (ds_read_b128, row per lane) and the V^T fragments
+//      (ds_read_b64_tr_b16) are both conflict-free, and the permutation is applied on the DMA's per-lane SOURCE address (the DMA writes
+//      lane-linear); addresses differ between k-steps / d-tiles by an XOR with a constant;
+//    * inside a wave the scores of block 1 are issued before the softmax of block 0 and the PV product of block 0 before the softmax of
+//      block 1 (the freed registers hold the second score set), so the wave's own softmax overlaps its matrix work.
+//  LDS: 2 x (16 KiB K + 16 KiB V) + the tiles' key-padding masks = 64.5 KiB, two workgroups per CU.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void causal128_attn_kernel(AttnArgs p) {
+    typedef bf16 T;
+    constexpr int HD = 128, TR = 64, KSTEPS = 8, DT = 4, TILE = TR * 256, STG = 2 * TILE;
+    constexpr float LOG2E = 1.4426950408889634f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* kms = reinterpret_cast<int*>(smem + 2 * STG);   // [2][64] key-padding masks of the two staged tiles
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, ql = lane & 31;
+    // grid (H * B, query blocks): the block index is the SLOWEST dimension and counts down, so that every workgroup of the heaviest query block
+    // (it sees the most keys) is dispatched before any of the next one -- the dispatcher's greedy placement then is longest-first (with the
+    // block index fastest, every CU slot drew 2-3 workgroups of random weight: 1152 workgroups on 512 slots finished 25 % apart).
+    // Blocks are right-aligned (the ragged block is the one that sees one key tile).
+    const int head = blockIdx.x % p.H, b = blockIdx.x / p.H, kvh = head / p.groups;
+    const int nqb = gridDim.y;
+    const int qblk = nqb - 1 - (int)blockIdx.y;
+    const int qbase = p.Sq - nqb * 128 + qblk * 128;
+    const int qi = qbase + wave * 32 + ql;
+    const bool q_valid = qi >= 0 && qi < p.Sq;
+    const int Sk = p.Sk;
+
+    Frag<T> qf[KSTEPS];
+    {
+        const T* qp = reinterpret_cast<const T*>(p.q) + (long)b * p.q_bs + (long)qi * p.q_ts + (long)head * p.q_hs;
+#pragma unroll
+        for (int t = 0; t < KSTEPS; ++t) qf[t] = q_valid ? load_frag(qp + 16 * t + 8 * h) : zero_frag<T>();
+    }
+    const int last_q = p.q_pos0 + min(p.Sq, qbase + 128) - 1;
+    const int ntiles = min((Sk + TR - 1) / TR, last_q / TR + 1);
+    const int* kmask_g = p.key_mask ? p.key_mask + (long)b * Sk : nullptr;
+
+    // ---- LDS-DMA requests of this wave: K pieces 4w .. 4w+3 and V pieces 4w .. 4w+3 (a piece = 4 key rows); lane -> row 4 piece + lane / 16,
+    // physical slot lane % 16, which holds the logical chunk slot ^ sw(row), sw(row) = ((row & 3) << 2) | ((row >> 2) & 3) = ((lane >> 4) << 2) | j.
+    // Addresses = wave-uniform tile base (scalar) + one 32-bit byte offset per piece and lane, the same for K and V (both caches have 256-byte rows).
+    const char* kg = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.k) + (long)b * p.k_bs + (long)kvh * p.k_hs);
+    const char* vg = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.v) + (long)b * p.v_bs + (long)kvh * p.v_hs);
+    const int prow0 = 16 * wave + (lane >> 4);                    // piece j: row prow0 + 4 j
+    const int pcb = ((lane & 15) ^ ((lane >> 4) << 2)) << 4;      // source chunk byte of piece j: pcb ^ (16 j)
+    unsigned int poff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) poff[j] = (unsigned int)((prow0 + 4 * j) * 256 + (pcb ^ (16 * j)));
+    int km_next = 1;
+    auto request = [&](int t) __attribute__((always_inline)) {
+        char* stage = smem + (t & 1) * STG;
+        const char* kt0 = kg + (size_t)t * (TR * 256);
+        const char* vt0 = vg + (size_t)t * (TR * 256);
+        if ((t + 1) * TR <= Sk) {   // wave-uniform: a whole tile
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __builtin_amdgcn_global_load_lds(GLB_PTR(kt0 + poff[j]), LDS_PTR(stage + (4 * wave + j) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(vt0 + poff[j]), LDS_PTR(stage + TILE + (4 * wave + j) * 1024), 16, 0, 0);
+            }
+        } else {   // the last, ragged tile: rows past the end re-read the last key (their scores are masked below)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned int off = (unsigned int)(min(prow0 + 4 * j, Sk - 1 - t * TR) * 256 + (pcb ^ (16 * j)));
+                __builtin_amdgcn_global_load_lds(GLB_PTR(kt0 + off), LDS_PTR(stage + (4 * wave + j) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(vt0 + off), LDS_PTR(stage + TILE + (4 * wave + j) * 1024), 16, 0, 0);
+            }
+        }
+        if (tid < TR) {
+            const int kt = t * TR + tid;
+            km_next = (kmask_g && kt < Sk) ? kmask_g[kt] : 1;
+        }
+    };
+    // ---- fragment addresses (byte offsets inside a stage)
+    const int swq = ((ql & 3) << 2) | ((ql >> 2) & 3);
+    const int k_off = 256 * ql + ((16 * h) ^ (16 * swq));                 // K[sub * 32 + ql][16 ks + 8 h ..]: (k_off + 8192 sub) ^ (32 ks)
+    int v_lo, v_hi;                                                      // V^T fragment rows kv0 + 4 hh + q4 (+ 8): (v_xx + 256 kv0) ^ (2 d0)
+    {
+        const int grp = lane >> 4, i = lane & 15, hh = grp >> 1, q4 = i >> 2, p4 = i & 3;
+        const int c_lo = 2 * (grp & 1) + (p4 >> 1);
+        v_lo = 256 * (4 * hh + q4) + 16 * (c_lo ^ ((q4 << 2) | hh)) + 8 * (p4 & 1);
+        v_hi = 256 * (4 * hh + q4 + 8) + 16 * (c_lo ^ ((q4 << 2) | ((hh + 2) & 3))) + 8 * (p4 & 1);
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float scale2 = p.scale * LOG2E;
+    const int q_pos = p.q_pos0 + qi;
+    const float FMIN = -3.4028234663852886e38f;  // torch.finfo(float32).min
+    const int wave_first_q = p.q_pos0 + qbase + wave * 32;
+    const int wave_last_q = p.q_pos0 + min(p.Sq, qbase + (wave + 1) * 32) - 1;
+    const bool wave_live = (wave_first_q - p.q_pos0 < p.Sq) && (wave_last_q >= p.q_pos0);   // wave-uniform: this wave has queries
+
+    auto qk_block = [&](const char* ks_, int sub, f32x16& s) __attribute__((always_inline)) {  // S^T = K . Q^T
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const Frag<T> a = load_frag(reinterpret_cast<const T*>(ks_ + ((k_off + 8192 * sub) ^ (32 * ks))));
+            mma32(a, qf[ks], s);
+        }
+    };
+    // scores -> unnormalised probabilities in place (online softmax, the reference's additive finfo.min masks); returns the O rescale factor.
+    // INTERIOR (compile time; the caller checks it per tile, wave-uniform): the block lies entirely in the past of every query of this wave
+    // and holds no padding key -- no mask arithmetic, the maximum is taken on the raw scores and the scale rides in the exponent's FMA.
+    auto soft_block = [&](int tile, int sub, auto INTERIOR, f32x16& s) __attribute__((always_inline)) -> float {
+        const int kbase = tile * TR + sub * 32;
+        if constexpr (decltype(INTERIOR)::value) {
+            float mr = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mr = fmaxf(mr, s[r]);
+            float lo, hi;
+            halves(mr, lo, hi);
+            const float mx = fmaxf(lo, hi) * scale2;
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale2, -m_new));
+                s[r] = pv;
+                psum += pv;
+            }
+            l_run = __builtin_fmaf(l_run, alpha, psum);
+            m_run = m_new;
+            return alpha;
+        } else {
+            const int* km = kms + (tile & 1) * TR + sub * 32;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kt = kbase + crow32(r, h);
+                float v = s[r] * scale2;
+                float add = 0.f;   // additive masks exactly as the reference builds them (fp32): causal min + padding min
+                if (kt > q_pos) add += FMIN;
+                if (km[crow32(r, h)] == 0) add += FMIN;
+                if (add != 0.f) v = __builtin_fmaf(s[r], p.scale, add);   // = finfo.min (score absorbed) or -inf; deliberately not rescaled by log2(e)
+                if (kt >= Sk) v = -INFINITY;
+                asm volatile("" : "+v"(v));   // the product is rounded here, not contracted into the exponent's subtraction below
+                s[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            {
+                float lo, hi;
+                halves(mx, lo, hi);
+                mx = fmaxf(lo, hi);
+            }
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(s[r] - m_use);
+                s[r] = pv;
+                psum += pv;
+            }
+            l_run = __builtin_fmaf(l_run, alpha, psum);
+            m_run = m_new;
+            return alpha;
+        }
+    };
+    // O^T += V^T . P^T.  The transposed reads are inline asm: through the builtin hipcc waits vmcnt(0) before every ds_read_b64_tr_b16 while an
+    // LDS-DMA is in flight (it cannot tell the tile being read from the tile being filled), which would serialise the prefetch.  The reads of
+    // two d-tiles are issued together, then one counted wait (cdna guide 5.7: asm loads are not in hipcc's bookkeeping).
+    auto pv_block = [&](unsigned int vs_lds, auto SUB, const f32x16& s) __attribute__((always_inline)) {
+        constexpr int sub = decltype(SUB)::value;
+        const Frag<T> p0 = pack_p(s, 0, (const T*)nullptr), p1 = pack_p(s, 1, (const T*)nullptr);
+#pragma unroll
+        for (int dp = 0; dp < DT; dp += 2) {
+            s16x4 lo[2][2], hi[2][2];
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) {
+                const unsigned int a_lo = vs_lds + (unsigned int)(v_lo ^ (64 * (dp + dd))), a_hi = vs_lds + (unsigned int)(v_hi ^ (64 * (dp + dd)));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[dd][0]) : "v"(a_lo), "i"(256 * (sub * 32)));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[dd][0]) : "v"(a_hi), "i"(256 * (sub * 32)));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[dd][1]) : "v"(a_lo), "i"(256 * (sub * 32 + 16)));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[dd][1]) : "v"(a_hi), "i"(256 * (sub * 32 + 16)));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0][0]), "+v"(hi[0][0]), "+v"(lo[0][1]), "+v"(hi[0][1]), "+v"(lo[1][0]), "+v"(hi[1][0]), "+v"(lo[1][1]), "+v"(hi[1][1]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) {
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    s16x8 t;
+                    t[0] = lo[dd][half][0]; t[1] = lo[dd][half][1]; t[2] = lo[dd][half][2]; t[3] = lo[dd][half][3];
+                    t[4] = hi[dd][half][0]; t[5] = hi[dd][half][1]; t[6] = hi[dd][half][2]; t[7] = hi[dd][half][3];
+                    Frag<T> f;
+                    f.v = __builtin_bit_cast(bf16x8_t, t);
+                    mma32(f, half ? p1 : p0, o[dp + dd]);
+                }
+            }
+        }
+    };
+    auto scale_o = [&](float alpha) __attribute__((always_inline)) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    };
+
+    // ---- prologue: tile 0 requested and landed
+    request(0);
+    if (tid < TR) kms[tid] = km_next;
+    __syncthreads();   // (vmcnt(0) + barrier: the DMA of every wave has landed)
+    for (int tile = 0; tile < ntiles; ++tile) {
+        if (tile + 1 < ntiles) request(tile + 1);   // into the buffer tile - 1 was read from: every wave has passed the barrier that ended it
+        const char* Kst = smem + (tile & 1) * STG;
+        const char* Vst = Kst + TILE;
+        const bool tile_pad = kmask_g ? (__any(kms[(tile & 1) * TR + lane] == 0) != 0) : false;
+        const int kb0 = tile * TR;
+        // wave-uniform: which of the tile's two 32-key blocks this wave needs (a block entirely in the future of all its queries is skipped),
+        // and whether the whole tile is interior (three straight-line bodies, no control flow inside a body)
+        const bool do0 = wave_live && kb0 < Sk && kb0 <= wave_last_q;
+        const bool do1 = wave_live && kb0 + 32 < Sk && kb0 + 32 <= wave_last_q;
+        // per block (wave-uniform): entirely in the past of every query of this wave and free of padding -> no mask arithmetic
+        const bool in0 = !tile_pad && (kb0 + 31 <= wave_first_q) && (kb0 + 31 < Sk);
+        const bool in1 = !tile_pad && (kb0 + 63 <= wave_first_q) && (kb0 + 63 < Sk);   // (in1 implies in0)
+        const unsigned int vs_lds = (unsigned int)(uintptr_t)LDS_PTR(Vst);
+        auto one_block = [&](auto SUB, auto INTERIOR) __attribute__((always_inline)) {
+            f32x16 sc;
+            qk_block(Kst, decltype(SUB)::value, sc);
+            scale_o(soft_block(tile, decltype(SUB)::value, INTERIOR, sc));
+            pv_block(vs_lds, SUB, sc);
+        };
+        const std::integral_constant<int, 0> B0;
+        const std::integral_constant<int, 1> B1;
+        // five straight-line bodies, no control flow inside a body
+        if (do1) {
+            if (in1) { one_block(B0, std::true_type{}); one_block(B1, std::true_type{}); }
+            else if (in0) { one_block(B0, std::true_type{}); one_block(B1, std::false_type{}); }
+            else { one_block(B0, std::false_type{}); one_block(B1, std::false_type{}); }
+        } else if (do0) {
+            if (in0) one_block(B0, std::true_type{});
+            else one_block(B0, std::false_type{});
+        }
+        if (tile + 1 < ntiles && tid < TR) kms[((tile + 1) & 1) * TR + tid] = km_next;
+        __syncthreads();   // tile + 1 has landed (every wave waited for its own pieces) and nobody reads this tile's buffer any more
+    }
+
+    // ---- normalise and store: lane q holds O^T[d][q], d = 32 dt + crow32(r, h)
+    float lo, hi;
+    halves(l_run, lo, hi);
+    const float l_tot = lo + hi;
+    const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (q_valid) {
+        T* op = reinterpret_cast<T*>(p.out) + (long)b * p.o_bs + (long)qi * p.o_ts + (long)head * p.o_hs;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                store4(op + 32 * d + 8 * rq + 4 * h, make_float4(o[d][4 * rq] * inv_l, o[d][4 * rq + 1] * inv_l, o[d][4 * rq + 2] * inv_l, o[d][4 * rq + 3] * inv_l));
+    }
+}
+
+static int launch_causal128(const AttnArgs& a, hipStream_t s) {
+    constexpr int LDS = 2 * 2 * 64 * 256 + 2 * 64 * 4;
+    static PerDeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(causal128_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    causal128_attn_kernel<<<dim3(a.H * a.B, (a.Sq + 127) / 128), dim3(256), LDS, s>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
 static int g_attn_variant = 0;
 extern "C" int ullsam_set_attn_variant(int v) { g_attn_variant = v; return 0; }
 
@@ -957,11 +1237,11 @@ extern "C" int ullsam_causal_attention(int dtype, const void* q, const void* k, 
     a.o_bs = a.q_bs; a.o_ts = a.q_ts; a.o_hs = hd;
     a.B = B; a.H = H; a.groups = H / KVH; a.Sq = Sq; a.Sk = Sk; a.key_mask = key_mask; a.q_pos0 = q_pos0;
     a.scale = 1.0f / sqrtf((float)hd);
-    a.left_align = g_attn_variant == 10;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    // 4 waves = 128 queries per workgroup (8 waves / 256 queries measured no faster end to end: 94.9 vs 94.5 ms per step)
-    // variant 1: 8-wave workgroups (256 queries) over 128-key tiles, one per CU -- twice the matrix work per staged tile
-    if (g_attn_variant == 1 && dtype == 1) return dispatch_hd<bf16, MODE_CAUSAL, 8>(a, hd, s);
+    // bf16, head_dim 128, contiguous 256-byte key rows (the KV-cache layout): the LDS-DMA kernel (variant 11 keeps the tiled kernel, for the
+    // bit-equality test and A/B)
+    if (dtype == 1 && hd == 128 && g_attn_variant != 11 && a.k_ts == 128 && a.v_ts == 128 && (((uintptr_t)k | (uintptr_t)v | (uintptr_t)q | (uintptr_t)out) & 15) == 0)
+        return launch_causal128(a, s);
     return dtype == 0 ? dispatch_hd<float, MODE_CAUSAL, 4>(a, hd, s) : dispatch_hd<bf16, MODE_CAUSAL, 4>(a, hd, s);
 }
 
