@@ -27,7 +27,7 @@ extern "C" {
 
 /* Bumped whenever an entry point is added or a signature changes.  The Python binding refuses a library that reports another
    version (a stale libullsam_hip.so would otherwise receive shifted arguments, e.g. a row count where the stream is expected). */
-#define ULLSAM_ABI_VERSION 3
+#define ULLSAM_ABI_VERSION 4
 
 const char* ullsam_last_error_string(void);
 int ullsam_abi_version(void); /* == ULLSAM_ABI_VERSION of the header the library was built from */
@@ -38,8 +38,13 @@ int ullsam_set_gemm_variant(int variant);
 /* measurement knob, not part of the reference's interface: key 0 = tile rows per raster group of the 256-row-tile GEMM kernels (default 4);
    key 1 = ring tile shapes the automatic dispatch may use (bit 0 256x256, bit 1 256x320, bit 2 272x256; default 7) */
 int ullsam_set_gemm_tuning(int key, int value);
-/* Attention A/B switch: 0 = production, 1 = windowed attention with one 7-wave workgroup per (window, head). */
+/* Attention kernel selection for A/B measurements and the kernel tests: 0 = production; 1 / 2 = windowed attention on the tiled kernel (7-wave /
+   4-wave workgroups) instead of the whole-window kernel; 3..8 = start stagger of the whole-window kernel's second resident workgroup; 9 = global
+   attention as two 4-wave workgroups; 11 = causal prefill on the tiled kernel instead of the LDS-DMA kernel (the bit-equality test's reference). */
 int ullsam_set_attn_variant(int variant);
+/* diagnostic hook, not part of the reference's interface: a device buffer (>= 8 x 8 bytes per wave of the launch) that the stamped build of the
+   causal prefill attention kernel fills with s_memtime sums (request issue / compute / wait + barrier per wave); NULL (default) = the product kernel */
+int ullsam_set_attn_debug(void* stamps);
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual.  Replaces every nn.Linear / 1x1 conv / stride==kernel conv:
  * image_encoder.py:227,238,387-395,88-104; common.py:21-26; modeling_internvl_sam.py:88-100;

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ULLSAM_HIP_LIB") or os.path.join(_HERE, "lib", "libullsam_hip.so")  # env: A/B a side build (developer switch)
 
-ABI_VERSION = 3  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
+ABI_VERSION = 4  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
 
 _lib = None
 
@@ -59,7 +59,7 @@ SIGNATURES = {
 }
 PLAIN = {"ullsam_last_error_string": ([], C.c_char_p), "ullsam_abi_version": ([], i32), "ullsam_device_count": ([], i32),
          "ullsam_set_gemm_variant": ([i32], i32), "ullsam_set_gemm_tuning": ([i32, i32], i32), "ullsam_set_attn_variant": ([i32], i32),
-         "ullsam_set_norm_variant": ([i32], i32)}
+         "ullsam_set_norm_variant": ([i32], i32), "ullsam_set_attn_debug": ([vp], i32)}
 
 
 class UllsamError(RuntimeError):

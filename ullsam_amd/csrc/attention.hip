@@ -45,7 +45,7 @@ struct AttnArgs {
     int grid_h, grid_w;     // token grid (64 x 64)
     int win, nwin_w, nwin;  // window size, windows per row, windows per image
     const void* bias_q; const void* bias_k; const void* bias_v;  // T [H*HD] slices of qkv.bias for pad tokens
-    int left_align;         // causal A/B (attn variant 10): query blocks left-aligned (the ragged block last) instead of right-aligned
+    unsigned long long* dbg; // diagnostic launches only (ullsam_set_attn_debug): s_memtime stamps of causal128_attn_kernel<true>
 };
 
 template <typename T, int HD, int TR = 64> struct KVTile {
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 1 : 2) void flash_attn_k
     // causal: the query blocks are RIGHT-aligned (block b covers queries Sq - (nblk - b) * 128 ...), so the ragged block is the first one,
     // which sees one key tile, instead of the last one, which sees them all (S = 1081: 57 of 128 rows live in the heaviest block = 11 % of
     // the kernel's work spent on padding rows)
-    const int qbase = ((MODE == MODE_CAUSAL && !p.left_align) ? p.Sq - (int)gridDim.x * NWAVES * 32 : 0) + qblk * NWAVES * 32;
+    const int qbase = (MODE == MODE_CAUSAL ? p.Sq - (int)gridDim.x * NWAVES * 32 : 0) + qblk * NWAVES * 32;
     const int qi = qbase + wave * 32 + ql;  // index within sequence / window
     bool q_valid = qi >= 0 && qi < p.Sq;
     long q_tok = qi;       // token index in the [B, tokens] tensors (for load and store)
@@ -916,6 +916,7 @@ static int launch_win14(const AttnArgs& a, hipStream_t s) {
 //      block 1 (the freed registers hold the second score set), so the wave's own softmax overlaps its matrix work.
 //  LDS: 2 x (16 KiB K + 16 KiB V) + the tiles' key-padding masks = 64.5 KiB, two workgroups per CU.
 // ------------------------------------------------------------------------------------------------------
+template <bool STAMP = false>
 __global__ __launch_bounds__(256, 2) void causal128_attn_kernel(AttnArgs p) {
     typedef bf16 T;
     constexpr int HD = 128, TR = 64, KSTEPS = 8, DT = 4, TILE = TR * 256, STG = 2 * TILE;
@@ -1039,7 +1040,13 @@ __global__ __launch_bounds__(256, 2) void causal128_attn_kernel(AttnArgs p) {
             m_run = m_new;
             return alpha;
         } else {
-            const int* km = kms + (tile & 1) * TR + sub * 32;
+            const int* km = kms + (tile & 1) * TR + sub * 32 + 4 * h;
+            int kmv[16];   // crow32(r, h) = (r & 3) + 8 (r >> 2) + 4 h: registers 4 g .. 4 g + 3 are four consecutive keys
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int4 w = *reinterpret_cast<const int4*>(km + 8 * g);
+                kmv[4 * g] = w.x; kmv[4 * g + 1] = w.y; kmv[4 * g + 2] = w.z; kmv[4 * g + 3] = w.w;
+            }
             float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1047,7 +1054,7 @@ __global__ __launch_bounds__(256, 2) void causal128_attn_kernel(AttnArgs p) {
                 float v = s[r] * scale2;
                 float add = 0.f;   // additive masks exactly as the reference builds them (fp32): causal min + padding min
                 if (kt > q_pos) add += FMIN;
-                if (km[crow32(r, h)] == 0) add += FMIN;
+                if (kmv[r] == 0) add += FMIN;
                 if (add != 0.f) v = __builtin_fmaf(s[r], p.scale, add);   // = finfo.min (score absorbed) or -inf; deliberately not rescaled by log2(e)
                 if (kt >= Sk) v = -INFINITY;
                 asm volatile("" : "+v"(v));   // the product is rounded here, not contracted into the exponent's subtraction below
@@ -1119,8 +1126,12 @@ __global__ __launch_bounds__(256, 2) void causal128_attn_kernel(AttnArgs p) {
     request(0);
     if (tid < TR) kms[tid] = km_next;
     __syncthreads();   // (vmcnt(0) + barrier: the DMA of every wave has landed)
+    unsigned long long st_dma = 0, st_cmp = 0, st_bar = 0, st_t0 = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long st_r0 = STAMP ? __builtin_amdgcn_s_memrealtime() : 0ull;   // (100 MHz, common to all CUs: loop entry)
     for (int tile = 0; tile < ntiles; ++tile) {
+        const unsigned long long s0 = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
         if (tile + 1 < ntiles) request(tile + 1);   // into the buffer tile - 1 was read from: every wave has passed the barrier that ended it
+        const unsigned long long s1 = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
         const char* Kst = smem + (tile & 1) * STG;
         const char* Vst = Kst + TILE;
         const bool tile_pad = kmask_g ? (__any(kms[(tile & 1) * TR + lane] == 0) != 0) : false;
@@ -1136,12 +1147,15 @@ __global__ __launch_bounds__(256, 2) void causal128_attn_kernel(AttnArgs p) {
         auto one_block = [&](auto SUB, auto INTERIOR) __attribute__((always_inline)) {
             f32x16 sc;
             qk_block(Kst, decltype(SUB)::value, sc);
-            scale_o(soft_block(tile, decltype(SUB)::value, INTERIOR, sc));
+            const float alpha = soft_block(tile, decltype(SUB)::value, INTERIOR, sc);
+            if (__any(alpha != 1.0f)) scale_o(alpha);   // wave-uniform: no row maximum moved in this block (the common case after the first tiles) -> 64 multiplies less
             pv_block(vs_lds, SUB, sc);
         };
         const std::integral_constant<int, 0> B0;
         const std::integral_constant<int, 1> B1;
         // five straight-line bodies, no control flow inside a body
+        // (Issuing block 1's scores before block 0's softmax -- an in-wave pipeline -- was built and measured equal: with the second score set live
+        // hipcc serialises the K fragment reads, one ds_read_b128 -> wait -> MFMA at a time, and the two waves of a SIMD already fill each other's gaps.)
         if (do1) {
             if (in1) { one_block(B0, std::true_type{}); one_block(B1, std::true_type{}); }
             else if (in0) { one_block(B0, std::true_type{}); one_block(B1, std::false_type{}); }
@@ -1150,8 +1164,15 @@ __global__ __launch_bounds__(256, 2) void causal128_attn_kernel(AttnArgs p) {
             if (in0) one_block(B0, std::true_type{});
             else one_block(B0, std::false_type{});
         }
+        const unsigned long long s2 = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
         if (tile + 1 < ntiles && tid < TR) kms[((tile + 1) & 1) * TR + tid] = km_next;
         __syncthreads();   // tile + 1 has landed (every wave waited for its own pieces) and nobody reads this tile's buffer any more
+        if (STAMP) { const unsigned long long s3 = __builtin_amdgcn_s_memtime(); st_dma += s1 - s0; st_cmp += s2 - s1; st_bar += s3 - s2; }
+    }
+    if (STAMP && p.dbg && lane == 0) {   // [workgroup][wave][8]: request issue, compute, wait + barrier, whole loop, tiles, block index
+        unsigned long long* d = p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        d[0] = st_dma; d[1] = st_cmp; d[2] = st_bar; d[3] = __builtin_amdgcn_s_memtime() - st_t0; d[4] = ntiles; d[5] = qblk;
+        d[6] = st_r0; d[7] = __builtin_amdgcn_s_memrealtime();
     }
 
     // ---- normalise and store: lane q holds O^T[d][q], d = 32 dt + crow32(r, h)
@@ -1172,14 +1193,20 @@ __global__ __launch_bounds__(256, 2) void causal128_attn_kernel(AttnArgs p) {
 static int launch_causal128(const AttnArgs& a, hipStream_t s) {
     constexpr int LDS = 2 * 2 * 64 * 256 + 2 * 64 * 4;
     static PerDeviceOnce attr;
-    if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(causal128_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    causal128_attn_kernel<<<dim3(a.H * a.B, (a.Sq + 127) / 128), dim3(256), LDS, s>>>(a);
+    if (attr.first()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(causal128_attn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(causal128_attn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    }
+    if (a.dbg) causal128_attn_kernel<true><<<dim3(a.H * a.B, (a.Sq + 127) / 128), dim3(256), LDS, s>>>(a);   // stamped diagnostic build (tools/probes/causal_stamps.py)
+    else causal128_attn_kernel<false><<<dim3(a.H * a.B, (a.Sq + 127) / 128), dim3(256), LDS, s>>>(a);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
 
 static int g_attn_variant = 0;
+static unsigned long long* g_attn_dbg = nullptr;
 extern "C" int ullsam_set_attn_variant(int v) { g_attn_variant = v; return 0; }
+extern "C" int ullsam_set_attn_debug(void* stamps) { g_attn_dbg = reinterpret_cast<unsigned long long*>(stamps); return 0; }
 
 // SAM ViT attention on the packed qkv activations [B, grid_h*grid_w, 3*D] (D = heads*hd, per token [3][heads][hd]).
 // window == 0 -> global attention.  rel_h/rel_w: [(2S-1), hd] in the activation dtype.  qkv_bias: [3*D] in the
@@ -1237,6 +1264,7 @@ extern "C" int ullsam_causal_attention(int dtype, const void* q, const void* k, 
     a.o_bs = a.q_bs; a.o_ts = a.q_ts; a.o_hs = hd;
     a.B = B; a.H = H; a.groups = H / KVH; a.Sq = Sq; a.Sk = Sk; a.key_mask = key_mask; a.q_pos0 = q_pos0;
     a.scale = 1.0f / sqrtf((float)hd);
+    a.dbg = g_attn_dbg;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // bf16, head_dim 128, contiguous 256-byte key rows (the KV-cache layout): the LDS-DMA kernel (variant 11 keeps the tiled kernel, for the
     // bit-equality test and A/B)
