@@ -375,9 +375,11 @@ def _spawn_ranks(n: int, argv) -> int:
 def traffic_record():
     """HBM-side bytes per GEMM launch: PMC counters cannot be read in-process, so the figure comes from the committed rocprofv3
     --pmc passes over this file (tools/collect_evidence.py), valid only for the kernel sources it was measured on."""
-    tpath = os.path.join(ROOT, "profiles", "r02_pmc_bench_traffic.json")
-    if not os.path.exists(tpath):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_bench_traffic.json")))
+    if not cands:
         return None, "no PMC record"
+    tpath = cands[-1]   # the latest round's record
     rec = json.load(open(tpath))
     from ullsam_amd import build as _b
     if rec.get("csrc_digest") != _b._digest():

@@ -393,10 +393,10 @@ def test_bench_host_helpers(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     os.makedirs(tmp_path / "profiles")
     assert bench.traffic_record()[0] is None                                      # no record
-    json.dump({"csrc_digest": "0" * 64, "hbm_bytes_per_launch": 1.0}, open(tmp_path / "profiles" / "r02_pmc_bench_traffic.json", "w"))
+    json.dump({"csrc_digest": "0" * 64, "hbm_bytes_per_launch": 1.0}, open(tmp_path / "profiles" / "r03_pmc_bench_traffic.json", "w"))
     val, why = bench.traffic_record()
     assert val is None and "stale" in why
-    json.dump({"csrc_digest": B._digest(), "hbm_bytes_per_launch": 123.4}, open(tmp_path / "profiles" / "r02_pmc_bench_traffic.json", "w"))
+    json.dump({"csrc_digest": B._digest(), "hbm_bytes_per_launch": 123.4}, open(tmp_path / "profiles" / "r03_pmc_bench_traffic.json", "w"))
     assert bench.traffic_record()[0] == 123
     # the digest names the kernel sources and flags, not the directory the tree is checked out in (the GPU box runs from a scratch path)
     d0 = B._digest()
