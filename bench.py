@@ -50,7 +50,7 @@ def init_random_(model: torch.nn.Module, seed: int = 0):
     g.manual_seed(seed)
     with torch.no_grad():
         for name, p in list(model.named_parameters()) + list(model.named_buffers()):
-            if not p.is_floating_point():
+            if not p.is_floating_point() or "pixel_mean" in name or "pixel_std" in name:   # (Sam's normalisation constants are not weights)
                 continue
             mean, std = param_init_rule(name, tuple(p.shape))
             p.normal_(mean, std, generator=g)
@@ -473,6 +473,7 @@ def main():
     ap.add_argument("--no-iou", action="store_true", help="skip the fp32 run that gives mask_iou_vs_fp32")
     ap.add_argument("--mode", default="mask", choices=["mask", "decode"], help="mask: the headline images/s path; decode: greedy tokens/s of the caption path")
     ap.add_argument("--stub", action="store_true", help="control-path self-test without a GPU (gloo, a stub step): measures nothing")
+    ap.add_argument("--vit-fp8", action="store_true", help="fp8 (e4m3) operands for the ViT's LayerNorm-fed linears (qkv, lin1): BASELINE configs[4] 'fp8 MFMA ViT path'; everything else bf16")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -499,6 +500,10 @@ def main():
         return
 
     model = build_model(a.vit, a.llm, dtype, device)
+    if a.vit_fp8:
+        if a.dtype != "bf16":
+            raise SystemExit("bench.py --vit-fp8 needs --dtype bf16")
+        (model.vision_model if hasattr(model, "vision_model") else model.image_encoder).fp8_linears = True
     if os.environ.get("ULLSAM_GEMM_VARIANT"):  # A/B switch for kernel experiments
         from ullsam_amd import _lib
         _lib.load().ullsam_set_gemm_variant(int(os.environ["ULLSAM_GEMM_VARIANT"]))
@@ -525,6 +530,7 @@ def main():
                                 + (f"InternLM2-{a.llm}-shaped prefill S={a.seq} + " if full else "")
                                 + f"prompt encoder + mask decoder + x4 upsample/threshold, 1 point prompt/image, batch {a.batch}/GPU"),
                    "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": a.seq if full else 0,
+                   "vit_linears": "fp8 e4m3 operands for qkv / lin1 (per-row / per-channel scales), proj / lin2 bf16" if a.vit_fp8 else "bf16",
                    "parallelism": f"dp{world} (images sharded, weights replicated, one RCCL all-gather of logits+masks per step, overlapped with the next step)",
                    "ranks": ranks_seen},
         "roofline": {"bound": "mfma", "kernel": "ullsam_gemm (every nn.Linear / conv-as-GEMM launch)", "achieved": round(ach, 2),
@@ -533,8 +539,10 @@ def main():
                      "launches_per_step": n_launch // max(a.steps, 1), "avg_launch_us": round(gemm_ms * 1e3 / max(n_launch, 1), 2),
                      "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4)},
     }
-    if rank == 0 and world == 1 and full and a.dtype == "bf16" and not a.no_iou:
+    if rank == 0 and world == 1 and a.dtype == "bf16" and not a.no_iou:
         line["mask_iou_vs_fp32"] = mask_iou_vs_fp32(model, a.vit, a.llm, inputs, device)
+    if a.vit_fp8:   # the GEMM timer wraps ops.gemm / gemm_qkv_rope only: the fp8 launches (ops.gemm_fp8) are outside `roofline`
+        line["roofline"]["note"] = "bf16 GEMM launches only; the fp8 qkv / lin1 launches are not in this figure"
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.vit, a.llm, a.seq)

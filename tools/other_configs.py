@@ -5,7 +5,8 @@ import argparse, json, os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUNS = [
-    ("configs[1] ViT-H + mask decoder, batch 8", ["bench.py", "--llm", "none", "--batch", "8", "--no-cpu-baseline", "--no-iou"], {}),
+    ("configs[1] ViT-H + mask decoder, batch 8", ["bench.py", "--llm", "none", "--batch", "8", "--no-cpu-baseline"], {}),
+    ("configs[1] with fp8 (e4m3) ViT linears (bench.py --vit-fp8)", ["bench.py", "--llm", "none", "--batch", "8", "--no-cpu-baseline", "--vit-fp8"], {}),
     ("decode (bench.py --mode decode)", ["bench.py", "--mode", "decode"], {}),
     ("config 3' ViT-B + 2B-shaped, batch 4", ["bench.py", "--vit", "b", "--llm", "2b", "--no-cpu-baseline", "--no-iou"], {}),
     ("configs[4] AMG 64x64 points on a 2048^2 tile (bf16)", ["tools/amg_bench.py"], {}),

@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "causal" 2>&1 | tail -4 > gpurun_out/t1.log
-python tools/attn_bench.py 11,0 2>&1 | grep causal >> gpurun_out/t1.log
-python tools/probes/causal_stamps.py >> gpurun_out/t1.log 2>&1
-cat gpurun_out/t1.log
+python bench.py --llm none --batch 8 --no-cpu-baseline > gpurun_out/b16.log 2>&1
+python bench.py --llm none --batch 8 --no-cpu-baseline --vit-fp8 > gpurun_out/b8.log 2>&1
+tail -1 gpurun_out/b16.log | cut -c1-1800; echo; tail -1 gpurun_out/b8.log | cut -c1-1800
