@@ -408,6 +408,42 @@ def test_sam_forward_golden():
     assert 1.0 - O.calc_iou(got, ref) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["points", "points_multi", "boxes_masks"])
+def test_sam_forward_batched_equals_per_image(dtype, kind):
+    """Sam.forward runs ONE decoder pass over all (image, prompt) pairs when the records have the same prompt structure (the reference loops
+    over the images, sam.py:96-129): every record's outputs must equal, bit for bit, what the same record gives alone."""
+    from ullsam_amd.build_sam import _build_sam
+    P = {}
+    P.update(U.vit_params(U.VIT_SMALL, 0, "image_encoder."))
+    P.update(O.fill_state(O.prompt_encoder_shapes(prefix="prompt_encoder."), 0))
+    P.update(O.fill_state(O.mask_decoder_shapes(prefix="mask_decoder."), 0))
+    sam = load(_build_sam(128, 2, 2, [1]), P, dtype)
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(3):
+        r = {"image": torch.from_numpy(U.rand_image((3, 768, 1024), 40 + i, 255.0)).to(DEV), "original_size": (600, 800)}
+        if kind in ("points", "points_multi"):
+            n = 1 if kind == "points" else 2
+            r["point_coords"] = torch.from_numpy(rng.uniform(50, 700, (n, 2, 2)).astype(np.float32)).to(DEV)
+            r["point_labels"] = torch.from_numpy(rng.integers(0, 2, (n, 2)).astype(np.int32)).to(DEV)
+        else:
+            b0 = rng.uniform(10, 300, (2, 2)).astype(np.float32)
+            r["boxes"] = torch.from_numpy(np.concatenate([b0, b0 + rng.uniform(50, 400, (2, 2)).astype(np.float32)], 1)).to(DEV)
+            r["mask_inputs"] = torch.from_numpy(rng.standard_normal((2, 1, 256, 256), dtype=np.float32)).to(DEV)
+        recs.append(r)
+    multi = kind != "points"
+    together = sam(recs, multimask_output=multi)
+    for r, t in zip(recs, together):
+        alone = sam([r], multimask_output=multi)[0]
+        for k in ("masks", "iou_predictions", "low_res_logits"):
+            assert t[k].shape == alone[k].shape and torch.equal(t[k], alone[k]), (kind, k)
+    # records of different structure still take the per-image loop
+    mixed = sam([recs[0], {"image": recs[1]["image"], "original_size": (600, 800), "boxes": torch.tensor([[10.0, 20.0, 300.0, 400.0]], device=DEV)}],
+                multimask_output=multi)
+    assert torch.equal(mixed[0]["low_res_logits"], together[0]["low_res_logits"])
+
+
 def test_checkpoint_files_load_and_run(tmp_path):
     """Checkpoint I/O end to end on the GPU (train_joint_v2.py:1254-1263 save format, :1466-1555 loading order, build_sam.py:103-106):
     a reference-shaped uLLSAM checkpoint file, a plain SAM state_dict file through the registry-style loader and an InternLM2

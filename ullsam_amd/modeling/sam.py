@@ -43,17 +43,49 @@ class Sam(nn.Module):
         else:
             toks = torch.cat([enc.forward_tokens(r["image"][None].to(self.device), mean, std) for r in batched_input], 0)
         pe_tok = self.prompt_encoder.dense_pe_tokens()
-        outputs = []
-        for i, rec in enumerate(batched_input):
+        sl = slice(1, None) if multimask_output else slice(0, 1)
+
+        def prompts(rec):
             points = (rec["point_coords"], rec["point_labels"]) if "point_coords" in rec else None
-            boxes, masks_in = rec.get("boxes", None), rec.get("mask_inputs", None)
+            return points, rec.get("boxes", None), rec.get("mask_inputs", None)
+
+        def signature(rec):   # records with equal signatures can share one decoder pass
+            pts, bx, mk = prompts(rec)
+            return (tuple(rec["image"].shape), tuple(int(v) for v in rec["original_size"]),
+                    None if pts is None else (tuple(pts[0].shape), tuple(pts[1].shape)),
+                    None if bx is None else tuple(bx.shape), None if mk is None else tuple(mk.shape))
+
+        outputs = []
+        if len(batched_input) > 1 and len({signature(r) for r in batched_input}) == 1:
+            # The reference loops over the images (sam.py:96-129); every image's prompts are independent of the other images', so the loop is one
+            # decoder pass over all (image, prompt) pairs: the prompt tensors are stacked, every prompt gets its image's tokens
+            # (tests/test_model_gpu.py::test_sam_forward_batched_equals_per_image: same bits as the loop).
+            cat = lambda xs: None if xs[0] is None else torch.cat([x.to(self.device) for x in xs], 0)
+            pr = [prompts(r) for r in batched_input]
+            points = None if pr[0][0] is None else (cat([p[0][0] for p in pr]), cat([p[0][1] for p in pr]))
+            boxes, masks_in = cat([p[1] for p in pr]), cat([p[2] for p in pr])
+            bs = self.prompt_encoder._get_batch_size(*pr[0])
+            P = bs * len(batched_input)
+            sparse = self.prompt_encoder.sparse_tokens(points, boxes)
+            if sparse.shape[1] == 0:
+                sparse = sparse.expand(P, 0, sparse.shape[-1])
+            dense = self.prompt_encoder.dense_tokens(P, masks_in, None)
+            img = toks if bs == 1 else toks.repeat_interleave(bs, 0)
+            low, iou = self.mask_decoder.predict_masks_tokens(img, pe_tok, sparse, dense, (g, g))
+            low, iou = low[:, sl].contiguous(), iou[:, sl]
+            rec0 = batched_input[0]
+            masks = self.postprocess_masks(low, input_size=rec0["image"].shape[-2:], original_size=rec0["original_size"], _threshold=self.mask_threshold)
+            for i in range(len(batched_input)):
+                outputs.append({"masks": masks[i * bs:(i + 1) * bs], "iou_predictions": iou[i * bs:(i + 1) * bs], "low_res_logits": low[i * bs:(i + 1) * bs]})
+            return outputs
+        for i, rec in enumerate(batched_input):
+            points, boxes, masks_in = prompts(rec)
             bs = self.prompt_encoder._get_batch_size(points, boxes, masks_in)
             sparse = self.prompt_encoder.sparse_tokens(points, boxes)
             if sparse.shape[1] == 0:
                 sparse = sparse.expand(bs, 0, sparse.shape[-1])
             dense = self.prompt_encoder.dense_tokens(bs, None if masks_in is None else masks_in.to(self.device), None)
             low, iou = self.mask_decoder.predict_masks_tokens(toks[i:i + 1], pe_tok, sparse, dense, (g, g))
-            sl = slice(1, None) if multimask_output else slice(0, 1)
             low, iou = low[:, sl].contiguous(), iou[:, sl]
             masks = self.postprocess_masks(low, input_size=rec["image"].shape[-2:], original_size=rec["original_size"],
                                            _threshold=self.mask_threshold)
