@@ -1303,6 +1303,37 @@ __device__ __forceinline__ void bf16x8_to_f32(const uint4 u, float (&o)[8]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { o[2 * j] = __uint_as_float(d[j] << 16); o[2 * j + 1] = __uint_as_float(d[j] & 0xffff0000u); }
 }
+// acc += a.lo * b.lo + a.hi * b.hi on packed bf16 pairs (fp32 accumulate; the products of two bf16 are exact in fp32).  gfx950 has no
+// compiler builtin for this opcode, hence the asm; the compiler cannot see that it is a DOT instruction, so the wait states it would
+// insert between a DOT result and a different VALU reader (3 on gfx90a and later) are supplied by dot_fence() after the last one.
+__device__ __forceinline__ void dot2c(float& acc, const unsigned int a, const unsigned int b) {
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void dot_fence() { asm volatile("s_nop 4" ::: "memory"); }
+// Sum each of the NV values of a lane over the 64 lanes; returns, in lane l, the total of value (l >> (6 - log2 NV)) ... see below.
+// Halving butterfly: at the step with partner distance o a lane keeps half of its values (which half: bit o of the lane) and adds the
+// partner's copy of the same half, so 16 values cost 8 + 4 + 2 + 1 exchanges and two more on the single value left, not 16 x 6.
+// After it lane l holds the total of value index  bit5(l) * 8 + bit4(l) * 4 + bit3(l) * 2 + bit2(l)  (NV = 16), complete in every lane.
+template <int NV>
+__device__ __forceinline__ float wave_sum_many(float (&v)[NV]) {
+    static_assert(NV == 16 || NV == 32, "");
+    const int lane = threadIdx.x & 63;
+    int o = 32;
+#pragma unroll
+    for (int n = NV; n > 1; n >>= 1, o >>= 1) {
+        const bool up = (lane & o) != 0;
+#pragma unroll
+        for (int i = 0; i < n / 2; ++i) {
+            const float lo = v[i], hi = v[i + n / 2];    // both read first: a select between two array elements must not become an indexed (scratch) access
+            v[i] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, o, 64);
+        }
+    }
+    float t = v[0];
+#pragma unroll
+    for (; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    return t;
+}
+
 template <int MM>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // A as bf16 [MM][K]
@@ -1330,65 +1361,65 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     const bf16* wr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) wr[r] = W + (size_t)min(rows[r], (long)p.N - 1) * p.ldw + lane * 8;
-    float acc[4][MM];
+    float acc[4 * MM];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int m = 0; m < MM; ++m) acc[r][m] = 0.f;
+    for (int i = 0; i < 4 * MM; ++i) acc[i] = 0.f;
     const char* xa = smem + lane * 16;
-#pragma unroll 2
-    for (int k0 = 0; k0 < K; k0 += 512) {
-        uint4 wv[4];
+    // Three register buffers of four 1 KiB row segments rotate: two steps of loads are in flight while the third is multiplied.  The dot
+    // products are opaque asm to the scheduler, which would otherwise serialise load -> wait -> 16 dots with one buffer; the
+    // sched_barriers pin "issue the loads, then compute".
+    uint4 b0[4], b1[4], b2[4];
+    auto fill = [&](uint4 (&b)[4], const int k) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) wv[r] = *reinterpret_cast<const uint4*>(wr[r] + k0);
-        float xf[MM][8];
+        for (int r = 0; r < 4; ++r) b[r] = *reinterpret_cast<const uint4*>(wr[r] + k);
+    };
+    auto step = [&](const uint4 (&b)[4], const int k) {
+        uint4 av[MM];
 #pragma unroll
-        for (int m = 0; m < MM; ++m) bf16x8_to_f32(*reinterpret_cast<const uint4*>(xa + ((size_t)m * KC + (k0 >> 3)) * 16), xf[m]);
+        for (int m = 0; m < MM; ++m) av[m] = *reinterpret_cast<const uint4*>(xa + ((size_t)m * KC + (k >> 3)) * 16);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float wf[8];
-            bf16x8_to_f32(wv[r], wf);
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int m = 0; m < MM; ++m)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[r][m] += wf[e] * xf[m][e];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int m = 0; m < MM; ++m) acc[r][m] = wave_sum(acc[r][m]);
-    if (lane != 0) return;
-    if (p.act == 3) {
-        const long oc = (rows[0] >> 7) * 64 + (rows[0] & 63);  // output column of gate row rows[0]
-#pragma unroll
-        for (int m = 0; m < MM; ++m) {
-            if (m >= p.M) break;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float o = silu_f(acc[j][m]) * acc[2 + j][m];
-                if (p.out_f32) reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + oc + j] = o;
-                else reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + oc + j] = (bf16)o;
+            for (int m = 0; m < MM; ++m) {
+                dot2c(acc[r * MM + m], b[r].x, av[m].x); dot2c(acc[r * MM + m], b[r].y, av[m].y);
+                dot2c(acc[r * MM + m], b[r].z, av[m].z); dot2c(acc[r * MM + m], b[r].w, av[m].w);
             }
-        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    fill(b0, 0);
+    if (512 < K) fill(b1, 512);
+    for (int k0 = 0; k0 < K; k0 += 1536) {
+        if (k0 + 1024 < K) fill(b2, k0 + 1024);
+        step(b0, k0);
+        if (k0 + 512 >= K) break;
+        if (k0 + 1536 < K) fill(b0, k0 + 1536);
+        step(b1, k0 + 512);
+        if (k0 + 1024 >= K) break;
+        if (k0 + 2048 < K) fill(b1, k0 + 2048);
+        step(b2, k0 + 1024);
+    }
+    dot_fence();
+    const float tot = wave_sum_many<4 * MM>(acc);       // lane l: the total of (r, m) = divmod(l >> SH, MM), complete in every lane
+    constexpr int SH = MM == 4 ? 2 : 1;
+    const int idx = lane >> SH, r = idx / MM, m = idx - r * MM;
+    if (p.act == 3) {
+        const float upv = __shfl_xor(tot, 32, 64);       // rows 2, 3 (the up rows) live 32 lanes above rows 0, 1
+        if ((lane & ((1 << SH) - 1)) || lane >= 32 || m >= p.M) return;
+        const long oc = (rows[0] >> 7) * 64 + (rows[0] & 63) + r;  // output column of gate row rows[r]
+        const float o = silu_f(tot) * upv;
+        if (p.out_f32) reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + oc] = o;
+        else reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + oc] = (bf16)o;
         return;
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const long n = rows[r];
-        if (n >= p.N) break;
-        const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int m = 0; m < MM; ++m) {
-            if (m >= p.M) break;
-            float v = acc[r][m] + bv;
-            if (p.act == 1) v = gelu_erf(v);
-            else if (p.act == 2) v = fmaxf(v, 0.f);
-            if (p.residual) v += p.residual[(size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + n];
-            if (p.out_f32) reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n] = v;
-            else reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + n] = (bf16)v;
-        }
-    }
+    const long n = rows[0] + r;
+    if ((lane & ((1 << SH) - 1)) || n >= p.N || m >= p.M) return;
+    float v = tot + (p.bias ? p.bias[n] : 0.f);
+    if (p.act == 1) v = gelu_erf(v);
+    else if (p.act == 2) v = fmaxf(v, 0.f);
+    if (p.residual) v += p.residual[(size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + n];
+    if (p.out_f32) reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n] = v;
+    else reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + n] = (bf16)v;
 }
 
 // Narrow weight matrices (wo, w2, wqkv at decode: N <= 8192) give the kernel above only ~4 waves per CU.  Here a workgroup owns
@@ -1408,38 +1439,46 @@ __global__ __launch_bounds__(256) void gemm_skinny_ksplit_kernel(GemmArgs p) {
     const bf16* ar[MM];
 #pragma unroll
     for (int m = 0; m < MM; ++m) ar[m] = A + (size_t)min(m, p.M - 1) * p.lda;
-    float acc[4][MM];
+    float acc[4 * MM];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int i = 0; i < 4 * MM; ++i) acc[i] = 0.f;
+    struct Buf { uint4 w[4], a[MM]; };
+    Buf b0, b1, b2;                                   // as in gemm_skinny_kernel: two steps of loads in flight behind the one being multiplied
+    auto fill = [&](Buf& b, const int k) {
 #pragma unroll
-        for (int m = 0; m < MM; ++m) acc[r][m] = 0.f;
-#pragma unroll 2
-    for (int k0 = 0; k0 < KQ; k0 += 512) {
-        uint4 wv4[4], av[MM];
+        for (int r = 0; r < 4; ++r) b.w[r] = *reinterpret_cast<const uint4*>(wr[r] + k);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) wv4[r] = *reinterpret_cast<const uint4*>(wr[r] + k0);
+        for (int m = 0; m < MM; ++m) b.a[m] = *reinterpret_cast<const uint4*>(ar[m] + k);
+    };
+    auto step = [&](const Buf& b) {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < MM; ++m) av[m] = *reinterpret_cast<const uint4*>(ar[m] + k0);
-        float xf[MM][8];
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int m = 0; m < MM; ++m) bf16x8_to_f32(av[m], xf[m]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float wf[8];
-            bf16x8_to_f32(wv4[r], wf);
-#pragma unroll
-            for (int m = 0; m < MM; ++m)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[r][m] += wf[e] * xf[m][e];
-        }
+            for (int m = 0; m < MM; ++m) {
+                dot2c(acc[r * MM + m], b.w[r].x, b.a[m].x); dot2c(acc[r * MM + m], b.w[r].y, b.a[m].y);
+                dot2c(acc[r * MM + m], b.w[r].z, b.a[m].z); dot2c(acc[r * MM + m], b.w[r].w, b.a[m].w);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    fill(b0, 0);
+    if (512 < KQ) fill(b1, 512);
+    for (int k0 = 0; k0 < KQ; k0 += 1536) {
+        if (k0 + 1024 < KQ) fill(b2, k0 + 1024);
+        step(b0);
+        if (k0 + 512 >= KQ) break;
+        if (k0 + 1536 < KQ) fill(b0, k0 + 1536);
+        step(b1);
+        if (k0 + 1024 >= KQ) break;
+        if (k0 + 2048 < KQ) fill(b1, k0 + 2048);
+        step(b2);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int m = 0; m < MM; ++m) {
-            const float t = wave_sum(acc[r][m]);
-            if (lane == 0) red[wv][r][m] = t;
-        }
+    dot_fence();
+    {
+        const float tot = wave_sum_many<4 * MM>(acc);
+        constexpr int SH = MM == 4 ? 2 : 1;
+        if ((lane & ((1 << SH) - 1)) == 0) (&red[wv][0][0])[lane >> SH] = tot;
+    }
     __syncthreads();
     if (tid >= 4 * MM) return;
     const int r = tid / MM, m = tid - r * MM;
