@@ -27,7 +27,7 @@ extern "C" {
 
 /* Bumped whenever an entry point is added or a signature changes.  The Python binding refuses a library that reports another
    version (a stale libullsam_hip.so would otherwise receive shifted arguments, e.g. a row count where the stream is expected). */
-#define ULLSAM_ABI_VERSION 4
+#define ULLSAM_ABI_VERSION 5
 
 const char* ullsam_last_error_string(void);
 int ullsam_abi_version(void); /* == ULLSAM_ABI_VERSION of the header the library was built from */
@@ -63,6 +63,17 @@ int ullsam_gemm(int dtype, const void* A, long lda, const void* W, long ldw, voi
 int ullsam_gemm_qkv_rope(int dtype, const void* A, long lda, const void* W, long ldw, const float* bias, int B, int S, int K, int KVH,
                          int G, const int* pos, const float* cos_tab, const float* sin_tab, int tab_rows, void* q_out, void* k_cache,
                          void* v_cache, int cap, int cache_pos0, void* workspace, long ws_bytes, void* stream);
+
+/* Decode step (InternVLSAMModel.generate's token loop, modeling_internlm2.py:1112-1149; M <= 4 rows, bf16 weights): the RMSNorm that
+ * precedes a layer's wqkv / w13 (modeling_internlm2.py:75-89, 598-618) folded into the GEMM that consumes it:
+ * C = act(bf16(x * rsqrt(mean(x^2) + eps) * norm_w) @ W^T + bias) (+ residual), x fp32 [M, K <= 4096], K % 2048 == 0; act as ullsam_gemm. */
+int ullsam_gemm_rmsnorm(const float* x, long ldx, const float* norm_w, float eps, const void* W, long ldw, void* C, long ldc, int out_f32,
+                        const float* bias, const float* residual, long ldr, int act, int M, int N, int K, void* stream);
+/* ... and the decode step's wqkv: ullsam_gemm_qkv_rope with S = 1 and B <= 4, the activations either bf16 `a` [B, K] (norm_w NULL) or the
+ * RMSNorm of fp32 x [B, K] as above. */
+int ullsam_decode_qkv_rope(const void* a, const float* x, long ldx, const float* norm_w, float eps, const void* W, long ldw, const float* bias,
+                           int B, int K, int KVH, int G, const int* pos, const float* cos_tab, const float* sin_tab, int tab_rows, void* q_out,
+                           void* k_cache, void* v_cache, int cap, int cache_pos0, void* stream);
 
 /* Row LayerNorm / RMSNorm, fp32 statistics.  image_encoder.py:151,161; common.py:38-43 (LayerNorm2d on NHWC rows);
  * modeling_internlm2.py:138-143 (rms=1); prompt_encoder.py:142-149 (no affine + post scale/shift); transformer.py norms. */

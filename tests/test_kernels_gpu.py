@@ -655,6 +655,69 @@ def test_gemm_decode_rows(ops, M):
             assert err(s, g / (1 + np.exp(-g)) * u) < 2e-3
 
 
+@pytest.mark.parametrize("M", [1, 3, 4])
+@pytest.mark.parametrize("K", [2048, 4096])
+def test_decode_gemm_with_rmsnorm_prologue_equals_norm_then_gemm(ops, M, K):
+    """ullsam_gemm_rmsnorm (the decode step's ffn_norm + w13, and a plain / biased narrow matrix) against the two separate launches:
+    the staged row is the one ullsam_norm writes (same element-to-thread assignment and order of sums), so the results are equal bit for bit."""
+    from ullsam_amd.packing import pack_w13
+    rng = np.random.default_rng(100 * M + K)
+    x = T(rng.standard_normal((M, K), dtype=np.float32) * 3)
+    nw = T(1 + 0.1 * rng.standard_normal(K, dtype=np.float32))
+    F = 1024
+    w13 = pack_w13(T(rng.standard_normal((F, K), dtype=np.float32) / math.sqrt(K), torch.bfloat16), T(rng.standard_normal((F, K), dtype=np.float32) / math.sqrt(K), torch.bfloat16))
+    wn = T(rng.standard_normal((1536, K), dtype=np.float32) / math.sqrt(K), torch.bfloat16)
+    xn = ops.norm(x, nw, None, 1e-5, torch.bfloat16, rms=True)
+    # oracle for the norm itself
+    xf = x.cpu().numpy()
+    ref = xf / np.sqrt((xf.astype(np.float64) ** 2).mean(-1, keepdims=True) + 1e-5) * nw.cpu().numpy()
+    assert err(xn.float().cpu().numpy(), ref) < 4e-2     # bf16 rounding of |values| < 16
+    a = ops.gemm_rmsnorm(x, nw, 1e-5, w13, act=ops.ACT_SWIGLU)
+    b = ops.gemm(xn, w13, act=ops.ACT_SWIGLU)
+    assert torch.equal(a, b)
+    a = ops.gemm_rmsnorm(x, nw, 1e-5, wn)
+    b = ops.gemm(xn, wn)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,KVH,G,past", [(4, 8, 4, 1081), (1, 2, 4, 0), (3, 4, 2, 17)])
+@pytest.mark.parametrize("normed", [False, True])
+def test_decode_qkv_rope_equals_gemm_then_rope_split(ops, B, KVH, G, past, normed):
+    """ullsam_decode_qkv_rope (wqkv + head split + RoPE + KV-cache append in one launch, optional RMSNorm prologue) against
+    norm -> gemm -> rope_split.  The separate path rounds qkv to bf16 before rotating, the fused epilogue rotates the fp32 sums: equal to
+    bf16 rounding (2^-8 relative), cache rows other than the appended one untouched, v rows equal bit for bit."""
+    hd, K, cap = 128, 2048, past + 8
+    rng = np.random.default_rng(B * 100 + KVH)
+    N = KVH * (G + 2) * hd
+    x = T(rng.standard_normal((B, K), dtype=np.float32))
+    nw = T(1 + 0.1 * rng.standard_normal(K, dtype=np.float32))
+    w = T(rng.standard_normal((N, K), dtype=np.float32) / math.sqrt(K), torch.bfloat16)
+    bias = T(0.1 * rng.standard_normal(N, dtype=np.float32))
+    pos = T(rng.integers(0, past + 1, size=(B, 1)).astype(np.int32), torch.int32)
+    inv = 1.0 / (10000.0 ** (np.arange(0, hd, 2, dtype=np.float32) / hd))
+    fr = np.arange(past + 4, dtype=np.float32)[:, None] * inv[None]
+    emb = np.concatenate([fr, fr], -1)
+    cos, sin = T(np.cos(emb).astype(np.float32)), T(np.sin(emb).astype(np.float32))
+    xn = ops.norm(x, nw, None, 1e-5, torch.bfloat16, rms=True) if normed else x.to(torch.bfloat16)
+    fill = lambda: (torch.full((B, KVH, cap, hd), 7.0, dtype=torch.bfloat16, device="cuda"), torch.full((B, KVH, cap, hd), -3.0, dtype=torch.bfloat16, device="cuda"))
+    k0, v0 = fill()
+    q0 = ops.rope_split(ops.gemm(xn, w, bias), k0, v0, pos, cos, sin, B, 1, KVH, G, hd, past)
+    k1, v1 = fill()
+    q1 = ops.decode_qkv_rope(x if normed else xn, nw if normed else None, 1e-5, w, bias, k1, v1, pos, cos, sin, B, KVH, G, past)
+    assert torch.equal(v0, v1)                      # bias + sum rounded once in both paths
+    assert err(q1.float().cpu().numpy(), q0.float().cpu().numpy()) < 4e-2     # |values| < 8: three bf16 roundings apart
+    assert err(k1[:, :, past].float().cpu().numpy(), k0[:, :, past].float().cpu().numpy()) < 4e-2
+    untouched = torch.ones(cap, dtype=torch.bool, device="cuda"); untouched[past] = False
+    assert torch.equal(k1[:, :, untouched], k0[:, :, untouched]) and bool((k1[:, :, untouched] == 7.0).all())
+    # and against the exact rotation of the fp32 products
+    qkv = (xn.float().cpu().numpy() @ w.float().cpu().numpy().T + bias.cpu().numpy()).reshape(B, KVH, G + 2, hd)
+    c, s_ = np.cos(emb)[pos.cpu().numpy()[:, 0]][:, None, None, :], np.sin(emb)[pos.cpu().numpy()[:, 0]][:, None, None, :]
+    rot = np.concatenate([-qkv[..., hd // 2:], qkv[..., :hd // 2]], -1)
+    ro = qkv * c + rot * s_
+    assert err(q1.float().cpu().numpy().reshape(B, KVH, G, hd), ro[:, :, :G]) < 2e-2   # one rounding of the result
+    assert err(k1[:, :, past].float().cpu().numpy(), ro[:, :, G]) < 2e-2
+
+
 @pytest.mark.parametrize("M,N,K", [(4324, 4096, 4096), (16384, 1280, 5120)])
 def test_gemm_256_split_k_tail_matches_unsplit(ops, M, N, K):
     """256x256 kernel: 272 tiles (16-tile tail cut 8 ways, 4-row reduce slabs) and 320 tiles (64-tile tail cut 4 ways, 16-row slabs):

@@ -178,6 +178,32 @@ def test_llm_7b_l1_golden_at_bench_rows():
         assert d.mean() < 1.2 * float(g["autocast_bf16_mean_err"]), (half, d.mean())
 
 
+def test_llm_7b_decode_step_fused_launches_equal_separate_launches():
+    """A decode step of the 7B-shaped layer (batch 2, left padding) with the RMSNorms and RoPE folded into the GEMMs (run_layers `fused`)
+    against the same step through norm / gemm / rope_split launches: the appended V rows are equal bit for bit (norm + wqkv are the same
+    sums), the K rows and the hidden state differ by the one bf16 rounding of qkv the separate path makes before rotating."""
+    g = U.gold("llm_7b_l1")
+    lm = _llm(U.LLM_7B_L1, torch.bfloat16)
+    emb = torch.from_numpy(U.llm_7b_l1_inputs(int(g["input_seed"]))).to(DEV)[:, -96:]
+    mask = torch.from_numpy(g["mask"]).to(DEV)[:, -96:]
+    S = emb.shape[1]
+    res = []
+    for fuse in (False, True):
+        lm.model.fuse_decode = fuse
+        cache = lm.model.new_cache(2, S + 8, DEV)
+        pos = (mask.long().cumsum(-1) - 1).clamp(min=0)
+        lm.model(inputs_embeds=emb, attention_mask=mask, position_ids=pos, past_key_values=cache, use_cache=True)
+        m2 = torch.cat([mask, torch.ones_like(mask[:, :1])], 1)
+        tok = torch.tensor([[11], [4242]], device=DEV)
+        out = lm.model(input_ids=tok, attention_mask=m2, position_ids=mask.long().sum(-1, keepdim=True), past_key_values=cache, use_cache=True)
+        res.append((out.last_hidden_state.float().cpu().numpy(), cache.k[0][:, :, S].float().cpu().numpy(), cache.v[0][:, :, S].float().cpu().numpy()))
+    lm.model.fuse_decode = True
+    (h0, k0, v0), (h1, k1, v1) = res
+    assert np.array_equal(v0, v1)
+    assert err(k0, k1) < 0.07 and np.abs(k0 - k1).mean() < 2e-3, (err(k0, k1), np.abs(k0 - k1).mean())
+    assert err(h0, h1) < 0.1 and np.abs(h0 - h1).mean() < 5e-3, (err(h0, h1), np.abs(h0 - h1).mean())
+
+
 def test_llm_tiny_bias_and_linear_rope_golden():
     """config.bias=True (wqkv / wo bias in the GEMM epilogue) and linear RoPE scaling (modeling_internlm2.py:184-200,300-308)."""
     from ullsam_amd.modeling.configuration_internlm2 import InternLM2Config

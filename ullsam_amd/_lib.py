@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ULLSAM_HIP_LIB") or os.path.join(_HERE, "lib", "libullsam_hip.so")  # env: A/B a side build (developer switch)
 
-ABI_VERSION = 4  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
+ABI_VERSION = 5  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
 
 _lib = None
 
@@ -20,6 +20,8 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
 SIGNATURES = {
     "ullsam_gemm": [i32, vp, i64, vp, i64, vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, i32, vp, i64, vp],
     "ullsam_gemm_qkv_rope": [i32, vp, i64, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, i64, vp],
+    "ullsam_gemm_rmsnorm": [vp, i64, vp, f32, vp, i64, vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, vp],
+    "ullsam_decode_qkv_rope": [vp, vp, i64, vp, f32, vp, i64, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp],
     "ullsam_norm": [vp, i32, i64, vp, i32, i64, vp, vp, i64, i32, f32, i32, i32, vp, vp, vp],
     "ullsam_norm_fanout": [vp, i64, i32, vp, vp, f32, vp, vp, vp, i32, vp, i64, vp],
     "ullsam_vit_attention": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],

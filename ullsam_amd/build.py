@@ -28,6 +28,11 @@ def _digest():
         if f.endswith((".hip", ".h")):
             h.update(f.encode())
             h.update(open(os.path.join(CSRC, f), "rb").read())
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    for f in sorted(os.listdir(inc)):                      # the public header carries ULLSAM_ABI_VERSION, compiled into runtime.hip
+        if f.endswith(".h"):
+            h.update(f.encode())
+            h.update(open(os.path.join(inc, f), "rb").read())
     h.update(" ".join(FLAGS[:-1] + ["include"]).encode())   # (the include directory by name: the digest must not depend on where the tree is checked out)
     return h.hexdigest()
 

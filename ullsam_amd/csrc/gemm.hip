@@ -53,6 +53,8 @@ struct GemmArgs {
     const float* row_scale;  // fp8 path: per-row scale of A (activation quantisation), per-column scale of W; null elsewhere
     const float* col_scale;
     unsigned long long* dbg;  // diagnostic launches only (ullsam_set_gemm_variant bit 15): s_memtime stamps of the ring kernel (tools/probes/ring8_stamps.py)
+    // decode-step prologue (skinny kernels only): A = bf16(RMSNorm(norm_x) * norm_w), normalised while the workgroup stages its rows in LDS
+    const float* norm_x; const float* norm_w; float norm_eps; long ldx;
     int group_m;     // tile rows per raster group of the 256-row-tile kernels (tiles of a group run column-major: group_m x tiles_n); 4 by default
 };
 
@@ -60,6 +62,7 @@ static int g_split_tail = 1;   // ullsam_set_gemm_variant(v | 64) disables the s
 static int g_gemm_variant = 0; // bits 0-3 force a kernel: 0 auto, 1 128x128, 3 256x256 two-buffer, 6 256x256 ring, 8 256x320 ring, 9 272x256 ring
 static int g_dbg = 0;          // ullsam_set_gemm_variant bit 15: stamp the ring kernel (tools/probes/ring8_stamps.py reads the stamps from the workspace)
 static int g_auto_mask = 7;    // ullsam_set_gemm_tuning(1, mask): ring tile shapes the auto dispatch may pick: bit 0 256x256, bit 1 256x320, bit 2 272x256
+static int g_skinny_mode = 0;  // ullsam_set_gemm_tuning(2, mode): K-split weight stream at M <= 4: 0 auto, 1 = 4 rows x 2 buffers, 2 = 8 rows x 2, 3 = 8 rows x 3, 4 = 4 rows x 3
 static int g_group_m = 4;      // ullsam_set_gemm_tuning(0, gm): raster group height (measured: 4 -> 83.26 ms per step, 8 -> 83.73, 2 -> 84.35)
 
 template <typename T>
@@ -1247,6 +1250,7 @@ extern "C" int ullsam_gemm_fp8(const void* A8, long lda, const float* a_scale, c
 extern "C" int ullsam_set_gemm_tuning(int key, int value) {
     if (key == 0 && value >= 1 && value <= 1024) { g_group_m = value; return 0; }
     if (key == 1 && value >= 0 && value <= 7) { g_auto_mask = value; return 0; }
+    if (key == 2 && value >= 0 && value <= 5) { g_skinny_mode = value; return 0; }
     ullsam_set_error("ullsam_set_gemm_tuning: unknown key %d / bad value %d", key, value);
     return -1;
 }
@@ -1334,20 +1338,76 @@ __device__ __forceinline__ float wave_sum_many(float (&v)[NV]) {
     return t;
 }
 
+// Stage A = bf16(x * rsqrt(mean(x^2) + eps) * w) for MM rows of K <= 4096 fp32 elements into LDS ([MM][K] bf16): the RMSNorm that precedes
+// wqkv and w13 in a decode layer (modeling_internlm2.py:75-89), folded into the GEMM's staging.  Same element-to-thread assignment and the
+// same order of sums as norm_block_kernel<.., 4, 4> (float4 i*256 + t of a row, wave butterfly, waves in order), so the normalised row
+// is the one the separate kernel writes.  `red` is 16 floats of LDS; ends with a barrier.
 template <int MM>
+struct NormRows { float4 v[MM][4]; float4 w[4]; };
+// The loads of stage_rmsnorm, issued BEFORE the kernel's first weight loads: a wave's vector-memory results return in order, so rows requested
+// behind the weight stream would not be usable until that whole stream had landed.
+template <int MM>
+__device__ __forceinline__ void stage_rmsnorm_load(NormRows<MM>& n, const GemmArgs& p) {
+    const int tid = threadIdx.x, M = p.M, nq = p.K >> 10;   // K % 1024 == 0: float4 i*256 + tid exists iff i < K / 1024 (uniform)
+    const long ldx = p.ldx;
+    const float* xb = p.norm_x + tid * 4;
+    const float* wb = p.norm_w + tid * 4;
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            n.v[m][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < nq && m < M) n.v[m][i] = *reinterpret_cast<const float4*>(xb + m * ldx + i * 1024);
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) n.w[i] = i < nq ? *reinterpret_cast<const float4*>(wb + i * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+template <int MM>
+__device__ __forceinline__ void stage_rmsnorm_finish(const NormRows<MM>& n, char* smem, float* red, const GemmArgs& p) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int K = p.K, nq = K >> 10;
+    float ss[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        ss[m] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ss[m] += (n.v[m][i].x * n.v[m][i].x + n.v[m][i].y * n.v[m][i].y) + (n.v[m][i].z * n.v[m][i].z + n.v[m][i].w * n.v[m][i].w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {     // wave_sum of the MM rows side by side (MM exchanges in flight per step; per row the order of wave_sum)
+        float t[MM];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) t[m] = __shfl_xor(ss[m], o, 64);
+#pragma unroll
+        for (int m = 0; m < MM; ++m) ss[m] += t[m];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < MM; ++m) red[wv * MM + m] = ss[m];
+    }
+    __syncthreads();
+    bf16* dst = reinterpret_cast<bf16*>(smem) + tid * 4;
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        const float tot = ((red[m] + red[MM + m]) + red[2 * MM + m]) + red[3 * MM + m];
+        const float rstd = rsqrtf(tot / (float)K + p.norm_eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= nq) continue;
+            const float4 o = make_float4(n.v[m][i].x * rstd * n.w[i].x, n.v[m][i].y * rstd * n.w[i].y, n.v[m][i].z * rstd * n.w[i].z, n.v[m][i].w * rstd * n.w[i].w);
+            store4(dst + (size_t)m * K + i * 1024, o);
+        }
+    }
+    __syncthreads();
+}
+
+template <int MM, bool NORM = false>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // A as bf16 [MM][K]
     const int tid = threadIdx.x, lane = tid & 63;
     const int K = p.K, KC = K >> 3;                 // 16-byte chunks per row
     const bf16* A = reinterpret_cast<const bf16*>(p.A);
     const bf16* W = reinterpret_cast<const bf16*>(p.W);
-    for (int idx = tid; idx < MM * KC; idx += 256) {
-        const int m = idx / KC, c = idx - m * KC;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (m < p.M) v = *reinterpret_cast<const uint4*>(A + (size_t)m * p.lda + c * 8);
-        *reinterpret_cast<uint4*>(smem + ((size_t)m * KC + c) * 16) = v;
-    }
-    __syncthreads();
     const long wid = (long)blockIdx.x * 4 + (tid >> 6);
     long rows[4];
     if (p.act == 3) {  // packed w13: 128-row blocks [64 gate | 64 up]; this wave: gate rows g, g+1 and their up rows
@@ -1357,10 +1417,40 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) rows[r] = wid * 4 + r;
     }
-    if (rows[0] >= p.N) return;
     const bf16* wr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) wr[r] = W + (size_t)min(rows[r], (long)p.N - 1) * p.ldw + lane * 8;
+    // the first two steps of the weight stream are requested before the activations are staged: the stream does not depend on them
+    uint4 b0[4], b1[4], b2[4];
+    auto fill = [&](uint4 (&b)[4], const int k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[r] = *reinterpret_cast<const uint4*>(wr[r] + k);
+    };
+    if constexpr (NORM) {
+        // Order pinned by the sched_barriers: the rows' loads, one step of weight loads, only then the arithmetic on the rows -- whose wait
+        // (vmcnt counts in order) then leaves the weight loads in flight.  No branch between the loads and that wait: the compiler would
+        // merge the branches' pending-load counts pessimistically and wait for the weights too.
+        static_assert(MM == 4, "");
+        NormRows<4> nrows;
+        __shared__ float nred[16];
+        stage_rmsnorm_load<4>(nrows, p);
+        __builtin_amdgcn_sched_barrier(0);
+        fill(b0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_rmsnorm_finish<4>(nrows, smem, nred, p);
+        fill(b1, 512 < K ? 512 : 0);
+    } else {
+        fill(b0, 0);
+        fill(b1, 512 < K ? 512 : 0);
+        for (int idx = tid; idx < MM * KC; idx += 256) {
+            const int m = idx / KC, c = idx - m * KC;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m < p.M) v = *reinterpret_cast<const uint4*>(A + (size_t)m * p.lda + c * 8);
+            *reinterpret_cast<uint4*>(smem + ((size_t)m * KC + c) * 16) = v;
+        }
+        __syncthreads();
+    }
+    if (rows[0] >= p.N) return;
     float acc[4 * MM];
 #pragma unroll
     for (int i = 0; i < 4 * MM; ++i) acc[i] = 0.f;
@@ -1368,11 +1458,6 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     // Three register buffers of four 1 KiB row segments rotate: two steps of loads are in flight while the third is multiplied.  The dot
     // products are opaque asm to the scheduler, which would otherwise serialise load -> wait -> 16 dots with one buffer; the
     // sched_barriers pin "issue the loads, then compute".
-    uint4 b0[4], b1[4], b2[4];
-    auto fill = [&](uint4 (&b)[4], const int k) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b[r] = *reinterpret_cast<const uint4*>(wr[r] + k);
-    };
     auto step = [&](const uint4 (&b)[4], const int k) {
         uint4 av[MM];
 #pragma unroll
@@ -1387,8 +1472,6 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
             }
         __builtin_amdgcn_sched_barrier(0);
     };
-    fill(b0, 0);
-    if (512 < K) fill(b1, 512);
     for (int k0 = 0; k0 < K; k0 += 1536) {
         if (k0 + 1024 < K) fill(b2, k0 + 1024);
         step(b0, k0);
@@ -1425,66 +1508,139 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
 // Narrow weight matrices (wo, w2, wqkv at decode: N <= 8192) give the kernel above only ~4 waves per CU.  Here a workgroup owns
 // four rows of W and its four waves split K; the activation rows are read straight from global memory (32..115 KB in total,
 // cache-resident) instead of being staged per workgroup, so nothing but 256 bytes of LDS is needed and a CU holds many workgroups.
-template <int MM>
+// NORM: the activations are RMSNorm(norm_x) * norm_w, staged as bf16 in LDS by stage_rmsnorm (K <= 4096, M <= 4) instead of read from
+// global memory.  act == 4 (R == 8 only): the wqkv epilogue of a decode step -- the workgroup owns rows d .. d+3 and d+64 .. d+67 of one
+// 128-row head slot, i.e. four rotate_half pairs, and writes q / the KV-cache rows directly (same arithmetic as the prefill epilogue).
+template <int MM, int R, int NB, bool NORM>
 __global__ __launch_bounds__(256) void gemm_skinny_ksplit_kernel(GemmArgs p) {
-    __shared__ float red[4][4][MM];
+    static_assert(R * MM == 16 || R * MM == 32, "the butterfly reduces 16 or 32 values per lane");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NORM: A as bf16 [MM][K]
+    __shared__ float red[4][R * MM];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int KQ = p.K >> 2;                          // this wave's K range (K % 2048 == 0)
     const bf16* A = reinterpret_cast<const bf16*>(p.A) + (size_t)wv * KQ + lane * 8;
     const bf16* W = reinterpret_cast<const bf16*>(p.W) + (size_t)wv * KQ + lane * 8;
-    const long n0 = (long)blockIdx.x * 4;
-    const bf16* wr[4];
+    const bool rope = R == 8 && p.act == 4;
+    const long n0 = rope ? (long)(blockIdx.x >> 4) * 128 + (blockIdx.x & 15) * 4 : (long)blockIdx.x * R;
+    auto row_of = [&](const int r) -> long { return rope ? n0 + (r & 3) + (r >> 2) * 64 : n0 + r; };
+    const bf16* wr[R];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) wr[r] = W + (size_t)min(n0 + r, (long)p.N - 1) * p.ldw;
+    for (int r = 0; r < R; ++r) wr[r] = W + (size_t)min(row_of(r), (long)p.N - 1) * p.ldw;
     const bf16* ar[MM];
 #pragma unroll
     for (int m = 0; m < MM; ++m) ar[m] = A + (size_t)min(m, p.M - 1) * p.lda;
-    float acc[4 * MM];
+    float acc[R * MM];
 #pragma unroll
-    for (int i = 0; i < 4 * MM; ++i) acc[i] = 0.f;
-    struct Buf { uint4 w[4], a[MM]; };
-    Buf b0, b1, b2;                                   // as in gemm_skinny_kernel: two steps of loads in flight behind the one being multiplied
+    for (int i = 0; i < R * MM; ++i) acc[i] = 0.f;
+    struct Buf { uint4 w[R], a[NORM ? 1 : MM]; };
     auto fill = [&](Buf& b, const int k) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) b.w[r] = *reinterpret_cast<const uint4*>(wr[r] + k);
+        for (int r = 0; r < R; ++r) b.w[r] = *reinterpret_cast<const uint4*>(wr[r] + k);
+        if constexpr (!NORM) {
 #pragma unroll
-        for (int m = 0; m < MM; ++m) b.a[m] = *reinterpret_cast<const uint4*>(ar[m] + k);
+            for (int m = 0; m < MM; ++m) b.a[m] = *reinterpret_cast<const uint4*>(ar[m] + k);
+        }
     };
-    auto step = [&](const Buf& b) {
+    const char* xa = smem + ((size_t)wv * KQ + lane * 8) * 2;
+    auto step = [&](const Buf& b, const int k) {
+        uint4 av[MM];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            if constexpr (NORM) av[m] = *reinterpret_cast<const uint4*>(xa + ((size_t)m * p.K + k) * 2);
+            else av[m] = b.a[m];
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int m = 0; m < MM; ++m) {
-                dot2c(acc[r * MM + m], b.w[r].x, b.a[m].x); dot2c(acc[r * MM + m], b.w[r].y, b.a[m].y);
-                dot2c(acc[r * MM + m], b.w[r].z, b.a[m].z); dot2c(acc[r * MM + m], b.w[r].w, b.a[m].w);
+                dot2c(acc[r * MM + m], b.w[r].x, av[m].x); dot2c(acc[r * MM + m], b.w[r].y, av[m].y);
+                dot2c(acc[r * MM + m], b.w[r].z, av[m].z); dot2c(acc[r * MM + m], b.w[r].w, av[m].w);
             }
         __builtin_amdgcn_sched_barrier(0);
     };
-    fill(b0, 0);
-    if (512 < KQ) fill(b1, 512);
-    for (int k0 = 0; k0 < KQ; k0 += 1536) {
-        if (k0 + 1024 < KQ) fill(b2, k0 + 1024);
-        step(b0);
-        if (k0 + 512 >= KQ) break;
-        if (k0 + 1536 < KQ) fill(b0, k0 + 1536);
-        step(b1);
-        if (k0 + 1024 >= KQ) break;
-        if (k0 + 2048 < KQ) fill(b1, k0 + 2048);
-        step(b2);
+    // NB register buffers rotate: NB - 1 steps of loads are in flight behind the one being multiplied (see gemm_skinny_kernel); the first
+    // loads are requested before the activations are staged
+    if constexpr (NB == 3) {
+        Buf b0, b1, b2;
+        NormRows<NORM ? 4 : 1> nrows;
+        if constexpr (NORM) stage_rmsnorm_load<4>(nrows, p);
+        __builtin_amdgcn_sched_barrier(0);
+        fill(b0, 0);
+        fill(b1, 512 < KQ ? 512 : 0);   // unconditional, order pinned: see gemm_skinny_kernel
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NORM) { __shared__ float nred[16]; stage_rmsnorm_finish<4>(nrows, smem, nred, p); }
+        for (int k0 = 0; k0 < KQ; k0 += 1536) {
+            if (k0 + 1024 < KQ) fill(b2, k0 + 1024);
+            step(b0, k0);
+            if (k0 + 512 >= KQ) break;
+            if (k0 + 1536 < KQ) fill(b0, k0 + 1536);
+            step(b1, k0 + 512);
+            if (k0 + 1024 >= KQ) break;
+            if (k0 + 2048 < KQ) fill(b1, k0 + 2048);
+            step(b2, k0 + 1024);
+        }
+    } else {
+        Buf b0, b1;
+        if constexpr (NORM) {   // one step of weights in flight under the staging (the rows' registers + two steps would cost the third workgroup per CU)
+            NormRows<4> nrows;
+            __shared__ float nred[16];
+            stage_rmsnorm_load<4>(nrows, p);
+            __builtin_amdgcn_sched_barrier(0);   // order pinned: see gemm_skinny_kernel
+            fill(b0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_rmsnorm_finish<4>(nrows, smem, nred, p);
+            fill(b1, 512 < KQ ? 512 : 0);
+        } else {
+            fill(b0, 0);
+            if (512 < KQ) fill(b1, 512);
+        }
+        for (int k0 = 0; k0 < KQ; k0 += 1024) {
+            step(b0, k0);
+            if (k0 + 512 >= KQ) break;
+            if (k0 + 1024 < KQ) fill(b0, k0 + 1024);
+            step(b1, k0 + 512);
+            if (k0 + 1536 < KQ) fill(b1, k0 + 1536);
+        }
     }
     dot_fence();
     {
-        const float tot = wave_sum_many<4 * MM>(acc);
-        constexpr int SH = MM == 4 ? 2 : 1;
-        if ((lane & ((1 << SH) - 1)) == 0) (&red[wv][0][0])[lane >> SH] = tot;
+        const float tot = wave_sum_many<R * MM>(acc);
+        constexpr int SH = R * MM == 16 ? 2 : 1;
+        if ((lane & ((1 << SH) - 1)) == 0) red[wv][lane >> SH] = tot;
     }
     __syncthreads();
-    if (tid >= 4 * MM) return;
+    if (tid >= R * MM) return;
     const int r = tid / MM, m = tid - r * MM;
+    if (m >= p.M) return;
+    auto total = [&](const int i) { return (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]); };
+    if (rope) {
+        if (r >= 4) return;                            // thread (r, m): the pair (row n0 + r, row n0 + 64 + r) of token m
+        const long n1 = n0 + r, n2 = n1 + 64;
+        const float x1 = total(r * MM + m) + (p.bias ? p.bias[n1] : 0.f), x2 = total((r + 4) * MM + m) + (p.bias ? p.bias[n2] : 0.f);
+        const int slot = (int)(n1 >> 7), d = (int)(n1 & 127);
+        const int gs = p.rope_G + 2, kv = slot / gs, g = slot - kv * gs;
+        const int b = m / p.rope_S, sq = m - b * p.rope_S;
+        bf16* dst;
+        float o1 = x1, o2 = x2;
+        if (g == gs - 1) {
+            dst = reinterpret_cast<bf16*>(p.rope_v) + (((long)b * p.rope_KVH + kv) * p.rope_cap + p.rope_pos0 + sq) * 128;
+        } else {
+            const int ps = min(max(p.rope_pos[m], 0), p.rope_rows - 1);
+            const float* cp = p.rope_cos + (size_t)ps * 128 + d;
+            const float* sp = p.rope_sin + (size_t)ps * 128 + d;
+            o1 = x1 * cp[0] - x2 * sp[0];              // q_embed = q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)
+            o2 = x2 * cp[64] + x1 * sp[64];
+            dst = g == gs - 2 ? reinterpret_cast<bf16*>(p.rope_k) + (((long)b * p.rope_KVH + kv) * p.rope_cap + p.rope_pos0 + sq) * 128
+                              : reinterpret_cast<bf16*>(p.rope_q) + (long)m * ((long)p.rope_KVH * p.rope_G * 128) + ((long)kv * p.rope_G + g) * 128;
+        }
+        dst[d] = (bf16)o1;
+        dst[d + 64] = (bf16)o2;
+        return;
+    }
     const long n = n0 + r;
-    if (n >= p.N || m >= p.M) return;
-    float v = (red[0][r][m] + red[1][r][m]) + (red[2][r][m] + red[3][r][m]);
+    if (n >= p.N) return;
+    float v = total(tid);
     if (p.bias) v += p.bias[n];
     if (p.act == 1) v = gelu_erf(v);
     else if (p.act == 2) v = fmaxf(v, 0.f);
@@ -1494,10 +1650,19 @@ __global__ __launch_bounds__(256) void gemm_skinny_ksplit_kernel(GemmArgs p) {
 }
 
 static int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
-    if (a.act != 3 && a.N <= 8192 && a.K % 2048 == 0) {  // narrow: K split over the waves of a workgroup
-        const dim3 g((unsigned)((a.N + 3) / 4));
-        if (a.M <= 4) gemm_skinny_ksplit_kernel<4><<<g, 256, 0, stream>>>(a);
-        else gemm_skinny_ksplit_kernel<8><<<g, 256, 0, stream>>>(a);
+    const bool normed = a.norm_x != nullptr;
+    if (normed && (a.M > 4 || a.K > 4096 || a.K % 2048 != 0 || a.ldx % 4 != 0)) { ullsam_set_error("skinny GEMM: the fused RMSNorm prologue needs M <= 4, K <= 4096, K %% 2048 == 0 (M=%d K=%d)", a.M, a.K); return -1; }
+    if (a.act == 4 && (a.M > 4 || a.K % 2048 != 0 || a.N % 128 != 0)) { ullsam_set_error("skinny GEMM: the RoPE epilogue needs M <= 4, K %% 2048 == 0 (M=%d K=%d)", a.M, a.K); return -1; }
+    if (a.act == 4 || (a.act != 3 && a.N <= 8192 && a.K % 2048 == 0 && g_skinny_mode != 5)) {  // narrow: K split over the waves of a workgroup
+        const dim3 g4((unsigned)((a.N + 3) / 4)), g8((unsigned)((a.N + 7) / 8));
+        const size_t lds = normed ? (size_t)4 * a.K * 2 : 0;
+        if (normed) gemm_skinny_ksplit_kernel<4, 8, 2, true><<<g8, 256, lds, stream>>>(a);
+        else if (a.act == 4) gemm_skinny_ksplit_kernel<4, 8, 2, false><<<g8, 256, 0, stream>>>(a);
+        else if (a.M > 4) gemm_skinny_ksplit_kernel<8, 4, 2, false><<<g4, 256, 0, stream>>>(a);
+        else if (g_skinny_mode == 1) gemm_skinny_ksplit_kernel<4, 4, 2, false><<<g4, 256, 0, stream>>>(a);
+        else if (g_skinny_mode == 3) gemm_skinny_ksplit_kernel<4, 8, 3, false><<<g8, 256, 0, stream>>>(a);
+        else if (g_skinny_mode == 4) gemm_skinny_ksplit_kernel<4, 4, 3, false><<<g4, 256, 0, stream>>>(a);
+        else gemm_skinny_ksplit_kernel<4, 8, 2, false><<<g8, 256, 0, stream>>>(a);   // measured (tools/probes/skinny_probe.py): the four shapes within 1 % of each other
         ULLSAM_LAUNCH_CHECK();
         return 0;
     }
@@ -1506,11 +1671,13 @@ static int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     const long waves = a.act == 3 ? (long)a.N / 4 : ((long)a.N + 3) / 4;
     const dim3 grid((unsigned)((waves + 3) / 4));
     static PerDeviceOnce attr4, attr8;
-    if (MM == 4) {
-        if (attr4.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+    if (normed) {
+        gemm_skinny_kernel<4, true><<<grid, 256, lds, stream>>>(a);   // <= 32 KiB of LDS: no attribute needed
+    } else if (MM == 4) {
+        if (attr4.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); }
         gemm_skinny_kernel<4><<<grid, 256, lds, stream>>>(a);
     } else {
-        if (attr8.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+        if (attr8.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); }
         gemm_skinny_kernel<8><<<grid, 256, lds, stream>>>(a);
     }
     ULLSAM_LAUNCH_CHECK();
@@ -1518,10 +1685,11 @@ static int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
 }
 
 struct RopeEpilogue { const int* pos; const float* cos; const float* sin; void* q; void* k; void* v; int S, KVH, G, cap, pos0, rows; };
+struct NormPrologue { const float* x; long ldx; const float* w; float eps; };
 
 static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw, void* C, long ldc, int out_f32,
                      const float* bias, const float* residual, long ldr, int res_row_mod, int act, int M, int N,
-                     int K, void* workspace, long ws_bytes, void* stream, const RopeEpilogue* rope) {
+                     int K, void* workspace, long ws_bytes, void* stream, const RopeEpilogue* rope, const NormPrologue* norm = nullptr) {
     ULLSAM_CHECK(dtype == ULLSAM_DT_F32 || dtype == ULLSAM_DT_BF16, "ullsam_gemm: bad dtype %d", dtype);
     ULLSAM_CHECK(M > 0 && N > 0 && K > 0, "ullsam_gemm: empty problem M=%d N=%d K=%d", M, N, K);
     const int esz = dtype == ULLSAM_DT_F32 ? 4 : 2;
@@ -1537,6 +1705,12 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     if (rope) {
         a.rope_pos = rope->pos; a.rope_cos = rope->cos; a.rope_sin = rope->sin; a.rope_q = rope->q; a.rope_k = rope->k; a.rope_v = rope->v;
         a.rope_S = rope->S; a.rope_KVH = rope->KVH; a.rope_G = rope->G; a.rope_cap = rope->cap; a.rope_pos0 = rope->pos0; a.rope_rows = rope->rows;
+    }
+    a.norm_x = nullptr; a.norm_w = nullptr; a.norm_eps = 0.f; a.ldx = 0;
+    if (norm) {
+        ULLSAM_CHECK(norm->x && norm->w && ((uintptr_t)norm->x & 15) == 0 && ((uintptr_t)norm->w & 15) == 0 && norm->ldx % 4 == 0,
+                     "ullsam_gemm: the RMSNorm prologue needs 16-byte aligned fp32 rows and weight");
+        a.norm_x = norm->x; a.norm_w = norm->w; a.norm_eps = norm->eps; a.ldx = norm->ldx;
     }
     a.A = A; a.W = W; a.C = C; a.bias = bias; a.residual = residual;
     a.M = M; a.N = N; a.K = K;
@@ -1560,9 +1734,10 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int variant = g_gemm_variant;
     // decode step: a handful of rows against the whole weight matrix
-    if (variant == 0 && act != 4 && dtype == ULLSAM_DT_BF16 && M <= 8 && K % 512 == 0 && lda % 8 == 0 && ldw % 8 == 0 &&
+    if (variant == 0 && (act != 4 || (M <= 4 && K % 2048 == 0)) && dtype == ULLSAM_DT_BF16 && M <= 8 && K % 512 == 0 && lda % 8 == 0 && ldw % 8 == 0 &&
         (size_t)(M <= 4 ? 4 : 8) * K * 2 <= 144 * 1024 && (act != 3 || N % 128 == 0))
         return launch_gemm_skinny(a, s);
+    ULLSAM_CHECK(!norm, "ullsam_gemm: the RMSNorm prologue exists in the decode-step kernels only (bf16, M <= 4, K <= 4096; got M=%d K=%d)", M, K);
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     // 256-row tiles run one per CU: use them when the last round of tiles is >= 74 % full (measured crossover, tools/gemm_bench.py:
     // 408 / 960 / 1280 / 1904 tiles win, 272 / 320 lose to the 128x128 kernel's finer granularity) or a split-K tail absorbs the sliver
@@ -1607,6 +1782,30 @@ extern "C" int ullsam_gemm(int dtype, const void* A, long lda, const void* W, lo
                            int K, void* workspace, long ws_bytes, void* stream) {
     ULLSAM_CHECK(act != 4, "ullsam_gemm: act 4 is ullsam_gemm_qkv_rope");
     return gemm_impl(dtype, A, lda, W, ldw, C, ldc, out_f32, bias, residual, ldr, res_row_mod, act, M, N, K, workspace, ws_bytes, stream, nullptr);
+}
+
+// Decode step: out = act(bf16(RMSNorm(x) * norm_w) @ W^T + bias) (+ residual) for M <= 4 rows of K <= 4096 fp32 elements -- the norm that precedes
+// w13 (and, through ullsam_decode_qkv_rope, wqkv) in a layer, folded into the weight stream's staging instead of a launch of its own.
+extern "C" int ullsam_gemm_rmsnorm(const float* x, long ldx, const float* norm_w, float eps, const void* W, long ldw, void* C, long ldc,
+                                   int out_f32, const float* bias, const float* residual, long ldr, int act, int M, int N, int K, void* stream) {
+    ULLSAM_CHECK(act != 4, "ullsam_gemm_rmsnorm: act 4 is ullsam_decode_qkv_rope");
+    NormPrologue n{x, ldx, norm_w, eps};
+    return gemm_impl(ULLSAM_DT_BF16, nullptr, K, W, ldw, C, ldc, out_f32, bias, residual, ldr, 0, act, M, N, K, nullptr, 0, stream, nullptr, &n);
+}
+
+// Decode step (one new token per sequence, B <= 4): wqkv with the optional RMSNorm prologue (norm_w NULL: `a` holds bf16 activations, x is
+// ignored) and the head split + RoPE + KV-cache append in the epilogue; arguments as ullsam_gemm_qkv_rope with S = 1.
+extern "C" int ullsam_decode_qkv_rope(const void* a, const float* x, long ldx, const float* norm_w, float eps, const void* W, long ldw,
+                                      const float* bias, int B, int K, int KVH, int G, const int* pos, const float* cos_tab,
+                                      const float* sin_tab, int tab_rows, void* q_out, void* k_cache, void* v_cache, int cap, int cache_pos0,
+                                      void* stream) {
+    ULLSAM_CHECK(B > 0 && B <= 4 && KVH > 0 && G > 0 && tab_rows > 0 && K % 2048 == 0, "ullsam_decode_qkv_rope: B=%d (1..4) K=%d (%% 2048)", B, K);
+    ULLSAM_CHECK(cache_pos0 + 1 <= cap, "ullsam_decode_qkv_rope: cache overflow (%d + 1 > %d)", cache_pos0, cap);
+    RopeEpilogue r{pos, cos_tab, sin_tab, q_out, k_cache, v_cache, 1, KVH, G, cap, cache_pos0, tab_rows};
+    NormPrologue n{x, ldx, norm_w, eps};
+    const int N = KVH * (G + 2) * 128;
+    return gemm_impl(ULLSAM_DT_BF16, norm_w ? nullptr : a, K, W, ldw, q_out, (long)KVH * G * 128, 0, bias, nullptr, 0, 0, 4, B, N, K, nullptr, 0,
+                     stream, &r, norm_w ? &n : nullptr);
 }
 
 // wqkv GEMM of InternLM2Attention with the head split, RoPE and the KV-cache append in its epilogue (modeling_internlm2.py:359-388):

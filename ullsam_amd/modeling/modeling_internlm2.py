@@ -127,6 +127,7 @@ class InternLM2Model(Packed):
         self.norm = InternLM2RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self._rope = None
         self.collect_all_hidden_states = False
+        self.fuse_decode = True   # decode steps use the fused norm / RoPE launches (tests switch it off to compare with the separate kernels)
         self.stage_probe = None   # diagnostic tap: stage_probe(layer_index, x) with the fp32 residual stream [B*S, D] after every layer
 
     def get_input_embeddings(self):
@@ -185,17 +186,23 @@ class InternLM2Model(Packed):
         if cache is None:
             tmp_k = torch.empty((B, KVH, S, hd), dtype=dt, device=x.device)
             tmp_v = torch.empty_like(tmp_k)
+        # a decode step of <= 4 sequences (bf16, head_dim 128, hidden <= 4096): norms and RoPE ride in the GEMMs' prologue / epilogue
+        fused = S == 1 and cache is not None and hd == 128 and ops.decode_fusable(B, cfg.hidden_size, dt) and self.fuse_decode
         for li, layer in enumerate(self.layers):
             if collect is not None:
                 collect.append(x.reshape(B, S, -1).to(dt))
             at, ff = layer.attention, layer.feed_forward
-            xn = ops.norm(x, layer.attention_norm.w(), None, layer.attention_norm.variance_epsilon, dt, rms=True)
             kc, vc = (cache.k[li], cache.v[li]) if cache is not None else (tmp_k, tmp_v)
-            if hd == 128 and S > 8:   # prefill: head split + RoPE + KV append in the wqkv GEMM's epilogue (no qkv round trip)
-                q = ops.gemm_qkv_rope(xn, at.wqkv.w(dt), at.wqkv.b(), kc, vc, pos, cos, sin, B, S, KVH, G, past)
+            if fused:   # decode step: RMSNorm -> wqkv -> head split + RoPE + KV append is ONE launch (the norm runs while the weight stream starts)
+                q = ops.decode_qkv_rope(x, layer.attention_norm.w(), layer.attention_norm.variance_epsilon, at.wqkv.w(dt), at.wqkv.b(), kc, vc,
+                                        pos, cos, sin, B, KVH, G, past)
             else:
-                qkv = ops.gemm(xn, at.wqkv.w(dt), at.wqkv.b())
-                q = ops.rope_split(qkv, kc, vc, pos, cos, sin, B, S, KVH, G, hd, past)
+                xn = ops.norm(x, layer.attention_norm.w(), None, layer.attention_norm.variance_epsilon, dt, rms=True)
+                if hd == 128 and S > 8:   # prefill: head split + RoPE + KV append in the wqkv GEMM's epilogue (no qkv round trip)
+                    q = ops.gemm_qkv_rope(xn, at.wqkv.w(dt), at.wqkv.b(), kc, vc, pos, cos, sin, B, S, KVH, G, past)
+                else:
+                    qkv = ops.gemm(xn, at.wqkv.w(dt), at.wqkv.b())
+                    q = ops.rope_split(qkv, kc, vc, pos, cos, sin, B, S, KVH, G, hd, past)
             if S > 1:
                 a = ops.causal_attention(q, kc, vc, key_mask, B, H, KVH, hd, S, Sk, past)
             elif dt == torch.bfloat16 and hd == 128 and G <= 8:  # decode step: streaming split-K kernel over the cache
@@ -205,8 +212,11 @@ class InternLM2Model(Packed):
                 a = ops.naive_attention(q, kc, vc, B, H, KVH, hd, 1, Sk, (H * hd, H * hd, hd), (KVH * cap * hd, hd, cap * hd),
                                         (KVH * cap * hd, hd, cap * hd), (H * hd, H * hd, hd), hd ** -0.5, key_mask=key_mask)
             ops.gemm(a, at.wo.w(dt), at.wo.b(), residual=x, out_f32=True, out=x)
-            xn = ops.norm(x, layer.ffn_norm.w(), None, layer.ffn_norm.variance_epsilon, dt, rms=True)
-            hmid = ops.gemm(xn, ff.w13(dt), act=ops.ACT_SWIGLU)
+            if fused:
+                hmid = ops.gemm_rmsnorm(x, layer.ffn_norm.w(), layer.ffn_norm.variance_epsilon, ff.w13(dt), act=ops.ACT_SWIGLU)
+            else:
+                xn = ops.norm(x, layer.ffn_norm.w(), None, layer.ffn_norm.variance_epsilon, dt, rms=True)
+                hmid = ops.gemm(xn, ff.w13(dt), act=ops.ACT_SWIGLU)
             ops.gemm(hmid, ff.w2.w(dt), None, residual=x, out_f32=True, out=x)
             if self.stage_probe is not None:
                 self.stage_probe(li, x)

@@ -347,6 +347,44 @@ def gemm_qkv_rope(x: torch.Tensor, wqkv: torch.Tensor, bias: Optional[torch.Tens
     return q
 
 
+def decode_fusable(M: int, K: int, dtype: torch.dtype) -> bool:
+    """Shapes the decode-step kernels with the fused RMSNorm prologue / RoPE epilogue take (csrc/gemm.hip launch_gemm_skinny)."""
+    return dtype == torch.bfloat16 and 1 <= M <= 4 and K <= 4096 and K % 2048 == 0
+
+
+def gemm_rmsnorm(x: torch.Tensor, norm_w: torch.Tensor, eps: float, w: torch.Tensor, act: int = ACT_NONE) -> torch.Tensor:
+    """act(bf16(RMSNorm(x) * norm_w) @ w^T) for a decode step's M <= 4 fp32 rows: the norm is computed while the weight stream starts."""
+    _chk(x, "x", torch.float32); _chk(norm_w, "norm_w", torch.float32); _chk(w, "w", torch.bfloat16)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and decode_fusable(M, K, w.dtype), (x.shape, w.shape)
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    out = torch.empty((M, n_out), dtype=torch.bfloat16, device=x.device)
+    _lib.call("ullsam_gemm_rmsnorm", x.data_ptr(), K, norm_w.data_ptr(), float(eps), w.data_ptr(), K, out.data_ptr(), n_out, 0, None, None, 0,
+              act, M, N, K, _stream())
+    return out
+
+
+def decode_qkv_rope(x: torch.Tensor, norm_w: Optional[torch.Tensor], eps: float, wqkv: torch.Tensor, bias: Optional[torch.Tensor], k_cache, v_cache,
+                    pos, cos_tab, sin_tab, B, KVH, G, cache_pos0) -> torch.Tensor:
+    """One new token per sequence (B <= 4): q = rope(split(h @ wqkv^T + bias)), k (rotated) / v appended to the caches at cache_pos0, where
+    h = bf16(RMSNorm(x) * norm_w) for fp32 x (norm_w given) or x itself (bf16, norm_w None)."""
+    _chk(wqkv, "wqkv", torch.bfloat16); _chk(pos, "position_ids", torch.int32); _chk(cos_tab, "cos", torch.float32); _chk(sin_tab, "sin", torch.float32)
+    _chk(k_cache, "k_cache", torch.bfloat16); _chk(v_cache, "v_cache", torch.bfloat16)
+    _chk(x, "x", torch.float32 if norm_w is not None else torch.bfloat16)
+    K = x.shape[1]
+    assert wqkv.shape == (KVH * (G + 2) * 128, K) and x.shape[0] == B and cos_tab.shape[1] == 128 and decode_fusable(B, K, wqkv.dtype)
+    if bias is not None:
+        _chk(bias, "bias", torch.float32)
+    if norm_w is not None:
+        _chk(norm_w, "norm_w", torch.float32)
+    q = torch.empty((B, KVH * G * 128), dtype=torch.bfloat16, device=x.device)
+    _lib.call("ullsam_decode_qkv_rope", None if norm_w is not None else x.data_ptr(), x.data_ptr() if norm_w is not None else None, K, _p(norm_w),
+              float(eps), wqkv.data_ptr(), K, _p(bias), B, K, KVH, G, pos.data_ptr(), cos_tab.data_ptr(), sin_tab.data_ptr(), cos_tab.shape[0],
+              q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_cache.shape[2], cache_pos0, _stream())
+    return q
+
+
 def argmax(logits: torch.Tensor) -> torch.Tensor:
     _chk(logits, "logits", torch.float32)
     R, V = logits.shape
