@@ -1536,11 +1536,45 @@ extern "C" int ullsam_tok2img_attention(int kv_dtype, const float* q, const void
 // workgroups (flash-decoding) and merged by decode_attn_merge_kernel.  K / V rows are 256 bytes (hd 128, bf16): 16 lanes per row,
 // 4 rows per wave load, fully coalesced; the dot product reduces over the 16 lanes with four DPP steps.  Key padding is the
 // reference's additive finfo.min.
+// lane ^ 16 / lane ^ 32 exchanges on gfx950's row-swap instructions (one VALU op + a select) instead of a ds_bpermute round trip:
+// v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of
+// the first with the lower half of the second; with both operands = v, a lane's partner value is in one of the two results.
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float lane_xor16(float v) {
+    const unsigned int u = __builtin_bit_cast(unsigned int, v);
+    const uint2v r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 16) ? r.x : r.y);
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+    const unsigned int u = __builtin_bit_cast(unsigned int, v);
+    const uint2v r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r.x : r.y);
+}
+// Sum over the 16 lanes of a DPP row, result in every lane: quad exchanges, then the half-row and row mirrors (after the quad steps a
+// lane's mirror partner holds the other quad's / half's sum).  Four VALU instructions instead of four ds_bpermute round trips; the
+// additions are those of the xor butterfly (own group's sum + partner group's sum).
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));  // row_mirror
+    return v;
+}
 template <int TQ>
 __global__ __launch_bounds__(256) void decode_attn_partial_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kc,
                                                                   const bf16* __restrict__ vc, const int* __restrict__ key_mask,
                                                                   float* __restrict__ ws, int G, int KVH, int Sk, long kv_bs,
-                                                                  long kv_hs, float scale, int nsplit) {
+                                                                  long kv_hs, float scale, int nsplit
+#ifdef ULLSAM_STAMP_DECODE
+                                                                  , unsigned long long* dbg
+#endif
+                                                                  ) {
+#ifdef ULLSAM_STAMP_DECODE
+    unsigned long long st[8]; st[0] = __builtin_amdgcn_s_memtime();
+#define DSTAMP(i) st[i] = __builtin_amdgcn_s_memtime()
+#else
+#define DSTAMP(i)
+#endif
     constexpr int HD = 128, EPL = 8, LPR = 16, RPW = 4;
     __shared__ float so[4][TQ][HD];
     __shared__ float sml[4][TQ][2];
@@ -1551,63 +1585,92 @@ __global__ __launch_bounds__(256) void decode_attn_partial_kernel(const bf16* __
     const int per = (Sk + nsplit - 1) / nsplit;
     const int s0 = split * per, s1 = min(Sk, s0 + per);
     const float FMIN = -3.4028234663852886e38f;
+    const bf16* kb = kc + (long)b * kv_bs + (long)kvh * kv_hs;
+    const bf16* vb = vc + (long)b * kv_bs + (long)kvh * kv_hs;
+    const int* km = key_mask ? key_mask + (long)b * Sk : nullptr;
+    // CH row groups (4 rows each) per trip, their K / V / mask loads issued together; the first trip's are requested before the queries
+    // are even converted and the next trip's before the current one is multiplied (sched_barriers keep the scheduler from sinking the
+    // loads back next to their uses): a workgroup's share of the cache costs one exposed memory latency in all.
+    constexpr int CH = 4;
+    struct Chunk { uint4 k[CH], v[CH]; int mk[CH]; };
+    auto request = [&](Chunk& ck, const int base) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int row = min(base + 4 * RPW * j + r, Sk - 1);
+            const long off = (long)row * HD + c * EPL;
+            ck.k[j] = *reinterpret_cast<const uint4*>(kb + off);
+            ck.v[j] = *reinterpret_cast<const uint4*>(vb + off);
+            ck.mk[j] = km ? km[row] : 1;
+        }
+    };
+    Chunk cur, nxt;
+    uint4 qraw[TQ];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) qraw[t] = t < G ? *reinterpret_cast<const uint4*>(q + ((long)pr * G + t) * HD + c * EPL) : make_uint4(0, 0, 0, 0);
+    const int base0 = s0 + wv * RPW;
+    request(cur, base0);
+    __builtin_amdgcn_sched_barrier(0);
     float qf[TQ][EPL];
 #pragma unroll
-    for (int t = 0; t < TQ; ++t) {
-        float tmp[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) tmp[e] = 0.f;
-        if (t < G) bf16x8_to_f32_attn(*reinterpret_cast<const uint4*>(q + ((long)pr * G + t) * HD + c * EPL), tmp);
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) qf[t][e] = tmp[e];
-    }
+    for (int t = 0; t < TQ; ++t) bf16x8_to_f32_attn(qraw[t], qf[t]);
     float m[TQ], l[TQ], o[TQ][EPL];
+#ifdef ULLSAM_STAMP_DECODE
+    DSTAMP(1);
+#endif
 #pragma unroll
     for (int t = 0; t < TQ; ++t) {
         m[t] = -1e30f; l[t] = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) o[t][e] = 0.f;
     }
-    const bf16* kb = kc + (long)b * kv_bs + (long)kvh * kv_hs;
-    const bf16* vb = vc + (long)b * kv_bs + (long)kvh * kv_hs;
-    const int* km = key_mask ? key_mask + (long)b * Sk : nullptr;
-    for (int row0 = s0 + wv * RPW; row0 < s1; row0 += 4 * RPW) {
-        const int row = row0 + r;
-        const bool valid = row < s1;
-        const long off = (long)min(row, Sk - 1) * HD + c * EPL;
-        float kf[EPL], vf[EPL];
-        bf16x8_to_f32_attn(*reinterpret_cast<const uint4*>(kb + off), kf);
-        bf16x8_to_f32_attn(*reinterpret_cast<const uint4*>(vb + off), vf);
-        const float add = (km && valid && km[row] == 0) ? FMIN : 0.f;
+    for (int base = base0; base < s1; base += 4 * RPW * CH) {
+        const bool more = base + 4 * RPW * CH < s1;
+        if (more) request(nxt, base + 4 * RPW * CH);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef ULLSAM_STAMP_DECODE
+        if (base == base0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DSTAMP(2); }
+#endif
 #pragma unroll
-        for (int t = 0; t < TQ; ++t) {
-            float sc = 0.f;
+        for (int j = 0; j < CH; ++j) {
+            const int row0 = base + 4 * RPW * j;
+            if (row0 >= s1) break;                      // wave-uniform
+            const bool valid = row0 + r < s1;
+            float kf[EPL], vf[EPL];
+            bf16x8_to_f32_attn(cur.k[j], kf);
+            bf16x8_to_f32_attn(cur.v[j], vf);
+            const float add = (valid && cur.mk[j] == 0) ? FMIN : 0.f;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) sc += qf[t][e] * kf[e];
+            for (int t = 0; t < TQ; ++t) {
+                float sc = 0.f;
 #pragma unroll
-            for (int x = 1; x < LPR; x <<= 1) sc += __shfl_xor(sc, x, 64);
-            sc = sc * scale + add;
-            const float mn = fmaxf(m[t], sc);
-            const float al = __expf(m[t] - mn), pv = valid ? __expf(sc - mn) : 0.f;
-            l[t] = l[t] * al + pv;
+                for (int e = 0; e < EPL; ++e) sc += qf[t][e] * kf[e];
+                sc = row16_sum(sc);                     // the 16 lanes of a key row (same sums as the xor butterfly, without LDS)
+                sc = sc * scale + add;
+                const float mn = fmaxf(m[t], sc);
+                const float al = __expf(m[t] - mn), pv = valid ? __expf(sc - mn) : 0.f;
+                l[t] = l[t] * al + pv;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) o[t][e] = o[t][e] * al + pv * vf[e];
-            m[t] = mn;
+                for (int e = 0; e < EPL; ++e) o[t][e] = o[t][e] * al + pv * vf[e];
+                m[t] = mn;
+            }
         }
+        if (more) cur = nxt;
     }
-#pragma unroll
-    for (int x = LPR; x < 64; x <<= 1) {  // merge the RPW row groups of the wave
+    DSTAMP(3);
+    auto merge_rows = [&](auto partner) {  // merge the RPW row groups of the wave: lane <-> lane ^ 16, then lane ^ 32
 #pragma unroll
         for (int t = 0; t < TQ; ++t) {
-            const float m2 = __shfl_xor(m[t], x, 64), l2 = __shfl_xor(l[t], x, 64);
+            const float m2 = partner(m[t]), l2 = partner(l[t]);
             const float mn = fmaxf(m[t], m2);
             const float a1 = __expf(m[t] - mn), a2 = __expf(m2 - mn);
             l[t] = l[t] * a1 + l2 * a2;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) o[t][e] = o[t][e] * a1 + __shfl_xor(o[t][e], x, 64) * a2;
+            for (int e = 0; e < EPL; ++e) o[t][e] = o[t][e] * a1 + partner(o[t][e]) * a2;
             m[t] = mn;
         }
-    }
+    };
+    merge_rows([](float v) { return lane_xor16(v); });
+    merge_rows([](float v) { return lane_xor32(v); });
     if (r == 0) {
 #pragma unroll
         for (int t = 0; t < TQ; ++t) {
@@ -1616,7 +1679,9 @@ __global__ __launch_bounds__(256) void decode_attn_partial_kernel(const bf16* __
             if (c == 0) { sml[wv][t][0] = m[t]; sml[wv][t][1] = l[t]; }
         }
     }
+    DSTAMP(4);
     __syncthreads();
+    DSTAMP(5);
     // partials: o [P][nsplit][G][HD], then ml [P][nsplit][G][2]
     float* wo = ws + ((long)pr * nsplit + split) * G * HD;
     float* wml = ws + (long)gridDim.y * nsplit * G * HD + ((long)pr * nsplit + split) * G * 2;
@@ -1635,20 +1700,48 @@ __global__ __launch_bounds__(256) void decode_attn_partial_kernel(const bf16* __
         wo[i] = acc;
         if (cc == 0) { wml[t * 2] = mn; wml[t * 2 + 1] = ll; }
     }
+#ifdef ULLSAM_STAMP_DECODE
+    DSTAMP(6);
+    if (dbg && lane == 0) {
+        unsigned long long* d = dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 8;
+        for (int i = 0; i < 7; ++i) d[i] = st[i];
+        d[7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
+#undef DSTAMP
 
 __global__ __launch_bounds__(128) void decode_attn_merge_kernel(const float* __restrict__ ws, bf16* __restrict__ out, int P, int G, int nsplit) {
-    constexpr int HD = 128;
+    constexpr int HD = 128, NS = 8;                      // splits per trip: their loads are independent and issued together
     const int pt = blockIdx.x, pr = pt / G, t = pt - pr * G, cc = threadIdx.x;
     const float* wo = ws + (long)pr * nsplit * G * HD;
     const float* wml = ws + (long)P * nsplit * G * HD + (long)pr * nsplit * G * 2;
     float mn = -1e30f;
-    for (int s2 = 0; s2 < nsplit; ++s2) mn = fmaxf(mn, wml[((long)s2 * G + t) * 2]);
+    for (int s0 = 0; s0 < nsplit; s0 += NS) {
+        float mv[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) mv[j] = s0 + j < nsplit ? wml[((long)(s0 + j) * G + t) * 2] : -1e30f;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) mn = fmaxf(mn, mv[j]);
+    }
     float acc = 0.f, ll = 0.f;
-    for (int s2 = 0; s2 < nsplit; ++s2) {
-        const float a = __expf(wml[((long)s2 * G + t) * 2] - mn);
-        acc += wo[((long)s2 * G + t) * HD + cc] * a;
-        ll += wml[((long)s2 * G + t) * 2 + 1] * a;
+    for (int s0 = 0; s0 < nsplit; s0 += NS) {
+        float mv[NS], lv[NS], ov[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const bool on = s0 + j < nsplit;
+            const long s2 = on ? s0 + j : 0;
+            mv[j] = on ? wml[(s2 * G + t) * 2] : -1e30f;
+            lv[j] = on ? wml[(s2 * G + t) * 2 + 1] : 0.f;
+            ov[j] = on ? wo[(s2 * G + t) * HD + cc] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {                   // (splits in order, as before: the sums are the same)
+            if (s0 + j >= nsplit) break;
+            const float a = __expf(mv[j] - mn);
+            acc += ov[j] * a;
+            ll += lv[j] * a;
+        }
     }
     out[((long)pr * G + t) * HD + cc] = (bf16)(acc / ll);
 }
@@ -1663,8 +1756,14 @@ extern "C" int ullsam_decode_attention(const void* q, const void* kc, const void
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(nsplit, P);
     const long kv_bs = (long)KVH * cap * hd, kv_hs = (long)cap * hd;
-    if (G <= 4) decode_attn_partial_kernel<4><<<grid, 256, 0, s>>>((const bf16*)q, (const bf16*)kc, (const bf16*)vc, key_mask, workspace, G, KVH, Sk, kv_bs, kv_hs, scale, nsplit);
-    else decode_attn_partial_kernel<8><<<grid, 256, 0, s>>>((const bf16*)q, (const bf16*)kc, (const bf16*)vc, key_mask, workspace, G, KVH, Sk, kv_bs, kv_hs, scale, nsplit);
+#ifdef ULLSAM_STAMP_DECODE
+#define DDBG , g_attn_dbg
+#else
+#define DDBG
+#endif
+    if (G <= 4) decode_attn_partial_kernel<4><<<grid, 256, 0, s>>>((const bf16*)q, (const bf16*)kc, (const bf16*)vc, key_mask, workspace, G, KVH, Sk, kv_bs, kv_hs, scale, nsplit DDBG);
+    else decode_attn_partial_kernel<8><<<grid, 256, 0, s>>>((const bf16*)q, (const bf16*)kc, (const bf16*)vc, key_mask, workspace, G, KVH, Sk, kv_bs, kv_hs, scale, nsplit DDBG);
+#undef DDBG
     ULLSAM_LAUNCH_CHECK();
     decode_attn_merge_kernel<<<P * G, 128, 0, s>>>(workspace, (bf16*)out, P, G, nsplit);
     ULLSAM_LAUNCH_CHECK();
