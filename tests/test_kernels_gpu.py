@@ -637,7 +637,7 @@ def test_gemm_decode_rows(ops, M):
     """M <= 8 rows in bf16 take the weight-streaming kernel (decode step): plain, bias + GELU, fp32 residual, SwiGLU, ragged N."""
     from ullsam_amd.packing import pack_w13
     rng = np.random.default_rng(M)
-    for N, K in ((4096, 4096), (1003, 512), (2048, 14336 if M <= 4 else 1536)):
+    for N, K in ((4096, 4096), (1003, 512), (2048, 14336 if M <= 4 else 1536), (17923, 1024), (18432, 2048)):   # the last: SwiGLU through the resident-workgroup kernel (M <= 4)
         a = T(rng.standard_normal((M, K), dtype=np.float32), torch.bfloat16)
         w = T((rng.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)).astype(np.float32), torch.bfloat16)
         bias, res = T(rng.standard_normal(N, dtype=np.float32)), T(rng.standard_normal((M, N), dtype=np.float32))
@@ -664,7 +664,7 @@ def test_decode_gemm_with_rmsnorm_prologue_equals_norm_then_gemm(ops, M, K):
     rng = np.random.default_rng(100 * M + K)
     x = T(rng.standard_normal((M, K), dtype=np.float32) * 3)
     nw = T(1 + 0.1 * rng.standard_normal(K, dtype=np.float32))
-    F = 1024
+    F = 1024 if K == 2048 else 9216    # the second: the persistent kernel (>= 4096 four-row units)
     w13 = pack_w13(T(rng.standard_normal((F, K), dtype=np.float32) / math.sqrt(K), torch.bfloat16), T(rng.standard_normal((F, K), dtype=np.float32) / math.sqrt(K), torch.bfloat16))
     wn = T(rng.standard_normal((1536, K), dtype=np.float32) / math.sqrt(K), torch.bfloat16)
     xn = ops.norm(x, nw, None, 1e-5, torch.bfloat16, rms=True)

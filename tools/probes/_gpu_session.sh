@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -x -q -m gpu -k "decode or generate" 2>&1 < /dev/null | tail -3
-timeout 400 python3 tools/decode_bench.py 4 1081 64 2>&1 < /dev/null | tail -1
-timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof2 -o sk -- python3 tools/decode_bench.py 4 1081 64 > gpurun_out/dec.log 2>&1 < /dev/null
-timeout 120 python3 tools/probes/ktrace_summary.py /tmp/prof2 < /dev/null | head -14
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -x -q -m gpu -k "decode or generate or gemm" 2>&1 < /dev/null | tail -4
+timeout 300 python bench.py --mode decode --no-cpu-baseline 2>&1 < /dev/null | tail -1 > gpurun_out/dec.log
+python3 -c "
+import json; d=json.loads(open('gpurun_out/dec.log').read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'])"

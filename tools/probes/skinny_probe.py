@@ -10,7 +10,11 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 dev = "cuda:0"
 D, F, QKV = 4096, 14336, 6144
 SHAPES = {"wqkv": (QKV, D, 0, False), "wo": (D, D, 0, True), "w13": (2 * F, D, 3, False), "w2": (D, F, 0, True)}
-L = 32
+if os.environ.get("SKINNY_ONLY"):
+    SHAPES = {k: v for k, v in SHAPES.items() if k in os.environ["SKINNY_ONLY"].split(",")}
+if os.environ.get("SKINNY_HEAD"):
+    SHAPES["head"] = (92553, D, 0, False)
+L = 32 if not os.environ.get('SKINNY_HEAD') else 4
 Ws = {k: [torch.randn(n, kk, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(L)] for k, (n, kk, _, _) in SHAPES.items()}
 xs = {D: torch.randn(M, D, device=dev, dtype=torch.bfloat16), F: torch.randn(M, F, device=dev, dtype=torch.bfloat16)}
 res = torch.zeros(M, D, device=dev, dtype=torch.float32)

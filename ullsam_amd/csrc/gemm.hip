@@ -62,7 +62,7 @@ static int g_split_tail = 1;   // ullsam_set_gemm_variant(v | 64) disables the s
 static int g_gemm_variant = 0; // bits 0-3 force a kernel: 0 auto, 1 128x128, 3 256x256 two-buffer, 6 256x256 ring, 8 256x320 ring, 9 272x256 ring
 static int g_dbg = 0;          // ullsam_set_gemm_variant bit 15: stamp the ring kernel (tools/probes/ring8_stamps.py reads the stamps from the workspace)
 static int g_auto_mask = 7;    // ullsam_set_gemm_tuning(1, mask): ring tile shapes the auto dispatch may pick: bit 0 256x256, bit 1 256x320, bit 2 272x256
-static int g_skinny_mode = 0;  // ullsam_set_gemm_tuning(2, mode): K-split weight stream at M <= 4: 0 auto, 1 = 4 rows x 2 buffers, 2 = 8 rows x 2, 3 = 8 rows x 3, 4 = 4 rows x 3
+static int g_skinny_mode = 0;  // ullsam_set_gemm_tuning(2, mode): weight streams at M <= 4 (A/B): 0 auto; K-split kernel 1 = 4 rows x 2 buffers, 3 = 8 rows x 3, 4 = 4 rows x 3; 5 = no K-split; 6 = no persistent kernel
 static int g_group_m = 4;      // ullsam_set_gemm_tuning(0, gm): raster group height (measured: 4 -> 83.26 ms per step, 8 -> 83.73, 2 -> 84.35)
 
 template <typename T>
@@ -1250,7 +1250,7 @@ extern "C" int ullsam_gemm_fp8(const void* A8, long lda, const float* a_scale, c
 extern "C" int ullsam_set_gemm_tuning(int key, int value) {
     if (key == 0 && value >= 1 && value <= 1024) { g_group_m = value; return 0; }
     if (key == 1 && value >= 0 && value <= 7) { g_auto_mask = value; return 0; }
-    if (key == 2 && value >= 0 && value <= 5) { g_skinny_mode = value; return 0; }
+    if (key == 2 && value >= 0 && value <= 8) { g_skinny_mode = value; return 0; }
     ullsam_set_error("ullsam_set_gemm_tuning: unknown key %d / bad value %d", key, value);
     return -1;
 }
@@ -1347,8 +1347,8 @@ struct NormRows { float4 v[MM][4]; float4 w[4]; };
 // The loads of stage_rmsnorm, issued BEFORE the kernel's first weight loads: a wave's vector-memory results return in order, so rows requested
 // behind the weight stream would not be usable until that whole stream had landed.
 template <int MM>
-__device__ __forceinline__ void stage_rmsnorm_load(NormRows<MM>& n, const GemmArgs& p) {
-    const int tid = threadIdx.x, M = p.M, nq = p.K >> 10;   // K % 1024 == 0: float4 i*256 + tid exists iff i < K / 1024 (uniform)
+__device__ __forceinline__ void stage_rmsnorm_load(NormRows<MM>& n, const GemmArgs& p, const bool active = true) {
+    const int tid = threadIdx.x & 255, M = active ? p.M : 0, nq = p.K >> 10;   // K % 1024 == 0: float4 i*256 + tid exists iff i < K / 1024 (uniform)
     const long ldx = p.ldx;
     const float* xb = p.norm_x + tid * 4;
     const float* wb = p.norm_w + tid * 4;
@@ -1363,8 +1363,8 @@ __device__ __forceinline__ void stage_rmsnorm_load(NormRows<MM>& n, const GemmAr
     for (int i = 0; i < 4; ++i) n.w[i] = i < nq ? *reinterpret_cast<const float4*>(wb + i * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 template <int MM>
-__device__ __forceinline__ void stage_rmsnorm_finish(const NormRows<MM>& n, char* smem, float* red, const GemmArgs& p) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+__device__ __forceinline__ void stage_rmsnorm_finish(const NormRows<MM>& n, char* smem, float* red, const GemmArgs& p, const bool active = true) {
+    const int tid = threadIdx.x & 255, lane = tid & 63, wv = tid >> 6;
     const int K = p.K, nq = K >> 10;
     float ss[MM];
 #pragma unroll
@@ -1381,7 +1381,7 @@ __device__ __forceinline__ void stage_rmsnorm_finish(const NormRows<MM>& n, char
 #pragma unroll
         for (int m = 0; m < MM; ++m) ss[m] += t[m];
     }
-    if (lane == 0) {
+    if (lane == 0 && active) {
 #pragma unroll
         for (int m = 0; m < MM; ++m) red[wv * MM + m] = ss[m];
     }
@@ -1393,7 +1393,7 @@ __device__ __forceinline__ void stage_rmsnorm_finish(const NormRows<MM>& n, char
         const float rstd = rsqrtf(tot / (float)K + p.norm_eps);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (i >= nq) continue;
+            if (i >= nq || !active) continue;
             const float4 o = make_float4(n.v[m][i].x * rstd * n.w[i].x, n.v[m][i].y * rstd * n.w[i].y, n.v[m][i].z * rstd * n.w[i].z, n.v[m][i].w * rstd * n.w[i].w);
             store4(dst + (size_t)m * K + i * 1024, o);
         }
@@ -1503,6 +1503,120 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     if (p.residual) v += p.residual[(size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + n];
     if (p.out_f32) reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n] = v;
     else reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + n] = (bf16)v;
+}
+
+// Wide weight matrices at M <= 4 (w13: 28672 rows, the LM head: 92553) as ONE resident workgroup per CU that walks its share of the
+// 4-row units: the activations are staged (and normalised) once per CU instead of once per 16 rows, nothing is left for a second,
+// partly filled round of workgroups, and a wave's stream of 1 KiB steps runs through the unit boundaries (the next unit's first steps are
+// already in flight while the finished unit is reduced and stored).  W waves per workgroup, chosen by the launcher so that
+// units = CUs x W x trips comes out even (w13: 7168 units = 256 x 7 x 4).
+template <bool NORM>
+__global__ __launch_bounds__(512) void gemm_skinny_persist_kernel(GemmArgs p, int units) {
+    constexpr int MM = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // A as bf16 [4][K]
+    __shared__ float nred[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, W = blockDim.x >> 6;
+    const int K = p.K, KC = K >> 3, KS = K >> 9;
+    const bf16* Wl = reinterpret_cast<const bf16*>(p.W) + lane * 8;
+    const int stride = gridDim.x * W, u0 = blockIdx.x * W + wv;
+    const int n_mine = u0 < units ? (units - 1 - u0) / stride + 1 : 0;
+    const int total = n_mine * KS;
+    const bool swiglu = p.act == 3;
+    auto row0_of = [&](const int u) -> long { return swiglu ? (long)(u >> 5) * 128 + 2 * (u & 31) : (long)u * 4; };
+    // fill cursor: (unit, k) of the next step to request.  Past the end the loads go to the matrix' first row (cache hits): no branch, so
+    // the compiler's load counting stays exact and a wait for one buffer never includes the next
+    int fu = u0, fk = 0, fleft = total;
+    auto fill_next = [&](uint4 (&b)[4]) {
+        const bool on = fleft > 0;
+        const long r0 = on ? row0_of(fu) : 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = swiglu ? r0 + (r & 1) + (r >> 1) * 64 : r0 + r;
+            b[r] = *reinterpret_cast<const uint4*>(Wl + (size_t)(on ? min(row, (long)p.N - 1) : 0) * p.ldw + (on ? fk : 0));
+        }
+        fk += 512;
+        if (fk >= K) { fk = 0; fu += stride; }
+        --fleft;
+    };
+    uint4 b0[4], b1[4], b2[4];
+    if constexpr (NORM) {
+        NormRows<4> nrows;
+        stage_rmsnorm_load<4>(nrows, p, tid < 256);
+        __builtin_amdgcn_sched_barrier(0);   // order pinned: see gemm_skinny_kernel
+        fill_next(b0);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_rmsnorm_finish<4>(nrows, smem, nred, p, tid < 256);
+        fill_next(b1);
+    } else {
+        fill_next(b0);
+        fill_next(b1);
+        const bf16* A = reinterpret_cast<const bf16*>(p.A);
+        for (int idx = tid; idx < MM * KC; idx += blockDim.x) {
+            const int m = idx / KC, c = idx - m * KC;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m < p.M) v = *reinterpret_cast<const uint4*>(A + (size_t)m * p.lda + c * 8);
+            *reinterpret_cast<uint4*>(smem + ((size_t)m * KC + c) * 16) = v;
+        }
+        __syncthreads();
+    }
+    float acc[4 * MM];
+#pragma unroll
+    for (int i = 0; i < 4 * MM; ++i) acc[i] = 0.f;
+    const char* xa = smem + lane * 16;
+    int cu = u0, ck = 0;
+    auto finish = [&]() {   // the unit's 16 sums: butterfly, epilogue on 16 lanes, accumulators back to zero
+        dot_fence();
+        const float tot = wave_sum_many<4 * MM>(acc);
+        const int idx = lane >> 2, r = idx >> 2, m = idx & 3;
+        const long r0 = row0_of(cu);
+        if (swiglu) {
+            const float upv = __shfl_xor(tot, 32, 64);
+            if (!(lane & 3) && lane < 32 && m < p.M) {
+                const long oc = (r0 >> 7) * 64 + (r0 & 63) + r;
+                const float o = silu_f(tot) * upv;
+                if (p.out_f32) reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + oc] = o;
+                else reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + oc] = (bf16)o;
+            }
+        } else {
+            const long n = r0 + r;
+            if (!(lane & 3) && n < p.N && m < p.M) {
+                float v = tot + (p.bias ? p.bias[n] : 0.f);
+                if (p.act == 1) v = gelu_erf(v);
+                else if (p.act == 2) v = fmaxf(v, 0.f);
+                if (p.residual) v += p.residual[(size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + n];
+                if (p.out_f32) reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n] = v;
+                else reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + n] = (bf16)v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4 * MM; ++i) acc[i] = 0.f;
+    };
+    auto step = [&](const uint4 (&b)[4]) {
+        uint4 av[MM];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) av[m] = *reinterpret_cast<const uint4*>(xa + ((size_t)m * KC + (ck >> 3)) * 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                dot2c(acc[r * MM + m], b[r].x, av[m].x); dot2c(acc[r * MM + m], b[r].y, av[m].y);
+                dot2c(acc[r * MM + m], b[r].z, av[m].z); dot2c(acc[r * MM + m], b[r].w, av[m].w);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        ck += 512;
+        if (ck >= K) { finish(); ck = 0; cu += stride; }
+    };
+    for (int g = 0; g < total; g += 3) {
+        fill_next(b2);
+        step(b0);
+        if (g + 1 >= total) break;
+        fill_next(b0);
+        step(b1);
+        if (g + 2 >= total) break;
+        fill_next(b1);
+        step(b2);
+    }
 }
 
 // Narrow weight matrices (wo, w2, wqkv at decode: N <= 8192) give the kernel above only ~4 waves per CU.  Here a workgroup owns
@@ -1669,6 +1783,25 @@ static int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     const int MM = a.M <= 4 ? 4 : 8;
     const size_t lds = (size_t)MM * a.K * 2;
     const long waves = a.act == 3 ? (long)a.N / 4 : ((long)a.N + 3) / 4;
+    // measured (tools/probes/skinny_probe.py, us per launch): w13 47.4 -> 45.3 with two resident workgroups per CU (45.8 with one, 46.9 with
+    // three); the LM head (92553 rows) 129 -> 137: its 5785 workgroups already amortise the ramp, so it keeps the kernel above
+    if (MM == 4 && (normed || a.act == 3) && waves >= 4096 && lds <= 64 * 1024 && g_skinny_mode != 5 && g_skinny_mode != 6) {
+        // one workgroup per CU; W waves each so that the units divide evenly (fewest idle wave-trips, ties to the larger W)
+        static PerDeviceOnce cu_once; static int n_cu = 256;
+        if (cu_once.first()) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n_cu = pr.multiProcessorCount; }
+        const int wpc = g_skinny_mode == 7 ? 1 : g_skinny_mode == 8 ? 3 : 2;   // workgroups per CU
+        const int n_wg = n_cu * wpc;
+        int W = 8; double best = 1e30;
+        for (int w = 8; w >= 4; --w) {
+            const long per = (long)n_wg * w, trips = (waves + per - 1) / per;
+            const double waste = (double)(trips * per) / (double)waves;
+            if (waste < best - 1e-9) { best = waste; W = w; }
+        }
+        if (normed) gemm_skinny_persist_kernel<true><<<n_wg, W * 64, lds, stream>>>(a, (int)waves);
+        else gemm_skinny_persist_kernel<false><<<n_wg, W * 64, lds, stream>>>(a, (int)waves);
+        ULLSAM_LAUNCH_CHECK();
+        return 0;
+    }
     const dim3 grid((unsigned)((waves + 3) / 4));
     static PerDeviceOnce attr4, attr8;
     if (normed) {
