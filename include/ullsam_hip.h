@@ -27,7 +27,7 @@ extern "C" {
 
 /* Bumped whenever an entry point is added or a signature changes.  The Python binding refuses a library that reports another
    version (a stale libullsam_hip.so would otherwise receive shifted arguments, e.g. a row count where the stream is expected). */
-#define ULLSAM_ABI_VERSION 5
+#define ULLSAM_ABI_VERSION 6
 
 const char* ullsam_last_error_string(void);
 int ullsam_abi_version(void); /* == ULLSAM_ABI_VERSION of the header the library was built from */
@@ -74,6 +74,35 @@ int ullsam_gemm_rmsnorm(const float* x, long ldx, const float* norm_w, float eps
 int ullsam_decode_qkv_rope(const void* a, const float* x, long ldx, const float* norm_w, float eps, const void* W, long ldw, const float* bias,
                            int B, int K, int KVH, int G, const int* pos, const float* cos_tab, const float* sin_tab, int tab_rows, void* q_out,
                            void* k_cache, void* v_cache, int cap, int cache_pos0, void* stream);
+
+/* ---- Training slice: backward kernels of the segmentation branch of train_joint_v2.py:1026-1100, everything
+ * downstream of the LLM's last hidden state (mlp2, prompt encoder, mask decoder, upsample, BCE + Dice).  fp32; torch.autograd.Function
+ * wrappers in ullsam_amd/training.py.  Buffers that receive atomics (d* of colsum / ln_bwd / attn_bwd / resize_bwd / index_add_rows,
+ * `sums`) are zeroed by the caller. */
+/* C[b](m,n) = (accumulate ? C : 0) + sum_k A[b](m,k) B[b](k,n), explicit element strides (nn.Linear backward: dX = dY W, dW = dY^T X;
+ * the hypernetwork product of mask_decoder.py:146-147 and its gradients) */
+int ullsam_train_matmul(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k, long b_b,
+                        long b_k, long b_n, long c_b, long c_m, long c_n, int accumulate, void* stream);
+/* out[c] += sum_r x[r*ld + c] (bias gradients; gradients of parameters broadcast over the batch) */
+int ullsam_train_colsum(const float* x, float* out, long rows, int cols, long ld, void* stream);
+/* nn.LayerNorm / LayerNorm2d backward on rows of D (w NULL: no affine, prompt_encoder.py:141-144); dw / db may be NULL */
+int ullsam_train_ln_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, long rows, int D, float eps, void* stream);
+/* kind 1 exact GELU, 2 ReLU: dy NULL -> out = act(x), else out = dy * act'(x) */
+int ullsam_train_act(const float* x, const float* dy, float* out, long n, int kind, void* stream);
+/* prompt_encoder.py:148 y = x * llm_scale_factor + llm_bias (dy NULL), else out = dy * s, ds += sum dy x, dt += sum dy */
+int ullsam_train_scale_shift(const float* x, const float* s, const float* t, const float* dy, float* out, float* ds, float* dt, long n, void* stream);
+/* transformer.py:220-242 attention backward; q/dq [B,Sq,H,hd], k,v/dk,dv [B,Sk,H,hd] by (batch, token, head) strides; hd <= 64 */
+int ullsam_train_attn_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk, float* dv, int B, int H,
+                          int hd, int Sq, int Sk, long q_bs, long q_ts, long q_hs, long k_bs, long k_ts, long k_hs, long v_bs, long v_ts,
+                          long v_hs, long o_bs, long o_ts, long o_hs, float scale, void* stream);
+/* adjoint of the bilinear upsample F.interpolate(align_corners=False) of train_joint_v2.py:1073-1078 (planes of oh x ow -> ih x iw) */
+int ullsam_train_resize_bwd(const float* dout, float* din, long planes, int ih, int iw, int oh, int ow, void* stream);
+/* calc_instance_loss (train_joint_v2.py:774-812) with BCELoss (:638-661) + DiceLoss (:605-636): x logits / t targets [P, npix];
+ * sums [P][4], losses [3] = (total, bce, dice); the backward scales by gscale[0] (the incoming gradient of the total) */
+int ullsam_train_seg_loss(const float* x, const float* t, float* sums, float* losses, int P, long npix, float smooth, void* stream);
+int ullsam_train_seg_loss_bwd(const float* x, const float* t, const float* sums, const float* gscale, float* dx, int P, long npix, float smooth, void* stream);
+/* dst[idx[r]] += src[r]: gradient of the point-label embedding table (prompt_encoder.py:76-96) */
+int ullsam_train_index_add_rows(const float* src, const int* idx, float* dst, long rows, int C, int nrows_dst, void* stream);
 
 /* Row LayerNorm / RMSNorm, fp32 statistics.  image_encoder.py:151,161; common.py:38-43 (LayerNorm2d on NHWC rows);
  * modeling_internlm2.py:138-143 (rms=1); prompt_encoder.py:142-149 (no affine + post scale/shift); transformer.py norms. */

@@ -516,7 +516,66 @@ def case_full_depth():
          mask_bits=np.packbits(f["mask"]), mask_fill=np.float64(f["mask"].mean()), iou_pred=f["iou_pred"],
          ac_mask_iou=np.float64(ac_iou), ac_iou_pred=b["iou_pred"], **out)
 
-CASES = {"chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
+def case_train_slice():
+    """Gradients of the reference's segmentation loss (train_joint_v2.py:1026-1100: text_aware_dense_feature -> prompt encoder -> mask
+    decoder -> bilinear upsample -> BCE + Dice, calc_instance_loss :774-812) with respect to every parameter downstream of the LLM's last
+    hidden state -- mlp2, the prompt encoder, the mask decoder -- on the `ullsam_tiny` composite (full-size decoder: 64 x 64 image tokens,
+    256 channels), two instances with two clicks each.  The LLM hidden states and the image embedding are inputs (seeded), as they are
+    constants for this slice.  train_joint_v2 imports torchvision / PIL / wandb at module level, which this container lacks and the
+    loss code does not use: empty stand-in modules are registered for the import only."""
+    import sys, types
+    from transformers import AutoTokenizer, GenerationConfig, get_cosine_schedule_with_warmup, AutoModel, AutoConfig  # noqa: F401 (resolved before the stand-ins exist: transformers probes for torchvision lazily)
+    for name in ("torchvision", "torchvision.transforms", "wandb", "PIL", "PIL.Image"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+    import train_joint_v2 as TJ
+    from modeling.configuration_internvl_chat import InternVLChatConfig
+    from modeling.modeling_internvl_sam import InternVLSAMModel
+    sam = _sam_small()
+    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_TINY),
+                             downsample_ratio=0.5, template="internlm2-chat", ps_version="v2", force_image_size=1024)
+    cfg.llm_config.rope_scaling = None
+    m = InternVLSAMModel(cfg, vision_model=sam.image_encoder, prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder)
+    fill_module(m, seed=0)
+    m.train()
+    for p_ in m.parameters():
+        p_.requires_grad_(True)
+    rng = np.random.default_rng(11)
+    hid = rng.standard_normal((1, 1024, LLM_TINY["hidden_size"]), dtype=np.float32)
+    img = rng.standard_normal((1, 256, 64, 64), dtype=np.float32)
+    pts = np.array([[[300.0, 340.0], [120.0, 800.0]], [[700.0, 610.0], [64.0, 64.0]]], np.float32)     # [instances, clicks, 2]
+    lbl = np.array([[1, 0], [1, 1]], np.int32)
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
+    gt = np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None]
+    with torch.enable_grad():
+        last = m.text_aware_dense_feature(torch.from_numpy(hid))                      # [1, 256, 64, 64]
+        bs = pts.shape[0]
+        last = last.repeat(bs, 1, 1, 1)                                               # train_joint_v2.py:1052-1054
+        sp, de = m.prompt_encoder(points=(torch.from_numpy(pts), torch.from_numpy(lbl)), boxes=None, masks=None, llm_hidden_states=last)
+        low, iou = m.mask_decoder(image_embeddings=torch.from_numpy(img), image_pe=m.prompt_encoder.get_dense_pe(),
+                                  sparse_prompt_embeddings=sp, dense_prompt_embeddings=de, multimask_output=False)
+        pred = torch.nn.functional.interpolate(low, (1024, 1024), mode="bilinear", align_corners=False)
+        loss, bce, dice, iou_val = TJ.calc_instance_loss(pred, torch.from_numpy(gt), TJ.BCELoss(), TJ.DiceLoss())
+        loss.backward()
+    out = {"hid": hid, "img_seed": 11, "pts": pts, "lbl": lbl, "loss": np.float32(loss.item()), "bce": np.float32(bce.item()),
+           "dice": np.float32(dice.item()), "low_sample": low.detach().numpy().reshape(-1)[::61].copy()}
+    names = []
+    for name, p_ in m.named_parameters():
+        if not name.startswith(("mlp2.", "prompt_encoder.", "mask_decoder.")) or p_.grad is None:
+            continue
+        g = p_.grad.numpy().reshape(-1)
+        stride = max(1, g.size // 2048)
+        names.append(name)
+        out["g:" + name] = g[::stride].copy()
+        out["n:" + name] = np.float32(np.sqrt((g.astype(np.float64) ** 2).sum()))
+    out["names"] = np.array(names)
+    save("train_slice", **out)
+
+
+CASES = {"train_slice": case_train_slice, "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
          "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full,
          "vit_h_d2": case_vit_h_d2, "llm_7b_l1": case_llm_7b_l1,
          "rope_variants": case_rope_variants, "llm_tiny_bias_linear": case_llm_tiny_bias_linear,

@@ -1,0 +1,74 @@
+"""Training slice: gradients of the reference's segmentation loss for every parameter downstream of the LLM's
+last hidden state, against the reference's own autograd (tests/golden/train_slice.npz, made by oracle/gen_golden.py::case_train_slice
+from train_joint_v2.py's calc_instance_loss / BCELoss / DiceLoss over the reference modules)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util as U
+from tests.test_model_gpu import _ullsam_tiny
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _inputs(g):
+    rng = np.random.default_rng(int(g["img_seed"]))
+    hid = rng.standard_normal((1, 1024, 256), dtype=np.float32)
+    img = rng.standard_normal((1, 256, 64, 64), dtype=np.float32)
+    assert np.array_equal(hid, g["hid"])
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
+    gt = np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None]
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    return t(hid), t(img), (t(g["pts"]), t(g["lbl"])), t(gt)
+
+
+def test_segmentation_loss_and_gradients_equal_the_reference_autograd():
+    """fp32: loss / bce / dice to 1e-5 relative; every parameter gradient the reference produces (125 tensors: mlp2, llm_scale_factor,
+    llm_bias, point / not-a-point embeddings, the whole two-way transformer, both transposed convolutions, the four hypernetwork MLPs)
+    within 1e-3 of the tensor's largest entry, and its L2 norm within 1e-3; parameters the reference leaves without a gradient (IoU head,
+    mask-input convolutions, box-corner embeddings) have none here either."""
+    from ullsam_amd.training import segmentation_loss
+    g = U.gold("train_slice")
+    m = _ullsam_tiny(torch.float32)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    trainable = {n: p for n, p in m.named_parameters() if n.startswith(("mlp2.", "prompt_encoder.", "mask_decoder."))}
+    for p in trainable.values():
+        p.requires_grad_(True)
+    hid, img, pts, gt = _inputs(g)
+    loss, bce, dice = segmentation_loss(m, hid, img, pts, gt)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"]), (loss.item(), float(g["loss"]))
+    assert abs(bce.item() - float(g["bce"])) < 1e-5 * float(g["bce"]) and abs(dice.item() - float(g["dice"])) < 1e-5 * float(g["dice"])
+    loss.backward()
+    names = [str(n) for n in g["names"]]
+    worst = (0.0, "")
+    for n in names:
+        ref = g["g:" + n].astype(np.float64)
+        p = trainable[n]
+        assert p.grad is not None, n
+        full = p.grad.float().cpu().numpy().reshape(-1).astype(np.float64)
+        stride = max(1, full.size // 2048)
+        got = full[::stride]
+        scale = np.abs(ref).max()
+        diff = np.abs(got - ref).max()
+        # (+ 1e-7 absolute: gradients that are zero in exact arithmetic -- every k_proj.bias, by softmax's shift invariance -- are ~1e-9 of
+        # rounding noise on both sides, against typical entries of 1e-3 ... 1)
+        assert diff < 1e-3 * scale + 1e-7, (n, diff, scale)
+        if scale > 1e-6:
+            worst = max(worst, (diff / scale, n))
+        nref = float(g["n:" + n])
+        assert abs(np.sqrt((full ** 2).sum()) - nref) < 1e-3 * nref + 1e-6, (n, np.sqrt((full ** 2).sum()), nref)
+    for n, p in trainable.items():
+        if n not in names:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{n}: the reference leaves this parameter without a gradient"
+    print("worst relative gradient error", worst)
+
+
+def test_training_slice_refuses_bf16():
+    from ullsam_amd.training import segmentation_loss
+    g = U.gold("train_slice")
+    m = _ullsam_tiny(torch.bfloat16)
+    hid, img, pts, gt = _inputs(g)
+    with pytest.raises(TypeError):
+        segmentation_loss(m, hid, img, pts, gt)

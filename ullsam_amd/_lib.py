@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ULLSAM_HIP_LIB") or os.path.join(_HERE, "lib", "libullsam_hip.so")  # env: A/B a side build (developer switch)
 
-ABI_VERSION = 5  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
+ABI_VERSION = 6  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
 
 _lib = None
 
@@ -22,6 +22,16 @@ SIGNATURES = {
     "ullsam_gemm_qkv_rope": [i32, vp, i64, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, i64, vp],
     "ullsam_gemm_rmsnorm": [vp, i64, vp, f32, vp, i64, vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, vp],
     "ullsam_decode_qkv_rope": [vp, vp, i64, vp, f32, vp, i64, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp],
+    "ullsam_train_matmul": [vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [i32, vp],
+    "ullsam_train_colsum": [vp, vp, i64, i32, i64, vp],
+    "ullsam_train_ln_bwd": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
+    "ullsam_train_act": [vp, vp, vp, i64, i32, vp],
+    "ullsam_train_scale_shift": [vp, vp, vp, vp, vp, vp, vp, i64, vp],
+    "ullsam_train_attn_bwd": [vp] * 7 + [i32] * 5 + [i64] * 12 + [f32, vp],
+    "ullsam_train_resize_bwd": [vp, vp, i64, i32, i32, i32, i32, vp],
+    "ullsam_train_seg_loss": [vp, vp, vp, vp, i32, i64, f32, vp],
+    "ullsam_train_seg_loss_bwd": [vp, vp, vp, vp, vp, i32, i64, f32, vp],
+    "ullsam_train_index_add_rows": [vp, vp, vp, i64, i32, i32, vp],
     "ullsam_norm": [vp, i32, i64, vp, i32, i64, vp, vp, i64, i32, f32, i32, i32, vp, vp, vp],
     "ullsam_norm_fanout": [vp, i64, i32, vp, vp, f32, vp, vp, vp, i32, vp, i64, vp],
     "ullsam_vit_attention": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],

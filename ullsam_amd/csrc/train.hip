@@ -1,0 +1,347 @@
+// Backward kernels of the segmentation branch of the reference's training step (train_joint_v2.py:1026-1100): everything downstream of
+// the LLM's last hidden state -- mlp2 (modeling_internvl_sam.py:95-100, 253-270), the prompt encoder's LLM-conditioned dense prompt and
+// point embeddings (prompt_encoder.py:131-203), the mask decoder (mask_decoder.py:112-149, transformer.py:62-242), the bilinear
+// upsample and the BCE + Dice loss (train_joint_v2.py:605-661, 774-812).  fp32 throughout.  These are correctness-first kernels
+// (one output per thread, fp32 FMA): the forward of the same step runs on the inference kernels; what is here is what autograd needs
+// on top of them.  ullsam_amd/training.py holds the torch.autograd.Function wrappers.
+#include "common.h"
+
+// ---- C[b](m, n) = (accumulate ? C : 0) + sum_k A[b](m, k) * B[b](k, n), every operand with explicit element strides -----------------
+// One kernel covers dX = dY W (B = W as stored), dW = dY^T X (A read transposed), the hypernetwork product and its two gradients.
+struct MmArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K, batch;
+    long a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n;
+    int accumulate;
+};
+__global__ __launch_bounds__(256) void matmul_f32_kernel(MmArgs p) {
+    __shared__ float As[16][17], Bs[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx, b = blockIdx.z;
+    const float* A = p.A + (long)b * p.a_b;
+    const float* B = p.B + (long)b * p.b_b;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < p.K; k0 += 16) {
+        As[ty][tx] = (m < p.M && k0 + tx < p.K) ? A[(long)m * p.a_m + (long)(k0 + tx) * p.a_k] : 0.f;
+        Bs[ty][tx] = (k0 + ty < p.K && n < p.N) ? B[(long)(k0 + ty) * p.b_k + (long)n * p.b_n] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc += As[ty][kk] * Bs[kk][tx];
+        __syncthreads();
+    }
+    if (m < p.M && n < p.N) {
+        float* c = p.C + (long)b * p.c_b + (long)m * p.c_m + (long)n * p.c_n;
+        *c = p.accumulate ? *c + acc : acc;
+    }
+}
+extern "C" int ullsam_train_matmul(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k,
+                                   long b_b, long b_k, long b_n, long c_b, long c_m, long c_n, int accumulate, void* stream) {
+    ULLSAM_CHECK(M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "train_matmul: M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    MmArgs a{A, B, C, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n, accumulate};
+    matmul_f32_kernel<<<dim3((N + 15) / 16, (M + 15) / 16, batch), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- out[c] += sum_r x[r][c]  (bias gradients, broadcast-parameter gradients); out is zeroed by the caller ------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int cols, long ld, long rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += x[r * ld + c];
+    atomicAdd(out + c, s);
+}
+extern "C" int ullsam_train_colsum(const float* x, float* out, long rows, int cols, long ld, void* stream) {
+    ULLSAM_CHECK(rows > 0 && cols > 0, "train_colsum: rows=%ld cols=%d", rows, cols);
+    const long rpb = 256;
+    colsum_kernel<<<dim3((cols + 255) / 256, (unsigned)((rows + rpb - 1) / rpb)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(x, out, rows, cols, ld, rpb);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- LayerNorm backward (rows of D elements, biased variance, optional affine): one wave per row -----------------------------------
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w;  dw += dy * xhat, db += dy (atomics; zeroed by the caller)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
+                                                     float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, long rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    const float* gr = dy + row * D;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += xr[i];
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+    for (int i = lane; i < D; i += 64) { const float d = xr[i] - mean; ss += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+    float sg = 0.f, sgx = 0.f;
+    for (int i = lane; i < D; i += 64) {
+        const float xh = (xr[i] - mean) * rstd, g = gr[i] * (w ? w[i] : 1.f);
+        sg += g; sgx += g * xh;
+    }
+    const float mg = wave_sum(sg) / (float)D, mgx = wave_sum(sgx) / (float)D;
+    for (int i = lane; i < D; i += 64) {
+        const float xh = (xr[i] - mean) * rstd, g = gr[i] * (w ? w[i] : 1.f);
+        dx[row * D + i] = rstd * (g - mg - xh * mgx);
+        if (dw) atomicAdd(dw + i, gr[i] * xh);
+        if (db) atomicAdd(db + i, gr[i]);
+    }
+}
+extern "C" int ullsam_train_ln_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, long rows, int D, float eps, void* stream) {
+    ULLSAM_CHECK(rows > 0 && D > 0, "train_ln_bwd: rows=%ld D=%d", rows, D);
+    ln_bwd_kernel<<<dim3((unsigned)((rows + 3) / 4)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(x, w, dy, dx, dw, db, rows, D, eps);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- activations: kind 1 = exact (erf) GELU, 2 = ReLU; fwd y = act(x), bwd dx = dy * act'(x) ---------------------------------------
+__global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out, long n, int kind) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    float r;
+    if (kind == 1) {
+        const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+        r = dy ? dy[i] * (cdf + v * 0.3989422804014327f * expf(-0.5f * v * v)) : v * cdf;
+    } else {
+        r = dy ? (v > 0.f ? dy[i] : 0.f) : fmaxf(v, 0.f);
+    }
+    out[i] = r;
+}
+extern "C" int ullsam_train_act(const float* x, const float* dy, float* out, long n, int kind, void* stream) {
+    ULLSAM_CHECK(n > 0 && (kind == 1 || kind == 2), "train_act: n=%ld kind=%d", n, kind);
+    act_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(x, dy, out, n, kind);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- y = x * s[0] + t[0] (prompt_encoder.py:148: llm_scale_factor / llm_bias); bwd dx = dy * s, ds += sum dy * x, dt += sum dy -------
+__global__ __launch_bounds__(256) void scale_shift_kernel(const float* __restrict__ x, const float* __restrict__ s, const float* __restrict__ t,
+                                                          const float* __restrict__ dy, float* __restrict__ out, float* __restrict__ ds,
+                                                          float* __restrict__ dt, long n) {
+    __shared__ float red[2][4];
+    const long i0 = (long)blockIdx.x * 1024 + threadIdx.x;
+    const float sc = s[0];
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < 4; ++j) {
+        const long i = i0 + 256 * j;
+        if (i >= n) break;
+        if (!dy) { out[i] = x[i] * sc + t[0]; continue; }
+        out[i] = dy[i] * sc;
+        a += dy[i] * x[i];
+        b += dy[i];
+    }
+    if (!dy) return;
+    a = wave_sum(a); b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(ds, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+        atomicAdd(dt, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    }
+}
+extern "C" int ullsam_train_scale_shift(const float* x, const float* s, const float* t, const float* dy, float* out, float* ds, float* dt, long n, void* stream) {
+    ULLSAM_CHECK(n > 0 && (!dy || (ds && dt)), "train_scale_shift: n=%ld", n);
+    scale_shift_kernel<<<dim3((unsigned)((n + 1023) / 1024)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(x, s, t, dy, out, ds, dt, n);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- softmax attention backward (transformer.py:220-242: scores = q k^T / sqrt(hd), softmax over keys, out = P v) -------------------
+// q / dq [B, Sq, H, hd] and k, v / dk, dv [B, Sk, H, hd] with element strides (batch, token, head); one workgroup per (query, head, batch)
+// recomputes its row of P, then dq directly and dk / dv by atomics (zeroed by the caller).  hd <= 64.
+struct AttnBwdArgs {
+    const float* q; const float* k; const float* v; const float* dout; float* dq; float* dk; float* dv;
+    long q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs;
+    int H, Sq, Sk, hd;
+    float scale;
+};
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = reinterpret_cast<float*>(smem);      // [Sk] scores -> P -> dS
+    float* qs = sc + ((p.Sk + 3) & ~3);              // [hd] q
+    float* gs = qs + 64;                             // [hd] dO
+    float* dqs = gs + 64;                            // [hd] dq accumulator
+    float* red = dqs + 64;                           // [256]
+    const int tid = threadIdx.x, hd = p.hd;
+    const int qi = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const float* qp = p.q + (long)b * p.q_bs + (long)qi * p.q_ts + (long)head * p.q_hs;
+    const float* gp = p.dout + (long)b * p.o_bs + (long)qi * p.o_ts + (long)head * p.o_hs;
+    if (tid < hd) { qs[tid] = qp[tid]; gs[tid] = gp[tid]; dqs[tid] = 0.f; }
+    __syncthreads();
+    const float* kb = p.k + (long)b * p.k_bs + (long)head * p.k_hs;
+    const float* vb = p.v + (long)b * p.v_bs + (long)head * p.v_hs;
+    auto block_reduce = [&](float v, const bool is_max) -> float {
+        red[tid] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] = is_max ? fmaxf(red[tid], red[tid + s]) : red[tid] + red[tid + s];
+            __syncthreads();
+        }
+        const float r = red[0];
+        __syncthreads();
+        return r;
+    };
+    float mx = -INFINITY;
+    for (int kt = tid; kt < p.Sk; kt += 256) {
+        const float* kp = kb + (long)kt * p.k_ts;
+        float acc = 0.f;
+        for (int d = 0; d < hd; ++d) acc += qs[d] * kp[d];
+        acc *= p.scale;
+        sc[kt] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = block_reduce(mx, true);
+    float sum = 0.f;
+    for (int kt = tid; kt < p.Sk; kt += 256) { const float e = expf(sc[kt] - mx); sc[kt] = e; sum += e; }
+    const float inv = 1.0f / block_reduce(sum, false);
+    // dP_j = dO . v_j;  D = sum_j P_j dP_j
+    float dsum = 0.f;
+    for (int kt = tid; kt < p.Sk; kt += 256) {
+        const float* vp = vb + (long)kt * p.v_ts;
+        float dp = 0.f;
+        for (int d = 0; d < hd; ++d) dp += gs[d] * vp[d];
+        const float pj = sc[kt] * inv;
+        dsum += pj * dp;
+    }
+    const float D = block_reduce(dsum, false);
+    float dql[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) dql[d] = 0.f;
+    float* dkb = p.dk + (long)b * p.k_bs + (long)head * p.k_hs;
+    float* dvb = p.dv + (long)b * p.v_bs + (long)head * p.v_hs;
+    for (int kt = tid; kt < p.Sk; kt += 256) {
+        const float* kp = kb + (long)kt * p.k_ts;
+        const float* vp = vb + (long)kt * p.v_ts;
+        float dp = 0.f;
+        for (int d = 0; d < hd; ++d) dp += gs[d] * vp[d];
+        const float pj = sc[kt] * inv;
+        const float dsj = pj * (dp - D) * p.scale;     // d loss / d (q . k_j)
+#pragma unroll
+        for (int d = 0; d < 64; ++d) {
+            if (d >= hd) break;
+            dql[d] += dsj * kp[d];
+            atomicAdd(dkb + (long)kt * p.k_ts + d, dsj * qs[d]);
+            atomicAdd(dvb + (long)kt * p.v_ts + d, pj * gs[d]);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 64; ++d) {
+        if (d >= hd) break;
+        const float t = wave_sum(dql[d]);
+        if ((tid & 63) == 0) atomicAdd(dqs + d, t);
+    }
+    __syncthreads();
+    if (tid < hd) p.dq[(long)b * p.q_bs + (long)qi * p.q_ts + (long)head * p.q_hs + tid] = dqs[tid];
+}
+extern "C" int ullsam_train_attn_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk, float* dv, int B,
+                                     int H, int hd, int Sq, int Sk, long q_bs, long q_ts, long q_hs, long k_bs, long k_ts, long k_hs, long v_bs,
+                                     long v_ts, long v_hs, long o_bs, long o_ts, long o_hs, float scale, void* stream) {
+    ULLSAM_CHECK(hd > 0 && hd <= 64 && Sk > 0 && Sk <= 32768 && Sq > 0 && Sq < 65536 * 16, "train_attn_bwd: hd=%d Sq=%d Sk=%d", hd, Sq, Sk);
+    AttnBwdArgs a{q, k, v, dout, dq, dk, dv, q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs, H, Sq, Sk, hd, scale};
+    const size_t lds = (size_t)(((Sk + 3) & ~3) + 64 * 3 + 256) * 4;
+    static PerDeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    attn_bwd_kernel<<<dim3(Sq, H, B), 256, lds, reinterpret_cast<hipStream_t>(stream)>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- bilinear upsample backward (F.interpolate(align_corners=False), train_joint_v2.py:1073-1078): the adjoint of resize_bilinear_kernel,
+// same taps (common.h tap_of); din is zeroed by the caller -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, long planes, int ih, int iw, int oh, int ow) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= planes * oh * ow) return;
+    const int x = (int)(i % ow), y = (int)((i / ow) % oh);
+    const long pl = i / ((long)ow * oh);
+    const Tap ty = tap_of(y, (float)ih / (float)oh, ih), tx = tap_of(x, (float)iw / (float)ow, iw);
+    const float g = dout[i];
+    float* d = din + pl * ih * iw;
+    atomicAdd(d + (long)ty.i0 * iw + tx.i0, g * (1.f - ty.l) * (1.f - tx.l));
+    atomicAdd(d + (long)ty.i0 * iw + tx.i1, g * (1.f - ty.l) * tx.l);
+    atomicAdd(d + (long)ty.i1 * iw + tx.i0, g * ty.l * (1.f - tx.l));
+    atomicAdd(d + (long)ty.i1 * iw + tx.i1, g * ty.l * tx.l);
+}
+extern "C" int ullsam_train_resize_bwd(const float* dout, float* din, long planes, int ih, int iw, int oh, int ow, void* stream) {
+    ULLSAM_CHECK(planes > 0 && ih > 0 && iw > 0 && oh > 0 && ow > 0, "train_resize_bwd: bad dims");
+    const long n = planes * oh * ow;
+    resize_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(dout, din, planes, ih, iw, oh, ow);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- BCE-with-logits (mean over pixels) + Dice (smooth 1e-7) per instance, mean over instances (train_joint_v2.py:605-661, 774-812) ------
+// sums [P][4] = (sum bce, sum p t, sum p, sum t) per instance (zeroed by the caller); losses [3] = (total, bce, dice)
+__global__ __launch_bounds__(256) void seg_loss_sums_kernel(const float* __restrict__ x, const float* __restrict__ t, float* __restrict__ sums, long npix) {
+    __shared__ float red[4][4];
+    const int inst = blockIdx.y;
+    const long i0 = (long)blockIdx.x * 1024 + threadIdx.x;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) {
+        const long i = i0 + 256 * j;
+        if (i >= npix) break;
+        const float xv = x[inst * npix + i], tv = t[inst * npix + i];
+        const float pr = 1.0f / (1.0f + expf(-xv));
+        a[0] += fmaxf(xv, 0.f) - xv * tv + log1pf(expf(-fabsf(xv)));   // BCEWithLogits, the numerically stable form torch uses
+        a[1] += pr * tv; a[2] += pr; a[3] += tv;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { a[c] = wave_sum(a[c]); if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = a[c]; }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(sums + inst * 4 + threadIdx.x, (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]));
+}
+__global__ void seg_loss_final_kernel(const float* __restrict__ sums, float* __restrict__ losses, int P, long npix, float smooth) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float bce = 0.f, dice = 0.f;
+    for (int i = 0; i < P; ++i) {
+        const float* s = sums + i * 4;
+        bce += s[0] / (float)npix;
+        dice += 1.0f - (2.0f * s[1] + smooth) / (s[2] + s[3] + smooth);
+    }
+    losses[1] = bce / (float)P; losses[2] = dice / (float)P; losses[0] = losses[1] + losses[2];
+}
+__global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, const float* __restrict__ sums,
+                                                           const float* __restrict__ gscale, float* __restrict__ dx, int P, long npix, float smooth) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int inst = blockIdx.y;
+    if (i >= npix) return;
+    const float* s = sums + inst * 4;
+    const float num = 2.0f * s[1] + smooth, den = s[2] + s[3] + smooth;
+    const float xv = x[inst * npix + i], tv = t[inst * npix + i];
+    const float pr = 1.0f / (1.0f + expf(-xv));
+    const float dbce = (pr - tv) / (float)npix;
+    const float ddice = -(2.0f * tv * den - num) / (den * den) * pr * (1.0f - pr);
+    dx[inst * npix + i] = gscale[0] * (dbce + ddice) / (float)P;
+}
+extern "C" int ullsam_train_seg_loss(const float* x, const float* t, float* sums, float* losses, int P, long npix, float smooth, void* stream) {
+    ULLSAM_CHECK(P > 0 && P < 65536 && npix > 0, "train_seg_loss: P=%d npix=%ld", P, npix);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    seg_loss_sums_kernel<<<dim3((unsigned)((npix + 1023) / 1024), P), 256, 0, s>>>(x, t, sums, npix);
+    ULLSAM_LAUNCH_CHECK();
+    seg_loss_final_kernel<<<1, 64, 0, s>>>(sums, losses, P, npix, smooth);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ullsam_train_seg_loss_bwd(const float* x, const float* t, const float* sums, const float* gscale, float* dx, int P, long npix,
+                                         float smooth, void* stream) {
+    ULLSAM_CHECK(P > 0 && P < 65536 && npix > 0, "train_seg_loss_bwd: P=%d npix=%ld", P, npix);
+    seg_loss_bwd_kernel<<<dim3((unsigned)((npix + 255) / 256), P), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(x, t, sums, gscale, dx, P, npix, smooth);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- dst[idx[r]] += src[r] (rows of C floats): gradients of the point-label embedding table (prompt_encoder.py:76-96) ----------------
+__global__ __launch_bounds__(256) void index_add_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, long rows, int C, int nrows_dst) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * C) return;
+    const long r = i / C;
+    const int c = (int)(i - r * C), k = idx[r];
+    if (k >= 0 && k < nrows_dst) atomicAdd(dst + (long)k * C + c, src[i]);
+}
+extern "C" int ullsam_train_index_add_rows(const float* src, const int* idx, float* dst, long rows, int C, int nrows_dst, void* stream) {
+    ULLSAM_CHECK(rows > 0 && C > 0 && nrows_dst > 0, "train_index_add_rows: bad dims");
+    index_add_rows_kernel<<<dim3((unsigned)((rows * C + 255) / 256)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(src, idx, dst, rows, C, nrows_dst);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,432 @@
+"""Training slice of SURVEY.md section 8 row f4: the segmentation branch of the reference's train step (train_joint_v2.py:1026-1100)
+with gradients for every parameter downstream of the LLM's last hidden state -- `mlp2`, the prompt encoder (llm_scale_factor, llm_bias,
+point / not-a-point embeddings) and the mask decoder (two-way transformer, output upscaling, hypernetwork MLPs).
+
+    loss, bce, dice = segmentation_loss(model, llm_hidden, image_embeddings, (coords, labels), gt_masks)
+    loss.backward()        # .grad of model.mlp2 / model.prompt_encoder / model.mask_decoder parameters
+
+is the drop-in for
+
+    last = model.text_aware_dense_feature(hidden); sparse, dense = model.prompt_encoder(points, None, None, last.repeat(bs, 1, 1, 1))
+    low, _ = model.mask_decoder(image_embeddings, model.prompt_encoder.get_dense_pe(), sparse, dense, multimask_output=False)
+    loss, bce, dice, _ = calc_instance_loss(F.interpolate(low, (S, S), mode="bilinear", align_corners=False), gt, BCELoss(), DiceLoss())
+
+Supported `trainable_modules` (train_joint_v2.py:1280-1359): "mask_decoder", "prompt_encoder", "mlp2"; the vision model, mlp1 and the
+LLM are not differentiated (their outputs enter as constants).  fp32 only.
+
+Every arithmetic step, forward and backward, is a HIP kernel (csrc/train.hip for the backward and the generic fp32 matmul; the
+inference kernels for norms, attention, sparse embeddings, upsample).  torch supplies the autograd tape and data movement (reshape /
+permute / cat / expand copies), nothing else.  These are correctness-first kernels: the step is gated on gradients equal to the
+reference's (tests/test_train_gpu.py, fixture tests/golden/train_slice.npz), not on speed.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import _lib, ops
+
+F32 = torch.float32
+
+
+def _s() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != F32:
+        raise TypeError(f"the training slice is fp32 (got {t.dtype}); load the model with torch.float32")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _mm(A, B, C, M, N, K, sa, sb, sc, batch=1, accumulate=False):
+    """C[b](m,n) (+)= sum_k A[b](m,k) B[b](k,n); sa = (batch, m, k) element strides of A, sb = (batch, k, n), sc = (batch, m, n)."""
+    _lib.call("ullsam_train_matmul", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, batch, *sa, *sb, *sc, int(accumulate), _s())
+
+
+def _colsum(x2d: torch.Tensor) -> torch.Tensor:
+    rows, cols = x2d.shape
+    out = torch.zeros((cols,), dtype=F32, device=x2d.device)
+    _lib.call("ullsam_train_colsum", x2d.data_ptr(), out.data_ptr(), rows, cols, cols, _s())
+    return out
+
+
+class LinearFn(Function):
+    """y = x W^T + b on rows (nn.Linear); dX = dY W, dW = dY^T X, db = column sums of dY."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _c(x), _c(w)
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty((M, N), dtype=F32, device=x.device)
+        _mm(x, w, y, M, N, K, (0, K, 1), (0, 1, K), (0, N, 1))
+        if b is not None:
+            y = ops.add_cast(y, _c(b).reshape(1, N), F32)
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        M, K = x.shape
+        N = w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=F32, device=x.device)
+            _mm(dy, w, dx, M, K, N, (0, N, 1), (0, K, 1), (0, K, 1))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((N, K), dtype=F32, device=x.device)
+            _mm(dy, x, dw, N, K, M, (0, 1, N), (0, K, 1), (0, K, 1))
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = _colsum(dy)
+        return dx, dw, db
+
+
+class LayerNormFn(Function):
+    """Row LayerNorm (nn.LayerNorm / LayerNorm2d on NHWC rows / F.layer_norm without affine)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = _c(x)
+        y = ops.norm(x, None if w is None else _c(w), None if b is None else _c(b), eps, F32)
+        ctx.save_for_backward(x, w)
+        ctx.eps = eps
+        ctx.affine = w is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        rows, D = x.shape
+        dx = torch.empty_like(x)
+        dw = torch.zeros((D,), dtype=F32, device=x.device) if ctx.affine else None
+        db = torch.zeros((D,), dtype=F32, device=x.device) if ctx.affine else None
+        _lib.call("ullsam_train_ln_bwd", x.data_ptr(), None if w is None else _c(w).data_ptr(), dy.data_ptr(), dx.data_ptr(),
+                  ops._p(dw), ops._p(db), rows, D, float(ctx.eps), _s())
+        return dx, dw, db, None
+
+
+class ActFn(Function):
+    """kind 1 = exact GELU (nn.GELU()), 2 = ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = _c(x)
+        y = torch.empty_like(x)
+        _lib.call("ullsam_train_act", x.data_ptr(), None, y.data_ptr(), x.numel(), kind, _s())
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        _lib.call("ullsam_train_act", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), ctx.kind, _s())
+        return dx, None
+
+
+class AddFn(Function):
+    """a + b with b's rows broadcast modularly over a's ([rows_a, C] + [rows_b, C], rows_a % rows_b == 0); the gradient of a broadcast
+    operand is the sum over its repeats."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        ctx.shapes = (a.shape, b.shape)
+        C = a.shape[-1]
+        return ops.add_cast(a.reshape(-1, C), b.reshape(-1, C), F32).reshape(a.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        sa, sb = ctx.shapes
+        dy = _c(dy)
+        da = dy if ctx.needs_input_grad[0] else None
+        db = None
+        if ctx.needs_input_grad[1]:
+            nb = math.prod(sb)
+            db = dy.reshape(sb) if nb == dy.numel() else _colsum(dy.reshape(-1, nb)).reshape(sb)
+        return da, db
+
+
+class BroadcastRowsFn(Function):
+    """[T, C] parameter rows repeated for P prompts (mask_decoder.py:119-120 output_tokens.expand); gradient = sum over the prompts."""
+
+    @staticmethod
+    def forward(ctx, x, P):
+        ctx.shape = x.shape
+        return _c(x).unsqueeze(0).expand(P, *x.shape).contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _colsum(_c(dy).reshape(dy.shape[0], -1)).reshape(ctx.shape), None
+
+
+class ScaleShiftFn(Function):
+    """x * llm_scale_factor + llm_bias (prompt_encoder.py:148), both one-element parameters."""
+
+    @staticmethod
+    def forward(ctx, x, s, t):
+        x, s, t = _c(x), _c(s), _c(t)
+        y = torch.empty_like(x)
+        _lib.call("ullsam_train_scale_shift", x.data_ptr(), s.data_ptr(), t.data_ptr(), None, y.data_ptr(), None, None, x.numel(), _s())
+        ctx.save_for_backward(x, s, t)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, s, t = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        ds = torch.zeros_like(s)
+        dt = torch.zeros_like(t)
+        _lib.call("ullsam_train_scale_shift", x.data_ptr(), s.data_ptr(), t.data_ptr(), dy.data_ptr(), dx.data_ptr(), ds.data_ptr(),
+                  dt.data_ptr(), x.numel(), _s())
+        return dx, ds, dt
+
+
+class AttentionFn(Function):
+    """softmax(q k^T / sqrt(hd)) v per head (transformer.py:220-242); q [B, Sq, H*hd], k / v [B, Sk, H*hd] rows."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, B, H, Sq, Sk):
+        q, k, v = _c(q), _c(k), _c(v)
+        C = q.shape[-1]
+        hd = C // H
+        st = lambda T: (T * C, C, hd)
+        out = ops.naive_attention(q, k, v, B, H, H, hd, Sq, Sk, st(Sq), st(Sk), st(Sk), st(Sq), 1.0 / math.sqrt(hd))
+        ctx.save_for_backward(q, k, v)
+        ctx.dims = (B, H, hd, Sq, Sk, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v = ctx.saved_tensors
+        B, H, hd, Sq, Sk, C = ctx.dims
+        dout = _c(dout)
+        dq = torch.empty_like(q)
+        dk = torch.zeros_like(k)
+        dv = torch.zeros_like(v)
+        st = lambda T: (T * C, C, hd)
+        _lib.call("ullsam_train_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), dout.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                  dv.data_ptr(), B, H, hd, Sq, Sk, *st(Sq), *st(Sk), *st(Sk), *st(Sq), 1.0 / math.sqrt(hd), _s())
+        return dq, dk, dv, None, None, None, None
+
+
+class HyperMasksFn(Function):
+    """masks[p] = hyper[p] [M, c] @ up[p]^T [c, pixels] (mask_decoder.py:146-147), up as rows [P, pixels, c]."""
+
+    @staticmethod
+    def forward(ctx, hyper, up):
+        hyper, up = _c(hyper), _c(up)
+        P, M, c = hyper.shape
+        npix = up.shape[1]
+        out = torch.empty((P, M, npix), dtype=F32, device=up.device)
+        _mm(hyper, up, out, M, npix, c, (M * c, c, 1), (npix * c, 1, c), (M * npix, npix, 1), batch=P)
+        ctx.save_for_backward(hyper, up)
+        return out
+
+    @staticmethod
+    def backward(ctx, dm):
+        hyper, up = ctx.saved_tensors
+        dm = _c(dm)
+        P, M, c = hyper.shape
+        npix = up.shape[1]
+        dh = torch.empty_like(hyper)
+        du = torch.empty_like(up)
+        _mm(dm, up, dh, M, c, npix, (M * npix, npix, 1), (npix * c, c, 1), (M * c, c, 1), batch=P)           # dH = dM U
+        _mm(dm, hyper, du, npix, c, M, (M * npix, 1, npix), (M * c, c, 1), (npix * c, c, 1), batch=P)        # dU = dM^T H
+        return dh, du
+
+
+class SparseEmbedFn(Function):
+    """Point prompts -> sparse embeddings (prompt_encoder.py:76-96): random-Fourier PE of the click + the label's embedding row; the
+    padding point and label -1 take not_a_point_embed alone.  table = [not_a_point, point_embeddings 0..3] (5 rows)."""
+
+    @staticmethod
+    def forward(ctx, table, coords, labels, G, img_hw):
+        table = _c(table)
+        P, Np = coords.shape[0], coords.shape[1]
+        C = table.shape[1]
+        out = ops.sparse_embed(coords, labels, None, G, table, P, Np, 1, C, img_hw[1], img_hw[0])
+        idx = torch.cat([labels.to(torch.int32) + 1, torch.zeros((P, 1), dtype=torch.int32, device=labels.device)], 1).contiguous()
+        ctx.save_for_backward(idx)
+        ctx.C = C
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dy = _c(dy)
+        dt = torch.zeros((5, ctx.C), dtype=F32, device=dy.device)
+        _lib.call("ullsam_train_index_add_rows", dy.data_ptr(), idx.data_ptr(), dt.data_ptr(), idx.numel(), ctx.C, 5, _s())
+        return dt, None, None, None, None
+
+
+class ResizeFn(Function):
+    """F.interpolate(x, (S, S), mode="bilinear", align_corners=False) on [P, 1, h, w]."""
+
+    @staticmethod
+    def forward(ctx, x, out_hw):
+        x = _c(x)
+        ctx.in_shape = x.shape
+        ctx.out_hw = out_hw
+        return ops.resize_bilinear(x, out_hw)[0]
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        shp = ctx.in_shape
+        dx = torch.zeros(shp, dtype=F32, device=dy.device)
+        planes = dx.numel() // (shp[-1] * shp[-2])
+        _lib.call("ullsam_train_resize_bwd", dy.data_ptr(), dx.data_ptr(), planes, shp[-2], shp[-1], ctx.out_hw[0], ctx.out_hw[1], _s())
+        return dx, None
+
+
+class SegLossFn(Function):
+    """calc_instance_loss(pred, gt, BCELoss(), DiceLoss()) (train_joint_v2.py:774-812): returns [3] = (total, bce, dice); only the total
+    is differentiable."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, smooth):
+        pred, gt = _c(pred), _c(gt)
+        P = pred.shape[0] * pred.shape[1]
+        npix = pred.numel() // P
+        sums = torch.zeros((P, 4), dtype=F32, device=pred.device)
+        losses = torch.empty((3,), dtype=F32, device=pred.device)
+        _lib.call("ullsam_train_seg_loss", pred.data_ptr(), gt.data_ptr(), sums.data_ptr(), losses.data_ptr(), P, npix, float(smooth), _s())
+        ctx.save_for_backward(pred, gt, sums)
+        ctx.dims = (P, npix, float(smooth))
+        return losses
+
+    @staticmethod
+    def backward(ctx, dl):
+        pred, gt, sums = ctx.saved_tensors
+        P, npix, smooth = ctx.dims
+        g = _c(dl)[:1].contiguous()       # the bce / dice entries are reported values (the reference returns them for logging)
+        dx = torch.empty_like(pred)
+        _lib.call("ullsam_train_seg_loss_bwd", pred.data_ptr(), gt.data_ptr(), sums.data_ptr(), g.data_ptr(), dx.data_ptr(), P, npix, smooth, _s())
+        return dx, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _linear(lin, x):
+    return LinearFn.apply(x, lin.weight, lin.bias)
+
+
+def _ln(norm, x):
+    return LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
+
+
+def _attention(at, q, k, v, B, Sq, Sk):
+    """transformer.py:220-242: projections, per-head softmax attention, output projection; rows [B*S, C]."""
+    q, k, v = _linear(at.q_proj, q), _linear(at.k_proj, k), _linear(at.v_proj, v)
+    return _linear(at.out_proj, AttentionFn.apply(q, k, v, B, at.num_heads, Sq, Sk))
+
+
+def _two_way_transformer(tr, keys, key_pe, tokens):
+    """TwoWayTransformer.forward (transformer.py:62-108) on rows: keys [P*N, C], key_pe [N, C] (constant), tokens [P*T, C]."""
+    P = tokens.shape[0]
+    T, N, C = tokens.shape[1], key_pe.shape[0], tokens.shape[2]
+    qpe = tokens.reshape(P * T, C)
+    queries = qpe
+    for blk in tr.layers:                                                        # TwoWayAttentionBlock.forward :151-184
+        if blk.skip_first_layer_pe:
+            queries = _attention(blk.self_attn, queries, queries, queries, P, T, T)
+        else:
+            q = AddFn.apply(queries, qpe)
+            queries = AddFn.apply(queries, _attention(blk.self_attn, q, q, queries, P, T, T))
+        queries = _ln(blk.norm1, queries)
+        q = AddFn.apply(queries, qpe)
+        k = AddFn.apply(keys, key_pe)
+        queries = _ln(blk.norm2, AddFn.apply(queries, _attention(blk.cross_attn_token_to_image, q, k, keys, P, T, N)))
+        m = blk.mlp
+        queries = _ln(blk.norm3, AddFn.apply(queries, _linear(m.lin2, ActFn.apply(_linear(m.lin1, queries), m.act_code))))
+        q = AddFn.apply(queries, qpe)
+        k = AddFn.apply(keys, key_pe)
+        keys = _ln(blk.norm4, AddFn.apply(keys, _attention(blk.cross_attn_image_to_token, k, q, queries, P, N, T)))
+    q = AddFn.apply(queries, qpe)
+    k = AddFn.apply(keys, key_pe)
+    queries = _ln(tr.norm_final_attn, AddFn.apply(queries, _attention(tr.final_attn_token_to_image, q, k, keys, P, T, N)))
+    return queries.reshape(P, T, C), keys
+
+
+def _conv_transpose_k2s2(ct, x_rows):
+    """nn.ConvTranspose2d(kernel 2, stride 2) on NHWC rows: every input pixel makes a 2x2 block of output pixels = one Linear with the
+    weight viewed as [(ky, kx, cout), cin]; rows out: [rows_in * 4, cout] in (pixel, ky, kx) order."""
+    cin, cout = ct.weight.shape[0], ct.weight.shape[1]
+    w = ct.weight.permute(2, 3, 1, 0).reshape(4 * cout, cin)                     # data movement only (autograd routes the gradient back)
+    b = BroadcastRowsFn.apply(ct.bias, 4).reshape(4 * cout)
+    return LinearFn.apply(x_rows, w, b).reshape(-1, cout)
+
+
+def dense_feature_rows(model, hidden: torch.Tensor) -> torch.Tensor:
+    """text_aware_dense_feature (modeling_internvl_sam.py:253-270) up to NHWC rows: hidden [B, n_tok, D_llm] -> [B, H*W, 256] (H = W = 64)."""
+    B, n, D = hidden.shape
+    ln, l1, l3 = model.mlp2[0], model.mlp2[1], model.mlp2[3]
+    x = _linear(l3, ActFn.apply(_linear(l1, _ln(ln, hidden.reshape(B * n, D))), 1))
+    g = int(math.sqrt(n))
+    r = model.downsample_ratio
+    f = x.reshape(B, g, g, -1)                                                  # the reference's reshapes / permutes, verbatim data movement
+    if model.ps_version != "v1":
+        f = f.permute(0, 2, 1, 3).contiguous()
+    n_, h, w, c = f.shape
+    f = f.reshape(n_, h, int(w / r), int(c * r)).permute(0, 2, 1, 3).contiguous()
+    f = f.reshape(n_, int(w / r), int(h / r), int(c * (r * r)))                 # = NHWC of the reference's [B, 256, 64, 64]
+    return f.reshape(B, -1, f.shape[-1])
+
+
+def segmentation_loss(model, llm_hidden: torch.Tensor, image_embeddings: torch.Tensor, points: Tuple[torch.Tensor, torch.Tensor],
+                      gt_masks: torch.Tensor, smooth: float = 1e-7) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """llm_hidden fp32 [1, n_img_tokens, D_llm] (the LLM's last hidden state over the image tokens, a constant here); image_embeddings
+    fp32 [1, C, H, W] (constant); points = (coords [P, n, 2], labels [P, n]) for P instances; gt_masks fp32 [P, 1, S, S].
+    Returns (total, bce, dice) as 0-d tensors; `total.backward()` fills the gradients."""
+    pe, md = model.prompt_encoder, model.mask_decoder
+    dev = llm_hidden.device
+    coords, labels = points[0].to(dev).float().contiguous(), points[1].to(dev).to(torch.int32).contiguous()
+    P = coords.shape[0]
+    Hh, Ww = pe.image_embedding_size
+    N, C = Hh * Ww, pe.embed_dim
+    # dense prompt: mlp2 -> inverse pixel shuffle -> per-pixel LayerNorm (no affine) * scale + bias, the same rows for every instance
+    rows = dense_feature_rows(model, _c(llm_hidden)).reshape(N, C)
+    dense = ScaleShiftFn.apply(LayerNormFn.apply(rows, None, None, 1e-5), pe.llm_scale_factor, pe.llm_bias)
+    # sparse prompt
+    table = torch.cat([pe.not_a_point_embed.weight] + [e.weight for e in pe.point_embeddings], 0)
+    sparse = SparseEmbedFn.apply(table, coords, labels, pe.pe_layer.G(), pe.input_image_size)
+    # mask decoder (mask_decoder.py:112-149)
+    out_tok = torch.cat([md.iou_token.weight, md.mask_tokens.weight], 0)
+    tokens = torch.cat([BroadcastRowsFn.apply(out_tok, P), sparse], 1)
+    img_rows = ops.transpose(_c(image_embeddings).reshape(1, C, N), 1, C, N).reshape(N, C)                   # NCHW -> rows (constant)
+    src = AddFn.apply(BroadcastRowsFn.apply(dense, P).reshape(P * N, C), img_rows)                          # repeat_interleave(image) + dense
+    hs, keys = _two_way_transformer(md.transformer, src, pe.dense_pe_tokens(), tokens)
+    up0, ln, up1 = md.output_upscaling[0], md.output_upscaling[1], md.output_upscaling[3]
+    c8 = C // 8
+    u = _conv_transpose_k2s2(up0, keys)                                                                      # [P*N*4, C/4]
+    u = ActFn.apply(LayerNormFn.apply(u, ln.weight, ln.bias, ln.eps), 1)
+    u = ActFn.apply(_conv_transpose_k2s2(up1, u), 1)                                                         # [P*N*16, C/8]
+    nm = md.num_mask_tokens
+    hyper = []
+    for i in range(nm):
+        x = hs[:, 1 + i, :]
+        mlp = md.output_hypernetworks_mlps[i]
+        for j, l in enumerate(mlp.layers):
+            x = _linear(l, x)
+            if j < mlp.num_layers - 1:
+                x = ActFn.apply(x, 2)
+        hyper.append(x)
+    hyper = torch.stack(hyper, 1)                                                                            # [P, 4, C/8]
+    m = HyperMasksFn.apply(hyper, u.reshape(P, N * 16, c8))                                                  # [P, 4, (i, j, ky, kx, ky2, kx2)]
+    m = m.reshape(P, nm, Hh, Ww, 2, 2, 2, 2).permute(0, 1, 2, 4, 6, 3, 5, 7).reshape(P, nm, 4 * Hh, 4 * Ww)  # y = 4i + 2ky + ky2, x likewise
+    low = m[:, 0:1].contiguous()                                                                             # multimask_output=False
+    S = model.vision_model.img_size
+    pred = ResizeFn.apply(low, (S, S))
+    losses = SegLossFn.apply(pred, _c(gt_masks.to(dev).float()), smooth)
+    return losses[0], losses[1], losses[2]
