@@ -91,10 +91,21 @@ int ullsam_train_ln_bwd(const float* x, const float* w, const float* dy, float* 
 int ullsam_train_act(const float* x, const float* dy, float* out, long n, int kind, void* stream);
 /* prompt_encoder.py:148 y = x * llm_scale_factor + llm_bias (dy NULL), else out = dy * s, ds += sum dy x, dt += sum dy */
 int ullsam_train_scale_shift(const float* x, const float* s, const float* t, const float* dy, float* out, float* ds, float* dt, long n, void* stream);
-/* transformer.py:220-242 attention backward; q/dq [B,Sq,H,hd], k,v/dk,dv [B,Sk,H,hd] by (batch, token, head) strides; hd <= 64 */
-int ullsam_train_attn_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk, float* dv, int B, int H,
-                          int hd, int Sq, int Sk, long q_bs, long q_ts, long q_hs, long k_bs, long k_ts, long k_hs, long v_bs, long v_ts,
-                          long v_hs, long o_bs, long o_ts, long o_hs, float scale, void* stream);
+/* softmax attention for the training path, forward (dout NULL: writes out) and backward (dout given: writes dq, adds dk / dv):
+ * transformer.py:220-242 (groups 1, causal -1, no mask) and modeling_internlm2.py:383-419 with the additive finfo.min masks of :834-870
+ * (groups = H / KV heads, causal = Sk - Sq, key_mask int32 [B, Sk]).  q / dq / out [B,Sq,H,hd], k, v / dk, dv [B,Sk,H/groups,hd] by
+ * (batch, token, head) strides; hd <= 128 */
+int ullsam_train_attention(const float* q, const float* k, const float* v, const float* dout, float* out, float* dq, float* dk, float* dv,
+                           int B, int H, int groups, int hd, int Sq, int Sk, int causal, const int* key_mask, long q_bs, long q_ts, long q_hs,
+                           long k_bs, long k_ts, long k_hs, long v_bs, long v_ts, long v_hs, long o_bs, long o_ts, long o_hs, float scale,
+                           void* stream);
+/* InternLM2RMSNorm backward (modeling_internlm2.py:75-89); dw may be NULL (frozen LLM) */
+int ullsam_train_rmsnorm_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, long rows, int D, float eps, void* stream);
+/* apply_rotary_pos_emb (modeling_internlm2.py:233-247) on rows [tokens, heads, hd]; adjoint != 0: its transpose (the backward) */
+int ullsam_train_rope(const float* x, const int* pos, const float* cos_tab, const float* sin_tab, float* out, long tokens, int heads, int hd,
+                      int tab_rows, int adjoint, void* stream);
+/* InternLM2MLP's silu(w1 x) * (w3 x) (modeling_internlm2.py:598-618): dy NULL -> out, else dg / du */
+int ullsam_train_swiglu(const float* g, const float* u, const float* dy, float* out, float* dg, float* du, long n, void* stream);
 /* adjoint of the bilinear upsample F.interpolate(align_corners=False) of train_joint_v2.py:1073-1078 (planes of oh x ow -> ih x iw) */
 int ullsam_train_resize_bwd(const float* dout, float* din, long planes, int ih, int iw, int oh, int ow, void* stream);
 /* calc_instance_loss (train_joint_v2.py:774-812) with BCELoss (:638-661) + DiceLoss (:605-636): x logits / t targets [P, npix];

@@ -575,7 +575,83 @@ def case_train_slice():
     save("train_slice", **out)
 
 
-CASES = {"train_slice": case_train_slice, "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
+def case_train_llm_slice():
+    """As case_train_slice, but the LLM hidden states are no longer an input: the vision features (seeded, constant -- the reference
+    computes them under no_grad, modeling_internvl_sam.py:243-244) go through pixel_shuffle + mlp1, are spliced into the token embeddings
+    (:136-158), run through the tiny InternLM2 (2 layers, frozen) and come out as hidden_states[-1] over the image tokens (:195-205) before
+    the segmentation branch.  Stored: the loss, the gradients of mlp1 (reached only through the LLM's backward), of mlp2 and of a few
+    decoder tensors, and a sample of d loss / d vision features."""
+    import sys, types
+    from transformers import AutoTokenizer, GenerationConfig, get_cosine_schedule_with_warmup, AutoModel, AutoConfig  # noqa: F401
+    for name in ("torchvision", "torchvision.transforms", "wandb", "PIL", "PIL.Image"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+    import train_joint_v2 as TJ
+    from modeling.configuration_internvl_chat import InternVLChatConfig
+    from modeling.modeling_internvl_sam import InternVLSAMModel
+    sam = _sam_small()
+    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_TINY),
+                             downsample_ratio=0.5, template="internlm2-chat", ps_version="v2", force_image_size=1024)
+    cfg.llm_config.rope_scaling = None
+    m = InternVLSAMModel(cfg, vision_model=sam.image_encoder, prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder)
+    fill_module(m, seed=0)
+    m.train()
+    for n_, p_ in m.named_parameters():
+        p_.requires_grad_(not n_.startswith(("language_model.", "vision_model.")))
+    rng = np.random.default_rng(12)
+    feat = rng.standard_normal((1, 256, 64, 64), dtype=np.float32)              # vision_model output (NCHW)
+    img = rng.standard_normal((1, 256, 64, 64), dtype=np.float32)               # image embedding for the decoder (second ViT call in the trainer)
+    ids = O.make_input_ids(n_text_pre=20, n_text_post=34, seed=1)
+    tids = torch.from_numpy(ids)
+    pts = np.array([[[300.0, 340.0], [120.0, 800.0]], [[700.0, 610.0], [64.0, 64.0]]], np.float32)
+    lbl = np.array([[1, 0], [1, 1]], np.int32)
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
+    gt = np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None]
+    with torch.enable_grad():
+        vf = torch.from_numpy(feat).requires_grad_(True)
+        features = m.pixel_shuffle(vf.permute(0, 2, 3, 1), scale_factor=m.downsample_ratio)
+        features = features.reshape(features.shape[0], -1, features.shape[-1])
+        vit_embeds = m.mlp1(features)                                            # extract_feature :245-249
+        emb = m.language_model.get_input_embeddings()(tids).clone()
+        B, N, C = emb.shape
+        emb = emb.reshape(B * N, C)
+        selected = tids.reshape(-1) == m.img_context_token_id
+        emb[selected] = emb[selected] * 0.0 + vit_embeds.reshape(-1, C)          # forward :136-152
+        emb = emb.reshape(B, N, C)
+        outputs = m.language_model(inputs_embeds=emb, attention_mask=torch.ones_like(tids), output_hidden_states=True, return_dict=True)
+        tok_idx = torch.nonzero(selected.reshape(B, N), as_tuple=True)[1]
+        hidden = outputs.hidden_states[-1][:, int(tok_idx.min()):int(tok_idx.max()) + 1, :]
+        last = m.text_aware_dense_feature(hidden)
+        bs = pts.shape[0]
+        last = last.repeat(bs, 1, 1, 1)
+        sp, de = m.prompt_encoder(points=(torch.from_numpy(pts), torch.from_numpy(lbl)), boxes=None, masks=None, llm_hidden_states=last)
+        low, iou = m.mask_decoder(image_embeddings=torch.from_numpy(img), image_pe=m.prompt_encoder.get_dense_pe(),
+                                  sparse_prompt_embeddings=sp, dense_prompt_embeddings=de, multimask_output=False)
+        pred = torch.nn.functional.interpolate(low, (1024, 1024), mode="bilinear", align_corners=False)
+        loss, bce, dice, iou_val = TJ.calc_instance_loss(pred, torch.from_numpy(gt), TJ.BCELoss(), TJ.DiceLoss())
+        loss.backward()
+    out = {"seed": 12, "ids": ids, "pts": pts, "lbl": lbl, "loss": np.float32(loss.item()), "bce": np.float32(bce.item()),
+           "dice": np.float32(dice.item()), "hidden_sample": hidden.detach().numpy().reshape(-1)[::97].copy(),
+           "g:vit_features": vf.grad.numpy().reshape(-1)[::257].copy(),
+           "n:vit_features": np.float32(np.sqrt((vf.grad.numpy().astype(np.float64) ** 2).sum()))}
+    names = []
+    keep = ("mlp1.", "mlp2.", "prompt_encoder.llm", "mask_decoder.transformer.layers.0.self_attn.q_proj", "mask_decoder.output_upscaling.0")
+    for name, p_ in m.named_parameters():
+        if not name.startswith(keep) or p_.grad is None:
+            continue
+        g = p_.grad.numpy().reshape(-1)
+        stride = max(1, g.size // 2048)
+        names.append(name)
+        out["g:" + name] = g[::stride].copy()
+        out["n:" + name] = np.float32(np.sqrt((g.astype(np.float64) ** 2).sum()))
+    out["names"] = np.array(names)
+    save("train_llm_slice", **out)
+
+
+CASES = {"train_slice": case_train_slice, "train_llm_slice": case_train_llm_slice, "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
          "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full,
          "vit_h_d2": case_vit_h_d2, "llm_7b_l1": case_llm_7b_l1,
          "rope_variants": case_rope_variants, "llm_tiny_bias_linear": case_llm_tiny_bias_linear,

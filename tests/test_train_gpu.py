@@ -72,3 +72,48 @@ def test_training_slice_refuses_bf16():
     hid, img, pts, gt = _inputs(g)
     with pytest.raises(TypeError):
         segmentation_loss(m, hid, img, pts, gt)
+
+
+def test_gradients_through_the_frozen_llm_reach_mlp1():
+    """Second slice: vision features -> pixel_shuffle -> mlp1 -> image-token splice -> InternLM2 (2 layers, frozen: RMSNorm, wqkv, RoPE,
+    causal grouped attention with the padding mask, wo, SwiGLU) -> hidden states of the image tokens -> the segmentation branch.  Against
+    tests/golden/train_llm_slice.npz (the reference's autograd through its own LLM): the hidden states, the loss, the gradients of mlp1
+    (reachable only through the LLM's backward), mlp2 and the sampled decoder tensors within 1e-3 of each tensor's largest entry, and
+    d loss / d vision features; the LLM's own parameters receive no gradient."""
+    from ullsam_amd import ops
+    from ullsam_amd.training import llm_image_hidden, segmentation_loss
+    g = U.gold("train_llm_slice")
+    m = _ullsam_tiny(torch.float32)
+    for n, p in m.named_parameters():
+        p.requires_grad_(not n.startswith(("language_model.", "vision_model.")))
+    rng = np.random.default_rng(int(g["seed"]))
+    feat = rng.standard_normal((1, 256, 64, 64), dtype=np.float32)
+    img = rng.standard_normal((1, 256, 64, 64), dtype=np.float32)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    rows = ops.transpose(t(feat).reshape(1, 256, 4096), 1, 256, 4096).requires_grad_(True)      # NHWC rows of the vision features
+    ids = t(g["ids"]).long()
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
+    gt = np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None]
+    hidden = llm_image_hidden(m, rows, ids, torch.ones_like(ids))
+    hs = hidden.detach().float().cpu().numpy().reshape(-1)[::97]
+    assert np.abs(hs - g["hidden_sample"]).max() < 2e-4 * max(1.0, np.abs(g["hidden_sample"]).max()), np.abs(hs - g["hidden_sample"]).max()
+    loss, bce, dice = segmentation_loss(m, hidden, t(img), (t(g["pts"]), t(g["lbl"])), t(gt))
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"]), (loss.item(), float(g["loss"]))
+    loss.backward()
+    params = dict(m.named_parameters())
+    worst = (0.0, "")
+    for n in [str(x) for x in g["names"]] + ["vit_features"]:
+        ref = g["g:" + n].astype(np.float64)
+        if n == "vit_features":   # the fixture's gradient is NCHW, ours NHWC rows
+            full = rows.grad.reshape(1, 4096, 256).permute(0, 2, 1).contiguous().cpu().numpy().reshape(-1).astype(np.float64)
+            got = full[::257]
+        else:
+            full = params[n].grad.float().cpu().numpy().reshape(-1).astype(np.float64)
+            got = full[::max(1, full.size // 2048)]
+        scale, diff = np.abs(ref).max(), np.abs(got - ref).max()
+        assert diff < 1e-3 * scale + 1e-7, (n, diff, scale)
+        worst = max(worst, (diff / scale, n))
+        nref = float(g["n:" + n])
+        assert abs(np.sqrt((full ** 2).sum()) - nref) < 1e-3 * nref + 1e-6, (n, np.sqrt((full ** 2).sum()), nref)
+    assert all(p.grad is None for n, p in params.items() if n.startswith("language_model."))
+    print("worst relative gradient error", worst)

@@ -148,30 +148,40 @@ extern "C" int ullsam_train_scale_shift(const float* x, const float* s, const fl
     return 0;
 }
 
-// ---- softmax attention backward (transformer.py:220-242: scores = q k^T / sqrt(hd), softmax over keys, out = P v) -------------------
-// q / dq [B, Sq, H, hd] and k, v / dk, dv [B, Sk, H, hd] with element strides (batch, token, head); one workgroup per (query, head, batch)
-// recomputes its row of P, then dq directly and dk / dv by atomics (zeroed by the caller).  hd <= 64.
-struct AttnBwdArgs {
-    const float* q; const float* k; const float* v; const float* dout; float* dq; float* dk; float* dv;
+// ---- softmax attention, forward and backward, for the training path ------------------------------------------------------------------
+// out = softmax(q k^T * scale + mask) v per head.  Covers the decoder's attention (transformer.py:220-242: no mask) and InternLM2's
+// (modeling_internlm2.py:383-419: grouped KV heads, the additive finfo.min causal + padding mask of :834-870).
+// q / dq / out [B, Sq, H, hd], k, v / dk, dv [B, Sk, H / groups, hd] with element strides (batch, token, head); causal >= 0: key j is
+// visible to query i iff j <= i + causal (causal = Sk - Sq); key_mask int32 [B, Sk] (0 = padding) or NULL.  One workgroup per
+// (query, head, batch) computes its row of P; the backward recomputes it, writes dq directly and adds dk / dv by atomics (zeroed by the
+// caller).  hd <= 128.
+struct AttnTrainArgs {
+    const float* q; const float* k; const float* v; const float* dout; float* out; float* dq; float* dk; float* dv;
     long q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs;
-    int H, Sq, Sk, hd;
+    int H, groups, Sq, Sk, hd, causal;
+    const int* key_mask;
     float scale;
 };
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs p) {
+template <bool BWD>
+__global__ __launch_bounds__(256) void attn_train_kernel(AttnTrainArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sc = reinterpret_cast<float*>(smem);      // [Sk] scores -> P -> dS
+    constexpr int MAXHD = 128;
+    float* sc = reinterpret_cast<float*>(smem);      // [Sk] scores -> exp
     float* qs = sc + ((p.Sk + 3) & ~3);              // [hd] q
-    float* gs = qs + 64;                             // [hd] dO
-    float* dqs = gs + 64;                            // [hd] dq accumulator
-    float* red = dqs + 64;                           // [256]
+    float* gs = qs + MAXHD;                          // [hd] dO (backward) / output accumulator (forward)
+    float* dqs = gs + MAXHD;                         // [hd] dq accumulator
+    float* red = dqs + MAXHD;                        // [256]
     const int tid = threadIdx.x, hd = p.hd;
-    const int qi = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int qi = blockIdx.x, head = blockIdx.y, b = blockIdx.z, kvh = head / p.groups;
     const float* qp = p.q + (long)b * p.q_bs + (long)qi * p.q_ts + (long)head * p.q_hs;
-    const float* gp = p.dout + (long)b * p.o_bs + (long)qi * p.o_ts + (long)head * p.o_hs;
-    if (tid < hd) { qs[tid] = qp[tid]; gs[tid] = gp[tid]; dqs[tid] = 0.f; }
+    if (tid < hd) {
+        qs[tid] = qp[tid];
+        gs[tid] = BWD ? p.dout[(long)b * p.o_bs + (long)qi * p.o_ts + (long)head * p.o_hs + tid] : 0.f;
+        dqs[tid] = 0.f;
+    }
     __syncthreads();
-    const float* kb = p.k + (long)b * p.k_bs + (long)head * p.k_hs;
-    const float* vb = p.v + (long)b * p.v_bs + (long)head * p.v_hs;
+    const float* kb = p.k + (long)b * p.k_bs + (long)kvh * p.k_hs;
+    const float* vb = p.v + (long)b * p.v_bs + (long)kvh * p.v_hs;
     auto block_reduce = [&](float v, const bool is_max) -> float {
         red[tid] = v;
         __syncthreads();
@@ -183,67 +193,173 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs p) {
         __syncthreads();
         return r;
     };
+    const float FMIN = -3.4028234663852886e38f;
     float mx = -INFINITY;
     for (int kt = tid; kt < p.Sk; kt += 256) {
         const float* kp = kb + (long)kt * p.k_ts;
         float acc = 0.f;
         for (int d = 0; d < hd; ++d) acc += qs[d] * kp[d];
         acc *= p.scale;
+        if (p.causal >= 0 && kt > qi + p.causal) acc += FMIN;                              // the reference's additive masks (two finfo.min add to -inf)
+        if (p.key_mask && p.key_mask[(long)b * p.Sk + kt] == 0) acc += FMIN;
         sc[kt] = acc;
         mx = fmaxf(mx, acc);
     }
     mx = block_reduce(mx, true);
     float sum = 0.f;
-    for (int kt = tid; kt < p.Sk; kt += 256) { const float e = expf(sc[kt] - mx); sc[kt] = e; sum += e; }
-    const float inv = 1.0f / block_reduce(sum, false);
-    // dP_j = dO . v_j;  D = sum_j P_j dP_j
-    float dsum = 0.f;
-    for (int kt = tid; kt < p.Sk; kt += 256) {
-        const float* vp = vb + (long)kt * p.v_ts;
-        float dp = 0.f;
-        for (int d = 0; d < hd; ++d) dp += gs[d] * vp[d];
-        const float pj = sc[kt] * inv;
-        dsum += pj * dp;
-    }
-    const float D = block_reduce(dsum, false);
-    float dql[64];
+    for (int kt = tid; kt < p.Sk; kt += 256) { const float e = mx == -INFINITY ? 0.f : expf(sc[kt] - mx); sc[kt] = e; sum += e; }
+    sum = block_reduce(sum, false);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    if constexpr (!BWD) {
+        // out[d] = sum_j P_j v_j[d]: per-thread partial rows, then LDS atomics
+        float ol[MAXHD];
 #pragma unroll
-    for (int d = 0; d < 64; ++d) dql[d] = 0.f;
-    float* dkb = p.dk + (long)b * p.k_bs + (long)head * p.k_hs;
-    float* dvb = p.dv + (long)b * p.v_bs + (long)head * p.v_hs;
-    for (int kt = tid; kt < p.Sk; kt += 256) {
-        const float* kp = kb + (long)kt * p.k_ts;
-        const float* vp = vb + (long)kt * p.v_ts;
-        float dp = 0.f;
-        for (int d = 0; d < hd; ++d) dp += gs[d] * vp[d];
-        const float pj = sc[kt] * inv;
-        const float dsj = pj * (dp - D) * p.scale;     // d loss / d (q . k_j)
+        for (int d = 0; d < MAXHD; ++d) ol[d] = 0.f;
+        for (int kt = tid; kt < p.Sk; kt += 256) {
+            const float pj = sc[kt] * inv;
+            if (pj == 0.f) continue;
+            const float* vp = vb + (long)kt * p.v_ts;
 #pragma unroll
-        for (int d = 0; d < 64; ++d) {
-            if (d >= hd) break;
-            dql[d] += dsj * kp[d];
-            atomicAdd(dkb + (long)kt * p.k_ts + d, dsj * qs[d]);
-            atomicAdd(dvb + (long)kt * p.v_ts + d, pj * gs[d]);
+            for (int d = 0; d < MAXHD; ++d) { if (d >= hd) break; ol[d] += pj * vp[d]; }
         }
-    }
 #pragma unroll
-    for (int d = 0; d < 64; ++d) {
-        if (d >= hd) break;
-        const float t = wave_sum(dql[d]);
-        if ((tid & 63) == 0) atomicAdd(dqs + d, t);
+        for (int d = 0; d < MAXHD; ++d) {
+            if (d >= hd) break;
+            const float t = wave_sum(ol[d]);
+            if ((tid & 63) == 0) atomicAdd(gs + d, t);
+        }
+        __syncthreads();
+        if (tid < hd) p.out[(long)b * p.o_bs + (long)qi * p.o_ts + (long)head * p.o_hs + tid] = gs[tid];
+        return;
+    } else {
+        // dP_j = dO . v_j;  D = sum_j P_j dP_j
+        float dsum = 0.f;
+        for (int kt = tid; kt < p.Sk; kt += 256) {
+            const float pj = sc[kt] * inv;
+            if (pj == 0.f) continue;
+            const float* vp = vb + (long)kt * p.v_ts;
+            float dp = 0.f;
+            for (int d = 0; d < hd; ++d) dp += gs[d] * vp[d];
+            dsum += pj * dp;
+        }
+        const float D = block_reduce(dsum, false);
+        float dql[MAXHD];
+#pragma unroll
+        for (int d = 0; d < MAXHD; ++d) dql[d] = 0.f;
+        float* dkb = p.dk + (long)b * p.k_bs + (long)kvh * p.k_hs;
+        float* dvb = p.dv + (long)b * p.v_bs + (long)kvh * p.v_hs;
+        for (int kt = tid; kt < p.Sk; kt += 256) {
+            const float pj = sc[kt] * inv;
+            if (pj == 0.f) continue;
+            const float* kp = kb + (long)kt * p.k_ts;
+            const float* vp = vb + (long)kt * p.v_ts;
+            float dp = 0.f;
+            for (int d = 0; d < hd; ++d) dp += gs[d] * vp[d];
+            const float dsj = pj * (dp - D) * p.scale;     // d loss / d (q . k_j)
+#pragma unroll
+            for (int d = 0; d < MAXHD; ++d) {
+                if (d >= hd) break;
+                dql[d] += dsj * kp[d];
+                atomicAdd(dkb + (long)kt * p.k_ts + d, dsj * qs[d]);
+                atomicAdd(dvb + (long)kt * p.v_ts + d, pj * gs[d]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < MAXHD; ++d) {
+            if (d >= hd) break;
+            const float t = wave_sum(dql[d]);
+            if ((tid & 63) == 0) atomicAdd(dqs + d, t);
+        }
+        __syncthreads();
+        if (tid < hd) p.dq[(long)b * p.q_bs + (long)qi * p.q_ts + (long)head * p.q_hs + tid] = dqs[tid];
     }
-    __syncthreads();
-    if (tid < hd) p.dq[(long)b * p.q_bs + (long)qi * p.q_ts + (long)head * p.q_hs + tid] = dqs[tid];
 }
-extern "C" int ullsam_train_attn_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk, float* dv, int B,
-                                     int H, int hd, int Sq, int Sk, long q_bs, long q_ts, long q_hs, long k_bs, long k_ts, long k_hs, long v_bs,
-                                     long v_ts, long v_hs, long o_bs, long o_ts, long o_hs, float scale, void* stream) {
-    ULLSAM_CHECK(hd > 0 && hd <= 64 && Sk > 0 && Sk <= 32768 && Sq > 0 && Sq < 65536 * 16, "train_attn_bwd: hd=%d Sq=%d Sk=%d", hd, Sq, Sk);
-    AttnBwdArgs a{q, k, v, dout, dq, dk, dv, q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs, H, Sq, Sk, hd, scale};
-    const size_t lds = (size_t)(((Sk + 3) & ~3) + 64 * 3 + 256) * 4;
+extern "C" int ullsam_train_attention(const float* q, const float* k, const float* v, const float* dout, float* out, float* dq, float* dk,
+                                      float* dv, int B, int H, int groups, int hd, int Sq, int Sk, int causal, const int* key_mask, long q_bs,
+                                      long q_ts, long q_hs, long k_bs, long k_ts, long k_hs, long v_bs, long v_ts, long v_hs, long o_bs,
+                                      long o_ts, long o_hs, float scale, void* stream) {
+    ULLSAM_CHECK(hd > 0 && hd <= 128 && Sk > 0 && Sk <= 30000 && Sq > 0 && B > 0 && B < 65536 && H > 0 && H < 65536 && groups > 0 && H % groups == 0,
+                 "train_attention: hd=%d Sq=%d Sk=%d H=%d groups=%d", hd, Sq, Sk, H, groups);
+    ULLSAM_CHECK((dout != nullptr) == (dq != nullptr) && (dout != nullptr || out != nullptr), "train_attention: forward needs out, backward needs dout / dq / dk / dv");
+    AttnTrainArgs a{q, k, v, dout, out, dq, dk, dv, q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs, H, groups, Sq, Sk, hd, causal, key_mask, scale};
+    const size_t lds = (size_t)(((Sk + 3) & ~3) + 128 * 3 + 256) * 4;
     static PerDeviceOnce attr;
-    if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-    attn_bwd_kernel<<<dim3(Sq, H, B), 256, lds, reinterpret_cast<hipStream_t>(stream)>>>(a);
+    if (attr.first()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_train_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_train_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dout) attn_train_kernel<true><<<dim3(Sq, H, B), 256, lds, s>>>(a);
+    else attn_train_kernel<false><<<dim3(Sq, H, B), 256, lds, s>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- RMSNorm backward (modeling_internlm2.py:75-89): y = x * rsqrt(mean(x^2) + eps) * w; one wave per row; dw (optional) by atomics ------
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, float* __restrict__ dw, long rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    const float* gr = dy + row * D;
+    float ss = 0.f;
+    for (int i = lane; i < D; i += 64) ss += xr[i] * xr[i];
+    const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+    float sgx = 0.f;
+    for (int i = lane; i < D; i += 64) sgx += gr[i] * w[i] * xr[i] * rstd;
+    const float mgx = wave_sum(sgx) / (float)D;
+    for (int i = lane; i < D; i += 64) {
+        const float xh = xr[i] * rstd;
+        dx[row * D + i] = rstd * (gr[i] * w[i] - xh * mgx);
+        if (dw) atomicAdd(dw + i, gr[i] * xh);
+    }
+}
+extern "C" int ullsam_train_rmsnorm_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, long rows, int D, float eps, void* stream) {
+    ULLSAM_CHECK(rows > 0 && D > 0, "train_rmsnorm_bwd: rows=%ld D=%d", rows, D);
+    rmsnorm_bwd_kernel<<<dim3((unsigned)((rows + 3) / 4)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(x, w, dy, dx, dw, rows, D, eps);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- rotary embedding (modeling_internlm2.py:233-247) on rows [B*S, heads, hd]: out = x cos + rotate_half(x) sin, rotate_half = cat(-x2, x1);
+// adjoint != 0: the transpose of that map (the backward).  cos / sin tables fp32 [tab_rows, hd] (cat(freqs, freqs)), pos int32 [B*S] ----------
+__global__ __launch_bounds__(256) void rope_train_kernel(const float* __restrict__ x, const int* __restrict__ pos, const float* __restrict__ cosT,
+                                                         const float* __restrict__ sinT, float* __restrict__ out, long tokens, int heads, int hd,
+                                                         int tab_rows, int adjoint) {
+    const int half = hd >> 1;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= tokens * heads * half) return;
+    const int d = (int)(i % half);
+    const long th = i / half, tok = th / heads;
+    const int p = min(max(pos[tok], 0), tab_rows - 1);
+    const float c1 = cosT[(long)p * hd + d], c2 = cosT[(long)p * hd + half + d], s1 = sinT[(long)p * hd + d], s2 = sinT[(long)p * hd + half + d];
+    const float a = x[th * hd + d], b = x[th * hd + half + d];
+    if (!adjoint) { out[th * hd + d] = a * c1 - b * s1; out[th * hd + half + d] = b * c2 + a * s2; }
+    else { out[th * hd + d] = a * c1 + b * s2; out[th * hd + half + d] = b * c2 - a * s1; }
+}
+extern "C" int ullsam_train_rope(const float* x, const int* pos, const float* cosT, const float* sinT, float* out, long tokens, int heads, int hd,
+                                 int tab_rows, int adjoint, void* stream) {
+    ULLSAM_CHECK(tokens > 0 && heads > 0 && hd > 0 && hd % 2 == 0 && tab_rows > 0, "train_rope: bad dims");
+    const long n = tokens * heads * (hd / 2);
+    rope_train_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(x, pos, cosT, sinT, out, tokens, heads, hd, tab_rows, adjoint);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- SwiGLU (modeling_internlm2.py:598-618): out = silu(g) * u; backward dg = dy u (s + g s (1 - s)), du = dy silu(g), s = sigmoid(g) ------
+__global__ __launch_bounds__(256) void swiglu_train_kernel(const float* __restrict__ g, const float* __restrict__ u, const float* __restrict__ dy,
+                                                           float* __restrict__ out, float* __restrict__ dg, float* __restrict__ du, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gv = g[i], uv = u[i], s = 1.0f / (1.0f + expf(-gv));
+    if (!dy) { out[i] = gv * s * uv; return; }
+    dg[i] = dy[i] * uv * (s + gv * s * (1.0f - s));
+    du[i] = dy[i] * gv * s;
+}
+extern "C" int ullsam_train_swiglu(const float* g, const float* u, const float* dy, float* out, float* dg, float* du, long n, void* stream) {
+    ULLSAM_CHECK(n > 0 && (dy ? (dg && du) : out != nullptr), "train_swiglu: n=%ld", n);
+    swiglu_train_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(g, u, dy, out, dg, du, n);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }

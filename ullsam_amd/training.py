@@ -11,8 +11,11 @@ is the drop-in for
     low, _ = model.mask_decoder(image_embeddings, model.prompt_encoder.get_dense_pe(), sparse, dense, multimask_output=False)
     loss, bce, dice, _ = calc_instance_loss(F.interpolate(low, (S, S), mode="bilinear", align_corners=False), gt, BCELoss(), DiceLoss())
 
-Supported `trainable_modules` (train_joint_v2.py:1280-1359): "mask_decoder", "prompt_encoder", "mlp2"; the vision model, mlp1 and the
-LLM are not differentiated (their outputs enter as constants).  fp32 only.
+`llm_image_hidden(model, vit_feature_rows, input_ids, attention_mask)` produces `llm_hidden` differentiably from the vision features through
+`mlp1` and the frozen LLM (second slice), so that `mlp1` trains too.
+
+Supported `trainable_modules` (train_joint_v2.py:1280-1359): "mask_decoder", "prompt_encoder", "mlp2", "mlp1"; the vision model is not
+differentiated yet (its output enters as a constant).  fp32 only.
 
 Every arithmetic step, forward and backward, is a HIP kernel (csrc/train.hip for the backward and the generic fp32 matmul; the
 inference kernels for norms, attention, sparse embeddings, upsample).  torch supplies the autograd tape and data movement (reshape /
@@ -194,31 +197,94 @@ class ScaleShiftFn(Function):
 
 
 class AttentionFn(Function):
-    """softmax(q k^T / sqrt(hd)) v per head (transformer.py:220-242); q [B, Sq, H*hd], k / v [B, Sk, H*hd] rows."""
+    """softmax(q k^T / sqrt(hd) + mask) v per head: q [B*Sq, H*hd] rows, k / v [B*Sk, KVH*hd] rows.  The decoder's attention
+    (transformer.py:220-242: KVH = H, no mask) and InternLM2's (modeling_internlm2.py:383-419: grouped KV heads, causal, padding mask)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, B, H, Sq, Sk):
+    def forward(ctx, q, k, v, B, H, KVH, Sq, Sk, causal, key_mask):
         q, k, v = _c(q), _c(k), _c(v)
-        C = q.shape[-1]
-        hd = C // H
-        st = lambda T: (T * C, C, hd)
-        out = ops.naive_attention(q, k, v, B, H, H, hd, Sq, Sk, st(Sq), st(Sk), st(Sk), st(Sq), 1.0 / math.sqrt(hd))
-        ctx.save_for_backward(q, k, v)
-        ctx.dims = (B, H, hd, Sq, Sk, C)
+        hd = q.shape[-1] // H
+        out = torch.empty_like(q)
+        ctx.save_for_backward(q, k, v, key_mask)
+        ctx.dims = (B, H, KVH, hd, Sq, Sk, causal)
+        AttentionFn._launch(q, k, v, None, out, None, None, None, ctx.dims, key_mask)
         return out
 
     @staticmethod
+    def _launch(q, k, v, dout, out, dq, dk, dv, dims, key_mask):
+        B, H, KVH, hd, Sq, Sk, causal = dims
+        sq, sk = (Sq * H * hd, H * hd, hd), (Sk * KVH * hd, KVH * hd, hd)
+        _lib.call("ullsam_train_attention", q.data_ptr(), k.data_ptr(), v.data_ptr(), ops._p(dout), ops._p(out), ops._p(dq), ops._p(dk),
+                  ops._p(dv), B, H, H // KVH, hd, Sq, Sk, causal, ops._p(key_mask), *sq, *sk, *sk, *sq, 1.0 / math.sqrt(hd), _s())
+
+    @staticmethod
     def backward(ctx, dout):
-        q, k, v = ctx.saved_tensors
-        B, H, hd, Sq, Sk, C = ctx.dims
-        dout = _c(dout)
-        dq = torch.empty_like(q)
-        dk = torch.zeros_like(k)
-        dv = torch.zeros_like(v)
-        st = lambda T: (T * C, C, hd)
-        _lib.call("ullsam_train_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), dout.data_ptr(), dq.data_ptr(), dk.data_ptr(),
-                  dv.data_ptr(), B, H, hd, Sq, Sk, *st(Sq), *st(Sk), *st(Sk), *st(Sq), 1.0 / math.sqrt(hd), _s())
-        return dq, dk, dv, None, None, None, None
+        q, k, v, key_mask = ctx.saved_tensors
+        dq, dk, dv = torch.empty_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        AttentionFn._launch(q, k, v, _c(dout), None, dq, dk, dv, ctx.dims, key_mask)
+        return dq, dk, dv, None, None, None, None, None, None, None
+
+
+class RMSNormFn(Function):
+    """InternLM2RMSNorm (modeling_internlm2.py:75-89)."""
+
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        x, w = _c(x), _c(w)
+        ctx.save_for_backward(x, w)
+        ctx.eps = eps
+        return ops.norm(x, w, None, eps, F32, rms=True)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        rows, D = x.shape
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w) if ctx.needs_input_grad[1] else None
+        _lib.call("ullsam_train_rmsnorm_bwd", x.data_ptr(), w.data_ptr(), _c(dy).data_ptr(), dx.data_ptr(), ops._p(dw), rows, D, float(ctx.eps), _s())
+        return dx, dw, None
+
+
+class RoPEFn(Function):
+    """apply_rotary_pos_emb (modeling_internlm2.py:233-247) on rows [tokens, heads*hd]; pos int32 [tokens]."""
+
+    @staticmethod
+    def forward(ctx, x, pos, cos, sin, heads):
+        x = _c(x)
+        ctx.save_for_backward(pos, cos, sin)
+        ctx.heads = heads
+        return RoPEFn._run(x, pos, cos, sin, heads, 0)
+
+    @staticmethod
+    def _run(x, pos, cos, sin, heads, adjoint):
+        out = torch.empty_like(x)
+        _lib.call("ullsam_train_rope", x.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), out.data_ptr(), x.shape[0], heads,
+                  x.shape[1] // heads, cos.shape[0], adjoint, _s())
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        pos, cos, sin = ctx.saved_tensors
+        return RoPEFn._run(_c(dy), pos, cos, sin, ctx.heads, 1), None, None, None, None
+
+
+class SwiGLUFn(Function):
+    """silu(g) * u (modeling_internlm2.py:617)."""
+
+    @staticmethod
+    def forward(ctx, g, u):
+        g, u = _c(g), _c(u)
+        ctx.save_for_backward(g, u)
+        out = torch.empty_like(g)
+        _lib.call("ullsam_train_swiglu", g.data_ptr(), u.data_ptr(), None, out.data_ptr(), None, None, g.numel(), _s())
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        g, u = ctx.saved_tensors
+        dg, du = torch.empty_like(g), torch.empty_like(u)
+        _lib.call("ullsam_train_swiglu", g.data_ptr(), u.data_ptr(), _c(dy).data_ptr(), None, dg.data_ptr(), du.data_ptr(), g.numel(), _s())
+        return dg, du
 
 
 class HyperMasksFn(Function):
@@ -329,7 +395,7 @@ def _ln(norm, x):
 def _attention(at, q, k, v, B, Sq, Sk):
     """transformer.py:220-242: projections, per-head softmax attention, output projection; rows [B*S, C]."""
     q, k, v = _linear(at.q_proj, q), _linear(at.k_proj, k), _linear(at.v_proj, v)
-    return _linear(at.out_proj, AttentionFn.apply(q, k, v, B, at.num_heads, Sq, Sk))
+    return _linear(at.out_proj, AttentionFn.apply(q, k, v, B, at.num_heads, at.num_heads, Sq, Sk, -1, None))
 
 
 def _two_way_transformer(tr, keys, key_pe, tokens):
@@ -430,3 +496,57 @@ def segmentation_loss(model, llm_hidden: torch.Tensor, image_embeddings: torch.T
     pred = ResizeFn.apply(low, (S, S))
     losses = SegLossFn.apply(pred, _c(gt_masks.to(dev).float()), smooth)
     return losses[0], losses[1], losses[2]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Second slice: the projector mlp1 and the (frozen) LLM between the vision features and the hidden states the first slice starts from.
+def llm_image_hidden(model, vit_feature_rows: torch.Tensor, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The LLM's last hidden state over the image tokens, differentiable with respect to `mlp1` (and to the vision features):
+    extract_feature's pixel_shuffle + mlp1 (modeling_internvl_sam.py:226-251), the image-token splice of forward (:136-158), InternLM2's
+    layers (modeling_internlm2.py:598-618, 345-419, 75-89; frozen weights receive no gradient work) and the image-token slice of :195-205.
+    vit_feature_rows fp32 [B, 64*64, 256] = the vision model's output as NHWC rows (a constant here: the reference computes it under
+    no_grad, :243-244); input_ids [B, S] with the <IMG_CONTEXT> run; returns [B, n_img_tokens, D_llm]."""
+    lm = model.language_model
+    cfg = lm.config
+    B, S = input_ids.shape
+    dev = vit_feature_rows.device
+    g = int(math.sqrt(vit_feature_rows.shape[1]))
+    r = model.downsample_ratio
+    f = _c(vit_feature_rows).reshape(B, g, g, -1)                               # pixel_shuffle, ps_version v2: data movement, as the reference writes it
+    n, h, w, c = f.shape
+    f = f.reshape(n, h, int(w * r), int(c / r)).permute(0, 2, 1, 3).contiguous()
+    f = f.reshape(n, int(w * r), int(h * r), int(c / (r * r)))
+    if model.ps_version != "v1":
+        f = f.permute(0, 2, 1, 3).contiguous()
+    f = f.reshape(-1, f.shape[-1])
+    ln, l1, l3 = model.mlp1[0], model.mlp1[1], model.mlp1[3]
+    vit_embeds = _linear(l3, ActFn.apply(_linear(l1, _ln(ln, f)), 1))            # [B*n_img, D]
+    D = vit_embeds.shape[-1]
+    ids = input_ids.reshape(-1)
+    sel = ids == model.img_context_token_id
+    n_sel = int(sel.sum())
+    if n_sel != vit_embeds.shape[0]:
+        raise ValueError(f"{n_sel} <IMG_CONTEXT> tokens for {vit_embeds.shape[0]} image embeddings")
+    x = lm.model.tok_embeddings.weight.detach()[ids].clone()                     # frozen embedding rows (a gather)
+    x = x.index_put((sel.nonzero(as_tuple=True)[0],), vit_embeds)                # input_embeds[selected] = vit_embeds  (:150-152)
+    H, KVH = cfg.num_attention_heads, cfg.num_key_value_heads
+    hd, G = cfg.hidden_size // H, H // KVH
+    cos, sin = lm.model.rope_tables(S, dev)
+    pos = torch.arange(S, dtype=torch.int32, device=dev).repeat(B).contiguous()  # position_ids default (modeling_internlm2.py:893-898)
+    key_mask = None if attention_mask is None else attention_mask.to(torch.int32).contiguous()
+    for layer in lm.model.layers:
+        at, ff = layer.attention, layer.feed_forward
+        xn = RMSNormFn.apply(x, layer.attention_norm.weight, layer.attention_norm.variance_epsilon)
+        qkv = LinearFn.apply(xn, at.wqkv.weight, at.wqkv.bias).reshape(B * S, KVH, G + 2, hd)   # 'b q (h gs d) -> b q h gs d' (:361-366)
+        q = RoPEFn.apply(qkv[:, :, :G].reshape(B * S, H * hd), pos, cos, sin, H)
+        k = RoPEFn.apply(qkv[:, :, G].reshape(B * S, KVH * hd), pos, cos, sin, KVH)
+        v = qkv[:, :, G + 1].reshape(B * S, KVH * hd)
+        a = AttentionFn.apply(q, k, v, B, H, KVH, S, S, 0, key_mask)
+        x = AddFn.apply(x, LinearFn.apply(a, at.wo.weight, at.wo.bias))
+        xn = RMSNormFn.apply(x, layer.ffn_norm.weight, layer.ffn_norm.variance_epsilon)
+        hmid = SwiGLUFn.apply(LinearFn.apply(xn, ff.w1.weight, None), LinearFn.apply(xn, ff.w3.weight, None))
+        x = AddFn.apply(x, LinearFn.apply(hmid, ff.w2.weight, None))
+    x = RMSNormFn.apply(x, lm.model.norm.weight, lm.model.norm.variance_epsilon).reshape(B, S, D)
+    idx = sel.reshape(B, S).nonzero(as_tuple=True)[1]
+    start, end = int(idx.min()), int(idx.max()) + 1                              # one span for the batch, as the reference takes it (:198-201)
+    return x[:, start:end]
