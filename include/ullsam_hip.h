@@ -98,7 +98,11 @@ int ullsam_train_scale_shift(const float* x, const float* s, const float* t, con
 int ullsam_train_attention(const float* q, const float* k, const float* v, const float* dout, float* out, float* dq, float* dk, float* dv,
                            int B, int H, int groups, int hd, int Sq, int Sk, int causal, const int* key_mask, long q_bs, long q_ts, long q_hs,
                            long k_bs, long k_ts, long k_hs, long v_bs, long v_ts, long v_hs, long o_bs, long o_ts, long o_hs, float scale,
-                           void* stream);
+                           const float* bias_h, const float* bias_w, float* dbias_h, float* dbias_w, int kw, void* stream);
+/* (bias_h [B,H,Sq,Sk/kw], bias_w [B,H,Sq,kw]: the ViT's decomposed relative-position terms, image_encoder.py:325-361, added to the logits
+ * as bias_h[q][key / kw] + bias_w[q][key % kw]; NULL elsewhere.  The backward writes dbias_h / dbias_w.) */
+/* adjoint of ullsam_im2col3x3 (neck conv3x3 as im2col + Linear): dcols [B*H*W, 9*C] -> dx [B,H,W,C] */
+int ullsam_train_col2im3x3(const float* dcols, float* dx, int B, int H, int W, int C, void* stream);
 /* InternLM2RMSNorm backward (modeling_internlm2.py:75-89); dw may be NULL (frozen LLM) */
 int ullsam_train_rmsnorm_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, long rows, int D, float eps, void* stream);
 /* apply_rotary_pos_emb (modeling_internlm2.py:233-247) on rows [tokens, heads, hd]; adjoint != 0: its transpose (the backward) */

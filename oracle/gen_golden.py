@@ -560,7 +560,7 @@ def case_train_slice():
         pred = torch.nn.functional.interpolate(low, (1024, 1024), mode="bilinear", align_corners=False)
         loss, bce, dice, iou_val = TJ.calc_instance_loss(pred, torch.from_numpy(gt), TJ.BCELoss(), TJ.DiceLoss())
         loss.backward()
-    out = {"hid": hid, "img_seed": 11, "pts": pts, "lbl": lbl, "loss": np.float32(loss.item()), "bce": np.float32(bce.item()),
+    out = {"hid_sample": hid.reshape(-1)[::1009].copy(), "img_seed": 11, "pts": pts, "lbl": lbl, "loss": np.float32(loss.item()), "bce": np.float32(bce.item()),
            "dice": np.float32(dice.item()), "low_sample": low.detach().numpy().reshape(-1)[::61].copy()}
     names = []
     for name, p_ in m.named_parameters():
@@ -651,7 +651,62 @@ def case_train_llm_slice():
     save("train_llm_slice", **out)
 
 
-CASES = {"train_slice": case_train_slice, "train_llm_slice": case_train_llm_slice, "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
+def case_train_vit_slice():
+    """As case_train_slice, with the image embedding no longer an input: a seeded image goes through the reference's vision model
+    (`_sam_small`: 2 blocks of width 128, one 14x14-windowed with 25 padded windows, one global over 64 x 64 tokens; neck) with gradients,
+    as the trainer's second ViT call does (train_joint_v2.py:1014-1021).  Stored: the loss and the gradient of every vision-model parameter."""
+    import sys, types
+    from transformers import AutoTokenizer, GenerationConfig, get_cosine_schedule_with_warmup, AutoModel, AutoConfig  # noqa: F401
+    for name in ("torchvision", "torchvision.transforms", "wandb", "PIL", "PIL.Image"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+    import train_joint_v2 as TJ
+    from modeling.configuration_internvl_chat import InternVLChatConfig
+    from modeling.modeling_internvl_sam import InternVLSAMModel
+    sam = _sam_small()
+    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_TINY),
+                             downsample_ratio=0.5, template="internlm2-chat", ps_version="v2", force_image_size=1024)
+    cfg.llm_config.rope_scaling = None
+    m = InternVLSAMModel(cfg, vision_model=sam.image_encoder, prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder)
+    fill_module(m, seed=0)
+    m.train()
+    for n_, p_ in m.named_parameters():
+        p_.requires_grad_(not n_.startswith("language_model."))
+    rng = np.random.default_rng(13)
+    hid = rng.standard_normal((1, 1024, LLM_TINY["hidden_size"]), dtype=np.float32)
+    x = rand_image((1, 3, 1024, 1024), seed=13)
+    pts = np.array([[[300.0, 340.0], [120.0, 800.0]], [[700.0, 610.0], [64.0, 64.0]]], np.float32)
+    lbl = np.array([[1, 0], [1, 1]], np.int32)
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
+    gt = np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None]
+    with torch.enable_grad():
+        image_embeddings = m.vision_model(torch.from_numpy(x))
+        last = m.text_aware_dense_feature(torch.from_numpy(hid)).repeat(pts.shape[0], 1, 1, 1)
+        sp, de = m.prompt_encoder(points=(torch.from_numpy(pts), torch.from_numpy(lbl)), boxes=None, masks=None, llm_hidden_states=last)
+        low, iou = m.mask_decoder(image_embeddings=image_embeddings, image_pe=m.prompt_encoder.get_dense_pe(),
+                                  sparse_prompt_embeddings=sp, dense_prompt_embeddings=de, multimask_output=False)
+        pred = torch.nn.functional.interpolate(low, (1024, 1024), mode="bilinear", align_corners=False)
+        loss, bce, dice, iou_val = TJ.calc_instance_loss(pred, torch.from_numpy(gt), TJ.BCELoss(), TJ.DiceLoss())
+        loss.backward()
+    out = {"seed": 13, "hid_sample": hid.reshape(-1)[::1009].copy(), "pts": pts, "lbl": lbl, "loss": np.float32(loss.item()), "bce": np.float32(bce.item()),
+           "dice": np.float32(dice.item()), "emb_sample": image_embeddings.detach().numpy().reshape(-1)[::997].copy()}
+    names = []
+    for name, p_ in m.named_parameters():
+        if not name.startswith("vision_model.") or p_.grad is None:
+            continue
+        g = p_.grad.numpy().reshape(-1)
+        stride = max(1, g.size // 2048)
+        names.append(name)
+        out["g:" + name] = g[::stride].copy()
+        out["n:" + name] = np.float32(np.sqrt((g.astype(np.float64) ** 2).sum()))
+    out["names"] = np.array(names)
+    save("train_vit_slice", **out)
+
+
+CASES = {"train_vit_slice": case_train_vit_slice, "train_slice": case_train_slice, "train_llm_slice": case_train_llm_slice, "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
          "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full,
          "vit_h_d2": case_vit_h_d2, "llm_7b_l1": case_llm_7b_l1,
          "rope_variants": case_rope_variants, "llm_tiny_bias_linear": case_llm_tiny_bias_linear,

@@ -16,7 +16,7 @@ def _inputs(g):
     rng = np.random.default_rng(int(g["img_seed"]))
     hid = rng.standard_normal((1, 1024, 256), dtype=np.float32)
     img = rng.standard_normal((1, 256, 64, 64), dtype=np.float32)
-    assert np.array_equal(hid, g["hid"])
+    assert np.array_equal(hid.reshape(-1)[::1009], g["hid_sample"])
     yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
     gt = np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None]
     t = lambda a: torch.from_numpy(a).to(DEV)
@@ -116,4 +116,42 @@ def test_gradients_through_the_frozen_llm_reach_mlp1():
         nref = float(g["n:" + n])
         assert abs(np.sqrt((full ** 2).sum()) - nref) < 1e-3 * nref + 1e-6, (n, np.sqrt((full ** 2).sum()), nref)
     assert all(p.grad is None for n, p in params.items() if n.startswith("language_model."))
+    print("worst relative gradient error", worst)
+
+
+def test_gradients_reach_every_vision_model_parameter():
+    """Third slice: the image goes through the vision model with gradients (the trainer's second ViT call, train_joint_v2.py:1014-1021):
+    patch embedding, pos_embed, a 14x14-windowed block with padded windows and a global block over 64 x 64 tokens (decomposed relative-position
+    terms and their tables included), the neck's 1x1 / 3x3 convolutions and LayerNorm2ds.  Against tests/golden/train_vit_slice.npz: the
+    image embedding, the loss and all 37 vision-model gradients within 1e-3 of each tensor's largest entry."""
+    from ullsam_amd.training import segmentation_loss, vision_feature_rows
+    g = U.gold("train_vit_slice")
+    m = _ullsam_tiny(torch.float32)
+    for n, p in m.named_parameters():
+        p.requires_grad_(n.startswith("vision_model."))
+    rng = np.random.default_rng(int(g["seed"]))
+    hid = rng.standard_normal((1, 1024, 256), dtype=np.float32)
+    assert np.array_equal(hid.reshape(-1)[::1009], g["hid_sample"])
+    from oracle import ullsam_oracle as O  # noqa: F401
+    x = U.rand_image((1, 3, 1024, 1024), seed=13)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
+    gt = np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None]
+    rows = vision_feature_rows(m.vision_model, t(x))
+    emb = rows.detach().reshape(1, 4096, 256).permute(0, 2, 1).contiguous().cpu().numpy().reshape(-1)[::997]     # NCHW order of the fixture
+    assert np.abs(emb - g["emb_sample"]).max() < 2e-4 * max(1.0, np.abs(g["emb_sample"]).max()), np.abs(emb - g["emb_sample"]).max()
+    loss, bce, dice = segmentation_loss(m, t(hid), None, (t(g["pts"]), t(g["lbl"])), t(gt), image_rows=rows)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"]), (loss.item(), float(g["loss"]))
+    loss.backward()
+    params = dict(m.named_parameters())
+    worst = (0.0, "")
+    for n in [str(v) for v in g["names"]]:
+        ref = g["g:" + n].astype(np.float64)
+        full = params[n].grad.float().cpu().numpy().reshape(-1).astype(np.float64)
+        got = full[::max(1, full.size // 2048)]
+        scale, diff = np.abs(ref).max(), np.abs(got - ref).max()
+        assert diff < 1e-3 * scale + 1e-7, (n, diff, scale)
+        worst = max(worst, (diff / scale, n))
+        nref = float(g["n:" + n])
+        assert abs(np.sqrt((full ** 2).sum()) - nref) < 1e-3 * nref + 1e-6, (n, np.sqrt((full ** 2).sum()), nref)
     print("worst relative gradient error", worst)

@@ -27,7 +27,8 @@ SIGNATURES = {
     "ullsam_train_ln_bwd": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
     "ullsam_train_act": [vp, vp, vp, i64, i32, vp],
     "ullsam_train_scale_shift": [vp, vp, vp, vp, vp, vp, vp, i64, vp],
-    "ullsam_train_attention": [vp] * 8 + [i32] * 7 + [vp] + [i64] * 12 + [f32, vp],
+    "ullsam_train_attention": [vp] * 8 + [i32] * 7 + [vp] + [i64] * 12 + [f32, vp, vp, vp, vp, i32, vp],
+    "ullsam_train_col2im3x3": [vp, vp, i32, i32, i32, i32, vp],
     "ullsam_train_rmsnorm_bwd": [vp, vp, vp, vp, vp, i64, i32, f32, vp],
     "ullsam_train_rope": [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp],
     "ullsam_train_swiglu": [vp, vp, vp, vp, vp, vp, i64, vp],

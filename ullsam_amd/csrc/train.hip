@@ -161,6 +161,9 @@ struct AttnTrainArgs {
     int H, groups, Sq, Sk, hd, causal;
     const int* key_mask;
     float scale;
+    // decomposed relative-position bias of the ViT (image_encoder.py:325-361): logits += bias_h[q][key / kw] + bias_w[q][key % kw];
+    // bias_h [B, H, Sq, Sk / kw], bias_w [B, H, Sq, kw]; the backward writes their gradients (one row each per workgroup)
+    const float* bias_h; const float* bias_w; float* dbias_h; float* dbias_w; int kw;
 };
 template <bool BWD>
 __global__ __launch_bounds__(256) void attn_train_kernel(AttnTrainArgs p) {
@@ -171,8 +174,13 @@ __global__ __launch_bounds__(256) void attn_train_kernel(AttnTrainArgs p) {
     float* gs = qs + MAXHD;                          // [hd] dO (backward) / output accumulator (forward)
     float* dqs = gs + MAXHD;                         // [hd] dq accumulator
     float* red = dqs + MAXHD;                        // [256]
+    float* dbs = red + 256;                          // [128 + 128] bias-gradient rows (backward with bias)
     const int tid = threadIdx.x, hd = p.hd;
     const int qi = blockIdx.x, head = blockIdx.y, b = blockIdx.z, kvh = head / p.groups;
+    const int kh_n = p.bias_h ? p.Sk / p.kw : 0;
+    const float* bh = p.bias_h ? p.bias_h + (((long)b * p.H + head) * p.Sq + qi) * kh_n : nullptr;
+    const float* bw = p.bias_h ? p.bias_w + (((long)b * p.H + head) * p.Sq + qi) * p.kw : nullptr;
+    if (BWD && p.bias_h) dbs[tid] = 0.f;
     const float* qp = p.q + (long)b * p.q_bs + (long)qi * p.q_ts + (long)head * p.q_hs;
     if (tid < hd) {
         qs[tid] = qp[tid];
@@ -200,6 +208,7 @@ __global__ __launch_bounds__(256) void attn_train_kernel(AttnTrainArgs p) {
         float acc = 0.f;
         for (int d = 0; d < hd; ++d) acc += qs[d] * kp[d];
         acc *= p.scale;
+        if (bh) acc += bh[kt / p.kw] + bw[kt % p.kw];
         if (p.causal >= 0 && kt > qi + p.causal) acc += FMIN;                              // the reference's additive masks (two finfo.min add to -inf)
         if (p.key_mask && p.key_mask[(long)b * p.Sk + kt] == 0) acc += FMIN;
         sc[kt] = acc;
@@ -255,7 +264,9 @@ __global__ __launch_bounds__(256) void attn_train_kernel(AttnTrainArgs p) {
             const float* vp = vb + (long)kt * p.v_ts;
             float dp = 0.f;
             for (int d = 0; d < hd; ++d) dp += gs[d] * vp[d];
-            const float dsj = pj * (dp - D) * p.scale;     // d loss / d (q . k_j)
+            const float dlogit = pj * (dp - D);
+            if (bh) { atomicAdd(dbs + kt / p.kw, dlogit); atomicAdd(dbs + 128 + kt % p.kw, dlogit); }
+            const float dsj = dlogit * p.scale;            // d loss / d (q . k_j)
 #pragma unroll
             for (int d = 0; d < MAXHD; ++d) {
                 if (d >= hd) break;
@@ -272,17 +283,24 @@ __global__ __launch_bounds__(256) void attn_train_kernel(AttnTrainArgs p) {
         }
         __syncthreads();
         if (tid < hd) p.dq[(long)b * p.q_bs + (long)qi * p.q_ts + (long)head * p.q_hs + tid] = dqs[tid];
+        if (bh) {
+            if (tid < kh_n) p.dbias_h[(((long)b * p.H + head) * p.Sq + qi) * kh_n + tid] = dbs[tid];
+            if (tid < p.kw) p.dbias_w[(((long)b * p.H + head) * p.Sq + qi) * p.kw + tid] = dbs[128 + tid];
+        }
     }
 }
 extern "C" int ullsam_train_attention(const float* q, const float* k, const float* v, const float* dout, float* out, float* dq, float* dk,
                                       float* dv, int B, int H, int groups, int hd, int Sq, int Sk, int causal, const int* key_mask, long q_bs,
                                       long q_ts, long q_hs, long k_bs, long k_ts, long k_hs, long v_bs, long v_ts, long v_hs, long o_bs,
-                                      long o_ts, long o_hs, float scale, void* stream) {
+                                      long o_ts, long o_hs, float scale, const float* bias_h, const float* bias_w, float* dbias_h,
+                                      float* dbias_w, int kw, void* stream) {
+    ULLSAM_CHECK(!bias_h || (bias_w && kw > 0 && kw <= 128 && Sk % kw == 0 && Sk / kw <= 128 && (!dout || (dbias_h && dbias_w))),
+                 "train_attention: decomposed bias needs Sk = kh * kw with kh, kw <= 128 (Sk=%d kw=%d)", Sk, kw);
     ULLSAM_CHECK(hd > 0 && hd <= 128 && Sk > 0 && Sk <= 30000 && Sq > 0 && B > 0 && B < 65536 && H > 0 && H < 65536 && groups > 0 && H % groups == 0,
                  "train_attention: hd=%d Sq=%d Sk=%d H=%d groups=%d", hd, Sq, Sk, H, groups);
     ULLSAM_CHECK((dout != nullptr) == (dq != nullptr) && (dout != nullptr || out != nullptr), "train_attention: forward needs out, backward needs dout / dq / dk / dv");
-    AttnTrainArgs a{q, k, v, dout, out, dq, dk, dv, q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs, H, groups, Sq, Sk, hd, causal, key_mask, scale};
-    const size_t lds = (size_t)(((Sk + 3) & ~3) + 128 * 3 + 256) * 4;
+    AttnTrainArgs a{q, k, v, dout, out, dq, dk, dv, q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs, H, groups, Sq, Sk, hd, causal, key_mask, scale, bias_h, bias_w, dbias_h, dbias_w, kw};
+    const size_t lds = (size_t)(((Sk + 3) & ~3) + 128 * 3 + 256 + 256) * 4;
     static PerDeviceOnce attr;
     if (attr.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_train_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
@@ -458,6 +476,31 @@ __global__ __launch_bounds__(256) void index_add_rows_kernel(const float* __rest
 extern "C" int ullsam_train_index_add_rows(const float* src, const int* idx, float* dst, long rows, int C, int nrows_dst, void* stream) {
     ULLSAM_CHECK(rows > 0 && C > 0 && nrows_dst > 0, "train_index_add_rows: bad dims");
     index_add_rows_kernel<<<dim3((unsigned)((rows * C + 255) / 256)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(src, idx, dst, rows, C, nrows_dst);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- adjoint of ullsam_im2col3x3 (the neck's 3x3 convolution, image_encoder.py:96-102, as im2col + Linear): dx[b,y,x,c] = sum over the nine
+// taps of dcols[(b, y - ty + 1, x - tx + 1)][(ty*3 + tx)*C + c] -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ dcols, float* __restrict__ dx, int B, int H, int W, int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * H * W * C) return;
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    float s = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yo = y - tap / 3 + 1, xo = x - tap % 3 + 1;
+        if (yo >= 0 && yo < H && xo >= 0 && xo < W) s += dcols[((((long)b * H + yo) * W + xo) * 9 + tap) * C + c];
+    }
+    dx[i] = s;
+}
+extern "C" int ullsam_train_col2im3x3(const float* dcols, float* dx, int B, int H, int W, int C, void* stream) {
+    ULLSAM_CHECK(B > 0 && H > 0 && W > 0 && C > 0, "train_col2im3x3: bad dims");
+    const long n = (long)B * H * W * C;
+    col2im3x3_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(dcols, dx, B, H, W, C);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }

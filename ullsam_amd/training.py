@@ -14,8 +14,10 @@ is the drop-in for
 `llm_image_hidden(model, vit_feature_rows, input_ids, attention_mask)` produces `llm_hidden` differentiably from the vision features through
 `mlp1` and the frozen LLM (second slice), so that `mlp1` trains too.
 
-Supported `trainable_modules` (train_joint_v2.py:1280-1359): "mask_decoder", "prompt_encoder", "mlp2", "mlp1"; the vision model is not
-differentiated yet (its output enters as a constant).  fp32 only.
+`vision_feature_rows(model.vision_model, pixel_values)` is the differentiable vision model (third slice); pass its result as `image_rows=`.
+
+Supported `trainable_modules` (train_joint_v2.py:1280-1359): "vision_model", "mlp1", "mlp2", "prompt_encoder", "mask_decoder" -- everything the
+reference trains; the LLM is frozen there and here (gradients flow through it, none are produced for it).  fp32 only.
 
 Every arithmetic step, forward and backward, is a HIP kernel (csrc/train.hip for the backward and the generic fp32 matmul; the
 inference kernels for norms, attention, sparse embeddings, upsample).  torch supplies the autograd tape and data movement (reshape /
@@ -197,32 +199,97 @@ class ScaleShiftFn(Function):
 
 
 class AttentionFn(Function):
-    """softmax(q k^T / sqrt(hd) + mask) v per head: q [B*Sq, H*hd] rows, k / v [B*Sk, KVH*hd] rows.  The decoder's attention
-    (transformer.py:220-242: KVH = H, no mask) and InternLM2's (modeling_internlm2.py:383-419: grouped KV heads, causal, padding mask)."""
+    """softmax(q k^T / sqrt(hd) + bias + mask) v per head: q [B*Sq, H*hd] rows, k / v [B*Sk, KVH*hd] rows.  The decoder's attention
+    (transformer.py:220-242: KVH = H, no mask), InternLM2's (modeling_internlm2.py:383-419: grouped KV heads, causal, padding mask) and the
+    ViT's (image_encoder.py:224-240: bias_h [B, H, Sq, Sk/kw] + bias_w [B, H, Sq, kw], the decomposed relative-position terms)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, B, H, KVH, Sq, Sk, causal, key_mask):
+    def forward(ctx, q, k, v, B, H, KVH, Sq, Sk, causal, key_mask, bias_h, bias_w, kw):
         q, k, v = _c(q), _c(k), _c(v)
+        if bias_h is not None:
+            bias_h, bias_w = _c(bias_h), _c(bias_w)
         hd = q.shape[-1] // H
         out = torch.empty_like(q)
-        ctx.save_for_backward(q, k, v, key_mask)
-        ctx.dims = (B, H, KVH, hd, Sq, Sk, causal)
-        AttentionFn._launch(q, k, v, None, out, None, None, None, ctx.dims, key_mask)
+        ctx.save_for_backward(q, k, v, key_mask, bias_h, bias_w)
+        ctx.dims = (B, H, KVH, hd, Sq, Sk, causal, kw)
+        AttentionFn._launch(q, k, v, None, out, None, None, None, ctx.dims, key_mask, bias_h, bias_w, None, None)
         return out
 
     @staticmethod
-    def _launch(q, k, v, dout, out, dq, dk, dv, dims, key_mask):
-        B, H, KVH, hd, Sq, Sk, causal = dims
+    def _launch(q, k, v, dout, out, dq, dk, dv, dims, key_mask, bias_h, bias_w, dbh, dbw):
+        B, H, KVH, hd, Sq, Sk, causal, kw = dims
         sq, sk = (Sq * H * hd, H * hd, hd), (Sk * KVH * hd, KVH * hd, hd)
         _lib.call("ullsam_train_attention", q.data_ptr(), k.data_ptr(), v.data_ptr(), ops._p(dout), ops._p(out), ops._p(dq), ops._p(dk),
-                  ops._p(dv), B, H, H // KVH, hd, Sq, Sk, causal, ops._p(key_mask), *sq, *sk, *sk, *sq, 1.0 / math.sqrt(hd), _s())
+                  ops._p(dv), B, H, H // KVH, hd, Sq, Sk, causal, ops._p(key_mask), *sq, *sk, *sk, *sq, 1.0 / math.sqrt(hd),
+                  ops._p(bias_h), ops._p(bias_w), ops._p(dbh), ops._p(dbw), kw, _s())
 
     @staticmethod
     def backward(ctx, dout):
-        q, k, v, key_mask = ctx.saved_tensors
+        q, k, v, key_mask, bias_h, bias_w = ctx.saved_tensors
         dq, dk, dv = torch.empty_like(q), torch.zeros_like(k), torch.zeros_like(v)
-        AttentionFn._launch(q, k, v, _c(dout), None, dq, dk, dv, ctx.dims, key_mask)
-        return dq, dk, dv, None, None, None, None, None, None, None
+        dbh = torch.empty_like(bias_h) if bias_h is not None else None
+        dbw = torch.empty_like(bias_w) if bias_w is not None else None
+        AttentionFn._launch(q, k, v, _c(dout), None, dq, dk, dv, ctx.dims, key_mask, bias_h, bias_w, dbh, dbw)
+        return dq, dk, dv, None, None, None, None, None, None, None, dbh, dbw, None
+
+
+class GatherRowsFn(Function):
+    """table[idx] (get_rel_pos, image_encoder.py:303-322, without interpolation); the gradient adds the rows back."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        ctx.save_for_backward(idx.to(torch.int32).contiguous())
+        ctx.shape = table.shape
+        return _c(table)[idx].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dt = torch.zeros(ctx.shape, dtype=F32, device=dy.device)
+        _lib.call("ullsam_train_index_add_rows", _c(dy).data_ptr(), idx.data_ptr(), dt.data_ptr(), idx.numel(), ctx.shape[1], ctx.shape[0], _s())
+        return dt, None
+
+
+class BmmNTFn(Function):
+    """C[b] = A[b] @ B[b]^T for A [b, M, K], B [b, N, K] (the einsums of add_decomposed_rel_pos, image_encoder.py:351-353)."""
+
+    @staticmethod
+    def forward(ctx, A, Bm):
+        A, Bm = _c(A), _c(Bm)
+        nb, M, K = A.shape
+        N = Bm.shape[1]
+        C = torch.empty((nb, M, N), dtype=F32, device=A.device)
+        _mm(A, Bm, C, M, N, K, (M * K, K, 1), (N * K, 1, K), (M * N, N, 1), batch=nb)
+        ctx.save_for_backward(A, Bm)
+        return C
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, Bm = ctx.saved_tensors
+        dC = _c(dC)
+        nb, M, K = A.shape
+        N = Bm.shape[1]
+        dA, dB = torch.empty_like(A), torch.empty_like(Bm)
+        _mm(dC, Bm, dA, M, K, N, (M * N, N, 1), (N * K, K, 1), (M * K, K, 1), batch=nb)          # dA = dC B
+        _mm(dC, A, dB, N, K, M, (M * N, 1, N), (M * K, K, 1), (N * K, K, 1), batch=nb)           # dB = dC^T A
+        return dA, dB
+
+
+class Im2col3x3Fn(Function):
+    """3x3 / pad 1 patches of NHWC rows (the neck's second convolution as im2col + Linear, image_encoder.py:96-102)."""
+
+    @staticmethod
+    def forward(ctx, x, B, H, W):
+        x = _c(x)
+        ctx.dims = (B, H, W, x.shape[-1])
+        return ops.im2col3x3(x, B, H, W, x.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dcols):
+        B, H, W, C = ctx.dims
+        dx = torch.empty((B * H * W, C), dtype=F32, device=dcols.device)
+        _lib.call("ullsam_train_col2im3x3", _c(dcols).data_ptr(), dx.data_ptr(), B, H, W, C, _s())
+        return dx, None, None, None
 
 
 class RMSNormFn(Function):
@@ -395,7 +462,7 @@ def _ln(norm, x):
 def _attention(at, q, k, v, B, Sq, Sk):
     """transformer.py:220-242: projections, per-head softmax attention, output projection; rows [B*S, C]."""
     q, k, v = _linear(at.q_proj, q), _linear(at.k_proj, k), _linear(at.v_proj, v)
-    return _linear(at.out_proj, AttentionFn.apply(q, k, v, B, at.num_heads, at.num_heads, Sq, Sk, -1, None))
+    return _linear(at.out_proj, AttentionFn.apply(q, k, v, B, at.num_heads, at.num_heads, Sq, Sk, -1, None, None, None, 0))
 
 
 def _two_way_transformer(tr, keys, key_pe, tokens):
@@ -450,10 +517,12 @@ def dense_feature_rows(model, hidden: torch.Tensor) -> torch.Tensor:
     return f.reshape(B, -1, f.shape[-1])
 
 
-def segmentation_loss(model, llm_hidden: torch.Tensor, image_embeddings: torch.Tensor, points: Tuple[torch.Tensor, torch.Tensor],
-                      gt_masks: torch.Tensor, smooth: float = 1e-7) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+def segmentation_loss(model, llm_hidden: torch.Tensor, image_embeddings: Optional[torch.Tensor], points: Tuple[torch.Tensor, torch.Tensor],
+                      gt_masks: torch.Tensor, smooth: float = 1e-7, image_rows: Optional[torch.Tensor] = None
+                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """llm_hidden fp32 [1, n_img_tokens, D_llm] (the LLM's last hidden state over the image tokens, a constant here); image_embeddings
-    fp32 [1, C, H, W] (constant); points = (coords [P, n, 2], labels [P, n]) for P instances; gt_masks fp32 [P, 1, S, S].
+    fp32 [1, C, H, W] (constant) or, instead, image_rows = vision_feature_rows(...) [1, H*W, C] (differentiable: trains the vision model);
+    points = (coords [P, n, 2], labels [P, n]) for P instances; gt_masks fp32 [P, 1, S, S].
     Returns (total, bce, dice) as 0-d tensors; `total.backward()` fills the gradients."""
     pe, md = model.prompt_encoder, model.mask_decoder
     dev = llm_hidden.device
@@ -470,7 +539,10 @@ def segmentation_loss(model, llm_hidden: torch.Tensor, image_embeddings: torch.T
     # mask decoder (mask_decoder.py:112-149)
     out_tok = torch.cat([md.iou_token.weight, md.mask_tokens.weight], 0)
     tokens = torch.cat([BroadcastRowsFn.apply(out_tok, P), sparse], 1)
-    img_rows = ops.transpose(_c(image_embeddings).reshape(1, C, N), 1, C, N).reshape(N, C)                   # NCHW -> rows (constant)
+    if image_rows is not None:                                                                               # vision_feature_rows(...): differentiable
+        img_rows = image_rows.reshape(N, C)
+    else:
+        img_rows = ops.transpose(_c(image_embeddings).reshape(1, C, N), 1, C, N).reshape(N, C)               # NCHW -> rows (constant)
     src = AddFn.apply(BroadcastRowsFn.apply(dense, P).reshape(P * N, C), img_rows)                          # repeat_interleave(image) + dense
     hs, keys = _two_way_transformer(md.transformer, src, pe.dense_pe_tokens(), tokens)
     up0, ln, up1 = md.output_upscaling[0], md.output_upscaling[1], md.output_upscaling[3]
@@ -541,7 +613,7 @@ def llm_image_hidden(model, vit_feature_rows: torch.Tensor, input_ids: torch.Ten
         q = RoPEFn.apply(qkv[:, :, :G].reshape(B * S, H * hd), pos, cos, sin, H)
         k = RoPEFn.apply(qkv[:, :, G].reshape(B * S, KVH * hd), pos, cos, sin, KVH)
         v = qkv[:, :, G + 1].reshape(B * S, KVH * hd)
-        a = AttentionFn.apply(q, k, v, B, H, KVH, S, S, 0, key_mask)
+        a = AttentionFn.apply(q, k, v, B, H, KVH, S, S, 0, key_mask, None, None, 0)
         x = AddFn.apply(x, LinearFn.apply(a, at.wo.weight, at.wo.bias))
         xn = RMSNormFn.apply(x, layer.ffn_norm.weight, layer.ffn_norm.variance_epsilon)
         hmid = SwiGLUFn.apply(LinearFn.apply(xn, ff.w1.weight, None), LinearFn.apply(xn, ff.w3.weight, None))
@@ -550,3 +622,61 @@ def llm_image_hidden(model, vit_feature_rows: torch.Tensor, input_ids: torch.Ten
     idx = sel.reshape(B, S).nonzero(as_tuple=True)[1]
     start, end = int(idx.min()), int(idx.max()) + 1                              # one span for the batch, as the reference takes it (:198-201)
     return x[:, start:end]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Third slice: the vision model (ImageEncoderViT.forward, image_encoder.py:106-117), reached through the decoder's image embedding.
+def vision_feature_rows(enc, pixel_values: torch.Tensor) -> torch.Tensor:
+    """pixel_values fp32 [B, 3, S, S] -> image embedding as NHWC rows [B, (S/16)^2, out_chans], differentiable with respect to every
+    parameter of the encoder: patch embedding, pos_embed, blocks (LayerNorm, qkv, windowed / global attention with the decomposed
+    relative-position terms and their tables, proj, MLP), neck (1x1 conv, LayerNorm2d, 3x3 conv, LayerNorm2d)."""
+    import torch.nn.functional as TF
+    S, p = enc.img_size, enc.patch_size
+    g = S // p
+    N, D, C = g * g, enc.embed_dim, enc.out_chans
+    B = pixel_values.shape[0]
+    cols = ops.patch_im2col(_c(pixel_values.float()), S, p, F32, None, None)                   # [B*N, 3*p*p], a constant
+    pe = enc.patch_embed.proj
+    x = LinearFn.apply(cols, pe.weight.reshape(D, -1), pe.bias)
+    if enc.pos_embed is not None:
+        x = AddFn.apply(x, enc.pos_embed.reshape(N, D))
+    for blk in enc.blocks:
+        at, ws = blk.attn, blk.window_size
+        heads, hd = at.num_heads, at.head_dim
+        t = _ln(blk.norm1, x).reshape(B, g, g, D)
+        if ws > 0:                                                                             # window_partition :243-264 (data movement; zero pad)
+            pad = (ws - g % ws) % ws
+            if pad:
+                t = TF.pad(t, (0, 0, 0, pad, 0, pad))
+            gp = g + pad
+            t = t.reshape(B, gp // ws, ws, gp // ws, ws, D).permute(0, 1, 3, 2, 4, 5).contiguous().reshape(-1, ws, ws, D)
+            Hh = ws
+        else:
+            Hh = g
+        Bw, T = t.shape[0], Hh * Hh
+        qkv = LinearFn.apply(t.reshape(Bw * T, D), at.qkv.weight, at.qkv.bias).reshape(Bw, T, 3, heads, hd)
+        q, k, v = (qkv[:, :, i].reshape(Bw * T, heads * hd) for i in range(3))
+        if at.rel_pos_h.shape[0] != 2 * Hh - 1 or at.rel_pos_w.shape[0] != 2 * Hh - 1:
+            raise NotImplementedError("get_rel_pos with interpolated tables (image_encoder.py:310-318) is not part of the training slice")
+        ar = torch.arange(Hh, device=x.device)
+        idx = (ar[:, None] - ar[None, :] + (Hh - 1)).reshape(-1)                                # relative_coords :320-322
+        Rh = GatherRowsFn.apply(at.rel_pos_h, idx).reshape(Hh, Hh, hd)
+        Rw = GatherRowsFn.apply(at.rel_pos_w, idx).reshape(Hh, Hh, hd)
+        q5 = q.reshape(Bw, Hh, Hh, heads, hd)                                                  # add_decomposed_rel_pos :325-361 (unscaled q)
+        rel_h = BmmNTFn.apply(q5.permute(1, 0, 2, 3, 4).reshape(Hh, Bw * Hh * heads, hd), Rh)   # [qh, (b, qw, head), kh]
+        rel_h = rel_h.reshape(Hh, Bw, Hh, heads, Hh).permute(1, 3, 0, 2, 4).reshape(Bw, heads, T, Hh)
+        rel_w = BmmNTFn.apply(q5.permute(2, 0, 1, 3, 4).reshape(Hh, Bw * Hh * heads, hd), Rw)   # [qw, (b, qh, head), kw]
+        rel_w = rel_w.reshape(Hh, Bw, Hh, heads, Hh).permute(1, 3, 2, 0, 4).reshape(Bw, heads, T, Hh)
+        a = AttentionFn.apply(q, k, v, Bw, heads, heads, T, T, -1, None, rel_h, rel_w, Hh)
+        a = LinearFn.apply(a, at.proj.weight, at.proj.bias)
+        if ws > 0:                                                                             # window_unpartition :267-290
+            a = a.reshape(B, gp // ws, gp // ws, ws, ws, D).permute(0, 1, 3, 2, 4, 5).contiguous().reshape(B, gp, gp, D)
+            if gp > g:
+                a = a[:, :g, :g, :].contiguous()
+        x = AddFn.apply(x, a.reshape(B * N, D))
+        m = blk.mlp
+        x = AddFn.apply(x, _linear(m.lin2, ActFn.apply(_linear(m.lin1, _ln(blk.norm2, x)), m.act_code)))
+    n0, n1, n2, n3 = enc.neck[0], enc.neck[1], enc.neck[2], enc.neck[3]
+    y = _ln(n1, LinearFn.apply(x, n0.weight.reshape(C, D), None))
+    z = LinearFn.apply(Im2col3x3Fn.apply(y, B, g, g), n2.weight.permute(0, 2, 3, 1).reshape(C, 9 * C), None)
+    return _ln(n3, z).reshape(B, N, C)
