@@ -706,7 +706,66 @@ def case_train_vit_slice():
     save("train_vit_slice", **out)
 
 
-CASES = {"train_vit_slice": case_train_vit_slice, "train_slice": case_train_slice, "train_llm_slice": case_train_llm_slice, "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
+def case_train_step():
+    """One whole step of the reference's trainer on the `ullsam_tiny` composite, as train_joint_v2.py:990-1100 runs it: model(pixel_values,
+    input_ids, ..., output_hidden_states=True) -> outputs.hidden_states (the text-aware dense feature), image_embeddings =
+    model.vision_model(pixel_values) with gradients, prompt encoder, mask decoder, upsample, calc_instance_loss; LLM frozen, everything else
+    trainable (setup_model_params :1280-1359).  Stored: the loss and a sample + norm of the gradient of EVERY trainable parameter."""
+    import sys, types
+    from transformers import AutoTokenizer, GenerationConfig, get_cosine_schedule_with_warmup, AutoModel, AutoConfig  # noqa: F401
+    for name in ("torchvision", "torchvision.transforms", "wandb", "PIL", "PIL.Image"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+    import train_joint_v2 as TJ
+    from modeling.configuration_internvl_chat import InternVLChatConfig
+    from modeling.modeling_internvl_sam import InternVLSAMModel
+    sam = _sam_small()
+    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_TINY),
+                             downsample_ratio=0.5, template="internlm2-chat", ps_version="v2", force_image_size=1024)
+    cfg.llm_config.rope_scaling = None
+    m = InternVLSAMModel(cfg, vision_model=sam.image_encoder, prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder)
+    fill_module(m, seed=0)
+    m.train()
+    for n_, p_ in m.named_parameters():
+        p_.requires_grad_(not n_.startswith("language_model."))
+    x = torch.from_numpy(rand_image((1, 3, 1024, 1024), seed=14))
+    ids = O.make_input_ids(n_text_pre=20, n_text_post=34, seed=1)
+    tids = torch.from_numpy(ids)
+    pts = np.array([[[300.0, 340.0], [120.0, 800.0]], [[700.0, 610.0], [64.0, 64.0]]], np.float32)
+    lbl = np.array([[1, 0], [1, 1]], np.int32)
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
+    gt = np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None]
+    with torch.enable_grad():
+        outputs = m(pixel_values=x, input_ids=tids, attention_mask=torch.ones_like(tids), image_flags=(tids == 92546)[..., None].long(),
+                    return_dict=True, use_cache=False, output_hidden_states=True)
+        last = outputs.hidden_states                                              # train_joint_v2.py:1010
+        image_embeddings = m.vision_model(x)                                      # :1020
+        bs = pts.shape[0]
+        last = last.repeat(bs, 1, 1, 1)
+        sp, de = m.prompt_encoder(points=(torch.from_numpy(pts), torch.from_numpy(lbl)), boxes=None, masks=None, llm_hidden_states=last)
+        low, iou = m.mask_decoder(image_embeddings=image_embeddings, image_pe=m.prompt_encoder.get_dense_pe(),
+                                  sparse_prompt_embeddings=sp, dense_prompt_embeddings=de, multimask_output=False)
+        pred = torch.nn.functional.interpolate(low, (1024, 1024), mode="bilinear", align_corners=False)
+        loss, bce, dice, iou_val = TJ.calc_instance_loss(pred, torch.from_numpy(gt), TJ.BCELoss(), TJ.DiceLoss())
+        loss.backward()
+    out = {"seed": 14, "ids": ids, "pts": pts, "lbl": lbl, "loss": np.float32(loss.item()), "bce": np.float32(bce.item()), "dice": np.float32(dice.item())}
+    names = []
+    for name, p_ in m.named_parameters():
+        if p_.grad is None:
+            continue
+        g = p_.grad.numpy().reshape(-1)
+        stride = max(1, g.size // 512)
+        names.append(name)
+        out["g:" + name] = g[::stride].copy()
+        out["n:" + name] = np.float32(np.sqrt((g.astype(np.float64) ** 2).sum()))
+    out["names"] = np.array(names)
+    save("train_step", **out)
+
+
+CASES = {"train_step": case_train_step, "train_vit_slice": case_train_vit_slice, "train_slice": case_train_slice, "train_llm_slice": case_train_llm_slice, "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
          "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full,
          "vit_h_d2": case_vit_h_d2, "llm_7b_l1": case_llm_7b_l1,
          "rope_variants": case_rope_variants, "llm_tiny_bias_linear": case_llm_tiny_bias_linear,

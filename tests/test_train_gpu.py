@@ -155,3 +155,40 @@ def test_gradients_reach_every_vision_model_parameter():
         nref = float(g["n:" + n])
         assert abs(np.sqrt((full ** 2).sum()) - nref) < 1e-3 * nref + 1e-6, (n, np.sqrt((full ** 2).sum()), nref)
     print("worst relative gradient error", worst)
+
+
+def test_whole_train_step_gradients_of_every_trainable_module():
+    """One whole step of the reference's trainer (train_joint_v2.py:990-1100 on the tiny composite; fixture train_step.npz: model(...) with
+    output_hidden_states, the second vision_model call, prompt encoder, mask decoder, upsample, calc_instance_loss; LLM frozen) against
+    ullsam_amd.training.train_step_loss: the loss and the gradient of every parameter the reference's step produces one for -- vision model,
+    mlp1, mlp2, prompt encoder, mask decoder -- within 1e-3 of the tensor's largest entry; none for the LLM."""
+    from ullsam_amd.training import train_step_loss
+    g = U.gold("train_step")
+    m = _ullsam_tiny(torch.float32)
+    for n, p in m.named_parameters():
+        p.requires_grad_(not n.startswith("language_model."))
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    x = t(U.rand_image((1, 3, 1024, 1024), seed=int(g["seed"])))
+    ids = t(g["ids"]).long()
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
+    gt = np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None]
+    loss, bce, dice = train_step_loss(m, x, ids, torch.ones_like(ids), (t(g["pts"]), t(g["lbl"])), t(gt))
+    assert abs(loss.item() - float(g["loss"])) < 2e-5 * float(g["loss"]), (loss.item(), float(g["loss"]))
+    loss.backward()
+    params = dict(m.named_parameters())
+    names = [str(v) for v in g["names"]]
+    assert {n.split(".")[0] for n in names} == {"vision_model", "mlp1", "mlp2", "prompt_encoder", "mask_decoder"}
+    worst = (0.0, "")
+    for n in names:
+        ref = g["g:" + n].astype(np.float64)
+        assert params[n].grad is not None, n
+        full = params[n].grad.float().cpu().numpy().reshape(-1).astype(np.float64)
+        got = full[::max(1, full.size // 512)]
+        scale, diff = np.abs(ref).max(), np.abs(got - ref).max()
+        assert diff < 1e-3 * scale + 1e-7, (n, diff, scale)
+        if scale > 1e-6:
+            worst = max(worst, (diff / scale, n))
+        nref = float(g["n:" + n])
+        assert abs(np.sqrt((full ** 2).sum()) - nref) < 1e-3 * nref + 1e-6, (n, np.sqrt((full ** 2).sum()), nref)
+    assert all(p.grad is None for n, p in params.items() if n.startswith("language_model."))
+    print(len(names), "gradients; worst relative error", worst)

@@ -680,3 +680,15 @@ def vision_feature_rows(enc, pixel_values: torch.Tensor) -> torch.Tensor:
     y = _ln(n1, LinearFn.apply(x, n0.weight.reshape(C, D), None))
     z = LinearFn.apply(Im2col3x3Fn.apply(y, B, g, g), n2.weight.permute(0, 2, 3, 1).reshape(C, 9 * C), None)
     return _ln(n3, z).reshape(B, N, C)
+
+
+def train_step_loss(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
+                    points: Tuple[torch.Tensor, torch.Tensor], gt_masks: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """The differentiable part of one step of train_joint_v2.py:943-1100 (batch 1, the reference's `loss = 0 * lm_loss + seg_loss`):
+    model(...) with output_hidden_states (the vision features enter the LLM path under no_grad, modeling_internvl_sam.py:243-244), the second
+    vision_model(pixel_values) call with gradients for the decoder, prompt encoder, mask decoder, upsample, BCE + Dice.  One vision-model
+    forward serves both uses (same values; the LLM path takes it detached).  Returns (total, bce, dice); total.backward() fills the
+    gradients of vision_model, mlp1, mlp2, prompt_encoder and mask_decoder parameters that require them."""
+    rows = vision_feature_rows(model.vision_model, pixel_values)
+    hidden = llm_image_hidden(model, rows.detach(), input_ids, attention_mask)
+    return segmentation_loss(model, hidden, None, points, gt_masks, image_rows=rows)
