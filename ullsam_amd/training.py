@@ -1,28 +1,25 @@
-"""Training slice of SURVEY.md section 8 row f4: the segmentation branch of the reference's train step (train_joint_v2.py:1026-1100)
-with gradients for every parameter downstream of the LLM's last hidden state -- `mlp2`, the prompt encoder (llm_scale_factor, llm_bias,
-point / not-a-point embeddings) and the mask decoder (two-way transformer, output upscaling, hypernetwork MLPs).
+"""Training: the differentiable part of one step of the reference's trainer (train_joint_v2.py:943-1100).
 
-    loss, bce, dice = segmentation_loss(model, llm_hidden, image_embeddings, (coords, labels), gt_masks)
-    loss.backward()        # .grad of model.mlp2 / model.prompt_encoder / model.mask_decoder parameters
+    loss, bce, dice = train_step_loss(model, pixel_values, input_ids, attention_mask, (coords, labels), gt_masks)
+    loss.backward()        # .grad of vision_model / mlp1 / mlp2 / prompt_encoder / mask_decoder parameters (the LLM is frozen)
 
 is the drop-in for
 
-    last = model.text_aware_dense_feature(hidden); sparse, dense = model.prompt_encoder(points, None, None, last.repeat(bs, 1, 1, 1))
+    outputs = model(pixel_values=..., input_ids=..., attention_mask=..., output_hidden_states=True)         # :990-1010
+    image_embeddings = model.vision_model(pixel_values)                                                      # :1020
+    sparse, dense = model.prompt_encoder(points, None, None, outputs.hidden_states.repeat(bs, 1, 1, 1))     # :1055-1060
     low, _ = model.mask_decoder(image_embeddings, model.prompt_encoder.get_dense_pe(), sparse, dense, multimask_output=False)
     loss, bce, dice, _ = calc_instance_loss(F.interpolate(low, (S, S), mode="bilinear", align_corners=False), gt, BCELoss(), DiceLoss())
 
-`llm_image_hidden(model, vit_feature_rows, input_ids, attention_mask)` produces `llm_hidden` differentiably from the vision features through
-`mlp1` and the frozen LLM (second slice), so that `mlp1` trains too.
+built from three pieces that can be used on their own: `vision_feature_rows` (the vision model), `llm_image_hidden` (pixel_shuffle, mlp1, the
+frozen LLM) and `segmentation_loss` (mlp2, prompt encoder, mask decoder, upsample, BCE + Dice).  Supported `trainable_modules`
+(train_joint_v2.py:1280-1359): "vision_model", "mlp1", "mlp2", "prompt_encoder", "mask_decoder" -- everything the reference trains.  fp32 only,
+one image per step.
 
-`vision_feature_rows(model.vision_model, pixel_values)` is the differentiable vision model (third slice); pass its result as `image_rows=`.
-
-Supported `trainable_modules` (train_joint_v2.py:1280-1359): "vision_model", "mlp1", "mlp2", "prompt_encoder", "mask_decoder" -- everything the
-reference trains; the LLM is frozen there and here (gradients flow through it, none are produced for it).  fp32 only.
-
-Every arithmetic step, forward and backward, is a HIP kernel (csrc/train.hip for the backward and the generic fp32 matmul; the
-inference kernels for norms, attention, sparse embeddings, upsample).  torch supplies the autograd tape and data movement (reshape /
-permute / cat / expand copies), nothing else.  These are correctness-first kernels: the step is gated on gradients equal to the
-reference's (tests/test_train_gpu.py, fixture tests/golden/train_slice.npz), not on speed.
+Every arithmetic step, forward and backward, is a HIP kernel (csrc/train.hip for the backward kernels, the generic fp32 matmul and the
+training attention; the inference kernels for norms, gathers, sparse embeddings, upsample).  torch supplies the autograd tape and data
+movement (reshape / permute / pad / cat / index copies), nothing else.  These are correctness-first kernels: the step is gated on gradients
+equal to the reference's autograd (tests/test_train_gpu.py; fixtures tests/golden/train_*.npz made by the reference itself), not on speed.
 """
 from __future__ import annotations
 
