@@ -276,10 +276,10 @@ def test_generator_min_mask_region_area_and_coco_rle():
 
 # ---- BASELINE configs[4] at its real size: 64x64 points on a 2048^2 tile, SAM ViT-H encoder, bf16 and fp8 ViT linears --------------------
 # A random-init decoder draws full-frame textures, not objects: every box is (nearly) the whole tile, so box NMS at SAM's 0.7 would keep ONE
-# record.  The score thresholds sit at the ~90th / ~87th percentile of this decoder's predicted-IoU / stability distributions (measured with
-# tools/probes/amg_full_probe.py) so that on the order of a hundred masks survive, and box NMS runs with threshold 1.0 (keeps all; the NMS
+# record.  The score thresholds sit at the ~87th / ~85th percentile of this decoder's predicted-IoU / stability distributions (measured with
+# tools/probes/amg_full_probe.py on bench.build_model's init: 154 bf16 / 171 fp8 candidates pass both) so that on the order of a hundred masks survive, and box NMS runs with threshold 1.0 (keeps all; the NMS
 # kernel itself is pinned at scale by test_box_nms_matches_oracle).
-REAL_AMG = dict(points_per_side=64, points_per_batch=64, pred_iou_thresh=0.4, stability_score_thresh=0.95, stability_score_offset=0.1,
+REAL_AMG = dict(points_per_side=64, points_per_batch=64, pred_iou_thresh=0.2, stability_score_thresh=0.87, stability_score_offset=0.1,
                 box_nms_thresh=1.0, output_mode="uncompressed_rle")
 
 

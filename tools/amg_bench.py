@@ -13,10 +13,10 @@ from ullsam_amd.automatic_mask_generator import SamAutomaticMaskGenerator
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 tile = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 vit = sys.argv[3] if len(sys.argv) > 3 else "h"
-stab = float(sys.argv[4]) if len(sys.argv) > 4 else 0.95
+stab = float(sys.argv[4]) if len(sys.argv) > 4 else 0.87
 off = float(sys.argv[5]) if len(sys.argv) > 5 else 0.1
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 3
-piou = float(sys.argv[7]) if len(sys.argv) > 7 else 0.4
+piou = float(sys.argv[7]) if len(sys.argv) > 7 else 0.2
 nms = float(sys.argv[8]) if len(sys.argv) > 8 else 1.0   # a random-init decoder's boxes are all full-frame: SAM's 0.7 would keep one record
 if os.environ.get("ULLSAM_GEMM_VARIANT"):
     from ullsam_amd import _lib

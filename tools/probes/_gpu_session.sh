@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_train_gpu.py -x -q -m gpu -s 2>&1 < /dev/null | tail -30
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 < /dev/null | tail -8 > gpurun_out/full_gpu.log
+cat gpurun_out/full_gpu.log
