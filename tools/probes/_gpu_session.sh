@@ -1,13 +1,7 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/ev
+mkdir -p gpurun_out
 export TMPDIR=/tmp
-SHA=7705191
-timeout 900 python3 tools/collect_evidence.py --round 03 --head $SHA --mode mask > gpurun_out/ev/mask.log 2>&1 < /dev/null
-timeout 600 python3 tools/collect_evidence.py --round 03 --head $SHA --mode decode > gpurun_out/ev/decode.log 2>&1 < /dev/null
-timeout 900 python3 tools/other_configs.py --round 03 --head $SHA > gpurun_out/ev/other.log 2>&1 < /dev/null
-cp profiles/r03_kernel_summary_HEAD.txt profiles/r03_pmc_bench_traffic.json profiles/r03_decode_summary.txt profiles/r03_other_configs.json gpurun_out/ev/
-timeout 600 python3 bench.py > gpurun_out/ev/bench_mask.json 2> gpurun_out/ev/bench_mask.err < /dev/null
-timeout 300 python3 bench.py --mode decode > gpurun_out/ev/bench_decode.json 2> gpurun_out/ev/bench_decode.err < /dev/null
-tail -3 gpurun_out/ev/mask.log; tail -2 gpurun_out/ev/decode.log; tail -3 gpurun_out/ev/other.log
-tail -1 gpurun_out/ev/bench_mask.json | cut -c1-900
-tail -1 gpurun_out/ev/bench_decode.json | cut -c1-300
+timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -x -q -m gpu -k "decode or generate" 2>&1 < /dev/null | tail -4
+timeout 400 python3 tools/decode_bench.py 4 1081 64 2>&1 < /dev/null | tail -1
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof2 -o sk -- python3 tools/decode_bench.py 4 1081 64 > gpurun_out/dec.log 2>&1 < /dev/null
+timeout 120 python3 tools/probes/ktrace_summary.py /tmp/prof2 decode_attn < /dev/null | head -6
