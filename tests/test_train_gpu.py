@@ -157,12 +157,16 @@ def test_gradients_reach_every_vision_model_parameter():
     print("worst relative gradient error", worst)
 
 
-def test_whole_train_step_gradients_of_every_trainable_module():
+@pytest.mark.parametrize("mfma_linear", [True, False])
+def test_whole_train_step_gradients_of_every_trainable_module(mfma_linear):
     """One whole step of the reference's trainer (train_joint_v2.py:990-1100 on the tiny composite; fixture train_step.npz: model(...) with
     output_hidden_states, the second vision_model call, prompt encoder, mask decoder, upsample, calc_instance_loss; LLM frozen) against
     ullsam_amd.training.train_step_loss: the loss and the gradient of every parameter the reference's step produces one for -- vision model,
     mlp1, mlp2, prompt encoder, mask decoder -- within 1e-3 of the tensor's largest entry; none for the LLM."""
+    import time
+    from ullsam_amd import training
     from ullsam_amd.training import train_step_loss
+    training.MFMA_LINEAR = mfma_linear      # nn.Linear on the fp32 MFMA GEMM where shapes allow / on the plain kernel everywhere
     g = U.gold("train_step")
     m = _ullsam_tiny(torch.float32)
     for n, p in m.named_parameters():
@@ -172,9 +176,12 @@ def test_whole_train_step_gradients_of_every_trainable_module():
     ids = t(g["ids"]).long()
     yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
     gt = np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
     loss, bce, dice = train_step_loss(m, x, ids, torch.ones_like(ids), (t(g["pts"]), t(g["lbl"])), t(gt))
     assert abs(loss.item() - float(g["loss"])) < 2e-5 * float(g["loss"]), (loss.item(), float(g["loss"]))
     loss.backward()
+    torch.cuda.synchronize(); print(f"step (forward + backward, mfma_linear={mfma_linear}): {time.perf_counter() - t0:.3f} s")
+    training.MFMA_LINEAR = True
     params = dict(m.named_parameters())
     names = [str(v) for v in g["names"]]
     assert {n.split(".")[0] for n in names} == {"vision_model", "mlp1", "mlp2", "prompt_encoder", "mask_decoder"}

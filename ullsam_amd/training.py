@@ -56,18 +56,32 @@ def _colsum(x2d: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _t2d(x: torch.Tensor) -> torch.Tensor:
+    """[R, C] -> [C, R] copy (HIP transpose kernel)."""
+    R, C = x.shape
+    return ops.transpose(x.reshape(1, R, C), 1, R, C).reshape(C, R)
+
+
+MFMA_LINEAR = True   # nn.Linear forward / backward on the fp32 MFMA GEMM of the inference path where its shapes allow (inner dimension % 32 == 0);
+#                     the one-output-per-thread matmul of csrc/train.hip otherwise (and always with MFMA_LINEAR = False: tests compare the two)
+
+
 class LinearFn(Function):
-    """y = x W^T + b on rows (nn.Linear); dX = dY W, dW = dY^T X, db = column sums of dY."""
+    """y = x W^T + b on rows (nn.Linear); dX = dY W, dW = dY^T X, db = column sums of dY.  Each product is ullsam_gemm's A W^T form: forward
+    with W as stored, dX with a transposed copy of W, dW with transposed copies of dY and X."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         x, w = _c(x), _c(w)
         M, K = x.shape
         N = w.shape[0]
-        y = torch.empty((M, N), dtype=F32, device=x.device)
-        _mm(x, w, y, M, N, K, (0, K, 1), (0, 1, K), (0, N, 1))
-        if b is not None:
-            y = ops.add_cast(y, _c(b).reshape(1, N), F32)
+        if MFMA_LINEAR and K % 32 == 0 and N % 4 == 0:
+            y = ops.gemm(x, w, None if b is None else _c(b), out_f32=True)
+        else:
+            y = torch.empty((M, N), dtype=F32, device=x.device)
+            _mm(x, w, y, M, N, K, (0, K, 1), (0, 1, K), (0, N, 1))
+            if b is not None:
+                y = ops.add_cast(y, _c(b).reshape(1, N), F32)
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
         return y
@@ -80,11 +94,17 @@ class LinearFn(Function):
         N = w.shape[0]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((M, K), dtype=F32, device=x.device)
-            _mm(dy, w, dx, M, K, N, (0, N, 1), (0, K, 1), (0, K, 1))
+            if MFMA_LINEAR and N % 32 == 0 and K % 4 == 0:
+                dx = ops.gemm(dy, _t2d(w), out_f32=True)                       # [M, N] x ([K, N])^T
+            else:
+                dx = torch.empty((M, K), dtype=F32, device=x.device)
+                _mm(dy, w, dx, M, K, N, (0, N, 1), (0, K, 1), (0, K, 1))
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((N, K), dtype=F32, device=x.device)
-            _mm(dy, x, dw, N, K, M, (0, 1, N), (0, K, 1), (0, K, 1))
+            if MFMA_LINEAR and M % 32 == 0 and K % 4 == 0:
+                dw = ops.gemm(_t2d(dy), _t2d(x), out_f32=True)                 # [N, M] x ([K, M])^T
+            else:
+                dw = torch.empty((N, K), dtype=F32, device=x.device)
+                _mm(dy, x, dw, N, K, M, (0, 1, N), (0, K, 1), (0, K, 1))
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = _colsum(dy)
         return dx, dw, db
