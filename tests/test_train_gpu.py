@@ -199,3 +199,37 @@ def test_whole_train_step_gradients_of_every_trainable_module(mfma_linear):
         assert abs(np.sqrt((full ** 2).sum()) - nref) < 1e-3 * nref + 1e-6, (n, np.sqrt((full ** 2).sum()), nref)
     assert all(p.grad is None for n, p in params.items() if n.startswith("language_model."))
     print(len(names), "gradients; worst relative error", worst)
+
+
+def test_segmentation_loss_gradient_by_central_differences_on_another_prompt_shape():
+    """A prompt shape no fixture has (ONE instance, three clicks of which one carries the padding label -1): the analytic gradient of a few
+    scalar parameters -- llm_bias, llm_scale_factor, an entry of not_a_point_embed (reached through the -1 click AND the padding point), of a
+    mask token, of a hypernetwork weight and of the first transposed convolution -- against central differences of the loss itself."""
+    from ullsam_amd.training import segmentation_loss
+    g = U.gold("train_slice")
+    m = _ullsam_tiny(torch.float32)
+    for n, p in m.named_parameters():
+        p.requires_grad_(n.startswith(("prompt_encoder.", "mask_decoder.")))
+    hid, img, _, gt = _inputs(g)
+    pts = torch.tensor([[[400.0, 300.0], [900.0, 128.0], [10.0, 10.0]]], device=DEV)
+    lbl = torch.tensor([[1, 0, -1]], device=DEV, dtype=torch.int32)
+    gt = gt[:1]
+    f = lambda: segmentation_loss(m, hid, img, (pts, lbl), gt)[0]
+    loss = f()
+    loss.backward()
+    pe, md = m.prompt_encoder, m.mask_decoder
+    probes = [(pe.llm_bias, 0), (pe.llm_scale_factor, 0), (pe.not_a_point_embed.weight, 17), (md.mask_tokens.weight, 5),
+              (md.output_hypernetworks_mlps[0].layers[2].weight, 100), (md.output_upscaling[0].weight, 4321)]
+    for p, i in probes:
+        if p.numel() > 4096:   # large tensors: the entry with the largest gradient (a tiny one drowns in the fp32 rounding of the loss)
+            i = int(p.grad.reshape(-1).abs().argmax())
+        ana = float(p.grad.reshape(-1)[i])
+        flat = p.data.reshape(-1)
+        old = float(flat[i])
+        eps = 2e-3
+        with torch.no_grad():
+            flat[i] = old + eps; lp = float(f().detach())
+            flat[i] = old - eps; lm_ = float(f().detach())
+            flat[i] = old
+        num = (lp - lm_) / (2 * eps)
+        assert abs(num - ana) < 3e-2 * abs(ana) + 1e-4, (tuple(p.shape), i, ana, num)   # fp32 loss: ~1e-7 of rounding over a 4e-3 step
