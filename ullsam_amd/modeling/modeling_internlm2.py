@@ -337,6 +337,9 @@ class InternLM2ForCausalLM(Packed):
         out = self.model(input_ids=None if inputs_embeds is not None else input_ids, inputs_embeds=inputs_embeds, attention_mask=mask,
                          position_ids=pos, past_key_values=cache, use_cache=True)
         done = torch.zeros(B, dtype=torch.bool, device=dev)
+        track_eos = eos_set != {-1}                        # eos_token_id=-1: run to max_new_tokens, no per-step stop bookkeeping
+        eos_t = torch.tensor(sorted(eos_set), dtype=torch.long, device=dev)
+        pad_t = torch.tensor(pad, dtype=torch.long, device=dev)
         new: List[torch.Tensor] = []
         h_last = out.last_hidden_state[:, -1]
         # The stop test ("every sequence has emitted eos") needs the token values on the host.  It is evaluated on a copy made
@@ -346,23 +349,23 @@ class InternLM2ForCausalLM(Packed):
         # With do_sample the test is made every step (blocking): a surplus step would draw from the global torch RNG and leave its state
         # different from a loop that stops at once, so later sampled calls would not reproduce against the reference loop.
         every = 0 if do_sample else max(1, int(kwargs.get("eos_check_every", 8)))
-        flags = torch.empty((max_new_tokens,), dtype=torch.bool, pin_memory=True) if eos_set != {-1} else None  # one pinned buffer per call
+        flags = torch.empty((max_new_tokens,), dtype=torch.bool, pin_memory=True) if track_eos else None  # one pinned buffer per call
         pending = []  # (step index, event)
         stop_at = None
-        mask_full = torch.ones((B, S + max_new_tokens), dtype=torch.long, device=dev)
+        mask_full = torch.ones((B, S + max_new_tokens), dtype=torch.int32, device=dev)   # int32: what the kernels take (no per-step conversion)
         mask_full[:, :S] = mask
-        pos_next = mask.sum(-1, keepdim=True)  # = cumsum(mask)[:, -1]: position id of the next token (cumsum - 1 of the extended mask)
+        pos_next = mask.sum(-1, keepdim=True).to(torch.int32)  # = cumsum(mask)[:, -1]: position id of the next token (cumsum - 1 of the extended mask)
         for step in range(max_new_tokens):
             logits = self.lm_head(h_last)  # fp32 [B, V], last position only
             if do_sample:
                 tok = _sample(logits, temperature, top_k, top_p)
             else:
                 tok = ops.argmax(logits.contiguous())
-            tok = torch.where(done, torch.full_like(tok, pad), tok)
+            if track_eos:
+                tok = torch.where(done, pad_t, tok)
+                done = done | torch.isin(tok, eos_t)
             new.append(tok)
-            for e in eos_set:
-                done = done | (tok == e)
-            if eos_set != {-1}:
+            if track_eos:
                 flags[step:step + 1].copy_(done.all().reshape(1), non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
