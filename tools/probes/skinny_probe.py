@@ -38,15 +38,11 @@ def timed(fn, reps=3):
     return best
 
 
-from ullsam_amd import _lib
-modes = [int(v) for v in os.environ.get("SKINNY_MODES", "0").split(",")]
-for mode in modes:
-    _lib.call("ullsam_set_gemm_tuning", 2, mode)
-    print(f"--- K-split mode {mode}")
-    for name, (n, kk, act, r) in SHAPES.items():
-        ms = timed(lambda: [one(name, i) for i in range(L)])
-        us = ms * 1e3 / L
-        print(f"{name:5s} N={n:6d} K={kk:6d}: {us:7.2f} us per launch, {n * kk * 2 / us / 1e6:5.2f} TB/s", flush=True)
-    ms = timed(lambda: [[one(nm, i) for nm in SHAPES] for i in range(L)])
-    tot = sum(n * kk * 2 for n, kk, _, _ in SHAPES.values())
-    print(f"chain of 4 x {L} layers: {ms * 1e3 / L:7.2f} us per layer, {tot / (ms * 1e3 / L) / 1e6:5.2f} TB/s")
+for name, (n, kk, act, r) in SHAPES.items():
+    ms = timed(lambda: [one(name, i) for i in range(L)])
+    us = ms * 1e3 / L
+    print(f"{name:5s} N={n:6d} K={kk:6d}: {us:7.2f} us per launch (host-issued back to back; GPU-side durations: rocprofv3 --kernel-trace + probes/ktrace_summary.py), "
+          f"{n * kk * 2 / us / 1e6:5.2f} TB/s", flush=True)
+ms = timed(lambda: [[one(nm, i) for nm in SHAPES] for i in range(L)])
+tot = sum(n * kk * 2 for n, kk, _, _ in SHAPES.values())
+print(f"chain of {len(SHAPES)} x {L} layers: {ms * 1e3 / L:7.2f} us per layer, {tot / (ms * 1e3 / L) / 1e6:5.2f} TB/s")

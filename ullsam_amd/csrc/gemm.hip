@@ -62,7 +62,6 @@ static int g_split_tail = 1;   // ullsam_set_gemm_variant(v | 64) disables the s
 static int g_gemm_variant = 0; // bits 0-3 force a kernel: 0 auto, 1 128x128, 3 256x256 two-buffer, 6 256x256 ring, 8 256x320 ring, 9 272x256 ring
 static int g_dbg = 0;          // ullsam_set_gemm_variant bit 15: stamp the ring kernel (tools/probes/ring8_stamps.py reads the stamps from the workspace)
 static int g_auto_mask = 7;    // ullsam_set_gemm_tuning(1, mask): ring tile shapes the auto dispatch may pick: bit 0 256x256, bit 1 256x320, bit 2 272x256
-static int g_skinny_mode = 0;  // ullsam_set_gemm_tuning(2, mode): weight streams at M <= 4 (A/B): 0 auto; K-split kernel 1 = 4 rows x 2 buffers, 3 = 8 rows x 3, 4 = 4 rows x 3; 5 = no K-split; 6 = no persistent kernel
 static int g_group_m = 4;      // ullsam_set_gemm_tuning(0, gm): raster group height (measured: 4 -> 83.26 ms per step, 8 -> 83.73, 2 -> 84.35)
 
 template <typename T>
@@ -1250,7 +1249,6 @@ extern "C" int ullsam_gemm_fp8(const void* A8, long lda, const float* a_scale, c
 extern "C" int ullsam_set_gemm_tuning(int key, int value) {
     if (key == 0 && value >= 1 && value <= 1024) { g_group_m = value; return 0; }
     if (key == 1 && value >= 0 && value <= 7) { g_auto_mask = value; return 0; }
-    if (key == 2 && value >= 0 && value <= 8) { g_skinny_mode = value; return 0; }
     ullsam_set_error("ullsam_set_gemm_tuning: unknown key %d / bad value %d", key, value);
     return -1;
 }
@@ -1625,7 +1623,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_persist_kernel(GemmArgs p, in
 // NORM: the activations are RMSNorm(norm_x) * norm_w, staged as bf16 in LDS by stage_rmsnorm (K <= 4096, M <= 4) instead of read from
 // global memory.  act == 4 (R == 8 only): the wqkv epilogue of a decode step -- the workgroup owns rows d .. d+3 and d+64 .. d+67 of one
 // 128-row head slot, i.e. four rotate_half pairs, and writes q / the KV-cache rows directly (same arithmetic as the prefill epilogue).
-template <int MM, int R, int NB, bool NORM>
+template <int MM, int R, bool NORM>
 __global__ __launch_bounds__(256) void gemm_skinny_ksplit_kernel(GemmArgs p) {
     static_assert(R * MM == 16 || R * MM == 32, "the butterfly reduces 16 or 32 values per lane");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // NORM: A as bf16 [MM][K]
@@ -1673,49 +1671,28 @@ __global__ __launch_bounds__(256) void gemm_skinny_ksplit_kernel(GemmArgs p) {
             }
         __builtin_amdgcn_sched_barrier(0);
     };
-    // NB register buffers rotate: NB - 1 steps of loads are in flight behind the one being multiplied (see gemm_skinny_kernel); the first
-    // loads are requested before the activations are staged
-    if constexpr (NB == 3) {
-        Buf b0, b1, b2;
-        NormRows<NORM ? 4 : 1> nrows;
-        if constexpr (NORM) stage_rmsnorm_load<4>(nrows, p);
-        __builtin_amdgcn_sched_barrier(0);
+    // Two register buffers rotate: one step of loads is in flight behind the one being multiplied (see gemm_skinny_kernel); the first loads are
+    // requested before the activations are staged
+    Buf b0, b1;
+    if constexpr (NORM) {   // one step of weights in flight under the staging (the rows' registers + two steps would cost the third workgroup per CU)
+        NormRows<4> nrows;
+        __shared__ float nred[16];
+        stage_rmsnorm_load<4>(nrows, p);
+        __builtin_amdgcn_sched_barrier(0);   // order pinned: see gemm_skinny_kernel
         fill(b0, 0);
-        fill(b1, 512 < KQ ? 512 : 0);   // unconditional, order pinned: see gemm_skinny_kernel
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NORM) { __shared__ float nred[16]; stage_rmsnorm_finish<4>(nrows, smem, nred, p); }
-        for (int k0 = 0; k0 < KQ; k0 += 1536) {
-            if (k0 + 1024 < KQ) fill(b2, k0 + 1024);
-            step(b0, k0);
-            if (k0 + 512 >= KQ) break;
-            if (k0 + 1536 < KQ) fill(b0, k0 + 1536);
-            step(b1, k0 + 512);
-            if (k0 + 1024 >= KQ) break;
-            if (k0 + 2048 < KQ) fill(b1, k0 + 2048);
-            step(b2, k0 + 1024);
-        }
+        stage_rmsnorm_finish<4>(nrows, smem, nred, p);
+        fill(b1, 512 < KQ ? 512 : 0);
     } else {
-        Buf b0, b1;
-        if constexpr (NORM) {   // one step of weights in flight under the staging (the rows' registers + two steps would cost the third workgroup per CU)
-            NormRows<4> nrows;
-            __shared__ float nred[16];
-            stage_rmsnorm_load<4>(nrows, p);
-            __builtin_amdgcn_sched_barrier(0);   // order pinned: see gemm_skinny_kernel
-            fill(b0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            stage_rmsnorm_finish<4>(nrows, smem, nred, p);
-            fill(b1, 512 < KQ ? 512 : 0);
-        } else {
-            fill(b0, 0);
-            if (512 < KQ) fill(b1, 512);
-        }
-        for (int k0 = 0; k0 < KQ; k0 += 1024) {
-            step(b0, k0);
-            if (k0 + 512 >= KQ) break;
-            if (k0 + 1024 < KQ) fill(b0, k0 + 1024);
-            step(b1, k0 + 512);
-            if (k0 + 1536 < KQ) fill(b1, k0 + 1536);
-        }
+        fill(b0, 0);
+        if (512 < KQ) fill(b1, 512);
+    }
+    for (int k0 = 0; k0 < KQ; k0 += 1024) {
+        step(b0, k0);
+        if (k0 + 512 >= KQ) break;
+        if (k0 + 1024 < KQ) fill(b0, k0 + 1024);
+        step(b1, k0 + 512);
+        if (k0 + 1536 < KQ) fill(b1, k0 + 1536);
     }
     dot_fence();
     {
@@ -1767,16 +1744,13 @@ static int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     const bool normed = a.norm_x != nullptr;
     if (normed && (a.M > 4 || a.K > 4096 || a.K % 2048 != 0 || a.ldx % 4 != 0)) { ullsam_set_error("skinny GEMM: the fused RMSNorm prologue needs M <= 4, K <= 4096, K %% 2048 == 0 (M=%d K=%d)", a.M, a.K); return -1; }
     if (a.act == 4 && (a.M > 4 || a.K % 2048 != 0 || a.N % 128 != 0)) { ullsam_set_error("skinny GEMM: the RoPE epilogue needs M <= 4, K %% 2048 == 0 (M=%d K=%d)", a.M, a.K); return -1; }
-    if (a.act == 4 || (a.act != 3 && a.N <= 8192 && a.K % 2048 == 0 && g_skinny_mode != 5)) {  // narrow: K split over the waves of a workgroup
+    if (a.act == 4 || (a.act != 3 && a.N <= 8192 && a.K % 2048 == 0)) {  // narrow: K split over the waves of a workgroup
         const dim3 g4((unsigned)((a.N + 3) / 4)), g8((unsigned)((a.N + 7) / 8));
         const size_t lds = normed ? (size_t)4 * a.K * 2 : 0;
-        if (normed) gemm_skinny_ksplit_kernel<4, 8, 2, true><<<g8, 256, lds, stream>>>(a);
-        else if (a.act == 4) gemm_skinny_ksplit_kernel<4, 8, 2, false><<<g8, 256, 0, stream>>>(a);
-        else if (a.M > 4) gemm_skinny_ksplit_kernel<8, 4, 2, false><<<g4, 256, 0, stream>>>(a);
-        else if (g_skinny_mode == 1) gemm_skinny_ksplit_kernel<4, 4, 2, false><<<g4, 256, 0, stream>>>(a);
-        else if (g_skinny_mode == 3) gemm_skinny_ksplit_kernel<4, 8, 3, false><<<g8, 256, 0, stream>>>(a);
-        else if (g_skinny_mode == 4) gemm_skinny_ksplit_kernel<4, 4, 3, false><<<g4, 256, 0, stream>>>(a);
-        else gemm_skinny_ksplit_kernel<4, 8, 2, false><<<g8, 256, 0, stream>>>(a);   // measured (tools/probes/skinny_probe.py): the four shapes within 1 % of each other
+        if (normed) gemm_skinny_ksplit_kernel<4, 8, true><<<g8, 256, lds, stream>>>(a);
+        else if (a.act == 4) gemm_skinny_ksplit_kernel<4, 8, false><<<g8, 256, 0, stream>>>(a);
+        else if (a.M > 4) gemm_skinny_ksplit_kernel<8, 4, false><<<g4, 256, 0, stream>>>(a);
+        else gemm_skinny_ksplit_kernel<4, 8, false><<<g8, 256, 0, stream>>>(a);   // (4 rows x 3 buffers, 4 x 2, 8 x 3 were measured within 1 % of this and removed)
         ULLSAM_LAUNCH_CHECK();
         return 0;
     }
@@ -1785,12 +1759,11 @@ static int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     const long waves = a.act == 3 ? (long)a.N / 4 : ((long)a.N + 3) / 4;
     // measured (tools/probes/skinny_probe.py, us per launch): w13 47.4 -> 45.3 with two resident workgroups per CU (45.8 with one, 46.9 with
     // three); the LM head (92553 rows) 129 -> 137: its 5785 workgroups already amortise the ramp, so it keeps the kernel above
-    if (MM == 4 && (normed || a.act == 3) && waves >= 4096 && lds <= 64 * 1024 && g_skinny_mode != 5 && g_skinny_mode != 6) {
+    if (MM == 4 && (normed || a.act == 3) && waves >= 4096 && lds <= 64 * 1024) {
         // one workgroup per CU; W waves each so that the units divide evenly (fewest idle wave-trips, ties to the larger W)
         static PerDeviceOnce cu_once; static int n_cu = 256;
         if (cu_once.first()) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n_cu = pr.multiProcessorCount; }
-        const int wpc = g_skinny_mode == 7 ? 1 : g_skinny_mode == 8 ? 3 : 2;   // workgroups per CU
-        const int n_wg = n_cu * wpc;
+        const int n_wg = n_cu * 2;   // two resident workgroups per CU (one: 45.8 us, three: 46.9, two: 45.3 for w13)
         int W = 8; double best = 1e30;
         for (int w = 8; w >= 4; --w) {
             const long per = (long)n_wg * w, trips = (waves + per - 1) / per;
