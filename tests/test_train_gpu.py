@@ -65,13 +65,30 @@ def test_segmentation_loss_and_gradients_equal_the_reference_autograd():
     print("worst relative gradient error", worst)
 
 
-def test_training_slice_refuses_bf16():
+def test_bf16_model_gets_the_fp32_step_on_its_rounded_weights():
+    """The trainer's default keeps the model in bf16 (train_joint_v2.py:1599,1676).  The step widens bf16 parameters and computes in fp32, so a
+    bf16 model's gradients are those of the fp32 model holding the same (bf16-rounded) weights, rounded to bf16: compared tensor by tensor on
+    the decoder-side slice."""
     from ullsam_amd.training import segmentation_loss
     g = U.gold("train_slice")
-    m = _ullsam_tiny(torch.bfloat16)
     hid, img, pts, gt = _inputs(g)
-    with pytest.raises(TypeError):
-        segmentation_loss(m, hid, img, pts, gt)
+    grads = []
+    for widen in (False, True):
+        m = _ullsam_tiny(torch.bfloat16)
+        if widen:
+            m = m.float()                                  # the same rounded weights, held in fp32
+        for n, p in m.named_parameters():
+            p.requires_grad_(n.startswith(("mlp2.", "prompt_encoder.", "mask_decoder.")))
+        loss, _, _ = segmentation_loss(m, hid, img, pts, gt)
+        loss.backward()
+        grads.append((float(loss.detach()), {n: p.grad for n, p in m.named_parameters() if p.grad is not None}))
+    (l16, g16), (l32, g32) = grads
+    assert abs(l16 - l32) < 1e-5 * abs(l32)               # (sums by atomics: the two runs differ in the order of additions)
+    assert set(g16) == set(g32) and len(g16) >= 125
+    for n in g16:
+        assert g16[n].dtype == torch.bfloat16
+        a, b = g16[n].float(), g32[n]
+        assert float((a - b).abs().max()) <= 2.0 ** -8 * float(b.abs().max()) + 1e-7, n   # one bf16 rounding of each entry
 
 
 def test_gradients_through_the_frozen_llm_reach_mlp1():

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 < /dev/null | grep -E "passed|failed|error" | tail -3
+timeout 900 python -m pytest tests/test_train_gpu.py -x -q -m gpu 2>&1 < /dev/null | tail -4

@@ -13,8 +13,8 @@ is the drop-in for
 
 built from three pieces that can be used on their own: `vision_feature_rows` (the vision model), `llm_image_hidden` (pixel_shuffle, mlp1, the
 frozen LLM) and `segmentation_loss` (mlp2, prompt encoder, mask decoder, upsample, BCE + Dice).  Supported `trainable_modules`
-(train_joint_v2.py:1280-1359): "vision_model", "mlp1", "mlp2", "prompt_encoder", "mask_decoder" -- everything the reference trains.  fp32 only,
-one image per step.
+(train_joint_v2.py:1280-1359): "vision_model", "mlp1", "mlp2", "prompt_encoder", "mask_decoder" -- everything the reference trains.  The
+arithmetic is fp32; the model may be fp32 or bf16 (bf16 parameters are widened on use and receive bf16 gradients).  One image per step.
 
 Every arithmetic step, forward and backward, is a HIP kernel (csrc/train.hip for the backward kernels, the generic fp32 matmul and the
 training attention; the inference kernels for norms, gathers, sparse embeddings, upsample).  torch supplies the autograd tape and data
@@ -39,8 +39,12 @@ def _s() -> int:
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
-    if t.dtype != F32:
-        raise TypeError(f"the training slice is fp32 (got {t.dtype}); load the model with torch.float32")
+    """fp32, contiguous.  bf16 parameters / inputs (the trainer's default `--dtype bfloat16` keeps the model in bf16, train_joint_v2.py:1676) are
+    widened here: the arithmetic of the step is fp32 throughout, and autograd hands every bf16 parameter its gradient rounded to bf16."""
+    if t.dtype == torch.bfloat16:
+        t = t.float()
+    elif t.dtype != F32:
+        raise TypeError(f"the training step computes in fp32 from fp32 or bf16 tensors (got {t.dtype})")
     return t if t.is_contiguous() else t.contiguous()
 
 
@@ -616,7 +620,7 @@ def llm_image_hidden(model, vit_feature_rows: torch.Tensor, input_ids: torch.Ten
     n_sel = int(sel.sum())
     if n_sel != vit_embeds.shape[0]:
         raise ValueError(f"{n_sel} <IMG_CONTEXT> tokens for {vit_embeds.shape[0]} image embeddings")
-    x = lm.model.tok_embeddings.weight.detach()[ids].clone()                     # frozen embedding rows (a gather)
+    x = lm.model.tok_embeddings.weight.detach()[ids].float().clone()             # frozen embedding rows (a gather)
     x = x.index_put((sel.nonzero(as_tuple=True)[0],), vit_embeds)                # input_embeds[selected] = vit_embeds  (:150-152)
     H, KVH = cfg.num_attention_heads, cfg.num_key_value_heads
     hd, G = cfg.hidden_size // H, H // KVH
