@@ -27,7 +27,7 @@ extern "C" {
 
 /* Bumped whenever an entry point is added or a signature changes.  The Python binding refuses a library that reports another
    version (a stale libullsam_hip.so would otherwise receive shifted arguments, e.g. a row count where the stream is expected). */
-#define ULLSAM_ABI_VERSION 6
+#define ULLSAM_ABI_VERSION 7
 
 const char* ullsam_last_error_string(void);
 int ullsam_abi_version(void); /* == ULLSAM_ABI_VERSION of the header the library was built from */
@@ -103,6 +103,12 @@ int ullsam_train_attention(const float* q, const float* k, const float* v, const
  * as bias_h[q][key / kw] + bias_w[q][key % kw]; NULL elsewhere.  The backward writes dbias_h / dbias_w.) */
 /* adjoint of ullsam_im2col3x3 (neck conv3x3 as im2col + Linear): dcols [B*H*W, 9*C] -> dx [B,H,W,C] */
 int ullsam_train_col2im3x3(const float* dcols, float* dx, int B, int H, int W, int C, void* stream);
+/* Row pass of the training attention in matrix form (large problems: the atomics of the kernel above serialise).  S [B*H, Sq, Sk] holds
+ * (q*scale) k^T from ullsam_train_matmul (have_p 0): logits = S + bias + masks, P = softmax in place.  dP NULL: forward, stop there (out = P v by
+ * ullsam_train_matmul).  dP = dO v^T given: dS = P (dP - sum_j P_j dP_j) overwrites dP and the decomposed-bias gradient rows are written; have_p 1:
+ * S already holds the P the forward kept. */
+int ullsam_train_attn_rows(float* S, float* dP, const float* bias_h, const float* bias_w, float* dbias_h, float* dbias_w, const int* key_mask,
+                           int B, int H, int Sq, int Sk, int kw, int causal, int have_p, void* stream);
 /* InternLM2RMSNorm backward (modeling_internlm2.py:75-89); dw may be NULL (frozen LLM) */
 int ullsam_train_rmsnorm_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, long rows, int D, float eps, void* stream);
 /* apply_rotary_pos_emb (modeling_internlm2.py:233-247) on rows [tokens, heads, hd]; adjoint != 0: its transpose (the backward) */

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_train_gpu.py -x -q -m gpu 2>&1 < /dev/null | tail -4
+timeout 1200 python tools/train_step_bench.py h 7b 2 2>&1 < /dev/null | tail -2

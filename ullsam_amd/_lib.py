@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ULLSAM_HIP_LIB") or os.path.join(_HERE, "lib", "libullsam_hip.so")  # env: A/B a side build (developer switch)
 
-ABI_VERSION = 6  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
+ABI_VERSION = 7  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
 
 _lib = None
 
@@ -29,6 +29,7 @@ SIGNATURES = {
     "ullsam_train_scale_shift": [vp, vp, vp, vp, vp, vp, vp, i64, vp],
     "ullsam_train_attention": [vp] * 8 + [i32] * 7 + [vp] + [i64] * 12 + [f32, vp, vp, vp, vp, i32, vp],
     "ullsam_train_col2im3x3": [vp, vp, i32, i32, i32, i32, vp],
+    "ullsam_train_attn_rows": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "ullsam_train_rmsnorm_bwd": [vp, vp, vp, vp, vp, i64, i32, f32, vp],
     "ullsam_train_rope": [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp],
     "ullsam_train_swiglu": [vp, vp, vp, vp, vp, vp, i64, vp],

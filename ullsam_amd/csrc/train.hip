@@ -313,6 +313,85 @@ extern "C" int ullsam_train_attention(const float* q, const float* k, const floa
     return 0;
 }
 
+// ---- attention backward, materialised form: one wave-row pass between batched matmuls ---------------------------------------------------------
+// The backward above adds dk / dv by atomics -- every query's workgroup into the same Sk x hd rows: 1.4 s for one global ViT-B block
+// (4096 x 4096 x 12 heads).  Large problems go through matrices instead (ullsam_amd/training.py AttentionFn.backward):
+//   forward: S = (q * scale) k^T by ullsam_train_matmul, THIS kernel per row with dP = NULL: logits = S + bias + masks, P = softmax(logits) in place
+//   (kept for the backward), out = P v by ullsam_train_matmul;
+//   backward: dP = dO v^T, THIS kernel per row with have_p: D = sum_j P_j dP_j, dS = P (dP - D) overwrites dP, the decomposed-bias gradient rows
+//   are reduced on the way; then dV = P^T dO, dQ = scale * dS k, dK = dS^T (q * scale).  No global atomics, sums in a fixed order.
+// S / dP [BH, Sq, Sk] (BH = batch * heads, b-major); bias_h [BH, Sq, Sk / kw], bias_w [BH, Sq, kw] or NULL; key_mask int32 [B, Sk] or NULL.
+__global__ __launch_bounds__(256) void attn_rows_bwd_kernel(float* __restrict__ S, float* __restrict__ dP, const float* __restrict__ bias_h,
+                                                            const float* __restrict__ bias_w, float* __restrict__ dbias_h, float* __restrict__ dbias_w,
+                                                            const int* __restrict__ key_mask, int H, int Sq, int Sk, int kw, int causal, int have_p) {
+    __shared__ float red[256];
+    __shared__ float dbs[256];
+    const int tid = threadIdx.x, qi = blockIdx.x;
+    const long bh = blockIdx.y, row = bh * Sq + qi;
+    const int b = (int)(bh / H);
+    float* s = S + row * Sk;
+    float* g = dP + row * Sk;
+    const int kh_n = bias_h ? Sk / kw : 0;
+    const float* bhp = bias_h ? bias_h + row * kh_n : nullptr;
+    const float* bwp = bias_h ? bias_w + row * kw : nullptr;
+    auto block_reduce = [&](float v, const bool is_max) -> float {
+        red[tid] = v;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) red[tid] = is_max ? fmaxf(red[tid], red[tid + st]) : red[tid] + red[tid + st];
+            __syncthreads();
+        }
+        const float r = red[0];
+        __syncthreads();
+        return r;
+    };
+    const float FMIN = -3.4028234663852886e38f;
+    float inv = 1.f;
+    if (!have_p) {   // S holds (q * scale) k^T: add bias and masks, softmax in place
+        float mx = -INFINITY;
+        for (int kt = tid; kt < Sk; kt += 256) {
+            float v = s[kt];
+            if (bhp) v += bhp[kt / kw] + bwp[kt % kw];
+            if (causal >= 0 && kt > qi + causal) v += FMIN;
+            if (key_mask && key_mask[(long)b * Sk + kt] == 0) v += FMIN;
+            s[kt] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = block_reduce(mx, true);
+        float sum = 0.f;
+        for (int kt = tid; kt < Sk; kt += 256) { const float e = mx == -INFINITY ? 0.f : expf(s[kt] - mx); s[kt] = e; sum += e; }
+        sum = block_reduce(sum, false);
+        inv = sum > 0.f ? 1.0f / sum : 0.f;
+    }
+    if (!dP) {   // forward use: P only
+        for (int kt = tid; kt < Sk; kt += 256) s[kt] *= inv;
+        return;
+    }
+    float ds = 0.f;
+    for (int kt = tid; kt < Sk; kt += 256) { const float pj = s[kt] * inv; s[kt] = pj; ds += pj * g[kt]; }
+    const float D = block_reduce(ds, false);
+    if (bhp) dbs[tid] = 0.f;
+    __syncthreads();
+    for (int kt = tid; kt < Sk; kt += 256) {
+        const float dl = s[kt] * (g[kt] - D);
+        g[kt] = dl;
+        if (bhp) { atomicAdd(dbs + kt / kw, dl); atomicAdd(dbs + 128 + kt % kw, dl); }   // LDS, this row only
+    }
+    if (bhp) {
+        __syncthreads();
+        if (tid < kh_n) dbias_h[row * kh_n + tid] = dbs[tid];
+        if (tid < kw) dbias_w[row * kw + tid] = dbs[128 + tid];
+    }
+}
+extern "C" int ullsam_train_attn_rows(float* S, float* dP, const float* bias_h, const float* bias_w, float* dbias_h, float* dbias_w,
+                                      const int* key_mask, int B, int H, int Sq, int Sk, int kw, int causal, int have_p, void* stream) {
+    ULLSAM_CHECK(B > 0 && H > 0 && (long)B * H < 65536 && Sq > 0 && Sk > 0, "train_attn_rows: bad dims");
+    ULLSAM_CHECK(!bias_h || (bias_w && (!dP || (dbias_h && dbias_w)) && kw > 0 && kw <= 128 && Sk % kw == 0 && Sk / kw <= 128), "train_attn_rows: bias needs Sk = kh * kw, kh, kw <= 128");
+    attn_rows_bwd_kernel<<<dim3(Sq, B * H), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(S, dP, bias_h, bias_w, dbias_h, dbias_w, key_mask, H, Sq, Sk, kw, causal, have_p);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- RMSNorm backward (modeling_internlm2.py:75-89): y = x * rsqrt(mean(x^2) + eps) * w; one wave per row; dw (optional) by atomics ------
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
                                                           float* __restrict__ dx, float* __restrict__ dw, long rows, int D, float eps) {

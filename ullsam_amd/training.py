@@ -66,6 +66,7 @@ def _t2d(x: torch.Tensor) -> torch.Tensor:
     return ops.transpose(x.reshape(1, R, C), 1, R, C).reshape(C, R)
 
 
+MATRIX_ATTN_FROM = 1 << 12   # attention through materialised score matrices from Sq * Sk >= this (below: one workgroup per query, backward by atomics)
 MFMA_LINEAR = True   # nn.Linear forward / backward on the fp32 MFMA GEMM of the inference path where its shapes allow (inner dimension % 32 == 0);
 #                     the one-output-per-thread matmul of csrc/train.hip otherwise (and always with MFMA_LINEAR = False: tests compare the two)
 
@@ -230,10 +231,45 @@ class AttentionFn(Function):
         if bias_h is not None:
             bias_h, bias_w = _c(bias_h), _c(bias_w)
         hd = q.shape[-1] // H
-        out = torch.empty_like(q)
-        ctx.save_for_backward(q, k, v, key_mask, bias_h, bias_w)
         ctx.dims = (B, H, KVH, hd, Sq, Sk, causal, kw)
-        AttentionFn._launch(q, k, v, None, out, None, None, None, ctx.dims, key_mask, bias_h, bias_w, None, None)
+        if Sq * Sk < MATRIX_ATTN_FROM:       # small: one workgroup per query; the backward recomputes P and adds dk / dv by atomics
+            out = torch.empty_like(q)
+            ctx.save_for_backward(q, k, v, key_mask, bias_h, bias_w)
+            ctx.matrix = False
+            AttentionFn._launch(q, k, v, None, out, None, None, None, ctx.dims, key_mask, bias_h, bias_w, None, None)
+            return out
+        # Matrix form (csrc/train.hip attn_rows_kernel): head-major copies, batched matmuls around one row pass; P is kept for the backward.
+        qs, kh, vh = AttentionFn._head_major(q, k, v, ctx.dims)
+        BH = B * H
+        P = torch.empty((BH, Sq, Sk), dtype=F32, device=q.device)
+        _mm(qs, kh, P, Sq, Sk, hd, (Sq * hd, hd, 1), (Sk * hd, 1, hd), (Sq * Sk, Sk, 1), batch=BH)          # S = (q scale) k^T
+        _lib.call("ullsam_train_attn_rows", P.data_ptr(), None, ops._p(bias_h), ops._p(bias_w), None, None, ops._p(key_mask), B, H, Sq, Sk, kw,
+                  causal, 0, _s())                                                                           # S <- P = softmax(S + bias + masks)
+        oh = torch.empty_like(qs)
+        _mm(P, vh, oh, Sq, hd, Sk, (Sq * Sk, Sk, 1), (Sk * hd, hd, 1), (Sq * hd, hd, 1), batch=BH)          # out = P v
+        ctx.save_for_backward(qs, kh, vh, P, bias_h, bias_w)
+        ctx.matrix = True
+        return oh.permute(0, 2, 1, 3).reshape(B * Sq, H * hd).contiguous()
+
+    @staticmethod
+    def _head_major(q, k, v, dims):
+        """[B*S, Hx*hd] rows -> [B, H, S, hd] copies (data movement); q comes back scaled by 1/sqrt(hd) (a HIP kernel), k / v repeated over
+        the KV group (repeat_kv, modeling_internlm2.py:250-259)."""
+        B, H, KVH, hd, Sq, Sk, _, _ = dims
+        G = H // KVH
+        hm = lambda t, S_, Hx: t.reshape(B, S_, Hx, hd).permute(0, 2, 1, 3).contiguous()
+        qh, kh, vh = hm(q, Sq, H), hm(k, Sk, KVH), hm(v, Sk, KVH)
+        if G > 1:
+            kh = kh.unsqueeze(2).expand(B, KVH, G, Sk, hd).reshape(B, H, Sk, hd).contiguous()
+            vh = vh.unsqueeze(2).expand(B, KVH, G, Sk, hd).reshape(B, H, Sk, hd).contiguous()
+        return AttentionFn._scaled(qh, 1.0 / math.sqrt(hd)), kh, vh
+
+    @staticmethod
+    def _scaled(t, factor):
+        sc = torch.full((1,), factor, dtype=F32, device=t.device)
+        zero = torch.zeros((1,), dtype=F32, device=t.device)
+        out = torch.empty_like(t)
+        _lib.call("ullsam_train_scale_shift", t.data_ptr(), sc.data_ptr(), zero.data_ptr(), None, out.data_ptr(), None, None, t.numel(), _s())
         return out
 
     @staticmethod
@@ -246,12 +282,35 @@ class AttentionFn(Function):
 
     @staticmethod
     def backward(ctx, dout):
-        q, k, v, key_mask, bias_h, bias_w = ctx.saved_tensors
-        dq, dk, dv = torch.empty_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        B, H, KVH, hd, Sq, Sk, causal, kw = ctx.dims
+        dout = _c(dout)
+        nones = (None,) * 7
+        if not ctx.matrix:
+            q, k, v, key_mask, bias_h, bias_w = ctx.saved_tensors
+            dbh = torch.empty_like(bias_h) if bias_h is not None else None
+            dbw = torch.empty_like(bias_w) if bias_w is not None else None
+            dq, dk, dv = torch.empty_like(q), torch.zeros_like(k), torch.zeros_like(v)
+            AttentionFn._launch(q, k, v, dout, None, dq, dk, dv, ctx.dims, key_mask, bias_h, bias_w, dbh, dbw)
+            return (dq, dk, dv) + nones + (dbh, dbw, None)
+        qs, kh, vh, P, bias_h, bias_w = ctx.saved_tensors
         dbh = torch.empty_like(bias_h) if bias_h is not None else None
         dbw = torch.empty_like(bias_w) if bias_w is not None else None
-        AttentionFn._launch(q, k, v, _c(dout), None, dq, dk, dv, ctx.dims, key_mask, bias_h, bias_w, dbh, dbw)
-        return dq, dk, dv, None, None, None, None, None, None, None, dbh, dbw, None
+        G, BH = H // KVH, B * H
+        doh = dout.reshape(B, Sq, H, hd).permute(0, 2, 1, 3).contiguous()
+        dP = torch.empty_like(P)
+        _mm(doh, vh, dP, Sq, Sk, hd, (Sq * hd, hd, 1), (Sk * hd, 1, hd), (Sq * Sk, Sk, 1), batch=BH)        # dP = dO v^T
+        _lib.call("ullsam_train_attn_rows", P.data_ptr(), dP.data_ptr(), ops._p(bias_h), ops._p(bias_w), ops._p(dbh), ops._p(dbw), None, B, H,
+                  Sq, Sk, kw, causal, 1, _s())                                                               # dP <- dS = P (dP - sum_j P_j dP_j)
+        dvh, dkh, dqs = torch.empty_like(kh), torch.empty_like(kh), torch.empty_like(qs)
+        _mm(P, doh, dvh, Sk, hd, Sq, (Sq * Sk, 1, Sk), (Sq * hd, hd, 1), (Sk * hd, hd, 1), batch=BH)        # dV = P^T dO
+        _mm(dP, qs, dkh, Sk, hd, Sq, (Sq * Sk, 1, Sk), (Sq * hd, hd, 1), (Sk * hd, hd, 1), batch=BH)        # dK = dS^T (q scale)
+        _mm(dP, kh, dqs, Sq, hd, Sk, (Sq * Sk, Sk, 1), (Sk * hd, hd, 1), (Sq * hd, hd, 1), batch=BH)        # d(q scale) = dS k
+        dqh = AttentionFn._scaled(dqs, 1.0 / math.sqrt(hd))
+        if G > 1:                                                                                   # the gradient of repeat_kv: sum over the group
+            red = lambda t: _colsum(t.reshape(B, KVH, G, Sk * hd).permute(2, 0, 1, 3).reshape(G, -1).contiguous()).reshape(B, KVH, Sk, hd)
+            dkh, dvh = red(dkh), red(dvh)
+        back = lambda t, S_, Hx: t.permute(0, 2, 1, 3).reshape(B * S_, Hx * hd).contiguous()
+        return (back(dqh, Sq, H), back(dkh, Sk, KVH), back(dvh, Sk, KVH)) + nones + (dbh, dbw, None)
 
 
 class GatherRowsFn(Function):
