@@ -250,3 +250,41 @@ def test_segmentation_loss_gradient_by_central_differences_on_another_prompt_sha
             flat[i] = old
         num = (lp - lm_) / (2 * eps)
         assert abs(num - ana) < 5e-2 * abs(ana) + 4e-4, (tuple(p.shape), i, ana, num)   # fp32 loss: ~2e-7 of rounding over a 4e-3 step = 1e-4 on the quotient
+
+
+def test_train_step_module_under_ddp_world_1():
+    """TrainStep wrapped in DistributedDataParallel (RCCL, world size 1: what one box offers): the hooks fire, the gradients equal the plain step's."""
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    from ullsam_amd.training import TrainStep, train_step_loss
+    g = U.gold("train_step")
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    x = t(U.rand_image((1, 3, 1024, 1024), seed=int(g["seed"])))
+    ids = t(g["ids"]).long()
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
+    gt = t(np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None])
+    m = _ullsam_tiny(torch.float32)
+    for n, p in m.named_parameters():
+        p.requires_grad_(not n.startswith("language_model."))
+    loss, _, _ = train_step_loss(m, x, ids, torch.ones_like(ids), (t(g["pts"]), t(g["lbl"])), gt)
+    loss.backward()
+    ref = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    for p in m.parameters():
+        p.grad = None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29581")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        step = DistributedDataParallel(TrainStep(m), device_ids=[0], find_unused_parameters=True)
+        loss2, _, _ = step(x, ids, torch.ones_like(ids), t(g["pts"]), t(g["lbl"]), gt)
+        loss2.backward()
+        torch.cuda.synchronize()
+    finally:
+        if own:
+            dist.destroy_process_group()
+    assert abs(float(loss2.detach()) - float(loss.detach())) < 1e-5 * abs(float(loss.detach()))
+    for n, r in ref.items():
+        got = dict(m.named_parameters())[n].grad
+        assert got is not None and float((got - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-7, n

@@ -772,3 +772,22 @@ def train_step_loss(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, 
     rows = vision_feature_rows(model.vision_model, pixel_values)
     hidden = llm_image_hidden(model, rows.detach(), input_ids, attention_mask)
     return segmentation_loss(model, hidden, None, points, gt_masks, image_rows=rows)
+
+
+class TrainStep(torch.nn.Module):
+    """`train_step_loss` as a module, so that the trainer's `DistributedDataParallel(model, ...)` wrapping (train_joint_v2.py:1690-1700) keeps
+    working: DDP hooks the parameters of `self.model` and all-reduces their gradients over RCCL while `backward()` runs; one process per GPU,
+    one image per process and step, as the reference launches it (scripts/train_all_joint_v2.sh: torchrun --nproc_per_node).
+
+        step = DistributedDataParallel(TrainStep(model), device_ids=[local_rank], find_unused_parameters=True)
+        loss, bce, dice = step(pixel_values, input_ids, attention_mask, points, point_labels, masks);  loss.backward();  optimizer.step()
+
+    (`find_unused_parameters=True`: the IoU head, the mask-input convolutions and the box-corner embeddings take no part in this loss, as in the
+    reference's own step.)"""
+
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+    def forward(self, pixel_values, input_ids, attention_mask, points, point_labels, gt_masks):
+        return train_step_loss(self.model, pixel_values, input_ids, attention_mask, (points, point_labels), gt_masks)
