@@ -219,70 +219,49 @@ __global__ __launch_bounds__(256) void attn_train_kernel(AttnTrainArgs p) {
     for (int kt = tid; kt < p.Sk; kt += 256) { const float e = mx == -INFINITY ? 0.f : expf(sc[kt] - mx); sc[kt] = e; sum += e; }
     sum = block_reduce(sum, false);
     const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    // P in place
+    for (int kt = tid; kt < p.Sk; kt += 256) sc[kt] *= inv;
+    __syncthreads();
     if constexpr (!BWD) {
-        // out[d] = sum_j P_j v_j[d]: per-thread partial rows, then LDS atomics
-        float ol[MAXHD];
-#pragma unroll
-        for (int d = 0; d < MAXHD; ++d) ol[d] = 0.f;
-        for (int kt = tid; kt < p.Sk; kt += 256) {
-            const float pj = sc[kt] * inv;
-            if (pj == 0.f) continue;
-            const float* vp = vb + (long)kt * p.v_ts;
-#pragma unroll
-            for (int d = 0; d < MAXHD; ++d) { if (d >= hd) break; ol[d] += pj * vp[d]; }
+        // out[d] = sum_j P_j v_j[d]: thread d walks the keys (this kernel serves the small problems; the large ones go through matrices)
+        if (tid < hd) {
+            float o = 0.f;
+            for (int kt = 0; kt < p.Sk; ++kt) o += sc[kt] * vb[(long)kt * p.v_ts + tid];
+            p.out[(long)b * p.o_bs + (long)qi * p.o_ts + (long)head * p.o_hs + tid] = o;
         }
-#pragma unroll
-        for (int d = 0; d < MAXHD; ++d) {
-            if (d >= hd) break;
-            const float t = wave_sum(ol[d]);
-            if ((tid & 63) == 0) atomicAdd(gs + d, t);
-        }
-        __syncthreads();
-        if (tid < hd) p.out[(long)b * p.o_bs + (long)qi * p.o_ts + (long)head * p.o_hs + tid] = gs[tid];
         return;
     } else {
+        float* dsl = sc + ((p.Sk + 3) & ~3) + 3 * MAXHD + 256 + 256;    // [Sk] dlogit * scale, behind the other LDS arrays
         // dP_j = dO . v_j;  D = sum_j P_j dP_j
         float dsum = 0.f;
         for (int kt = tid; kt < p.Sk; kt += 256) {
-            const float pj = sc[kt] * inv;
-            if (pj == 0.f) continue;
             const float* vp = vb + (long)kt * p.v_ts;
             float dp = 0.f;
             for (int d = 0; d < hd; ++d) dp += gs[d] * vp[d];
-            dsum += pj * dp;
+            dsl[kt] = dp;
+            dsum += sc[kt] * dp;
         }
         const float D = block_reduce(dsum, false);
-        float dql[MAXHD];
-#pragma unroll
-        for (int d = 0; d < MAXHD; ++d) dql[d] = 0.f;
         float* dkb = p.dk + (long)b * p.k_bs + (long)kvh * p.k_hs;
         float* dvb = p.dv + (long)b * p.v_bs + (long)kvh * p.v_hs;
         for (int kt = tid; kt < p.Sk; kt += 256) {
-            const float pj = sc[kt] * inv;
-            if (pj == 0.f) continue;
-            const float* kp = kb + (long)kt * p.k_ts;
-            const float* vp = vb + (long)kt * p.v_ts;
-            float dp = 0.f;
-            for (int d = 0; d < hd; ++d) dp += gs[d] * vp[d];
-            const float dlogit = pj * (dp - D);
-            if (bh) { atomicAdd(dbs + kt / p.kw, dlogit); atomicAdd(dbs + 128 + kt % p.kw, dlogit); }
+            const float pj = sc[kt];
+            const float dlogit = pj * (dsl[kt] - D);
             const float dsj = dlogit * p.scale;            // d loss / d (q . k_j)
-#pragma unroll
-            for (int d = 0; d < MAXHD; ++d) {
-                if (d >= hd) break;
-                dql[d] += dsj * kp[d];
+            dsl[kt] = dsj;
+            if (pj == 0.f) continue;
+            if (bh) { atomicAdd(dbs + kt / p.kw, dlogit); atomicAdd(dbs + 128 + kt % p.kw, dlogit); }
+            for (int d = 0; d < hd; ++d) {
                 atomicAdd(dkb + (long)kt * p.k_ts + d, dsj * qs[d]);
                 atomicAdd(dvb + (long)kt * p.v_ts + d, pj * gs[d]);
             }
         }
-#pragma unroll
-        for (int d = 0; d < MAXHD; ++d) {
-            if (d >= hd) break;
-            const float t = wave_sum(dql[d]);
-            if ((tid & 63) == 0) atomicAdd(dqs + d, t);
-        }
         __syncthreads();
-        if (tid < hd) p.dq[(long)b * p.q_bs + (long)qi * p.q_ts + (long)head * p.q_hs + tid] = dqs[tid];
+        if (tid < hd) {                                    // dq[d] = sum_j dS_j k_j[d]
+            float a = 0.f;
+            for (int kt = 0; kt < p.Sk; ++kt) a += dsl[kt] * kb[(long)kt * p.k_ts + tid];
+            p.dq[(long)b * p.q_bs + (long)qi * p.q_ts + (long)head * p.q_hs + tid] = a;
+        }
         if (bh) {
             if (tid < kh_n) p.dbias_h[(((long)b * p.H + head) * p.Sq + qi) * kh_n + tid] = dbs[tid];
             if (tid < p.kw) p.dbias_w[(((long)b * p.H + head) * p.Sq + qi) * p.kw + tid] = dbs[128 + tid];
@@ -296,11 +275,11 @@ extern "C" int ullsam_train_attention(const float* q, const float* k, const floa
                                       float* dbias_w, int kw, void* stream) {
     ULLSAM_CHECK(!bias_h || (bias_w && kw > 0 && kw <= 128 && Sk % kw == 0 && Sk / kw <= 128 && (!dout || (dbias_h && dbias_w))),
                  "train_attention: decomposed bias needs Sk = kh * kw with kh, kw <= 128 (Sk=%d kw=%d)", Sk, kw);
-    ULLSAM_CHECK(hd > 0 && hd <= 128 && Sk > 0 && Sk <= 30000 && Sq > 0 && B > 0 && B < 65536 && H > 0 && H < 65536 && groups > 0 && H % groups == 0,
+    ULLSAM_CHECK(hd > 0 && hd <= 128 && Sk > 0 && Sk <= 16000 && Sq > 0 && B > 0 && B < 65536 && H > 0 && H < 65536 && groups > 0 && H % groups == 0,
                  "train_attention: hd=%d Sq=%d Sk=%d H=%d groups=%d", hd, Sq, Sk, H, groups);
     ULLSAM_CHECK((dout != nullptr) == (dq != nullptr) && (dout != nullptr || out != nullptr), "train_attention: forward needs out, backward needs dout / dq / dk / dv");
     AttnTrainArgs a{q, k, v, dout, out, dq, dk, dv, q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs, H, groups, Sq, Sk, hd, causal, key_mask, scale, bias_h, bias_w, dbias_h, dbias_w, kw};
-    const size_t lds = (size_t)(((Sk + 3) & ~3) + 128 * 3 + 256 + 256) * 4;
+    const size_t lds = (size_t)(2 * ((Sk + 3) & ~3) + 128 * 3 + 256 + 256) * 4;
     static PerDeviceOnce attr;
     if (attr.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_train_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
