@@ -7,7 +7,8 @@
 #include "common.h"
 
 // ---- C[b](m, n) = (accumulate ? C : 0) + sum_k A[b](m, k) * B[b](k, n), every operand with explicit element strides -----------------
-// One kernel covers dX = dY W (B = W as stored), dW = dY^T X (A read transposed), the hypernetwork product and its two gradients.
+// One kernel covers dX = dY W (B = W as stored), dW = dY^T X (A read transposed), the hypernetwork product and its two gradients, the
+// attention score / probability products of the matrix-form attention and the rel-pos einsums.
 struct MmArgs {
     const float* A; const float* B; float* C;
     int M, N, K, batch;
@@ -15,30 +16,57 @@ struct MmArgs {
     int accumulate;
 };
 __global__ __launch_bounds__(256) void matmul_f32_kernel(MmArgs p) {
-    __shared__ float As[16][17], Bs[16][17];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx, b = blockIdx.z;
+    // 64 x 64 outputs per workgroup, 4 x 4 per thread, K in steps of 16 through LDS.  The element -> thread assignment of the two tile loads
+    // follows the operand's unit stride (k-fastest for a row-major operand, m- / n-fastest for a transposed one), so both are coalesced.
+    __shared__ float As[16][65], Bs[16][65];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, b = blockIdx.z;
     const float* A = p.A + (long)b * p.a_b;
     const float* B = p.B + (long)b * p.b_b;
-    float acc = 0.f;
+    const bool a_kfast = p.a_k <= p.a_m, b_nfast = p.b_n <= p.b_k;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
     for (int k0 = 0; k0 < p.K; k0 += 16) {
-        As[ty][tx] = (m < p.M && k0 + tx < p.K) ? A[(long)m * p.a_m + (long)(k0 + tx) * p.a_k] : 0.f;
-        Bs[ty][tx] = (k0 + ty < p.K && n < p.N) ? B[(long)(k0 + ty) * p.b_k + (long)n * p.b_n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int am = a_kfast ? idx >> 4 : idx & 63, ak = a_kfast ? idx & 15 : idx >> 6;
+            As[ak][am] = (m0 + am < p.M && k0 + ak < p.K) ? A[(long)(m0 + am) * p.a_m + (long)(k0 + ak) * p.a_k] : 0.f;
+            const int bn = b_nfast ? idx & 63 : idx >> 4, bk = b_nfast ? idx >> 6 : idx & 15;
+            Bs[bk][bn] = (k0 + bk < p.K && n0 + bn < p.N) ? B[(long)(k0 + bk) * p.b_k + (long)(n0 + bn) * p.b_n] : 0.f;
+        }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) acc += As[ty][kk] * Bs[kk][tx];
+        for (int kk = 0; kk < 16; ++kk) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { av[i] = As[kk][ty * 4 + i]; bv[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+        }
         __syncthreads();
     }
-    if (m < p.M && n < p.N) {
-        float* c = p.C + (long)b * p.c_b + (long)m * p.c_m + (long)n * p.c_n;
-        *c = p.accumulate ? *c + acc : acc;
-    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+            if (m < p.M && n < p.N) {
+                float* c = p.C + (long)b * p.c_b + (long)m * p.c_m + (long)n * p.c_n;
+                *c = p.accumulate ? *c + acc[i][j] : acc[i][j];
+            }
+        }
 }
 extern "C" int ullsam_train_matmul(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k,
                                    long b_b, long b_k, long b_n, long c_b, long c_m, long c_n, int accumulate, void* stream) {
     ULLSAM_CHECK(M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "train_matmul: M=%d N=%d K=%d batch=%d", M, N, K, batch);
     MmArgs a{A, B, C, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n, accumulate};
-    matmul_f32_kernel<<<dim3((N + 15) / 16, (M + 15) / 16, batch), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
+    matmul_f32_kernel<<<dim3((N + 63) / 64, (M + 63) / 64, batch), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
