@@ -288,3 +288,38 @@ def test_train_step_module_under_ddp_world_1():
     for n, r in ref.items():
         got = dict(m.named_parameters())[n].grad
         assert got is not None and float((got - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-7, n
+
+
+def test_bf16_model_runs_the_frozen_llm_on_bf16_gemms():
+    """A bf16 model's frozen LLM linears (wqkv, wo, w1, w3, w2) run on the bf16 MFMA GEMM, forward and dX -- the trainer's autocast semantics:
+    activations rounded to bf16 at each GEMM, fp32 accumulation.  Against the same rounded weights held in fp32 (the fp32-arithmetic step): the
+    hidden states and the gradients that pass through the LLM (mlp1, d loss / d vision features) agree to bf16-activation noise."""
+    from ullsam_amd import ops
+    from ullsam_amd.training import llm_image_hidden, segmentation_loss
+    g = U.gold("train_llm_slice")
+    rng = np.random.default_rng(int(g["seed"]))
+    feat = rng.standard_normal((1, 256, 64, 64), dtype=np.float32)
+    img = rng.standard_normal((1, 256, 64, 64), dtype=np.float32)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    ids = t(g["ids"]).long()
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
+    gt = t(np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None])
+    res = []
+    for widen in (False, True):
+        m = _ullsam_tiny(torch.bfloat16)
+        if widen:
+            m = m.float()
+        for n, p in m.named_parameters():
+            p.requires_grad_(n.startswith("mlp1."))
+        rows = ops.transpose(t(feat).reshape(1, 256, 4096), 1, 256, 4096).requires_grad_(True)
+        hidden = llm_image_hidden(m, rows, ids, torch.ones_like(ids))
+        loss, _, _ = segmentation_loss(m, hidden, t(img), (t(g["pts"]), t(g["lbl"])), gt)
+        loss.backward()
+        res.append((hidden.detach().float(), float(loss.detach()), rows.grad.float(), {n: p.grad.float() for n, p in m.named_parameters() if p.grad is not None}))
+    (h16, l16, r16, g16), (h32, l32, r32, g32) = res
+    rel = lambda a, b: float((a - b).abs().max()) / float(b.abs().max())
+    assert float((h16 - h32).abs().max()) > 0, "the bf16 model must not have taken the fp32 GEMM path"
+    assert rel(h16, h32) < 3e-2 and abs(l16 - l32) < 2e-3 * abs(l32), (rel(h16, h32), l16, l32)
+    assert rel(r16, r32) < 6e-2, rel(r16, r32)
+    for n in g32:
+        assert rel(g16[n], g32[n]) < 6e-2, (n, rel(g16[n], g32[n]))

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_train_gpu.py -x -q -m gpu 2>&1 < /dev/null | grep -E "passed|failed|Error" | tail -3
-timeout 900 python tools/train_step_bench.py b 2b 2 2>&1 < /dev/null | tail -1
-timeout 900 python tools/train_step_bench.py h 7b 2 2>&1 < /dev/null | tail -1
+timeout 900 python tools/train_step_bench.py h 7b 2 bf16 2>&1 < /dev/null | tail -1
+timeout 900 python tools/train_step_bench.py b 2b 2 bf16 2>&1 < /dev/null | tail -1

@@ -1,6 +1,6 @@
 """Wall time of one training step (ullsam_amd.training.train_step_loss + backward) at the shapes of the models the reference ships
 (SAM ViT-B + InternLM2-1.8B-shaped) or the bench's (ViT-H + 7B-shaped).  Correctness of the step is gated by tests/test_train_gpu.py; this
-only times it.   usage: python tools/train_step_bench.py [b|h] [2b|7b] [instances]"""
+only times it.   usage: python tools/train_step_bench.py [b|h] [2b|7b] [instances] [fp32|bf16]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,8 +12,9 @@ from ullsam_amd.utils.synthetic import microscopy_batch
 vit = sys.argv[1] if len(sys.argv) > 1 else "b"
 llm = sys.argv[2] if len(sys.argv) > 2 else "2b"
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+dt = torch.bfloat16 if (len(sys.argv) > 4 and sys.argv[4] == "bf16") else torch.float32
 dev = "cuda:0"
-m = bench.build_model(vit, llm, torch.float32, dev)
+m = bench.build_model(vit, llm, dt, dev)
 for n, p in m.named_parameters():
     p.requires_grad_(not n.startswith("language_model."))
 imgs, pts = microscopy_batch([3])
@@ -33,6 +34,7 @@ for it in range(3):
     torch.cuda.synchronize(); t2 = time.perf_counter()
     times.append((t1 - t0, t2 - t1))
 fw, bw = times[-1]
-print(json.dumps({"workload": f"train step, ViT-{vit.upper()} + InternLM2-{llm}-shaped (frozen) + decoder, fp32, {P} instances, S = {ids.shape[1]}",
+mode = 'bf16 model (frozen LLM on bf16 GEMMs, the rest fp32 arithmetic)' if dt == torch.bfloat16 else 'fp32'
+print(json.dumps({"workload": f"train step, ViT-{vit.upper()} + InternLM2-{llm}-shaped (frozen) + decoder, {mode}, {P} instances, S = {ids.shape[1]}",
                   "forward_s": round(fw, 3), "backward_s": round(bw, 3), "loss": round(float(loss.detach()), 4),
                   "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))

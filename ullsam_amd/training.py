@@ -115,6 +115,43 @@ class LinearFn(Function):
         return dx, dw, db
 
 
+_WT_CACHE = {}
+
+
+def _transposed_frozen(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] frozen weight -> its [K, N] copy, made once per weight version (the dX GEMM of a frozen bf16 Linear reads W^T row-major)."""
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    t = _WT_CACHE.get(key)
+    if t is None:
+        if len(_WT_CACHE) > 4096:
+            _WT_CACHE.clear()
+        t = _WT_CACHE[key] = w.detach().t().contiguous()
+    return t
+
+
+class FrozenLinearBf16Fn(Function):
+    """y = x W^T (+ b) for a FROZEN bf16 weight (the LLM of a bf16 model, train_joint_v2.py:1599,1676: autocast semantics): activations are
+    rounded to bf16 at the GEMM's door, the products run on the inference path's bf16 MFMA GEMM with fp32 accumulation and fp32 results,
+    forward (W as stored) and backward (dX = dY W, with the cached W^T); there is no weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = _c(x)
+        ctx.w = w
+        return ops.gemm(ops.cast(x, torch.bfloat16), w.detach(), None if b is None else _c(b), out_f32=True)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.gemm(ops.cast(_c(dy), torch.bfloat16), _transposed_frozen(ctx.w), out_f32=True), None, None
+
+
+def _frozen_linear(x, w, b):
+    """nn.Linear with a frozen weight inside llm_image_hidden: bf16 weights take the bf16 GEMM, fp32 weights the fp32 path."""
+    if w.dtype == torch.bfloat16 and not w.requires_grad and w.shape[1] % 64 == 0 and w.shape[0] % 64 == 0:
+        return FrozenLinearBf16Fn.apply(x, w, b)
+    return LinearFn.apply(x, w, b)
+
+
 class LayerNormFn(Function):
     """Row LayerNorm (nn.LayerNorm / LayerNorm2d on NHWC rows / F.layer_norm without affine)."""
 
@@ -689,15 +726,15 @@ def llm_image_hidden(model, vit_feature_rows: torch.Tensor, input_ids: torch.Ten
     for layer in lm.model.layers:
         at, ff = layer.attention, layer.feed_forward
         xn = RMSNormFn.apply(x, layer.attention_norm.weight, layer.attention_norm.variance_epsilon)
-        qkv = LinearFn.apply(xn, at.wqkv.weight, at.wqkv.bias).reshape(B * S, KVH, G + 2, hd)   # 'b q (h gs d) -> b q h gs d' (:361-366)
+        qkv = _frozen_linear(xn, at.wqkv.weight, at.wqkv.bias).reshape(B * S, KVH, G + 2, hd)   # 'b q (h gs d) -> b q h gs d' (:361-366)
         q = RoPEFn.apply(qkv[:, :, :G].reshape(B * S, H * hd), pos, cos, sin, H)
         k = RoPEFn.apply(qkv[:, :, G].reshape(B * S, KVH * hd), pos, cos, sin, KVH)
         v = qkv[:, :, G + 1].reshape(B * S, KVH * hd)
         a = AttentionFn.apply(q, k, v, B, H, KVH, S, S, 0, key_mask, None, None, 0)
-        x = AddFn.apply(x, LinearFn.apply(a, at.wo.weight, at.wo.bias))
+        x = AddFn.apply(x, _frozen_linear(a, at.wo.weight, at.wo.bias))
         xn = RMSNormFn.apply(x, layer.ffn_norm.weight, layer.ffn_norm.variance_epsilon)
-        hmid = SwiGLUFn.apply(LinearFn.apply(xn, ff.w1.weight, None), LinearFn.apply(xn, ff.w3.weight, None))
-        x = AddFn.apply(x, LinearFn.apply(hmid, ff.w2.weight, None))
+        hmid = SwiGLUFn.apply(_frozen_linear(xn, ff.w1.weight, None), _frozen_linear(xn, ff.w3.weight, None))
+        x = AddFn.apply(x, _frozen_linear(hmid, ff.w2.weight, None))
     x = RMSNormFn.apply(x, lm.model.norm.weight, lm.model.norm.variance_epsilon).reshape(B, S, D)
     idx = sel.reshape(B, S).nonzero(as_tuple=True)[1]
     start, end = int(idx.min()), int(idx.max()) + 1                              # one span for the batch, as the reference takes it (:198-201)
