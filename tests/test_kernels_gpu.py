@@ -678,6 +678,11 @@ def test_decode_gemm_with_rmsnorm_prologue_equals_norm_then_gemm(ops, M, K):
     a = ops.gemm_rmsnorm(x, nw, 1e-5, wn)
     b = ops.gemm(xn, wn)
     assert torch.equal(a, b)
+    if K == 4096:   # a wide plain matrix (N > 8192): the resident-workgroup kernel's general epilogue behind the norm prologue
+        wb = T(rng.standard_normal((17412, K), dtype=np.float32) / math.sqrt(K), torch.bfloat16)
+        a = ops.gemm_rmsnorm(x, nw, 1e-5, wb)
+        ref2 = xn.float().cpu().numpy() @ wb.float().cpu().numpy().T
+        assert err(a.float().cpu().numpy(), ref2) < 3e-2
 
 
 @pytest.mark.parametrize("B,KVH,G,past", [(4, 8, 4, 1081), (1, 2, 4, 0), (3, 4, 2, 17)])
