@@ -150,7 +150,9 @@ def make_inputs(B, S, device, full: bool):
 
 def mask_path_compute(model, inputs, dtype):
     """One pass of the hot path over the batch (app.py:580-645's call sequence; prompt encoder / mask decoder / upsample run once
-    over the B images -- one image per prompt) -> (low-res logits, thresholded masks)."""
+    over the B images -- one image per prompt) -> (low-res logits, thresholded masks).  One HIP stream: cutting the batch into shards on
+    2 / 4 streams was measured again in round 4 (tools/probes/streams_ab.py, same process) at 91.0 / 105.3 ms per step against 77.6 --
+    the tile shapes are chosen so that the whole batch fills whole rounds of the 256 CUs, and half batches do not."""
     from ullsam_amd import ops
     x32, pts, lbl, ids = inputs
     B = x32.shape[0]

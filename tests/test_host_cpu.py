@@ -460,3 +460,104 @@ def test_bench_init_rule_is_the_fixture_filler_rule():
     assert 0.2 < float((a[0, 0] > 0.45).mean()) < 0.7
     x, y = int(pa[0, 0, 0]), int(pa[0, 0, 1])
     assert a[0, 0, y, x] > 0.45
+
+
+def test_hot_kernels_compile_without_spills():
+    """The kernels the bench step and the decode step spend their time in must compile with no spilled registers and no scratch: a spilled
+    pointer behind an LDS-DMA request waits for the DMA, and spills inside a counted-wait loop serialise it.  Read from
+    the code objects of the SHIPPED library (tools/kernel_resources.py), so a compiler or source change that starts spilling fails here."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as KR
+    ks = KR.kernels()
+    assert len(ks) > 100, len(ks)
+    hot = {n: r for n, r in ks.items() if any(re.search(h, n) for h in KR.HOT_BF16)}
+    assert len(hot) >= 12, sorted(hot)
+    for must in ("gemm_ring8_kernel", "causal128_attn_kernel", "win14_attn_kernel", "gemm_skinny", "norm_block_kernel"):
+        assert any(must in n for n in hot), must
+    bad = {n: (r.get("vgpr_spill_count", 0), r.get("private_segment_fixed_size", 0)) for n, r in hot.items()
+           if r.get("vgpr_spill_count", 0) or r.get("sgpr_spill_count", 0) or r.get("private_segment_fixed_size", 0)}
+    assert not bad, bad
+    assert all(r.get("vgpr_count", 0) <= 512 for r in ks.values())
+
+
+def test_transposed_weight_cache_follows_the_weight():
+    """training._TransposeCache (the W^T copies of frozen bf16 linears): keyed on the parameter object, so a freed-and-rebuilt model at the
+    same addresses cannot meet a stale copy; in-place updates of the parameter are seen through its version counter; bounded in bytes."""
+    import gc
+    from ullsam_amd import training as T
+    c = T._TransposeCache(max_bytes=4 * 8 * 4 + 16 * 16 * 4)
+    w = torch.nn.Parameter(torch.randn(4, 8))
+    t = c.get(w)
+    assert t.shape == (8, 4) and torch.equal(t, w.detach().t()) and c.get(w) is t
+    with torch.no_grad():
+        w.mul_(2.0)                                   # an optimizer step / load_state_dict: version bump
+    t2 = c.get(w)
+    assert t2 is not t and torch.equal(t2, w.detach().t())
+    addr = w.data_ptr()
+    del w, t, t2
+    gc.collect()
+    assert len(c) == 0 and c.bytes >= 0               # the entry died with its weight
+    w_new = torch.nn.Parameter(torch.randn(4, 8))     # may or may not reuse `addr`: either way nothing stale can be returned
+    assert torch.equal(c.get(w_new), w_new.detach().t()), addr
+    big = torch.nn.Parameter(torch.randn(16, 16))
+    c.get(big)
+    assert c.bytes <= c.max_bytes
+    big2 = torch.nn.Parameter(torch.randn(16, 16))
+    c.get(big2)                                       # over budget: the cache is dropped, then refilled
+    assert c.bytes <= c.max_bytes and len(c) == 1
+    T.invalidate_transposed_weights()
+    assert len(T._WT_CACHE) == 0
+
+
+def _gloo_uneven_worker(rank, world, port, q):
+    """bench.py's make_step / timed_steps under gloo with UNEQUAL per-rank step times: rank 1 sleeps in every step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import time
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        batch, calls = 2, [0]
+        base = bench.stub_compute(batch, rank)
+
+        def compute():
+            calls[0] += 1
+            if rank == 1:
+                time.sleep(0.05)
+            low, mk = base()
+            return low + float(calls[0]), mk          # every step's payload is different: the LAST gather must carry the last step's values
+
+        step = bench.make_step(compute, batch, world)
+        t0 = time.perf_counter()
+        dt, gathered = bench.timed_steps(step, warmup=2, steps=6, world=world, device="cpu")
+        wall = time.perf_counter() - t0
+        ok = gathered is not None and gathered[0].shape[0] == batch * world and calls[0] == 8
+        # rows of rank r carry rank r's stub image + the step counter of the LAST step (8): nothing dropped, nothing from an earlier step
+        for r in range(world):
+            want = bench.stub_compute(batch, r)()[0] + 8.0
+            ok = ok and torch.equal(gathered[0][r * batch:(r + 1) * batch], want)
+        ok = ok and step.drain() is None              # nothing left in flight
+        q.put((rank, bool(ok), dt, wall))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_overlapped_gather_with_unequal_step_times():
+    """One rank is 50 ms per step slower than the other: the one-in-flight gather handle must neither deadlock nor drop the last exchange,
+    and the reported time is the MAX over ranks (both ranks report the slow rank's time)."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_uneven_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert [r[:2] for r in res] == [(0, True), (1, True)], res
+    dts = [r[2] for r in res]
+    assert abs(dts[0] - dts[1]) < 1e-9 and dts[0] >= 6 * 0.05      # the all-reduced MAX: >= the slow rank's six sleeps, identical on both ranks

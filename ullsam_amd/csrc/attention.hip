@@ -300,16 +300,16 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 1 : 2) void flash_attn_k
         __syncthreads();
     } else     if (REL) {
         const int NE = 2 * G - 1;  // rows per table (<= 127)
-        const T* tabs[2] = {reinterpret_cast<const T*>(p.rel_h), reinterpret_cast<const T*>(p.rel_w)};
 #pragma unroll 1
         for (int it = 0; it < 2; ++it) {
             const int tb = FAST64 ? 1 - it : it;  // FAST64: width table first (its slab is then recycled for rel_h)
+            const T* const tab = reinterpret_cast<const T*>(tb == 0 ? p.rel_h : p.rel_w);   // (a select, not an indexed pointer array: that array lived in scratch)
             __syncthreads();
             // stage table rows 0..127 into the contiguous K|V region (128 rows of RS bytes)
             for (int idx = tid; idx < 128 * CPR; idx += NT) {
                 const int row = idx / CPR, ch = idx - row * CPR;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (row < NE) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(tabs[tb] + (long)row * HD) + ch * 16);
+                if (row < NE) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(tab + (long)row * HD) + ch * 16);
                 *reinterpret_cast<uint4*>(Ks + row * RS + ch * 16) = v;
             }
             __syncthreads();

@@ -59,7 +59,7 @@ struct GemmArgs {
 };
 
 static int g_split_tail = 1;   // ullsam_set_gemm_variant(v | 64) disables the split-K tails (A/B)
-static int g_gemm_variant = 0; // bits 0-3 force a kernel: 0 auto, 1 128x128, 3 256x256 two-buffer, 6 256x256 ring, 8 256x320 ring, 9 272x256 ring
+static int g_gemm_variant = 0; // bits 0-3 force a kernel: 0 auto, 1 128x128, 3 256x256 two-buffer, 6 256x256 ring, 8 256x320 ring, 9 272x256 ring, 10 208x256 ring (RoPE GEMM only)
 static int g_dbg = 0;          // ullsam_set_gemm_variant bit 15: stamp the ring kernel (tools/probes/ring8_stamps.py reads the stamps from the workspace)
 static int g_auto_mask = 7;    // ullsam_set_gemm_tuning(1, mask): ring tile shapes the auto dispatch may pick: bit 0 256x256, bit 1 256x320, bit 2 272x256
 static int g_group_m = 4;      // ullsam_set_gemm_tuning(0, gm): raster group height (measured: 4 -> 83.26 ms per step, 8 -> 83.73, 2 -> 84.35)
@@ -722,7 +722,7 @@ static int launch_gemm_v3(GemmArgs a, hipStream_t stream) {
 // 1.25, vit.qkv 3 rounds of 1.25 x the work instead of 4; 272x256 <9,8,4> -- the bench's 4 x 1081 = 4324 prompt rows are 16 x 272: llm.wo / w2
 // one round of 256 tiles, llm.w13 7 whole rounds instead of 7.44.  The LDS-staged epilogue (odd shapes) uses up to 128 rows x 320 fp32 = 160 KiB.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MI0, int MI1, int NTW, bool STAMP = false>   // sub-tile rows of the upper / lower wave row, sub-tile columns per wave
+template <int MI0, int MI1, int NTW, bool STAMP = false, int EMODE = 0>   // sub-tile rows of the upper / lower wave row, sub-tile columns per wave; EMODE 1: wqkv + RoPE epilogue (act 4)
 __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned long long t_entry = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;   // (diagnostic build) the workgroup's first instruction
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     //   SwiGLU (NTW 4):  128 (wb >> 1) + 64 (j >> 1) + 32 (wb & 1) + 8 (r >> 2) + 4 (j & 1) + (r & 3)          fp32 out:  R
     static_assert(NTW == 4 || NTW == 5, "epilogue layouts below: four sub-tiles in two pairs, optionally a fifth on its own");
     constexpr int WW = 16 * NTW;
-    const int perm = p.out_f32 ? 0 : (p.act == 3 ? 2 : 1);
+    const int perm = EMODE == 1 ? 2 : p.out_f32 ? 0 : (p.act == 3 ? 2 : 1);   // (RoPE pairs column d with d + 64 of a head slot like SwiGLU pairs gate with up)
     auto w_row = [&](int R) {
         const int wb = R / WW, q = R - wb * WW, j = q >> 4, r = q & 15;
         if (perm == 1) return j < 4 ? WW * wb + 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3) : WW * wb + 64 + r;
@@ -811,21 +811,17 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     };
 
-    // this lane's 4 NTW output columns keep their bias in registers across the K loop (sub-tile t: fp32 4 at 16 t + 4 g4; bf16 4 at
-    // 32 (t >> 1) + 8 g4 + 4 (t & 1) for t < 4 and at 64 + 4 g4 for the fifth)
-    float bv[4 * NTW];
-#pragma unroll
-    for (int e = 0; e < 4 * NTW; ++e) bv[e] = 0.f;
-    if (p.bias && p.act != 3) {
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const int col = n0 + wn * WW + ((p.out_f32 || t == 4) ? 16 * t + 4 * g4 : 32 * (t >> 1) + 8 * g4 + 4 * (t & 1));
-            if (col < p.N) {
-                const float4 x = *reinterpret_cast<const float4*>(p.bias + col);
-                bv[4 * t] = x.x; bv[4 * t + 1] = x.y; bv[4 * t + 2] = x.z; bv[4 * t + 3] = x.w;
-            }
+    // Bias: the tile's BN bias values travel by LDS-DMA into the ring slot that a request for "stage st1" would have used, issued between the
+    // main loop and the peeled tail (whose waits are vmcnt(0)), and are read back after the loop.  (Rounds 1-3 held a lane's 4 NTW values in
+    // registers across the K loop: 16-20 VGPRs that made the 256x320 instantiation spill.)  Columns past N read the last aligned group.
+    const bool has_bias = p.bias && p.act != 3 && EMODE == 0;
+    char* const bias_lds = smem + (st1 & 3) * STG;
+    auto bias_dma = [&]() __attribute__((always_inline)) {
+        if (has_bias && wave < (BN * 4 + 1023) / 1024) {
+            const int c = min(n0 + wave * 256 + lane * 4, p.N - 4);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(p.bias + c), LDS_PTR(bias_lds + wave * 1024), 16, 0, 0);
         }
-    }
+    };
     // prologue: stages 0 and 1 requested, stage 0 landed
     stage(0);
     if (1 < st1) { stage(1); wait_one_left(); }
@@ -898,6 +894,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
         auto run = [&](auto NA_c, auto NB_c) __attribute__((always_inline)) {
             int s = 0;
             for (; s + 2 < st1; ++s) body(s, NA_c, NB_c, std::true_type{});
+            bias_dma();
             for (; s < st1; ++s) body(s, NA_c, NB_c, std::false_type{});
         };
         constexpr int NA_LO = PA / 8, NA_HI = (PA + 7) / 8, NB_LO = PB / 8, NB_HI = (PB + 7) / 8;
@@ -911,6 +908,18 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
     stamp(1);
+    // this lane's 4 NTW bias values (sub-tile t: fp32 4 at 16 t + 4 g4; bf16 4 at 32 (t >> 1) + 8 g4 + 4 (t & 1) for t < 4 and at 64 + 4 g4 for the fifth)
+    float bv[4 * NTW];
+#pragma unroll
+    for (int e = 0; e < 4 * NTW; ++e) bv[e] = 0.f;
+    if (has_bias) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int col = wn * WW + ((p.out_f32 || t == 4) ? 16 * t + 4 * g4 : 32 * (t >> 1) + 8 * g4 + 4 * (t & 1));
+            const float4 x = *reinterpret_cast<const float4*>(bias_lds + col * 4);
+            bv[4 * t] = x.x; bv[4 * t + 1] = x.y; bv[4 * t + 2] = x.z; bv[4 * t + 3] = x.w;
+        }
+    }
 
     // ---- epilogue.  acc[i][j][r] = C[m0 + row_w + 16 i + mm][n0 + ncol(j) + r]: straight from the accumulators where the layout allows
     {
@@ -919,7 +928,62 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
         const int rowp = row0 & ~1;   // after pair_swap the lane pair (mm, mm ^ 1) owns rows rowp + 16 i and rowp + 16 i + 1
         const bool direct = p.vec_ok && (p.N & 7) == 0 && (p.M & 1) == 0;
         auto gst = [&](void* ptr, u32x4 v) __attribute__((always_inline)) { *reinterpret_cast<u32x4*>(ptr) = v; };
-        if (direct && !p.out_f32 && p.act != 3) {
+        if constexpr (EMODE == 1) {
+            // wqkv + RoPE + KV-cache append (modeling_internlm2.py:359-388, 233-247), straight from the accumulators.  The tile's 256 columns are two
+            // 128-wide head slots; with the SwiGLU-style row permutation this lane holds, of output row row0 + 16 i, columns d .. d + 7 of a slot
+            // (sub-tiles 0 / 1) and their rotate_half partners d + 64 .. d + 71 (sub-tiles 2 / 3), d = 32 (wn & 1) + 8 g4 < 64.  cos / sin rows are
+            // cat(freqs, freqs) (:160-166): the values at d + 64 are those at d, so one 8-wide cos and sin segment per row serves both halves.
+            // The position ids of all rows are fetched first, the cos / sin segments one row ahead of their use.
+            const int slot = (n0 >> 7) + (wn >> 1), d = 32 * (wn & 1) + 8 * g4;
+            const int gs = p.rope_G + 2, kv = slot / gs, g = slot - kv * gs;
+            const bool live = slot < p.rope_KVH * gs;          // (N is a multiple of 128 only: the upper slot of the last tile column may lie past it)
+            const bool rotate = g != gs - 1;                   // v is not rotated
+            float bl[8], bh[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bl[e] = (p.bias && live) ? p.bias[slot * 128 + d + e] : 0.f; bh[e] = (p.bias && live) ? p.bias[slot * 128 + d + 64 + e] : 0.f; }
+            T* const Q = reinterpret_cast<T*>(p.rope_q);
+            T* const KVc = reinterpret_cast<T*>(g == gs - 2 ? p.rope_k : p.rope_v);
+            int ps[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int gm = row0 + 16 * i;
+                ps[i] = (live && rotate && gm < p.M && (i < MI1 || i < mi)) ? min(max(p.rope_pos[gm], 0), p.rope_rows - 1) : 0;
+            }
+            float4 cn[2], sn[2];
+            auto load_cs = [&](int i, float4 (&c)[2], float4 (&s_)[2]) __attribute__((always_inline)) {
+                const float* cp = p.rope_cos + (size_t)ps[i] * 128 + d;
+                const float* sp = p.rope_sin + (size_t)ps[i] * 128 + d;
+                c[0] = *reinterpret_cast<const float4*>(cp); c[1] = *reinterpret_cast<const float4*>(cp + 4);
+                s_[0] = *reinterpret_cast<const float4*>(sp); s_[1] = *reinterpret_cast<const float4*>(sp + 4);
+            };
+            if (rotate) load_cs(0, cn, sn);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const float4 c0 = cn[0], c1 = cn[1], s0 = sn[0], s1 = sn[1];
+                if (rotate && i + 1 < MI) load_cs(i + 1, cn, sn);
+                const int gm = row0 + 16 * i;
+                if (!(i < MI1 || i < mi) || gm >= p.M || !live) continue;
+                float x[8], y[8], lo[8], hi[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { x[e] = acc[i][e >> 2][e & 3] + bl[e]; y[e] = acc[i][2 + (e >> 2)][e & 3] + bh[e]; }
+                if (rotate) {   // q_embed = q cos + rotate_half(q) sin, rotate_half = cat(-x2, x1)  (same fp32 products and sums as rope_split_kernel / epilogue_rows)
+                    const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { lo[e] = x[e] * cv[e] - y[e] * sv[e]; hi[e] = y[e] * cv[e] + x[e] * sv[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { lo[e] = x[e]; hi[e] = y[e]; }
+                }
+                T* dst;
+                if (g < p.rope_G) dst = Q + (size_t)gm * ((size_t)p.rope_KVH * p.rope_G * 128) + (size_t)(kv * p.rope_G + g) * 128 + d;
+                else {
+                    const int bi = gm / p.rope_S, sq = gm - bi * p.rope_S;
+                    dst = KVc + (((size_t)bi * p.rope_KVH + kv) * p.rope_cap + p.rope_pos0 + sq) * 128 + d;
+                }
+                gst(dst, (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(lo[4], lo[5]), pack_bf16x2(lo[6], lo[7])});
+                gst(dst + 64, (u32x4){pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3]), pack_bf16x2(hi[4], hi[5]), pack_bf16x2(hi[6], hi[7])});
+            }
+        } else if (direct && !p.out_f32 && p.act != 3) {
             // bf16 (+bias, +GELU / ReLU): sub-tiles (2 h, 2 h + 1) are this lane's 8 columns of the 32-column group h; the two groups are 128 contiguous
             // bytes of a row -> pair_swap; the fifth sub-tile of a 320-wide tile is 4 columns (8 bytes) of the lane's own row
             const int colb = n0 + wn * WW + (odd ? 32 : 0) + 8 * g4;
@@ -927,6 +991,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
             const int col5 = n0 + wn * WW + 64 + 4 * g4;
             T* cp5 = reinterpret_cast<T*>(p.C) + (size_t)row0 * p.ldc + col5;
             auto drain = [&](auto ACT) __attribute__((always_inline)) {
+                uint2 w5 = make_uint2(0u, 0u);   // (NTW == 5) the even sub-tile row's fifth sub-tile, waiting for its odd partner
                 auto actf = [&](float v) __attribute__((always_inline)) {
                     if constexpr (decltype(ACT)::value == 1) return gelu_erfc5(v);   // results are rounded to bf16: the one-transcendental form (common.h), gated by tests/test_kernels_gpu.py
                     else if constexpr (decltype(ACT)::value == 2) return fmaxf(v, 0.f);
@@ -949,11 +1014,25 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
                         gst(cp + (size_t)(16 * i + 1) * p.ldc, s1);
                     }
                     if constexpr (NTW == 5) {
-                        if (row0 + 16 * i < p.M && col5 < p.N) {
-                            uint2 w;
-                            w.x = pack_bf16x2(actf(acc[i][4][0] + bv[16]), actf(acc[i][4][1] + bv[17]));
-                            w.y = pack_bf16x2(actf(acc[i][4][2] + bv[18]), actf(acc[i][4][3] + bv[19]));
-                            *reinterpret_cast<uint2*>(cp5 + (size_t)(16 * i) * p.ldc) = w;
+                        // the fifth sub-tile: 4 columns (8 bytes) of the lane's own row.  Sub-tile rows (i, i + 1) trade across the 16-lane rows
+                        // of the wave (v_permlane16_swap: odd rows of its first operand <-> even rows of its second): lane (mm, g4) ends up with
+                        // columns 8 (g4 >> 1) .. +7 of row 16 (i + (g4 & 1)) + mm -> ONE 16-byte store per lane and pair instead of two 8-byte ones
+                        // (the tile's store tail is issue-bound: profiles/r03_ring_stamps.txt, 8.0-8.3 k cycles against 4.3-4.9 k at 272x256)
+                        uint2 w;
+                        w.x = pack_bf16x2(actf(acc[i][4][0] + bv[16]), actf(acc[i][4][1] + bv[17]));
+                        w.y = pack_bf16x2(actf(acc[i][4][2] + bv[18]), actf(acc[i][4][3] + bv[19]));
+                        if constexpr (MI0 == MI1 && MI % 2 == 0) {
+                            if (i & 1) {
+                                const auto rx = __builtin_amdgcn_permlane16_swap(w5.x, w.x, false, false);
+                                const auto ry = __builtin_amdgcn_permlane16_swap(w5.y, w.y, false, false);
+                                const int r5 = row0 + 16 * (i - 1 + (g4 & 1));
+                                if (r5 < p.M && col5 < p.N)
+                                    gst(reinterpret_cast<T*>(p.C) + (size_t)r5 * p.ldc + (n0 + wn * WW + 64 + 8 * (g4 >> 1)), (u32x4){rx[0], ry[0], rx[1], ry[1]});
+                            } else {
+                                w5 = w;
+                            }
+                        } else {
+                            if (row0 + 16 * i < p.M && col5 < p.N) *reinterpret_cast<uint2*>(cp5 + (size_t)(16 * i) * p.ldc) = w;
                         }
                     }
                 }
@@ -1073,28 +1152,46 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     if (STAMP && p.dbg && (tid & 255) == 0) p.dbg[((size_t)bid * 2 + grp) * 4 + 3] = t_entry;
 }
 
-template <int MI0, int MI1, int NTW>
+template <int MI0, int MI1, int NTW, int EMODE = 0>
 static int launch_gemm_ring8(GemmArgs a, hipStream_t stream) {
     constexpr int BM = 16 * (MI0 + MI1), BN = 64 * NTW;
     constexpr int LDS = (4 * (BM + BN) * 64 > 16 * MI0 * BN * 4) ? 4 * (BM + BN) * 64 : 16 * MI0 * BN * 4;   // the ring, or the epilogue's staging rows
     static_assert(LDS <= 163840, "160 KiB of LDS per CU");
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW, false, EMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if constexpr (EMODE == 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     }
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     a.full_tiles = a.tiles_m * a.tiles_n;
     a.ksplit = 1;
-    if (a.dbg) gemm_ring8_kernel<MI0, MI1, NTW, true><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);   // stamped diagnostic build (tools/probes/ring8_stamps.py)
-    else gemm_ring8_kernel<MI0, MI1, NTW><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
+    if constexpr (EMODE == 0) {
+        if (a.dbg) {   // stamped diagnostic build (tools/probes/ring8_stamps.py)
+            gemm_ring8_kernel<MI0, MI1, NTW, true><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
+            ULLSAM_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    gemm_ring8_kernel<MI0, MI1, NTW, false, EMODE><<<dim3(a.full_tiles), dim3(512), LDS, stream>>>(a);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
 static int launch_gemm_v6(const GemmArgs& a, hipStream_t stream) { return launch_gemm_ring8<8, 8, 4>(a, stream); }   // 256 x 256
 static int launch_gemm_v8(const GemmArgs& a, hipStream_t stream) { return launch_gemm_ring8<8, 8, 5>(a, stream); }   // 256 x 320
 static int launch_gemm_v9(const GemmArgs& a, hipStream_t stream) { return launch_gemm_ring8<9, 8, 4>(a, stream); }   // 272 x 256
+// The wqkv GEMM with the RoPE epilogue (act 4) on the ring kernel: the tile height among 208 / 256 / 272 rows that covers the problem in the
+// fewest tile-rounds of the 256 CUs (cost of a tile = its area).  The bench's 4324 x 6144 launch: 256x256 = 408 tiles = 1.59 rounds run as 2
+// (cost 2.0, 215 us on the two-buffer kernel in round 3), 272x256 = 384 tiles (2.125), 208x256 = 504 tiles = 1.97 rounds (1.625).
+static int launch_gemm_ring_rope(const GemmArgs& a, hipStream_t stream, int force) {
+    auto cost = [&](int bm) { const long t = (long)((a.M + bm - 1) / bm) * ((a.N + 255) / 256); return (double)((t + 255) / 256) * bm / 256.0; };
+    const double c208 = cost(208), c256 = cost(256), c272 = cost(272);
+    int pick = (c208 < c256 && c208 < c272) ? 208 : (c272 < c256 ? 272 : 256);
+    if (force) pick = force;
+    if (pick == 208) return launch_gemm_ring8<7, 6, 4, 1>(a, stream);
+    if (pick == 272) return launch_gemm_ring8<9, 8, 4, 1>(a, stream);
+    return launch_gemm_ring8<8, 8, 4, 1>(a, stream);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) GEMM for the ViT's LayerNorm-fed linears (BASELINE configs[4], "fp8 MFMA ViT path"): the 256x256 staggered
@@ -1854,6 +1951,11 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     // the ring kernels keep a lane's bias columns in registers, fetched as float4 at 4-column offsets: whole, aligned groups only
     const bool bias_v4 = !bias || (N % 4 == 0 && ((uintptr_t)bias & 15) == 0);
     const bool ring_ok = dtype == ULLSAM_DT_BF16 && act <= 3 && K % 64 == 0 && K >= 128 && bias_v4 && (act != 3 || N % 256 == 0);
+    // wqkv + RoPE (act 4), bf16, >= 1024 rows: the ring kernel with the epilogue straight from the accumulators (variant 3 keeps the two-buffer
+    // kernel with the LDS-staged epilogue for A/B and the bit-level comparison; variants 6 / 9 / 10 force the 256- / 272- / 208-row tile)
+    if (act == 4 && dtype == ULLSAM_DT_BF16 && M >= 1024 && K % 64 == 0 && K >= 256 && (variant == 0 || variant == 6 || variant == 9 || variant == 10) &&
+        (((uintptr_t)rope->q | (uintptr_t)rope->k | (uintptr_t)rope->v) & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0))
+        return launch_gemm_ring_rope(a, s, variant == 6 ? 256 : variant == 9 ? 272 : variant == 10 ? 208 : 0);
     if (variant == 6 || variant == 8 || variant == 9) {
         if (!ring_ok || (variant == 8 && act == 3)) { ullsam_set_error("ullsam_gemm: the ring kernels need bf16, K %% 64 == 0, K >= 128, no RoPE epilogue (256x320: no SwiGLU)"); return -1; }
         return variant == 6 ? launch_gemm_v6(a, s) : variant == 8 ? launch_gemm_v8(a, s) : launch_gemm_v9(a, s);

@@ -115,18 +115,53 @@ class LinearFn(Function):
         return dx, dw, db
 
 
-_WT_CACHE = {}
+class _TransposeCache:
+    """W^T copies of frozen weights, keyed on the parameter OBJECT through weak references: an entry dies with its weight (a model that is
+    freed and rebuilt at the same addresses cannot meet a stale copy), it remembers the weight's `_version` and `data_ptr()` (an in-place
+    update or a `.data` swap drops it), and the cache is bounded in BYTES -- a 7B bf16 LLM's transposes are a second copy of its linears
+    (~13 GB), which is the budget; `clear()` (also called by `invalidate_transposed_weights`, e.g. after load_state_dict / a LoRA merge done
+    through `.data` in place) frees them."""
+
+    def __init__(self, max_bytes: int = 16 << 30):
+        from torch.utils.weak import WeakIdKeyDictionary   # keyed on identity: Tensor.__eq__ is elementwise
+        self._d = WeakIdKeyDictionary()
+        self.max_bytes = max_bytes
+        self.bytes = 0
+
+    def get(self, w: torch.Tensor) -> torch.Tensor:
+        e = self._d.get(w)
+        if e is not None and e[1] == w._version and e[2] == w.data_ptr() and e[0].shape == (w.shape[1], w.shape[0]) and e[0].dtype == w.dtype:
+            return e[0]
+        if e is not None:
+            self.bytes -= e[0].numel() * e[0].element_size()
+        t = w.detach().t().contiguous()
+        nb = t.numel() * t.element_size()
+        if self.bytes + nb > self.max_bytes:
+            self.clear()
+        self._d[w] = (t, w._version, w.data_ptr())
+        self.bytes += nb
+        return t
+
+    def clear(self):
+        self._d.clear()
+        self.bytes = 0
+
+    def __len__(self):
+        return len(self._d)
+
+
+_WT_CACHE = _TransposeCache()
+
+
+def invalidate_transposed_weights():
+    """Drop every cached W^T.  Needed only after edits that autograd's version counter cannot see (writes through `.data` that keep the
+    storage: `w.data.copy_()`, a LoRA merge, EMA) -- in-place ops on the parameter itself and reallocation are detected."""
+    _WT_CACHE.clear()
 
 
 def _transposed_frozen(w: torch.Tensor) -> torch.Tensor:
     """[N, K] frozen weight -> its [K, N] copy, made once per weight version (the dX GEMM of a frozen bf16 Linear reads W^T row-major)."""
-    key = (w.data_ptr(), w._version, tuple(w.shape))
-    t = _WT_CACHE.get(key)
-    if t is None:
-        if len(_WT_CACHE) > 4096:
-            _WT_CACHE.clear()
-        t = _WT_CACHE[key] = w.detach().t().contiguous()
-    return t
+    return _WT_CACHE.get(w)
 
 
 class FrozenLinearBf16Fn(Function):
@@ -172,8 +207,10 @@ class LayerNormFn(Function):
         dx = torch.empty_like(x)
         dw = torch.zeros((D,), dtype=F32, device=x.device) if ctx.affine else None
         db = torch.zeros((D,), dtype=F32, device=x.device) if ctx.affine else None
-        _lib.call("ullsam_train_ln_bwd", x.data_ptr(), None if w is None else _c(w).data_ptr(), dy.data_ptr(), dx.data_ptr(),
+        wf = None if w is None else _c(w)   # (a bf16 weight is widened into a temporary: it must outlive the launch)
+        _lib.call("ullsam_train_ln_bwd", x.data_ptr(), None if wf is None else wf.data_ptr(), dy.data_ptr(), dx.data_ptr(),
                   ops._p(dw), ops._p(db), rows, D, float(ctx.eps), _s())
+        del wf
         return dx, dw, db, None
 
 

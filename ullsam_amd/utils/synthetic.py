@@ -73,3 +73,55 @@ def param_init_rule(name: str, shape) -> Tuple[float, float]:
         return 0.0, shape[0] ** -0.5
     fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
     return 0.0, max(fan_in, 1) ** -0.5
+
+
+def fixture_param(name: str, shape, seed: int = 0) -> np.ndarray:
+    """The VALUES the reference-generated parity fixtures were filled with (oracle/ullsam_oracle.py::fill_param, bit for bit: tests/test_host_cpu.py):
+    an independent numpy stream per parameter name, `default_rng([seed, crc32(name)])`, standard normal draws mapped by the per-name rule above.
+    bench.py fills its model with these (seed 0) so that its four default tiles are the tiles of tests/golden/full_depth.npz on the fixture's own
+    weights, and its bf16 masks can be scored against the REFERENCE's fp32 masks stored there."""
+    import math
+    import zlib
+    shape = tuple(int(s) for s in shape)
+    x = np.random.default_rng([int(seed), zlib.crc32(name.encode())]).standard_normal(shape, dtype=np.float32)
+    leaf = name.split(".")[-1]
+    f32 = np.float32
+    if "llm_scale_factor" in name:
+        return (0.1 + 0.02 * x).astype(f32)
+    if "llm_bias" in name:
+        return (0.05 + 0.02 * x).astype(f32)
+    if "positional_encoding_gaussian_matrix" in name:
+        return x
+    if "rel_pos" in name:
+        return (0.1 * x).astype(f32)
+    if "pos_embed" in name:
+        return (0.05 * x).astype(f32)
+    is_norm = ("norm" in name) or name.endswith(("neck.1.weight", "neck.3.weight", "neck.1.bias", "neck.3.bias")) \
+        or name.startswith(("mlp1.0.", "mlp2.0.")) or ".mlp1.0." in name or ".mlp2.0." in name \
+        or "output_upscaling.1." in name or "mask_downscaling.1." in name or "mask_downscaling.4." in name
+    if is_norm:
+        return (1.0 + 0.1 * x).astype(f32) if leaf == "weight" else (0.05 * x).astype(f32)
+    if leaf == "bias" or len(shape) == 1:
+        return (0.05 * x).astype(f32)
+    if any(k in name for k in ("tok_embeddings", "iou_token", "mask_tokens", "point_embeddings", "not_a_point_embed", "no_mask_embed")):
+        return (0.5 * x).astype(f32)
+    if "output_upscaling" in name and len(shape) == 4:   # ConvTranspose2d [Cin, Cout, 2, 2]
+        return (x / math.sqrt(shape[0])).astype(f32)
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+    return (x / math.sqrt(max(fan_in, 1))).astype(f32)
+
+
+def fill_model_like_fixtures(model, seed: int = 0, workers: int = 32):
+    """Every floating-point parameter / persistent buffer of `model` <- fixture_param(name) (produced on a thread pool -- numpy's generators
+    release the GIL -- and copied straight into the device tensors).  Sam's pixel_mean / pixel_std (constants, not weights) are left alone."""
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    sd = {k: v for k, v in model.state_dict().items() if v.is_floating_point() and "pixel_mean" not in k and "pixel_std" not in k}
+
+    def one(kv):
+        k, v = kv
+        v.copy_(torch.from_numpy(fixture_param(k, tuple(v.shape), seed)).to(v.dtype))
+
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(one, sd.items()))
+    return model
