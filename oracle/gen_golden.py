@@ -447,26 +447,28 @@ def _build_full_depth():
     return m
 
 
+FULL_TILE_SEEDS = (3, 5, 27, 32)   # fp32 mask fill 0.951 / 0.528 / 0.481 / 0.597 (tools/probes/fill_scan.py): three of the four masks cut through the middle of the logits' distribution
+
+
 def case_full_depth():
     """The bench configuration at FULL depth through the reference (app.py:580-645 call sequence): ViT-H x 32 blocks + a 7B-shaped
-    InternLM2 x 32 layers at S = 1081 + prompt encoder + mask decoder + x4 upsample, on a synthetic microscopy tile
-    (ullsam_amd/utils/synthetic.py), in fp32 and under torch.autocast("cpu", bfloat16).  Stores strided samples after ViT block
-    8 / 16 / 24 / 32 and LLM layer 8 / 16 / 24 / 32, the image embedding, the dense feature, the low-res logits, the mask, and
-    the reference's own autocast-vs-fp32 error at every one of those stages (the bound our bf16 mode is held to)."""
+    InternLM2 x 32 layers at S = 1081 + prompt encoder + mask decoder + x4 upsample, on FOUR synthetic microscopy tiles
+    (ullsam_amd/utils/synthetic.py; the tiles bench.py times), in fp32 and under torch.autocast("cpu", bfloat16).  Per tile it stores strided
+    samples after ViT block 8 / 16 / 24 / 32 and LLM layer 8 / 16 / 24 / 32, the image embedding, the dense feature, the low-res logits, the
+    mask, and the reference's own autocast-vs-fp32 error at every one of those stages (the bound our bf16 mode is held to).  Keys carry the
+    tile's index: `low_0`, `vit8_2_ac_mean_err`, ...; `tile_seeds` lists the tiles."""
     from ullsam_amd.utils.synthetic import microscopy_batch
-    tile_seed = int(os.environ.get("FULL_DEPTH_TILE_SEED", "3"))
+    seeds = tuple(int(v) for v in os.environ.get("FULL_DEPTH_TILE_SEEDS", ",".join(map(str, FULL_TILE_SEEDS))).split(","))
     t = time.time()
     m = _build_full_depth()
     fill_module_inplace(m, seed=0)
     print(f"  built + filled in {time.time() - t:.0f}s")
-    x_np, pts = microscopy_batch([tile_seed])
     lbl = np.array([[1]], np.int32)
     ids = O.make_input_ids(n_text_pre=20, n_text_post=34, seed=1)
     assert ids.shape[1] == 1081
     tids = torch.from_numpy(ids)
-    x = torch.from_numpy(x_np)
 
-    def run():
+    def run(x, pts):
         st = {}
         hooks = []
         for i in FULL_STAGES_VIT:
@@ -491,30 +493,37 @@ def case_full_depth():
         st["mask"] = (up[0, 0].sigmoid() > 0.5).numpy()     # app.py:640-645
         return st
 
-    t = time.time()
-    f = run()
-    print(f"  reference fp32 full-depth forward {time.time() - t:.0f}s")
-    t = time.time()
-    with torch.autocast("cpu", dtype=torch.bfloat16, cache_enabled=False):
-        b = run()
-    print(f"  reference autocast-bf16 full-depth forward {time.time() - t:.0f}s")
     out = {}
-    print("  stage            mean|x|    autocast mean|d|  max|d|   rel")
-    for k in [f"vit{i + 1}" for i in FULL_STAGES_VIT] + ["img_emb"] + [f"llm{i + 1}" for i in FULL_STAGES_LLM] + ["dense_feat", "low"]:
-        d = np.abs(b[k].astype(np.float64) - f[k])
-        out[k] = f[k]
-        out[k + "_ac_mean_err"] = np.float64(d.mean())
-        out[k + "_ac_max_err"] = np.float64(d.max())
-        out[k + "_mean_abs"] = np.float64(np.abs(f[k]).mean())
-        print(f"  {k:14s} {np.abs(f[k]).mean():10.4f} {d.mean():14.5f} {d.max():10.4f} {d.mean() / np.abs(f[k]).mean():8.4f}")
-    ac_iou = O.calc_iou(b["mask"], f["mask"])
-    lo = f["low"].reshape(-1)
-    print(f"  mask fill {f['mask'].mean():.4f}; autocast mask IoU vs fp32 {ac_iou:.6f}; low-res logits mean|x| {np.abs(lo).mean():.3f}, "
-          f"share within the autocast mean error of 0: {(np.abs(lo) < out['low_ac_mean_err']).mean():.5f}; "
-          f"percentiles {np.percentile(lo, [1, 10, 25, 50, 75, 90, 99]).round(2)}")
-    save("full_depth", weight_seed=0, tile_seed=tile_seed, ids_seed=1, stride=FULL_STRIDE, pts=pts, lbl=lbl,
-         mask_bits=np.packbits(f["mask"]), mask_fill=np.float64(f["mask"].mean()), iou_pred=f["iou_pred"],
-         ac_mask_iou=np.float64(ac_iou), ac_iou_pred=b["iou_pred"], **out)
+    for ti, seed in enumerate(seeds):
+        x_np, pts = microscopy_batch([seed])
+        x = torch.from_numpy(x_np)
+        t = time.time()
+        f = run(x, pts)
+        t32 = time.time() - t
+        t = time.time()
+        with torch.autocast("cpu", dtype=torch.bfloat16, cache_enabled=False):
+            b = run(x, pts)
+        print(f"  tile {seed}: reference fp32 forward {t32:.0f}s, autocast-bf16 forward {time.time() - t:.0f}s")
+        print("  stage            mean|x|    autocast mean|d|  max|d|   rel")
+        for k in [f"vit{i + 1}" for i in FULL_STAGES_VIT] + ["img_emb"] + [f"llm{i + 1}" for i in FULL_STAGES_LLM] + ["dense_feat", "low"]:
+            d = np.abs(b[k].astype(np.float64) - f[k])
+            out[f"{k}_{ti}"] = f[k]
+            out[f"{k}_{ti}_ac_mean_err"] = np.float64(d.mean())
+            out[f"{k}_{ti}_ac_max_err"] = np.float64(d.max())
+            out[f"{k}_{ti}_mean_abs"] = np.float64(np.abs(f[k]).mean())
+            print(f"  {k:14s} {np.abs(f[k]).mean():10.4f} {d.mean():14.5f} {d.max():10.4f} {d.mean() / np.abs(f[k]).mean():8.4f}")
+        ac_iou = O.calc_iou(b["mask"], f["mask"])
+        lo = f["low"].reshape(-1)
+        print(f"  mask fill {f['mask'].mean():.4f}; autocast mask IoU vs fp32 {ac_iou:.6f}; low-res logits mean|x| {np.abs(lo).mean():.3f}, "
+              f"share within the autocast mean error of 0: {(np.abs(lo) < out[f'low_{ti}_ac_mean_err']).mean():.5f}; "
+              f"percentiles {np.percentile(lo, [1, 10, 25, 50, 75, 90, 99]).round(2)}", flush=True)
+        out[f"pts_{ti}"] = pts
+        out[f"mask_bits_{ti}"] = np.packbits(f["mask"])
+        out[f"mask_fill_{ti}"] = np.float64(f["mask"].mean())
+        out[f"iou_pred_{ti}"] = f["iou_pred"]
+        out[f"ac_mask_iou_{ti}"] = np.float64(ac_iou)
+        out[f"ac_iou_pred_{ti}"] = b["iou_pred"]
+    save("full_depth", weight_seed=0, tile_seeds=np.asarray(seeds, np.int64), ids_seed=1, stride=FULL_STRIDE, lbl=lbl, **out)
 
 def case_train_slice():
     """Gradients of the reference's segmentation loss (train_joint_v2.py:1026-1100: text_aware_dense_feature -> prompt encoder -> mask

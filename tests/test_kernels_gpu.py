@@ -360,6 +360,54 @@ def test_vit_attention(ops, dtype, heads, hd, grid, window):
     assert e < (1e-4 if dtype == torch.float32 else 3e-2) * max(1.0, scale), (e, scale)
 
 
+@pytest.mark.parametrize("B,heads,qscale", [(4, 16, 1.0), (1, 3, 1.0), (2, 4, 6.0)])
+def test_vit_global_attention_dma_kernel_against_the_tiled_kernel_and_float64(ops, B, heads, qscale):
+    """vitglob_attn_kernel (bf16, head_dim 80, 64 x 64 grid: K / V by LDS-DMA in 32-key stages into swizzled rings, the two waves of a SIMD half an
+    interval apart, the rel_w term in the MFMA's initial accumulator, the O rescale skipped when no maximum moved) against the tiled
+    flash_attn_kernel<bf16, 80, VIT_GLOBAL, 8, FAST64> (attention variant 12) on the same operands: same MFMA order; the exponent's argument is
+    rounded once instead of twice and the running maximum follows the true one lazily (probabilities up to 2^5 instead of 1 between rescales), so
+    the outputs agree to bf16 rounding noise -- the bench's shape, a pair count that is not a multiple of the 8 XCDs, and queries scaled up so that
+    the maximum keeps moving by more than the lazy threshold (the rescale branch is taken again and again) -- and both agree with a float64 softmax
+    including the decomposed rel-pos bias (image_encoder.py:325-361), the new kernel no worse than the tiled one."""
+    from ullsam_amd import _lib
+    lib = _lib.load()
+    hd, grid, D = 80, 64, heads * 80
+    g = torch.Generator(device=DEV); g.manual_seed(B * 100 + heads)
+    qkv = torch.randn(B * grid * grid, 3 * D, device=DEV, generator=g)
+    qkv[:, :D] *= qscale
+    qkv = qkv.bfloat16()
+    rh = (torch.randn(2 * grid - 1, hd, device=DEV, generator=g) * 0.1).bfloat16()
+    rw = (torch.randn(2 * grid - 1, hd, device=DEV, generator=g) * 0.1).bfloat16()
+    bias = torch.zeros(3 * D, device=DEV).bfloat16()
+    new = ops.vit_attention(qkv, rh, rw, bias, B, heads, hd, grid, grid, 0)
+    try:
+        lib.ullsam_set_attn_variant(12)
+        old = ops.vit_attention(qkv, rh, rw, bias, B, heads, hd, grid, grid, 0)
+    finally:
+        lib.ullsam_set_attn_variant(0)
+    torch.cuda.synchronize()
+    dn = (new.float() - old.float()).abs()
+    assert float(dn.max()) <= 2.0 ** -6 * max(1.0, float(old.float().abs().max())), float(dn.max())     # within two bf16 rounding steps of the largest output
+    # float64 reference of one (image, head) pair on the operands as the kernel sees them
+    b, h = B - 1, heads - 1
+    t = qkv.double().reshape(B, grid * grid, 3, heads, hd)
+    q, k, v = t[b, :, 0, h], t[b, :, 1, h], t[b, :, 2, h]
+    idx = torch.arange(grid, device=DEV)
+    rel = idx[:, None] - idx[None, :] + grid - 1                          # get_rel_pos: q - k + (G - 1)
+    Rh, Rw = rh.double()[rel], rw.double()[rel]                           # [q coord, k coord, hd]
+    qg = q.reshape(grid, grid, hd)
+    bh = torch.einsum("hwc,hkc->hwk", qg, Rh)                             # [qh, qw, kh]
+    bw = torch.einsum("hwc,wkc->hwk", qg, Rw)                             # [qh, qw, kw]
+    sc = (q @ k.T) / math.sqrt(hd) + (bh[:, :, :, None] + bw[:, :, None, :]).reshape(grid * grid, grid * grid)
+    ref = torch.softmax(sc, -1) @ v
+    got = new.double().reshape(B, grid * grid, heads, hd)[b, :, h]
+    got_old = old.double().reshape(B, grid * grid, heads, hd)[b, :, h]
+    e_new, e_old = float((got - ref).abs().max()), float((got_old - ref).abs().max())
+    print(f"vit global attention vs float64: LDS-DMA kernel {e_new:.3e}, tiled kernel {e_old:.3e} (mean {float((got - ref).abs().mean()):.2e} / {float((got_old - ref).abs().mean()):.2e})")
+    assert e_new < 3e-2 * max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().mean()) <= 1.15 * float((got_old - ref).abs().mean()) + 1e-6
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,S,H,KVH,pad", [(2, 70, 2, 1, 9), (1, 200, 4, 2, 0), (1, 1081, 2, 2, 0)])
 def test_rope_and_causal_attention(ops, dtype, B, S, H, KVH, pad):

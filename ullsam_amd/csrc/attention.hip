@@ -1203,6 +1203,351 @@ static int launch_causal128(const AttnArgs& a, hipStream_t s) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------
+//  vitglob_attn_kernel: SAM ViT-H global attention (image_encoder.py:224-240 with the decomposed rel-pos bias of :325-361) for bf16,
+//  head_dim 80 on the 64 x 64 token grid -- the production path of the four global blocks.  Same mathematics and MFMA order as
+//  flash_attn_kernel<bf16, 80, MODE_VIT_GLOBAL, 8, FAST64> (results equal to a rounding of the exponent's argument: tests/test_kernels_gpu.py),
+//  different data movement and a leaner softmax.
+//  The tiled kernel stages every 128-key K / V tile global -> registers -> LDS with two barriers per tile and drains its in-wave pipeline
+//  at every tile end: matrix pipe busy 32 %, 6.6 M LDS bank conflicts per launch, waves parked 28 % of their cycles (round 3).  Here
+//    * one 8-wave workgroup per 256 queries of a (image, head) pair; K and V arrive by LDS-DMA (global_load_lds_dwordx4) in 32-key stages
+//      (a 32-key block is half a grid row, the unit the FAST64 softmax works in): per stage every wave issues ONE K piece and ONE V piece
+//      (4 key rows of 256 bytes each), two to three stages ahead of their use; rings of four K and four V stages;
+//      ONE s_barrier per stage behind a counted vmcnt(2) -- nothing is staged through registers and the wait never drains the DMA queue;
+//    * the image of a stage is the causal kernel's: plain 256-byte rows, 16-byte chunk ch of row r at slot ch ^ (((r & 3) << 2) | ((r >> 2) & 3))
+//      (cdna guide T10, layout (b): K row reads and transposed V reads both conflict-free), the permutation applied on the DMA's per-lane source
+//      address.  A head's row is only 160 bytes: lanes whose chunk would be 10 .. 15 fetch a valid dummy (K) or the 32 constant bytes
+//      {bf16 1.0, 0, ...} (V chunks 10 / 11: the column of ones at V[:, 80] that makes row 80 of O^T the softmax denominator, zeros after);
+//    * a wave's pipeline runs THROUGH the stage boundaries (scores of block j + 1 and a PV product around the softmax of block j), and the two
+//      waves of a SIMD (w, w + 4) run the interval's matrix half and softmax half in opposite order: one feeds the matrix pipe while the other is
+//      in its exponentials; the O rescale is skipped when no row maximum of the wave moved (a multiply by exactly 1);
+//    * workgroups are numbered so that the 16 query blocks of a (image, head) pair run on one XCD (its K / V, 1.3 MB, stay in that L2).
+//  LDS: 32 KiB K ring + 32 KiB V ring + 22 KiB rel-pos table staging + 8 x 8 KiB rel_h tables = 150 KiB, one workgroup per CU.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+__global__ __launch_bounds__(512) void vitglob_attn_kernel(AttnArgs p) {
+    typedef bf16 T;
+    constexpr int HD = 80, KSTEPS = 5, DT = 3, G = 64, NB = 128, STAGE = 32 * 256, NE = 2 * G - 1;
+    constexpr int RS = HD * 2 + 16;          // row stride of the rel-pos table staging area (the tiled kernel's K stride)
+    constexpr int KRING = 0, VRING = 4 * STAGE, TSTAGE = 8 * STAGE, RELH = TSTAGE + 128 * RS;   // K and V rings of four stages: slot = j & 3, a compile-time constant in the loop unrolled by four
+    constexpr float LOG2E = 1.4426950408889634f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, ql = lane & 31;
+    // workgroup -> ((image, head) pair, query block): ids go round robin over the 8 XCDs, so id % 8 picks the XCD; an XCD walks its pairs one
+    // after the other, the 16 query blocks of a pair on neighbouring CUs of that XCD at the same time (speed only: any placement is correct)
+    const int npair = p.B * p.H;
+    int pair, qblk;
+    {
+        const int bid = blockIdx.x;
+        if ((npair & 7) == 0) { const int xcd = bid & 7, idx = bid >> 3; pair = xcd + 8 * (idx >> 4); qblk = idx & 15; }
+        else { pair = bid >> 4; qblk = bid & 15; }
+    }
+    const int head = pair % p.H, b = pair / p.H;
+    const int qi = qblk * 256 + wave * 32 + ql;
+    const int qh = qi >> 6, qw = qi & 63;
+
+    Frag<T> qf[KSTEPS];
+    {
+        const T* qp = reinterpret_cast<const T*>(p.q) + (long)b * p.q_bs + (long)qi * p.q_ts + (long)head * p.q_hs;
+#pragma unroll
+        for (int t = 0; t < KSTEPS; ++t) qf[t] = load_frag(qp + 16 * t + 8 * h);
+    }
+
+    // ---- LDS-DMA requests of this wave: piece `wave` of a K stage and of a V stage (4 key rows).  lane -> row 4 wave + lane / 16, physical
+    // slot lane % 16, which holds the logical chunk slot ^ sw(row), sw(row) = ((row & 3) << 2) | ((row >> 2) & 3) = ((lane >> 4) << 2) | (wave & 3)
+    const long k_row = p.k_ts * 2, v_row = p.v_ts * 2;                       // bytes between consecutive keys of a head
+    const char* kg = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.k) + (long)b * p.k_bs + (long)head * p.k_hs);
+    const char* vg = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.v) + (long)b * p.v_bs + (long)head * p.v_hs);
+    const int prow = 4 * wave + (lane >> 4);
+    const int pch = (lane & 15) ^ (((lane >> 4) << 2) | (wave & 3));         // logical chunk this lane's slot holds
+    const unsigned int k_off = (unsigned int)(prow * k_row) + 16u * (unsigned int)(pch < 10 ? pch : pch - 10);   // (chunks 10 .. 15 of a K row are never read: any valid bytes)
+    const bool v_real = pch < 10;                                           // chunks 10 .. 15 of a V row: this lane requests nothing (the constant chunks 10 / 11 are written once, below)
+    const unsigned int v_off = (unsigned int)(prow * v_row) + 16u * (unsigned int)(v_real ? pch : 0);
+    // One request = one global_load_lds_dwordx4 in its SGPR-base form (wave-uniform 64-bit stage address + this lane's 32-bit byte offset), written as
+    // asm: through the builtin hipcc builds a 64-bit per-lane address with four VALU instructions per request in a loop that is VALU-bound.  M0 (the
+    // LDS base of the piece) is saved and restored inside the statement (cdna guide 5.7); the DMA has no register destination, and its completion is
+    // counted by the loop's own s_waitcnt vmcnt.
+    auto glds = [&](const char* base, unsigned int off, unsigned int lds_addr) __attribute__((always_inline)) {
+        unsigned int keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_addr) : "memory");
+    };
+    const unsigned int kring_lds = (unsigned int)(uintptr_t)LDS_PTR(smem + KRING) + (unsigned int)wave * 1024u;
+    const unsigned int vring_dma = (unsigned int)(uintptr_t)LDS_PTR(smem + VRING) + (unsigned int)wave * 1024u;
+    auto req_k = [&](int j) __attribute__((always_inline)) {                 // stage min(j, NB - 1) -> K ring slot j & 3
+        const int js = min(j, NB - 1);
+        glds(kg + (size_t)js * (32 * k_row), k_off, kring_lds + (unsigned int)((j & 3) * STAGE));
+    };
+    auto req_v = [&](int j) __attribute__((always_inline)) {
+        const int js = min(j, NB - 1);
+        if (v_real) glds(vg + (size_t)js * (32 * v_row), v_off, vring_dma + (unsigned int)((j & 3) * STAGE));   // (lanes of chunks >= 10: masked off, LDS untouched)
+    };
+    // chunks 10 / 11 of every V row of the four ring slots: {bf16 1.0, 0 x 7} and zeros -- the column of ones at V[:, 80] (row 80 of O^T = V^T P^T becomes
+    // the softmax denominator) and the zero columns 81 .. 95; the DMA never writes them (its lanes for chunks >= 10 are masked off)
+    if (tid < 256) {
+        const int slot = tid >> 6, row = (tid >> 1) & 31, c = 10 + (tid & 1);
+        *reinterpret_cast<uint4*>(smem + VRING + slot * STAGE + row * 256 + 16 * (c ^ (((row & 3) << 2) | ((row >> 2) & 3)))) = make_uint4(c == 10 ? 0x00003F80u : 0u, 0u, 0u, 0u);
+    }
+    req_k(0); req_v(0); req_k(1); req_v(1); req_k(2);   // land under the table phase
+
+    // ---- rel-pos tables (the tiled kernel's arithmetic): T^T[e][q] = RelTable[e][:] . q[:] by MFMA, scattered to relh[kh][q]; the width table goes
+    // through the same slab first and ends in 32 registers per lane (key columns 32 par + crow32(r, h)), both in log2 units
+    float* relh = reinterpret_cast<float*>(smem + RELH) + wave * (64 * 32);
+    char* Ts = smem + TSTAGE;
+    float rw[2][16];
+#pragma unroll 1
+    for (int it = 0; it < 2; ++it) {
+        const int tb = 1 - it;   // width table first (its slab is then recycled for rel_h)
+        const T* const tab = reinterpret_cast<const T*>(tb == 0 ? p.rel_h : p.rel_w);
+        __syncthreads();
+        for (int idx = tid; idx < 128 * 10; idx += 512) {
+            const int row = idx / 10, ch = idx - row * 10;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < NE) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(tab + (long)row * HD) + ch * 16);
+            *reinterpret_cast<uint4*>(Ts + row * RS + ch * 16) = v;
+        }
+        __syncthreads();
+        const int qc = tb == 0 ? qh : qw;
+#pragma unroll 1
+        for (int t = 0; t < 4; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const Frag<T> a = load_frag(reinterpret_cast<const T*>(Ts + (32 * t + ql) * RS) + 16 * ks + 8 * h);
+                mma32(a, qf[ks], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int e = 32 * t + crow32(r, h);
+                const int kk = qc + (G - 1) - e;  // rel index e = q - k + (G-1)  (get_rel_pos, image_encoder.py:318-322)
+                if (e < NE && kk >= 0 && kk < G) relh[kk * 32 + ql] = acc[r] * LOG2E;
+            }
+        }
+        if (tb == 1) {
+            __syncthreads();  // both lane halves of every wave have scattered their rel_w entries
+#pragma unroll
+            for (int i = 0; i < 32; ++i) rw[i >> 4][i & 15] = relh[(32 * (i >> 4) + crow32(i & 15, h)) * 32 + ql];
+        }
+    }
+    __syncthreads();   // (vmcnt(0) + barrier: the first five stages have landed too)
+
+    // ---- fragment addresses inside a stage: one register per k-step / d-tile, the stage's ring slot is an immediate offset
+    const int swq = ((ql & 3) << 2) | ((ql >> 2) & 3);
+    const int kf_off = 256 * ql + ((16 * h) ^ (16 * swq));                 // K[ql][16 ks + 8 h ..] at kf_off ^ (32 ks)
+    const char* kfa[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) kfa[ks] = smem + KRING + (kf_off ^ (32 * ks));
+    unsigned int va_lo[DT], va_hi[DT];                                   // V^T fragment rows 4 hh + q4 (+ 8) of a stage, d-tile d: ^ (64 d)
+    {
+        const int grp = lane >> 4, i = lane & 15, hh = grp >> 1, q4 = i >> 2, p4 = i & 3;
+        const int c_lo = 2 * (grp & 1) + (p4 >> 1);
+        const int v_lo = 256 * (4 * hh + q4) + 16 * (c_lo ^ ((q4 << 2) | hh)) + 8 * (p4 & 1);
+        const int v_hi = 256 * (4 * hh + q4 + 8) + 16 * (c_lo ^ ((q4 << 2) | ((hh + 2) & 3))) + 8 * (p4 & 1);
+        const unsigned int vring_lds = (unsigned int)(uintptr_t)LDS_PTR(smem + VRING);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) { va_lo[d] = vring_lds + (unsigned int)(v_lo ^ (64 * d)); va_hi[d] = vring_lds + (unsigned int)(v_hi ^ (64 * d)); }
+    }
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY;
+    const float scale2 = p.scale * LOG2E;
+    // The rel_w term of a score rides in the MFMA's initial accumulator, in units of the raw score (rw / scale2): the softmax then needs ONE fma
+    // and one exponential per score -- p = 2^(s' scale2 - m_off) with s' = k.q + rw / scale2 -- and takes its maximum on the raw s' (scale2 > 0).
+    // (The tiled kernel rounds s scale2 + rw first and subtracts the offset after: same mathematics, one rounding apart.)
+    {
+        const float inv_scale2 = 1.0f / scale2;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) rw[i >> 4][i & 15] *= inv_scale2;
+    }
+
+    auto qk_block = [&](auto SLOT, auto PAR, f32x16& s) __attribute__((always_inline)) {  // S'^T = K . Q^T + rel_w / scale2, K ring slot SLOT
+        constexpr int slot = decltype(SLOT)::value, par = decltype(PAR)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = rw[par][r];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const Frag<T> a = load_frag(reinterpret_cast<const T*>(kfa[ks] + slot * STAGE));
+            mma32(a, qf[ks], s);
+        }
+    };
+    // raw scores -> unnormalised probabilities in place (online softmax); returns the factor the running O must be scaled by.  A 32-key block is half
+    // a grid row: its rel_h term is uniform over the block (added to the block maximum, folded into the exponent's offset)
+    auto soft_block = [&](int j, f32x16& s) __attribute__((always_inline)) -> float {
+        const float rh64 = relh[(j >> 1) * 32 + ql];
+        // (v_max3_f32 as asm: through fmaxf hipcc puts a canonicalising v_max_f32 x, x in front of every MFMA result -- 16 more instructions in a
+        // VALU-bound loop.  The scores were written by MFMAs at least one PV product or one barrier earlier: no MFMA -> VALU hazard at this place.)
+        float mr;   // (ONE statement: hipcc pads every asm statement's boundary with an s_nop, and a chain of eight would carry eight of them)
+        asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %0, %0, %8, %9\n\t"
+            "v_max3_f32 %0, %0, %10, %11\n\tv_max3_f32 %0, %0, %12, %13\n\tv_max3_f32 %0, %0, %14, %15\n\tv_max_f32 %0, %0, %16"
+            : "=&v"(mr)
+            : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]), "v"(s[10]), "v"(s[11]),
+              "v"(s[12]), "v"(s[13]), "v"(s[14]), "v"(s[15]));
+        float lo, hi;
+        halves(mr, lo, hi);
+        const float mx = __builtin_fmaf(max3_raw(lo, hi, hi), scale2, rh64);
+        // The running maximum only has to keep the exponentials in range, so it FOLLOWS the true maximum lazily: it moves (and O is rescaled) when
+        // some row of the wave exceeds it by more than 2^LAZY, not at every new record (random scores set a record in some row of a 32-row wave in
+        // ~60 % of the 128 blocks; each rescale is 24 v_pk_mul_f32).  Until then the probabilities of that row are at most 2^LAZY = 8 instead of 1 -- the
+        // same relative precision in bf16, fp32 sums -- and the final O / l is unchanged up to rounding (tests: no worse than the tiled kernel
+        // against a float64 softmax).  (cdna guide T13; the decision covers the whole block, and PV(j-1) is complete before O is rescaled.)
+        constexpr float LAZY = 3.0f;
+        float alpha = 1.0f;
+        if (__any(mx > m_run + LAZY)) {      // wave-uniform (m_run = -inf at the first block: taken)
+            const float m_new = fmaxf(m_run, mx);     // (every block holds 32 finite scores: no -inf bookkeeping)
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf -> 0
+            m_run = m_new;
+        }
+        const float m_off = rh64 - m_run;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale2, m_off));  // raw v_exp_f32: underflow to 0 is the intent
+        return alpha;
+    };
+    // O^T += V^T . P^T, V ring slot SLOT.  Transposed reads as inline asm (through the builtin hipcc waits vmcnt(0) before every ds_read_b64_tr_b16
+    // while an LDS-DMA is in flight), the reads of a d-tile issued together, one counted wait per d-tile.
+    auto pv_block = [&](auto SLOT, const Frag<T>& p0, const Frag<T>& p1) __attribute__((always_inline)) {
+        constexpr int slot = decltype(SLOT)::value;
+        // all twelve transposed reads of the block are issued first (24 registers), then each d-tile's pair of MFMAs behind a COUNTED wait: LDS
+        // operations return in order, so "at most 8 / 4 / 0 outstanding" covers d-tile 0 / 1 / 2 whatever else the compiler has queued behind them
+        s16x4 lo[DT][2], hi[DT][2];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[d][0]) : "v"(va_lo[d]), "i"(slot * STAGE));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[d][0]) : "v"(va_hi[d]), "i"(slot * STAGE));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[d][1]) : "v"(va_lo[d]), "i"(slot * STAGE + 4096));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[d][1]) : "v"(va_hi[d]), "i"(slot * STAGE + 4096));
+        }
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            if (d == 0) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(lo[0][0]), "+v"(hi[0][0]), "+v"(lo[0][1]), "+v"(hi[0][1]) :: "memory");
+            else if (d == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(lo[1][0]), "+v"(hi[1][0]), "+v"(lo[1][1]), "+v"(hi[1][1]) :: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[2][0]), "+v"(hi[2][0]), "+v"(lo[2][1]), "+v"(hi[2][1]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                s16x8 t;
+                t[0] = lo[d][half][0]; t[1] = lo[d][half][1]; t[2] = lo[d][half][2]; t[3] = lo[d][half][3];
+                t[4] = hi[d][half][0]; t[5] = hi[d][half][1]; t[6] = hi[d][half][2]; t[7] = hi[d][half][3];
+                Frag<T> f;
+                f.v = __builtin_bit_cast(bf16x8_t, t);
+                mma32(f, half ? p1 : p0, o[d]);
+            }
+        }
+    };
+    auto scale_o = [&](float alpha) __attribute__((always_inline)) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    };
+
+    // ---- main loop.  Per interval (one s_barrier) every wave requests K(j+3) and V(j+2), computes the scores of block j+1, the softmax of block j
+    // and one PV product.  The two waves of a SIMD (wave w and w + 4) run the interval's two halves in OPPOSITE order, so that one is in its matrix
+    // half while the other is in its softmax (VALU) half:
+    //     waves 0-3:  scores(j+1), PV(j-1) | softmax(j)            waves 4-7:  softmax(j) | scores(j+1), PV(j)
+    // (per wave the order of operations on O is the same in both: ... x alpha_j, + PV(j), x alpha_j+1 ...).
+    //   RAW: K(j+1) was requested in interval j-2, V(j-1) / V(j) in intervals j-3 / j-2, and the vmcnt(2) that ended interval j-1 left only that
+    //        interval's own two requests in flight, behind the barrier every wave passed.
+    //   WAR: K(j+3) goes to the slot of K(j-1), last read in interval j-2; V(j+2) to the slot of V(j-2), last read in interval j-1 (waves 0-3).
+    //   Past the last stage the requests repeat stage NB-1 into slots nobody reads any more, so the counted wait needs no special case.
+    // Four intervals per loop trip: ring slots, rel_w parity and score registers are compile-time constants.
+    f32x16 sc0, sc1;
+    Frag<T> p0, p1;
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+    qk_block(I0{}, I0{}, sc0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15" ::: "memory");   // the only place where a softmax (waves 4-7, asm v_max3) directly follows the MFMAs that wrote its scores
+    __builtin_amdgcn_sched_barrier(0);
+    auto finish = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto soft_pack = [&](int j, f32x16& s_cur) __attribute__((always_inline)) {
+        const float alpha = soft_block(j, s_cur);
+        if (__any(alpha != 1.0f)) scale_o(alpha);   // wave-uniform: no row maximum moved (the common case after the first stages): 48 multiplies by 1 skipped
+        p0 = pack_p(s_cur, 0, (const T*)nullptr);
+        p1 = pack_p(s_cur, 1, (const T*)nullptr);
+    };
+    if (wave < 4) {
+        // interval j with j & 3 == JM: scores of block j+1 (slot (JM+1)&3, parity (JM+1)&1), PV of block j-1 (slot (JM+3)&3), softmax of block j
+        auto interval = [&](int j, auto JM, f32x16& s_cur, f32x16& s_next) __attribute__((always_inline)) {
+            constexpr int jm = decltype(JM)::value;
+            req_k(j + 3);
+            req_v(j + 2);
+            if (j + 1 < NB) qk_block(std::integral_constant<int, (jm + 1) & 3>{}, std::integral_constant<int, (jm + 1) & 1>{}, s_next);
+            if (j > 0) pv_block(std::integral_constant<int, (jm + 3) & 3>{}, p0, p1);
+            soft_pack(j, s_cur);
+            finish();
+        };
+#pragma unroll 1
+        for (int j = 0; j < NB; j += 4) {
+            interval(j, I0{}, sc0, sc1);
+            interval(j + 1, I1{}, sc1, sc0);
+            interval(j + 2, I2{}, sc0, sc1);
+            interval(j + 3, I3{}, sc1, sc0);
+        }
+        pv_block(std::integral_constant<int, (NB - 1) & 3>{}, p0, p1);
+    } else {
+        auto interval = [&](int j, auto JM, f32x16& s_cur, f32x16& s_next) __attribute__((always_inline)) {
+            constexpr int jm = decltype(JM)::value;
+            soft_pack(j, s_cur);
+            req_k(j + 3);     // (waves 4-7 issue their requests after their softmax half: the eight waves' sixteen requests of an interval then do not queue
+            req_v(j + 2);     //  at the address unit all at once behind the barrier -- 449 -> 424 us per launch)
+            if (j + 1 < NB) qk_block(std::integral_constant<int, (jm + 1) & 3>{}, std::integral_constant<int, (jm + 1) & 1>{}, s_next);
+            pv_block(JM, p0, p1);
+            finish();
+        };
+#pragma unroll 1
+        for (int j = 0; j < NB; j += 4) {
+            interval(j, I0{}, sc0, sc1);
+            interval(j + 1, I1{}, sc1, sc0);
+            interval(j + 2, I2{}, sc0, sc1);
+            interval(j + 3, I3{}, sc1, sc0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two dummy requests of the last interval (nothing may be in flight into LDS at the end)
+
+    // ---- normalise and store: lane q holds O^T[d][q], d = 32 dt + crow32(r, h); row 80 of O^T (d-tile 2, register 8 of the lower lane half) is the denominator
+    float lo, hi;
+    halves(o[DT - 1][8], lo, hi);
+    const float l_tot = lo;
+    const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    T* op = reinterpret_cast<T*>(p.out) + (long)b * p.o_bs + (long)qi * p.o_ts + (long)head * p.o_hs;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int dd = 32 * d + 8 * rq + 4 * h;
+            if (dd < HD) store4(op + dd, make_float4(o[d][4 * rq] * inv_l, o[d][4 * rq + 1] * inv_l, o[d][4 * rq + 2] * inv_l, o[d][4 * rq + 3] * inv_l));
+        }
+}
+
+static int launch_vitglob(const AttnArgs& a, hipStream_t s) {
+    constexpr int LDS = 8 * 32 * 256 + 128 * (80 * 2 + 16) + 8 * 64 * 32 * 4;
+    static PerDeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vitglob_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    vitglob_attn_kernel<<<dim3(a.B * a.H * 16), dim3(512), LDS, s>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
 static int g_attn_variant = 0;
 static unsigned long long* g_attn_dbg = nullptr;
 extern "C" int ullsam_set_attn_variant(int v) { g_attn_variant = v; return 0; }
@@ -1247,6 +1592,9 @@ extern "C" int ullsam_vit_attention(int dtype, const void* qkv, void* out, const
     // bf16 on SAM's 64x64 grid: one 8-wave workgroup per 256 queries over 128-key tiles (a staged K/V tile feeds twice the queries: half the
     // staging traffic, LDS writes and barriers per score) -- identical results, 543 vs 576 us per ViT-H layer at batch 4 (same-process A/B,
     // tools/probes/attn8_check.py); variant 9 keeps the two 4-wave workgroups with 64-key tiles
+    // SAM ViT-H's own shape (head_dim 80): the LDS-DMA kernel; variant 12 keeps the tiled 8-wave kernel (bit-equality test, A/B)
+    if (dtype == 1 && grid_h == 64 && grid_w == 64 && hd == 80 && g_attn_variant != 9 && g_attn_variant != 12 && (((uintptr_t)qkv | (uintptr_t)out) & 15) == 0)
+        return launch_vitglob(a, s);
     if (dtype == 1 && grid_h == 64 && grid_w == 64 && g_attn_variant != 9) return dispatch_hd<bf16, MODE_VIT_GLOBAL, 8>(a, hd, s);
     return dtype == 0 ? dispatch_hd<float, MODE_VIT_GLOBAL, 4>(a, hd, s) : dispatch_hd<bf16, MODE_VIT_GLOBAL, 4>(a, hd, s);
 }
