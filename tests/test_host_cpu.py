@@ -440,8 +440,8 @@ def test_bench_gpus2_control_path_runs_end_to_end_in_stub_mode():
 
 
 def test_bench_init_rule_is_the_fixture_filler_rule():
-    """bench.py draws its random weights by ullsam_amd.utils.synthetic.param_init_rule; the reference-generated fixtures (incl. the
-    full-depth one) were filled by oracle.fill_param.  Same (mean, std) for every parameter of the composite model, so the bench's
+    """bench.py fills its model by ullsam_amd.utils.synthetic.fixture_param (rule table: param_init_rule); the reference-generated fixtures
+    (incl. the full-depth one) were filled by oracle.fill_param.  Same (mean, std) for every parameter of the composite model, so the bench's
     `mask_iou_vs_fp32` is measured on the weight statistics the full-depth parity fixture pins."""
     from ullsam_amd.utils.synthetic import microscopy_batch, param_init_rule
     P = {}
@@ -450,9 +450,17 @@ def test_bench_init_rule_is_the_fixture_filler_rule():
     P.update(O.mask_decoder_shapes(prefix="mask_decoder."))
     P.update(O.internlm2_shapes(256, 2, 2, 1, 512, 1000, prefix="language_model."))
     P.update(O.projector_shapes(256))
+    from ullsam_amd.utils.synthetic import fixture_param
+    import bench
     for k, shp in P.items():
         (m0, s0), (m1, s1) = O.fill_rule(k, shp), param_init_rule(k, shp)
         assert abs(m0 - m1) < 1e-6 and abs(s0 - s1) < 1e-6 * max(1.0, s1), (k, shp, (m0, s0), (m1, s1))
+        assert np.array_equal(O.fill_param(k, shp, 0), fixture_param(k, shp, 0)), k      # bench.py's weights ARE the fixtures' weights, bit for bit
+    # bench.py's default tiles on rank 0 are the tiles of the full-depth fixture (its masks are scored against the reference's there)
+    g = U.gold("full_depth")
+    assert [int(v) for v in g["tile_seeds"]] == list(bench.FIXTURE_TILE_SEEDS) == bench.tile_seeds(0, 4)
+    assert bench.tile_seeds(1, 4) != bench.tile_seeds(0, 4) and len(set(bench.tile_seeds(0, 8) + bench.tile_seeds(1, 8))) == 16
+    assert sum(0.3 <= float(g[f"mask_fill_{i}"]) <= 0.7 for i in range(4)) >= 2
     # the synthetic tile: deterministic, two intensity populations, the click lies inside a cell
     a, pa = microscopy_batch([3])
     b, pb = microscopy_batch([3])
