@@ -58,6 +58,10 @@ struct GemmArgs {
     int group_m;     // tile rows per raster group of the 256-row-tile kernels (tiles of a group run column-major: group_m x tiles_n); 4 by default
 };
 
+#ifndef ULLSAM_RING_ASM_DMA
+#define ULLSAM_RING_ASM_DMA 1
+#endif
+static constexpr bool g_asm_dma = ULLSAM_RING_ASM_DMA != 0;   // (side builds with -DULLSAM_RING_ASM_DMA=0 keep the builtin for A/B)
 static int g_split_tail = 1;   // ullsam_set_gemm_variant(v | 64) disables the split-K tails (A/B)
 static int g_gemm_variant = 0; // bits 0-3 force a kernel: 0 auto, 1 128x128, 3 256x256 two-buffer, 6 256x256 ring, 8 256x320 ring, 9 272x256 ring, 10 208x256 ring (RoPE GEMM only)
 static int g_dbg = 0;          // ullsam_set_gemm_variant bit 15: stamp the ring kernel (tools/probes/ring8_stamps.py reads the stamps from the workspace)
@@ -722,6 +726,16 @@ static int launch_gemm_v3(GemmArgs a, hipStream_t stream) {
 // 1.25, vit.qkv 3 rounds of 1.25 x the work instead of 4; 272x256 <9,8,4> -- the bench's 4 x 1081 = 4324 prompt rows are 16 x 272: llm.wo / w2
 // one round of 256 tiles, llm.w13 7 whole rounds instead of 7.44.  The LDS-staged epilogue (odd shapes) uses up to 128 rows x 320 fp32 = 160 KiB.
 // ---------------------------------------------------------------------------------------------------------------
+// One LDS-DMA request in its SGPR-base form: wave-uniform 64-bit address + this lane's 32-bit byte offset -> LDS at `lds_addr` + 16 lane.  As asm,
+// because through the builtin hipcc adds the two with a 64-bit VALU instruction (v_lshl_add_u64) per request inside the ring loop's load slot, the
+// critical path of a stage.  M0 (the LDS base) is saved and restored inside the statement (cdna guide 5.7); no register destination; completion is
+// counted by the loop's own s_waitcnt vmcnt.
+__device__ __forceinline__ void glds16_sbase(const char* base, unsigned int off, unsigned int lds_addr) {
+    unsigned int keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_addr) : "memory");
+}
+
 template <int MI0, int MI1, int NTW, bool STAMP = false, int EMODE = 0>   // sub-tile rows of the upper / lower wave row, sub-tile columns per wave; EMODE 1: wqkv + RoPE epilogue (act 4)
 __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -855,8 +869,13 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
                 const char* bk = b_base + (size_t)(s + 2) * 64;
                 auto request = [&](int qi) __attribute__((always_inline)) {   // request qi of this wave: A0 B0 A1 B1 A2 B2 (qi is a constant after unrolling)
                     const int i = qi >> 1;
-                    if (MORE && !(qi & 1) && i < NA) __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_off[i]), LDS_PTR(base + (wave + 8 * i) * 1024), 16, 0, 0);
-                    if (MORE && (qi & 1) && i < NB) __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + ASZ + (wave + 8 * i) * 1024), 16, 0, 0);
+                    if (g_asm_dma) {
+                        if (MORE && !(qi & 1) && i < NA) glds16_sbase(ak, a_off[i], (unsigned int)(uintptr_t)LDS_PTR(base + (wave + 8 * i) * 1024));
+                        if (MORE && (qi & 1) && i < NB) glds16_sbase(bk, b_off[i], (unsigned int)(uintptr_t)LDS_PTR(base + ASZ + (wave + 8 * i) * 1024));
+                    } else {
+                        if (MORE && !(qi & 1) && i < NA) __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_off[i]), LDS_PTR(base + (wave + 8 * i) * 1024), 16, 0, 0);
+                        if (MORE && (qi & 1) && i < NB) __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_off[i]), LDS_PTR(base + ASZ + (wave + 8 * i) * 1024), 16, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 // requests and reads alternated: one request, then three reads, ... (the order round 2 measured best)
