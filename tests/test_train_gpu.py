@@ -323,3 +323,80 @@ def test_bf16_model_runs_the_frozen_llm_on_bf16_gemms():
     assert rel(r16, r32) < 6e-2, rel(r16, r32)
     for n in g32:
         assert rel(g16[n], g32[n]) < 6e-2, (n, rel(g16[n], g32[n]))
+
+
+def _trainer_losses(pred, gt, smooth=1e-7):
+    """The trainer's OWN loss code (torch; train_joint_v2.py:605-665, 774-812: BCEWithLogits and Dice per instance, batch means), as it runs
+    unchanged on top of the modules' outputs."""
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(pred.flatten(2), gt.flatten(2), reduction="none").mean(-1)
+    p = pred.sigmoid().flatten(2)
+    t = gt.flatten(2)
+    dice = 1 - (2 * (p * t).sum(-1) + smooth) / (p.sum(-1) + t.sum(-1) + smooth)
+    return (bce + dice).mean(), bce.mean(), dice.mean()
+
+
+def test_reference_trainer_step_runs_on_the_modules_own_forwards():
+    """train_joint_v2.py:988-1100 line for line, WITHOUT the training.train_step_loss entry point: model.train(); outputs = model(pixel_values,
+    input_ids, attention_mask, labels, output_hidden_states=True); image_embeddings = model.vision_model(pixel_values); model.prompt_encoder(
+    points, boxes=None, masks=None, llm_hidden_states=outputs.hidden_states.repeat(bs, 1, 1, 1)); model.mask_decoder(...); the trainer's own
+    F.interpolate and losses; loss = 0 * outputs.loss + seg_loss; backward.  In train() mode with gradients enabled the modules' forwards
+    dispatch to the autograd graph over the HIP kernels (eval() / no_grad keeps the inference kernels).  Checked against the reference's own
+    autograd (fixture train_step.npz): the loss and all 168 parameter gradients; and eval() mode still returns the inference path's tensors."""
+    import torch.nn.functional as F
+    g = U.gold("train_step")
+    m = _ullsam_tiny(torch.float32)
+    for n, p in m.named_parameters():
+        p.requires_grad_(not n.startswith("language_model."))
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    pixel_values = t(U.rand_image((1, 3, 1024, 1024), seed=int(g["seed"])))
+    input_ids = t(g["ids"]).long()
+    attention_mask = torch.ones_like(input_ids)
+    labels = input_ids.clone()
+    points, point_labels = t(g["pts"]), t(g["lbl"])
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
+    masks = t(np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None])
+    # eval(): the inference kernels, no graph
+    m.eval()
+    out_eval = m(pixel_values=pixel_values, input_ids=input_ids, attention_mask=attention_mask, return_dict=True, use_cache=False, output_hidden_states=True)
+    assert not out_eval.hidden_states.requires_grad and not m.vision_model(pixel_values).requires_grad
+    # ---- the trainer's step (train_joint_v2.py:944, 988-1100)
+    m.train()
+    outputs = m(pixel_values=pixel_values, input_ids=input_ids, attention_mask=attention_mask, image_flags=None, labels=labels, return_dict=True,
+                use_cache=False, img_context_token_id=92546, output_hidden_states=True)
+    loss = outputs.loss
+    assert loss is not None and torch.isfinite(loss) and not loss.requires_grad
+    last_hidden_state = outputs.hidden_states
+    assert last_hidden_state.shape == (1, 256, 64, 64) and last_hidden_state.requires_grad
+    assert float((last_hidden_state.detach() - out_eval.hidden_states.float()).abs().max()) < 1e-3      # same values as the inference path
+    image_embeddings = m.vision_model(pixel_values)
+    image_pe = m.prompt_encoder.get_dense_pe().to(DEV)
+    bs = points.shape[0]
+    if last_hidden_state.shape[0] != bs:
+        last_hidden_state = last_hidden_state.repeat(bs, 1, 1, 1)
+    sparse_embeddings, dense_embeddings = m.prompt_encoder(points=(points, point_labels), boxes=None, masks=None, llm_hidden_states=last_hidden_state)
+    low_res_masks, iou_predictions = m.mask_decoder(image_embeddings=image_embeddings, image_pe=image_pe, sparse_prompt_embeddings=sparse_embeddings,
+                                                    dense_prompt_embeddings=dense_embeddings, multimask_output=False)
+    assert low_res_masks.shape == (bs, 1, 256, 256) and iou_predictions.shape == (bs, 1)
+    pred_masks = F.interpolate(low_res_masks, (m.vision_model.img_size, m.vision_model.img_size), mode="bilinear", align_corners=False)
+    seg_loss, bce, dice = _trainer_losses(pred_masks, masks)
+    loss = 0 * loss + seg_loss
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g["loss"])) < 2e-5 * float(g["loss"]), (loss.item(), float(g["loss"]))
+    params = dict(m.named_parameters())
+    names = [str(v) for v in g["names"]]
+    worst = (0.0, "")
+    for n in names:
+        ref = g["g:" + n].astype(np.float64)
+        assert params[n].grad is not None, n
+        full = params[n].grad.float().cpu().numpy().reshape(-1).astype(np.float64)
+        got = full[::max(1, full.size // 512)]
+        scale, diff = np.abs(ref).max(), np.abs(got - ref).max()
+        assert diff < 1e-3 * scale + 1e-7, (n, diff, scale)
+        if scale > 1e-6:
+            worst = max(worst, (diff / scale, n))
+    assert all(p.grad is None for n, p in params.items() if n.startswith("language_model."))
+    print(len(names), "gradients through the modules' own forwards; worst relative error", worst)
+    # validation as the trainer runs it (train_joint_v2.py:917: torch.no_grad()) stays on the inference kernels even in train() mode
+    with torch.no_grad():
+        assert not m.vision_model(pixel_values).requires_grad

@@ -165,9 +165,12 @@ class ImageEncoderViT(Packed):
         out = ops.norm(z, *n3.wb(), n3.eps, torch.float32)
         return out.reshape(B, N, C)
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        B = x.shape[0]
-        g = self.img_size // self.patch_size
-        tok = self.forward_tokens(x)
-        return ops.transpose(tok, B, g * g, self.out_chans).reshape(B, self.out_chans, g, g).to(self.compute_dtype)
+        from .. import training
+        if training.wants_autograd(self, x):     # train() mode with gradients on (train_joint_v2.py:1015-1021): the differentiable graph
+            return training.vision_forward(self, x)
+        with torch.no_grad():
+            B = x.shape[0]
+            g = self.img_size // self.patch_size
+            tok = self.forward_tokens(x)
+            return ops.transpose(tok, B, g * g, self.out_chans).reshape(B, self.out_chans, g, g).to(self.compute_dtype)

@@ -114,8 +114,11 @@ class MaskDecoder(Packed):
             raise ValueError(f"image_embeddings batch {b} is incompatible with {P} prompts (reference repeat_interleave semantics)")
         return self.predict_masks_tokens(img, pe, sparse_prompt_embeddings, dense, (h, w))
 
-    @torch.no_grad()
     def forward(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output: bool):
-        masks, iou_pred = self.predict_masks(image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings)
-        sl = slice(1, None) if multimask_output else slice(0, 1)  # mask_decoder.py:100-105
-        return masks[:, sl, :, :], iou_pred[:, sl]
+        from .. import training
+        if training.wants_autograd(self, image_embeddings, sparse_prompt_embeddings, dense_prompt_embeddings):   # train_joint_v2.py:1063-1069
+            return training.mask_decoder_forward(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output)
+        with torch.no_grad():
+            masks, iou_pred = self.predict_masks(image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings)
+            sl = slice(1, None) if multimask_output else slice(0, 1)  # mask_decoder.py:100-105
+            return masks[:, sl, :, :], iou_pred[:, sl]

@@ -115,12 +115,22 @@ class InternVLSAMModel(Packed):
         x = x.reshape(n, int(w * scale_factor), int(h * scale_factor), int(c / (scale_factor * scale_factor)))
         return x.permute(0, 2, 1, 3).contiguous()
 
-    @torch.no_grad()
     def forward(self, pixel_values, input_ids=None, attention_mask=None, position_ids=None, image_flags=None, past_key_values=None,
                 labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
                 img_context_token_id=None):
         if return_dict is False:
             raise NotImplementedError("tuple outputs are not provided; use return_dict=True (what app.py / train_joint_v2.py pass)")
+        from .. import training
+        if training.wants_autograd(self) and past_key_values is None and position_ids is None:
+            # train() mode with gradients on (train_joint_v2.py:988-998): mlp1 -> frozen LLM -> mlp2 as an autograd graph over HIP kernels
+            return training.composite_forward(self, pixel_values, input_ids, attention_mask, labels, output_hidden_states)
+        with torch.no_grad():
+            return self._forward_inference(pixel_values, input_ids, attention_mask, position_ids, image_flags, past_key_values, labels, use_cache,
+                                           output_attentions, output_hidden_states, return_dict, img_context_token_id)
+
+    def _forward_inference(self, pixel_values, input_ids=None, attention_mask=None, position_ids=None, image_flags=None, past_key_values=None,
+                           labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
+                           img_context_token_id=None):
         B, S = input_ids.shape
         dev = input_ids.device
         lm = self.language_model

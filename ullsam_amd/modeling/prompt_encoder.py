@@ -127,8 +127,14 @@ class PromptEncoder(Packed):
             return masks.shape[0]
         return 1
 
-    @torch.no_grad()
     def forward(self, points, boxes, masks, llm_hidden_states: Optional[torch.Tensor] = None):
+        from .. import training
+        if training.wants_autograd(self, llm_hidden_states):   # train() mode with gradients on (train_joint_v2.py:1055-1060)
+            return training.prompt_encoder_forward(self, points, boxes, masks, llm_hidden_states)
+        with torch.no_grad():
+            return self._forward_inference(points, boxes, masks, llm_hidden_states)
+
+    def _forward_inference(self, points, boxes, masks, llm_hidden_states: Optional[torch.Tensor] = None):
         bs = self._get_batch_size(points, boxes, masks)
         h, w = self.image_embedding_size
         C = self.embed_dim

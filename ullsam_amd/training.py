@@ -726,7 +726,8 @@ def segmentation_loss(model, llm_hidden: torch.Tensor, image_embeddings: Optiona
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # Second slice: the projector mlp1 and the (frozen) LLM between the vision features and the hidden states the first slice starts from.
-def llm_image_hidden(model, vit_feature_rows: torch.Tensor, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+def llm_image_hidden(model, vit_feature_rows: torch.Tensor, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                     return_all: bool = False):
     """The LLM's last hidden state over the image tokens, differentiable with respect to `mlp1` (and to the vision features):
     extract_feature's pixel_shuffle + mlp1 (modeling_internvl_sam.py:226-251), the image-token splice of forward (:136-158), InternLM2's
     layers (modeling_internlm2.py:598-618, 345-419, 75-89; frozen weights receive no gradient work) and the image-token slice of :195-205.
@@ -775,6 +776,8 @@ def llm_image_hidden(model, vit_feature_rows: torch.Tensor, input_ids: torch.Ten
     x = RMSNormFn.apply(x, lm.model.norm.weight, lm.model.norm.variance_epsilon).reshape(B, S, D)
     idx = sel.reshape(B, S).nonzero(as_tuple=True)[1]
     start, end = int(idx.min()), int(idx.max()) + 1                              # one span for the batch, as the reference takes it (:198-201)
+    if return_all:
+        return x[:, start:end], x
     return x[:, start:end]
 
 
@@ -834,6 +837,131 @@ def vision_feature_rows(enc, pixel_values: torch.Tensor) -> torch.Tensor:
     y = _ln(n1, LinearFn.apply(x, n0.weight.reshape(C, D), None))
     z = LinearFn.apply(Im2col3x3Fn.apply(y, B, g, g), n2.weight.permute(0, 2, 3, 1).reshape(C, 9 * C), None)
     return _ln(n3, z).reshape(B, N, C)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# The same graph behind the MODULES' own forward: in train() mode, with gradients enabled and something to differentiate, ImageEncoderViT /
+# PromptEncoder / MaskDecoder / InternVLSAMModel.forward dispatch here, so that the reference's trainer (train_joint_v2.py:988-1100: model(...),
+# model.vision_model(...), model.prompt_encoder(...), model.mask_decoder(...), then its own F.interpolate and calc_instance_loss) runs
+# without edits.  NCHW <-> row conversions are torch data movement (permute / reshape); the arithmetic is the Functions above.
+def wants_autograd(module: torch.nn.Module, *tensors) -> bool:
+    """train() mode + autograd on + a parameter of the module or one of the given inputs to differentiate.  eval() models (what build_sam and
+    app.py use) and calls under torch.no_grad() (the trainer's validation) stay on the inference kernels."""
+    if not (module.training and torch.is_grad_enabled()):
+        return False
+    if any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        return True
+    return any(p.requires_grad for p in module.parameters())
+
+
+def _rows_to_nchw(rows: torch.Tensor, B: int, h: int, w: int) -> torch.Tensor:
+    return rows.reshape(B, h, w, -1).permute(0, 3, 1, 2)
+
+
+def _nchw_to_rows(x: torch.Tensor) -> torch.Tensor:
+    B, C, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * h * w, C)
+
+
+def vision_forward(enc, pixel_values: torch.Tensor) -> torch.Tensor:
+    """ImageEncoderViT.forward with gradients (image_encoder.py:106-117): [B, 3, S, S] -> [B, out_chans, S/16, S/16] fp32."""
+    g = enc.img_size // enc.patch_size
+    return _rows_to_nchw(vision_feature_rows(enc, pixel_values), pixel_values.shape[0], g, g)
+
+
+def prompt_encoder_forward(pe, points, boxes, masks, llm_hidden_states):
+    """PromptEncoder.forward with gradients (prompt_encoder.py:153-203) for what the reference's training step passes: point prompts (+ the
+    pad point) and the LLM dense prompt; -> (sparse [P, n + 1, C], dense [P, C, h, w]) fp32."""
+    if boxes is not None or masks is not None:
+        raise NotImplementedError("the differentiable prompt encoder covers the trainer's step: points + llm_hidden_states (train_joint_v2.py:1055-1060)")
+    if points is None:
+        raise NotImplementedError("the differentiable prompt encoder needs point prompts")
+    h, w = pe.image_embedding_size
+    C = pe.embed_dim
+    dev = pe.no_mask_embed.weight.device
+    coords, labels = points[0].to(dev).float().contiguous(), points[1].to(dev).to(torch.int32).contiguous()
+    P = coords.shape[0]
+    table = torch.cat([pe.not_a_point_embed.weight] + [e.weight for e in pe.point_embeddings], 0)
+    sparse = SparseEmbedFn.apply(table, coords, labels, pe.pe_layer.G(), pe.input_image_size)
+    if llm_hidden_states is not None:
+        x = llm_hidden_states
+        n = x.shape[0]
+        rows = _nchw_to_rows(_c(x) if not x.requires_grad else x.float())
+        dense_rows = ScaleShiftFn.apply(LayerNormFn.apply(rows, None, None, 1e-5), pe.llm_scale_factor, pe.llm_bias)
+        dense = _rows_to_nchw(dense_rows, n, h, w)
+        if n != P:
+            dense = dense.reshape(P, -1, h, w)   # same failure mode as the reference's reshape (:195-197)
+    else:
+        dense = _rows_to_nchw(BroadcastRowsFn.apply(pe.no_mask_embed.weight.reshape(1, C), P * h * w).reshape(P * h * w, C), P, h, w)
+    return sparse, dense
+
+
+def mask_decoder_forward(md, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output: bool):
+    """MaskDecoder.forward with gradients (mask_decoder.py:71-149): -> (masks [P, 1 or 3, 4h, 4w], iou_pred [P, 1 or 3]) fp32."""
+    B, C, h, w = image_embeddings.shape
+    N = h * w
+    sparse = sparse_prompt_embeddings if sparse_prompt_embeddings.dtype == F32 else sparse_prompt_embeddings.float()
+    P = sparse.shape[0]
+    if B != 1 and B != P:
+        raise ValueError(f"image_embeddings batch {B} is incompatible with {P} prompts (reference repeat_interleave semantics)")
+    out_tok = torch.cat([md.iou_token.weight, md.mask_tokens.weight], 0)
+    tokens = torch.cat([BroadcastRowsFn.apply(out_tok, P), sparse], 1)
+    img_rows = _nchw_to_rows(image_embeddings.float())                                     # [B*N, C]
+    d = dense_prompt_embeddings
+    if d.shape[0] != P:
+        d = d.expand(P, C, h, w)
+    src = AddFn.apply(_nchw_to_rows(d.float()), img_rows)                                  # repeat_interleave(image, P) + dense (:126-127)
+    key_pe = _nchw_to_rows(image_pe[:1].detach().float()).contiguous()
+    hs, keys = _two_way_transformer(md.transformer, src, key_pe, tokens)
+    up0, ln, up1 = md.output_upscaling[0], md.output_upscaling[1], md.output_upscaling[3]
+    c8 = C // 8
+    u = _conv_transpose_k2s2(up0, keys)
+    u = ActFn.apply(LayerNormFn.apply(u, ln.weight, ln.bias, ln.eps), 1)
+    u = ActFn.apply(_conv_transpose_k2s2(up1, u), 1)
+    nm = md.num_mask_tokens
+
+    def mlp(m, x):
+        for j, l in enumerate(m.layers):
+            x = _linear(l, x)
+            if j < m.num_layers - 1:
+                x = ActFn.apply(x, 2)
+        return x
+
+    hyper = torch.stack([mlp(md.output_hypernetworks_mlps[i], hs[:, 1 + i, :]) for i in range(nm)], 1)
+    m = HyperMasksFn.apply(hyper, u.reshape(P, N * 16, c8))
+    m = m.reshape(P, nm, h, w, 2, 2, 2, 2).permute(0, 1, 2, 4, 6, 3, 5, 7).reshape(P, nm, 4 * h, 4 * w)
+    iou = mlp(md.iou_prediction_head, hs[:, 0, :])
+    sl = slice(1, None) if multimask_output else slice(0, 1)                               # mask_decoder.py:100-105
+    return m[:, sl, :, :], iou[:, sl]
+
+
+def composite_forward(model, pixel_values, input_ids, attention_mask=None, labels=None, output_hidden_states=None):
+    """InternVLSAMModel.forward with gradients (modeling_internvl_sam.py:106-224 as train_joint_v2.py:988-998 calls it): the vision model runs
+    without gradients here, as in the reference (extract_feature, :243-244); mlp1 -> frozen LLM -> mlp2 is differentiable; `.loss` is the
+    language-model loss of the reference's forward as a VALUE (the trainer multiplies it by zero, :1096; the LLM is frozen); `.hidden_states`
+    is the dense feature [B, 256, 64, 64] the segmentation branch continues from."""
+    from .modeling.outputs import CausalLMOutputWithPast
+    lm = model.language_model
+    B, S = input_ids.shape
+    with torch.no_grad():
+        img_tok = model.vision_model.forward_tokens(pixel_values)                          # [B, 4096, 256] fp32
+        g = int(math.sqrt(img_tok.shape[1]))
+        image_embeddings = ops.transpose(img_tok, B, g * g, img_tok.shape[-1]).reshape(B, -1, g, g).to(model.dtype)
+    hidden_img, hidden_all = llm_image_hidden(model, img_tok, input_ids, attention_mask, return_all=True)
+    loss = None
+    logits_fn = lambda: lm.lm_head(hidden_all.detach())
+    if labels is not None:
+        with torch.no_grad():
+            logits = logits_fn()
+            loss = torch.nn.functional.cross_entropy(logits[..., :-1, :].reshape(-1, lm.vocab_size), labels[..., 1:].reshape(-1).to(logits.device))
+    hs = None
+    if output_hidden_states:
+        hs = _rows_to_nchw(dense_feature_rows(model, hidden_img), B, g, g)
+    ret = CausalLMOutputWithPast(loss=loss, logits=None, logits_fn=logits_fn, past_key_values=None, hidden_states=hs, attentions=None)
+    ret.image_embeddings = image_embeddings
+    ret.image_tokens = img_tok
+    ret.dense_feature_tokens = None
+    return ret
 
 
 def train_step_loss(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
