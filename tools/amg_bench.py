@@ -1,8 +1,9 @@
 """Throughput of the automatic mask generator (BASELINE.json configs[4] shape: 64x64 point grid on a 2048^2 tile, SAM ViT-H;
 ULLSAM_FP8=1 switches the encoder's LayerNorm-fed linears to the fp8 (e4m3) MFMA path of that config).  Synthetic microscopy tile, random-init
-weights; the default thresholds are those of tests/test_amg_gpu.py::test_generator_real_size_vit_h_2048_tile_bf16_and_fp8 (the ~90th / ~87th
-percentile of the random decoder's scores, box NMS at 1.0), so that masks SURVIVE and box NMS + RLE emission are inside the timed tile.
-usage: [ULLSAM_FP8=1] python tools/amg_bench.py [points_per_side] [tile] [vit] [stability_thresh] [stability_offset] [iters] [pred_iou_thresh]"""
+encoder, the STRUCTURED disc-drawing decoder of ullsam_amd.utils.synthetic.blob_decoder_init (no weights exist offline, and a random decoder's
+masks are full-frame textures whose boxes are all the whole tile); thresholds of tests/test_amg_gpu.py::test_generator_real_size_vit_h_2048_tile_with_box_nms:
+predicted IoU 0.90, stability 0.92 at offset 1.0, box NMS at SAM's 0.7 -- every filter removes candidates and a few hundred records survive.
+usage: [ULLSAM_FP8=1] python tools/amg_bench.py [points_per_side] [tile] [vit] [stability_thresh] [stability_offset] [iters] [pred_iou_thresh] [box_nms]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,15 +14,16 @@ from ullsam_amd.automatic_mask_generator import SamAutomaticMaskGenerator
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 tile = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 vit = sys.argv[3] if len(sys.argv) > 3 else "h"
-stab = float(sys.argv[4]) if len(sys.argv) > 4 else 0.87
-off = float(sys.argv[5]) if len(sys.argv) > 5 else 0.1
+stab = float(sys.argv[4]) if len(sys.argv) > 4 else 0.92
+off = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 3
-piou = float(sys.argv[7]) if len(sys.argv) > 7 else 0.2
-nms = float(sys.argv[8]) if len(sys.argv) > 8 else 1.0   # a random-init decoder's boxes are all full-frame: SAM's 0.7 would keep one record
+piou = float(sys.argv[7]) if len(sys.argv) > 7 else 0.90
+nms = float(sys.argv[8]) if len(sys.argv) > 8 else 0.7
 if os.environ.get("ULLSAM_GEMM_VARIANT"):
     from ullsam_amd import _lib
     _lib.load().ullsam_set_gemm_variant(int(os.environ["ULLSAM_GEMM_VARIANT"]))
-sam = build_model(vit, "none", torch.bfloat16, "cuda:0")
+from ullsam_amd.utils.synthetic import blob_decoder_init
+sam = blob_decoder_init(build_model(vit, "none", torch.bfloat16, "cuda:0"))
 fp8 = os.environ.get("ULLSAM_FP8") == "1"
 sam.image_encoder.fp8_linears = fp8
 gen = SamAutomaticMaskGenerator(sam, points_per_side=side, points_per_batch=64, pred_iou_thresh=piou, stability_score_thresh=stab,
