@@ -407,3 +407,28 @@ def test_generator_real_size_fp8_encoder_against_bf16():
           f"mask IoU of matched pairs min {min(ious):.4f} mean {float(np.mean(ious)):.4f}")
     assert share >= 0.8, share
     assert min(ious) >= 0.94 and float(np.mean(ious)) >= 0.96, ious     # the fp8 path's stated accuracy (README / DESIGN 7c): mask IoU ~0.97 vs bf16, a correctness demonstration
+
+
+def test_generate_batch_equals_generate_per_tile_under_rccl_world_1():
+    """generate_batch (tiles sharded over ranks, ragged records gathered) with an RCCL process group of one rank -- what one box offers -- returns
+    exactly the per-tile `generate` results in tile order; the world-2 split is covered under gloo (tests/test_host_cpu.py)."""
+    import os
+    import torch.distributed as dist
+    from ullsam_amd.automatic_mask_generator import SamAutomaticMaskGenerator
+    from ullsam_amd.utils.synthetic import blob_decoder_init
+    sam, _ = _small_sam()
+    blob_decoder_init(sam)
+    imgs = [torch.from_numpy(U.rand_image((3, 512, 640), 30 + i, 255.0)) for i in range(3)]
+    gen = SamAutomaticMaskGenerator(sam, points_per_side=8, points_per_batch=64, pred_iou_thresh=0.90, stability_score_thresh=0.92, output_mode="uncompressed_rle")
+    want = [gen.generate(im) for im in imgs]
+    assert sum(len(w) for w in want) > 0
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29583")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        got = gen.generate_batch(imgs)
+    finally:
+        if own:
+            dist.destroy_process_group()
+    assert got == want

@@ -569,3 +569,53 @@ def test_gloo_world2_overlapped_gather_with_unequal_step_times():
     assert [r[:2] for r in res] == [(0, True), (1, True)], res
     dts = [r[2] for r in res]
     assert abs(dts[0] - dts[1]) < 1e-9 and dts[0] >= 6 * 0.05      # the all-reduced MAX: >= the slow rank's six sleeps, identical on both ranks
+
+
+def _gloo_amg_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from ullsam_amd import parallel
+    from ullsam_amd.automatic_mask_generator import SamAutomaticMaskGenerator
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        class StubGenerator(SamAutomaticMaskGenerator):          # the sharding / gather logic of generate_batch without a GPU model
+            def __init__(self):
+                self.calls = []
+
+            def generate(self, image):
+                self.calls.append(int(image))
+                n = int(image) % 4                                # ragged: 0 .. 3 records per tile, RLE lists of different lengths
+                return [{"tile": int(image), "k": k, "segmentation": {"size": [8, 8], "counts": list(range(int(image) + k + 1))}} for k in range(n)]
+
+        ok = True
+        for n_tiles in (5, 2, 1, 0):                              # ragged split, even split, fewer tiles than ranks, nothing at all
+            gen = StubGenerator()
+            res = gen.generate_batch(list(range(10, 10 + n_tiles)))
+            a, b = parallel.shard_range(n_tiles, rank, world)
+            ok = ok and gen.calls == list(range(10 + a, 10 + b))  # this rank generated exactly its own share
+            ok = ok and len(res) == n_tiles
+            for i, recs in enumerate(res):
+                t = 10 + i
+                ok = ok and [r["tile"] for r in recs] == [t] * (t % 4) and all(r["segmentation"]["counts"] == list(range(t + r["k"] + 1)) for r in recs)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_mask_generator_shards_tiles_and_gathers_ragged_records():
+    """SamAutomaticMaskGenerator.generate_batch under a world-2 gloo group: every rank generates only its share of the tiles, and all ranks end
+    up with every tile's (ragged) record list in tile order -- including more ranks than tiles and no tiles at all."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_amg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)], res

@@ -173,6 +173,17 @@ class SamAutomaticMaskGenerator:
         data["crop_boxes"] = torch.tensor([crop_box for _ in range(len(data["rles"]))], device=data["boxes"].device).reshape(-1, 4)
         return data
 
+    def generate_batch(self, images, group=None) -> List[List[Dict[str, Any]]]:
+        """Several tiles (BASELINE configs[4]: 2048^2 tiles over the 8 GPUs of a node): tiles are independent units, so with torch.distributed
+        initialised (one process per GPU) every rank generates the masks of its contiguous share of `images` (parallel.shard_range) and the
+        ragged record lists are exchanged once at the end (parallel.gather_sharded_lists); every rank returns all tiles' records in tile order.
+        Without a process group it is a loop over `generate`."""
+        from . import parallel
+        rank, ws = parallel.world()
+        a, b = parallel.shard_range(len(images), rank, ws)
+        mine = [self.generate(images[i]) for i in range(a, b)]
+        return parallel.gather_sharded_lists(mine, len(images), group)
+
     @torch.no_grad()
     def generate(self, image) -> List[Dict[str, Any]]:
         """image: HxWx3 uint8 / float array (0..255) or a [3,H,W] tensor.  Returns SAM-style records sorted as generated."""

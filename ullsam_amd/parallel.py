@@ -128,3 +128,23 @@ def gather_mask_results_async(low_res_logits: torch.Tensor, masks_u8: torch.Tens
                               counts: Optional[List[int]] = None, group=None) -> _Pending:
     """Same exchange, returned as a handle: `.wait()` gives (logits, masks, token ids).  Lets step k+1's compute overlap it."""
     return packed_all_gather([low_res_logits, masks_u8, token_ids], counts, group, async_op=True)
+
+
+def gather_sharded_lists(local: list, n_items: int, group=None) -> list:
+    """Units of work (tiles of the automatic mask generator, BASELINE configs[4]) are dealt to the ranks by `shard_range`; every rank passes the
+    results of ITS units (a list with one entry per local unit, each entry any picklable object -- e.g. a tile's ragged list of mask records) and
+    gets back the results of all `n_items` units in unit order.  One collective (all_gather_object: sizes, then the pickled payloads as byte
+    tensors over RCCL / gloo); a rank that holds zero units still takes part."""
+    rank, ws = world()
+    a, b = shard_range(n_items, rank, ws)
+    assert len(local) == b - a, (len(local), a, b)
+    if ws == 1:
+        return list(local)
+    parts = [None] * ws
+    dist.all_gather_object(parts, list(local), group=group)
+    out = []
+    for r in range(ws):
+        ra, rb = shard_range(n_items, r, ws)
+        assert len(parts[r]) == rb - ra, (r, len(parts[r]), ra, rb)
+        out.extend(parts[r])
+    return out
