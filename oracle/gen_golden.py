@@ -543,12 +543,15 @@ def case_train_slice():
     import train_joint_v2 as TJ
     from modeling.configuration_internvl_chat import InternVLChatConfig
     from modeling.modeling_internvl_sam import InternVLSAMModel
-    sam = _sam_small()
-    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_TINY),
+    sam = _sam_small(depth=2, embed_dim=768, heads=12, glob=(1,)) if real_dims else _sam_small()
+    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_7B_L1) if real_dims else dict(LLM_TINY),
                              downsample_ratio=0.5, template="internlm2-chat", ps_version="v2", force_image_size=1024)
     cfg.llm_config.rope_scaling = None
     m = InternVLSAMModel(cfg, vision_model=sam.image_encoder, prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder)
-    fill_module(m, seed=0)
+    if real_dims:
+        fill_module_inplace(m, seed=0)
+    else:
+        fill_module(m, seed=0)
     m.train()
     for p_ in m.parameters():
         p_.requires_grad_(True)
@@ -601,12 +604,15 @@ def case_train_llm_slice():
     import train_joint_v2 as TJ
     from modeling.configuration_internvl_chat import InternVLChatConfig
     from modeling.modeling_internvl_sam import InternVLSAMModel
-    sam = _sam_small()
-    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_TINY),
+    sam = _sam_small(depth=2, embed_dim=768, heads=12, glob=(1,)) if real_dims else _sam_small()
+    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_7B_L1) if real_dims else dict(LLM_TINY),
                              downsample_ratio=0.5, template="internlm2-chat", ps_version="v2", force_image_size=1024)
     cfg.llm_config.rope_scaling = None
     m = InternVLSAMModel(cfg, vision_model=sam.image_encoder, prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder)
-    fill_module(m, seed=0)
+    if real_dims:
+        fill_module_inplace(m, seed=0)
+    else:
+        fill_module(m, seed=0)
     m.train()
     for n_, p_ in m.named_parameters():
         p_.requires_grad_(not n_.startswith(("language_model.", "vision_model.")))
@@ -675,12 +681,15 @@ def case_train_vit_slice():
     import train_joint_v2 as TJ
     from modeling.configuration_internvl_chat import InternVLChatConfig
     from modeling.modeling_internvl_sam import InternVLSAMModel
-    sam = _sam_small()
-    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_TINY),
+    sam = _sam_small(depth=2, embed_dim=768, heads=12, glob=(1,)) if real_dims else _sam_small()
+    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_7B_L1) if real_dims else dict(LLM_TINY),
                              downsample_ratio=0.5, template="internlm2-chat", ps_version="v2", force_image_size=1024)
     cfg.llm_config.rope_scaling = None
     m = InternVLSAMModel(cfg, vision_model=sam.image_encoder, prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder)
-    fill_module(m, seed=0)
+    if real_dims:
+        fill_module_inplace(m, seed=0)
+    else:
+        fill_module(m, seed=0)
     m.train()
     for n_, p_ in m.named_parameters():
         p_.requires_grad_(not n_.startswith("language_model."))
@@ -715,8 +724,11 @@ def case_train_vit_slice():
     save("train_vit_slice", **out)
 
 
-def case_train_step():
-    """One whole step of the reference's trainer on the `ullsam_tiny` composite, as train_joint_v2.py:990-1100 runs it: model(pixel_values,
+def case_train_step(real_dims: bool = False):
+    """(real_dims: the same step on a composite with the bench configuration's HEAD DIMENSIONS -- SAM ViT-B width (768 = 12 heads x 64, one
+    windowed + one global block on the 64 x 64 token grid) and ONE 7B-shaped InternLM2 layer (hidden 4096, 32 heads / 8 KV heads x 128,
+    intermediate 14336) -> fixture train_step_real.)
+    One whole step of the reference's trainer on the `ullsam_tiny` composite, as train_joint_v2.py:990-1100 runs it: model(pixel_values,
     input_ids, ..., output_hidden_states=True) -> outputs.hidden_states (the text-aware dense feature), image_embeddings =
     model.vision_model(pixel_values) with gradients, prompt encoder, mask decoder, upsample, calc_instance_loss; LLM frozen, everything else
     trainable (setup_model_params :1280-1359).  Stored: the loss and a sample + norm of the gradient of EVERY trainable parameter."""
@@ -731,12 +743,15 @@ def case_train_step():
     import train_joint_v2 as TJ
     from modeling.configuration_internvl_chat import InternVLChatConfig
     from modeling.modeling_internvl_sam import InternVLSAMModel
-    sam = _sam_small()
-    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_TINY),
+    sam = _sam_small(depth=2, embed_dim=768, heads=12, glob=(1,)) if real_dims else _sam_small()
+    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_7B_L1) if real_dims else dict(LLM_TINY),
                              downsample_ratio=0.5, template="internlm2-chat", ps_version="v2", force_image_size=1024)
     cfg.llm_config.rope_scaling = None
     m = InternVLSAMModel(cfg, vision_model=sam.image_encoder, prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder)
-    fill_module(m, seed=0)
+    if real_dims:
+        fill_module_inplace(m, seed=0)
+    else:
+        fill_module(m, seed=0)
     m.train()
     for n_, p_ in m.named_parameters():
         p_.requires_grad_(not n_.startswith("language_model."))
@@ -771,10 +786,10 @@ def case_train_step():
         out["g:" + name] = g[::stride].copy()
         out["n:" + name] = np.float32(np.sqrt((g.astype(np.float64) ** 2).sum()))
     out["names"] = np.array(names)
-    save("train_step", **out)
+    save("train_step_real" if real_dims else "train_step", **out)
 
 
-CASES = {"train_step": case_train_step, "train_vit_slice": case_train_vit_slice, "train_slice": case_train_slice, "train_llm_slice": case_train_llm_slice, "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
+CASES = {"train_step": case_train_step, "train_step_real": lambda: case_train_step(real_dims=True), "train_vit_slice": case_train_vit_slice, "train_slice": case_train_slice, "train_llm_slice": case_train_llm_slice, "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
          "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full,
          "vit_h_d2": case_vit_h_d2, "llm_7b_l1": case_llm_7b_l1,
          "rope_variants": case_rope_variants, "llm_tiny_bias_linear": case_llm_tiny_bias_linear,

@@ -400,3 +400,80 @@ def test_reference_trainer_step_runs_on_the_modules_own_forwards():
     # validation as the trainer runs it (train_joint_v2.py:917: torch.no_grad()) stays on the inference kernels even in train() mode
     with torch.no_grad():
         assert not m.vision_model(pixel_values).requires_grad
+
+
+def _ullsam_real_dims(dtype):
+    """The composite at the bench configuration's HEAD DIMENSIONS: SAM ViT-B width (768 = 12 heads x 64; one windowed + one global block on the
+    64 x 64 grid) and one 7B-shaped InternLM2 layer (hidden 4096, 32 heads / 8 KV heads x 128, intermediate 14336), filled like the fixtures."""
+    from ullsam_amd.build_sam import _build_sam
+    from ullsam_amd.modeling.configuration_internvl_chat import InternVLChatConfig
+    from ullsam_amd.modeling.modeling_internvl_sam import InternVLSAMModel
+    from tests.test_model_gpu import _fill_model_from_rule
+    c = U.LLM_7B_L1
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        with torch.device(DEV):
+            sam = _build_sam(768, 2, 12, [1])
+            cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]},
+                                     llm_config=dict(architectures=["InternLM2ForCausalLM"], vocab_size=c["vocab"], hidden_size=c["hidden"],
+                                                     intermediate_size=c["inter"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
+                                                     num_key_value_heads=c["kv_heads"], bias=False, max_position_embeddings=32768,
+                                                     rope_theta=c["rope_theta"], rms_norm_eps=c["eps"]),
+                                     downsample_ratio=0.5, template="internlm2-chat", ps_version="v2", force_image_size=1024)
+            m = InternVLSAMModel(cfg, vision_model=sam.image_encoder, prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder)
+    finally:
+        torch.set_default_dtype(old)
+    return _fill_model_from_rule(m.to(DEV).to(dtype), 0)
+
+
+def test_whole_train_step_gradients_at_real_head_dimensions():
+    """The reference trainer's step (train_joint_v2.py:990-1100; fixture train_step_real.npz = the reference's own autograd) on a composite with the
+    bench configuration's head dimensions -- ViT width 768 (12 heads x 64), a windowed and a GLOBAL block on the 64 x 64 grid (the matrix-form
+    attention: 4096 x 4096 scores per head), one 7B-shaped InternLM2 layer (32 heads / 8 KV heads x 128, 14336 intermediate) with the MFMA linears
+    on their real shapes -- through the modules' own forwards: the loss and every parameter gradient within 1e-3 of the tensor's largest entry."""
+    import torch.nn.functional as F
+    from ullsam_amd import training
+    assert training.MFMA_LINEAR
+    g = U.gold("train_step_real")
+    m = _ullsam_real_dims(torch.float32)
+    for n, p in m.named_parameters():
+        p.requires_grad_(not n.startswith("language_model."))
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    pixel_values = t(U.rand_image((1, 3, 1024, 1024), seed=int(g["seed"])))
+    input_ids = t(g["ids"]).long()
+    points, point_labels = t(g["pts"]), t(g["lbl"])
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
+    masks = t(np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None])
+    m.train()
+    torch.cuda.synchronize(); t0 = __import__("time").perf_counter()
+    outputs = m(pixel_values=pixel_values, input_ids=input_ids, attention_mask=torch.ones_like(input_ids), return_dict=True, use_cache=False,
+                output_hidden_states=True)
+    image_embeddings = m.vision_model(pixel_values)
+    bs = points.shape[0]
+    sparse, dense = m.prompt_encoder(points=(points, point_labels), boxes=None, masks=None, llm_hidden_states=outputs.hidden_states.repeat(bs, 1, 1, 1))
+    low, _ = m.mask_decoder(image_embeddings=image_embeddings, image_pe=m.prompt_encoder.get_dense_pe(), sparse_prompt_embeddings=sparse,
+                            dense_prompt_embeddings=dense, multimask_output=False)
+    pred = F.interpolate(low, (1024, 1024), mode="bilinear", align_corners=False)
+    loss, bce, dice = _trainer_losses(pred, masks)
+    loss.backward()
+    torch.cuda.synchronize(); print(f"step at real head dimensions (forward + backward, fp32): {__import__('time').perf_counter() - t0:.3f} s, "
+                                    f"peak memory {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
+    assert abs(loss.item() - float(g["loss"])) < 5e-5 * float(g["loss"]), (loss.item(), float(g["loss"]))
+    params = dict(m.named_parameters())
+    names = [str(v) for v in g["names"]]
+    assert {n.split(".")[0] for n in names} == {"vision_model", "mlp1", "mlp2", "prompt_encoder", "mask_decoder"}
+    worst = (0.0, "")
+    for n in names:
+        ref = g["g:" + n].astype(np.float64)
+        assert params[n].grad is not None, n
+        full = params[n].grad.float().cpu().numpy().reshape(-1).astype(np.float64)
+        got = full[::max(1, full.size // 512)]
+        scale, diff = np.abs(ref).max(), np.abs(got - ref).max()
+        assert diff < 1e-3 * scale + 1e-7, (n, diff, scale)
+        if scale > 1e-6:
+            worst = max(worst, (diff / scale, n))
+        nref = float(g["n:" + n])
+        assert abs(np.sqrt((full ** 2).sum()) - nref) < 1e-3 * nref + 1e-6, (n, np.sqrt((full ** 2).sum()), nref)
+    assert all(p.grad is None for n, p in params.items() if n.startswith("language_model."))
+    print(len(names), "gradients at real head dimensions; worst relative error", worst)
