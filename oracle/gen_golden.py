@@ -543,15 +543,12 @@ def case_train_slice():
     import train_joint_v2 as TJ
     from modeling.configuration_internvl_chat import InternVLChatConfig
     from modeling.modeling_internvl_sam import InternVLSAMModel
-    sam = _sam_small(depth=2, embed_dim=768, heads=12, glob=(1,)) if real_dims else _sam_small()
-    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_7B_L1) if real_dims else dict(LLM_TINY),
+    sam = _sam_small()
+    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_TINY),
                              downsample_ratio=0.5, template="internlm2-chat", ps_version="v2", force_image_size=1024)
     cfg.llm_config.rope_scaling = None
     m = InternVLSAMModel(cfg, vision_model=sam.image_encoder, prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder)
-    if real_dims:
-        fill_module_inplace(m, seed=0)
-    else:
-        fill_module(m, seed=0)
+    fill_module(m, seed=0)
     m.train()
     for p_ in m.parameters():
         p_.requires_grad_(True)
@@ -587,8 +584,10 @@ def case_train_slice():
     save("train_slice", **out)
 
 
-def case_train_llm_slice():
-    """As case_train_slice, but the LLM hidden states are no longer an input: the vision features (seeded, constant -- the reference
+def case_train_llm_slice(pad: int = 0):
+    """(pad > 0: the prompt is LEFT-PADDED by `pad` positions with attention_mask = 0 there -- the additive finfo.min padding mask of
+    modeling_internlm2.py:114-125 in the training attention's forward and backward -> fixture train_llm_slice_pad.)
+    As case_train_slice, but the LLM hidden states are no longer an input: the vision features (seeded, constant -- the reference
     computes them under no_grad, modeling_internvl_sam.py:243-244) go through pixel_shuffle + mlp1, are spliced into the token embeddings
     (:136-158), run through the tiny InternLM2 (2 layers, frozen) and come out as hidden_states[-1] over the image tokens (:195-205) before
     the segmentation branch.  Stored: the loss, the gradients of mlp1 (reached only through the LLM's backward), of mlp2 and of a few
@@ -604,15 +603,12 @@ def case_train_llm_slice():
     import train_joint_v2 as TJ
     from modeling.configuration_internvl_chat import InternVLChatConfig
     from modeling.modeling_internvl_sam import InternVLSAMModel
-    sam = _sam_small(depth=2, embed_dim=768, heads=12, glob=(1,)) if real_dims else _sam_small()
-    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_7B_L1) if real_dims else dict(LLM_TINY),
+    sam = _sam_small()
+    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_TINY),
                              downsample_ratio=0.5, template="internlm2-chat", ps_version="v2", force_image_size=1024)
     cfg.llm_config.rope_scaling = None
     m = InternVLSAMModel(cfg, vision_model=sam.image_encoder, prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder)
-    if real_dims:
-        fill_module_inplace(m, seed=0)
-    else:
-        fill_module(m, seed=0)
+    fill_module(m, seed=0)
     m.train()
     for n_, p_ in m.named_parameters():
         p_.requires_grad_(not n_.startswith(("language_model.", "vision_model.")))
@@ -620,6 +616,10 @@ def case_train_llm_slice():
     feat = rng.standard_normal((1, 256, 64, 64), dtype=np.float32)              # vision_model output (NCHW)
     img = rng.standard_normal((1, 256, 64, 64), dtype=np.float32)               # image embedding for the decoder (second ViT call in the trainer)
     ids = O.make_input_ids(n_text_pre=20, n_text_post=34, seed=1)
+    amask = np.ones_like(ids)
+    if pad:
+        ids = np.concatenate([np.full((1, pad), 2, ids.dtype), ids], 1)          # pad token id 2, masked out
+        amask = np.concatenate([np.zeros((1, pad), amask.dtype), amask], 1)
     tids = torch.from_numpy(ids)
     pts = np.array([[[300.0, 340.0], [120.0, 800.0]], [[700.0, 610.0], [64.0, 64.0]]], np.float32)
     lbl = np.array([[1, 0], [1, 1]], np.int32)
@@ -636,7 +636,7 @@ def case_train_llm_slice():
         selected = tids.reshape(-1) == m.img_context_token_id
         emb[selected] = emb[selected] * 0.0 + vit_embeds.reshape(-1, C)          # forward :136-152
         emb = emb.reshape(B, N, C)
-        outputs = m.language_model(inputs_embeds=emb, attention_mask=torch.ones_like(tids), output_hidden_states=True, return_dict=True)
+        outputs = m.language_model(inputs_embeds=emb, attention_mask=torch.from_numpy(amask), output_hidden_states=True, return_dict=True)
         tok_idx = torch.nonzero(selected.reshape(B, N), as_tuple=True)[1]
         hidden = outputs.hidden_states[-1][:, int(tok_idx.min()):int(tok_idx.max()) + 1, :]
         last = m.text_aware_dense_feature(hidden)
@@ -648,7 +648,7 @@ def case_train_llm_slice():
         pred = torch.nn.functional.interpolate(low, (1024, 1024), mode="bilinear", align_corners=False)
         loss, bce, dice, iou_val = TJ.calc_instance_loss(pred, torch.from_numpy(gt), TJ.BCELoss(), TJ.DiceLoss())
         loss.backward()
-    out = {"seed": 12, "ids": ids, "pts": pts, "lbl": lbl, "loss": np.float32(loss.item()), "bce": np.float32(bce.item()),
+    out = {"seed": 12, "ids": ids, "attention_mask": amask, "pts": pts, "lbl": lbl, "loss": np.float32(loss.item()), "bce": np.float32(bce.item()),
            "dice": np.float32(dice.item()), "hidden_sample": hidden.detach().numpy().reshape(-1)[::97].copy(),
            "g:vit_features": vf.grad.numpy().reshape(-1)[::257].copy(),
            "n:vit_features": np.float32(np.sqrt((vf.grad.numpy().astype(np.float64) ** 2).sum()))}
@@ -663,7 +663,7 @@ def case_train_llm_slice():
         out["g:" + name] = g[::stride].copy()
         out["n:" + name] = np.float32(np.sqrt((g.astype(np.float64) ** 2).sum()))
     out["names"] = np.array(names)
-    save("train_llm_slice", **out)
+    save("train_llm_slice_pad" if pad else "train_llm_slice", **out)
 
 
 def case_train_vit_slice():
@@ -681,15 +681,12 @@ def case_train_vit_slice():
     import train_joint_v2 as TJ
     from modeling.configuration_internvl_chat import InternVLChatConfig
     from modeling.modeling_internvl_sam import InternVLSAMModel
-    sam = _sam_small(depth=2, embed_dim=768, heads=12, glob=(1,)) if real_dims else _sam_small()
-    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_7B_L1) if real_dims else dict(LLM_TINY),
+    sam = _sam_small()
+    cfg = InternVLChatConfig(vision_config={"architectures": ["SAM-ViT-B-16"]}, llm_config=dict(LLM_TINY),
                              downsample_ratio=0.5, template="internlm2-chat", ps_version="v2", force_image_size=1024)
     cfg.llm_config.rope_scaling = None
     m = InternVLSAMModel(cfg, vision_model=sam.image_encoder, prompt_encoder=sam.prompt_encoder, mask_decoder=sam.mask_decoder)
-    if real_dims:
-        fill_module_inplace(m, seed=0)
-    else:
-        fill_module(m, seed=0)
+    fill_module(m, seed=0)
     m.train()
     for n_, p_ in m.named_parameters():
         p_.requires_grad_(not n_.startswith("language_model."))
@@ -789,7 +786,7 @@ def case_train_step(real_dims: bool = False):
     save("train_step_real" if real_dims else "train_step", **out)
 
 
-CASES = {"train_step": case_train_step, "train_step_real": lambda: case_train_step(real_dims=True), "train_vit_slice": case_train_vit_slice, "train_slice": case_train_slice, "train_llm_slice": case_train_llm_slice, "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
+CASES = {"train_step": case_train_step, "train_step_real": lambda: case_train_step(real_dims=True), "train_vit_slice": case_train_vit_slice, "train_slice": case_train_slice, "train_llm_slice": case_train_llm_slice, "train_llm_slice_pad": lambda: case_train_llm_slice(pad=37), "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
          "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full,
          "vit_h_d2": case_vit_h_d2, "llm_7b_l1": case_llm_7b_l1,
          "rope_variants": case_rope_variants, "llm_tiny_bias_linear": case_llm_tiny_bias_linear,

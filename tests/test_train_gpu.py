@@ -91,15 +91,18 @@ def test_bf16_model_gets_the_fp32_step_on_its_rounded_weights():
         assert float((a - b).abs().max()) <= 2.0 ** -8 * float(b.abs().max()) + 1e-7, n   # one bf16 rounding of each entry
 
 
-def test_gradients_through_the_frozen_llm_reach_mlp1():
-    """Second slice: vision features -> pixel_shuffle -> mlp1 -> image-token splice -> InternLM2 (2 layers, frozen: RMSNorm, wqkv, RoPE,
+@pytest.mark.parametrize("fixture", ["train_llm_slice", "train_llm_slice_pad"])
+def test_gradients_through_the_frozen_llm_reach_mlp1(fixture):
+    """(train_llm_slice_pad: the same slice with the prompt LEFT-PADDED by 37 positions and attention_mask = 0 there: the training attention's
+    key_mask branches -- padded keys, fully masked padded query rows, causal + padding summing to -inf -- forward and backward.)
+    Second slice: vision features -> pixel_shuffle -> mlp1 -> image-token splice -> InternLM2 (2 layers, frozen: RMSNorm, wqkv, RoPE,
     causal grouped attention with the padding mask, wo, SwiGLU) -> hidden states of the image tokens -> the segmentation branch.  Against
     tests/golden/train_llm_slice.npz (the reference's autograd through its own LLM): the hidden states, the loss, the gradients of mlp1
     (reachable only through the LLM's backward), mlp2 and the sampled decoder tensors within 1e-3 of each tensor's largest entry, and
     d loss / d vision features; the LLM's own parameters receive no gradient."""
     from ullsam_amd import ops
     from ullsam_amd.training import llm_image_hidden, segmentation_loss
-    g = U.gold("train_llm_slice")
+    g = U.gold(fixture)
     m = _ullsam_tiny(torch.float32)
     for n, p in m.named_parameters():
         p.requires_grad_(not n.startswith(("language_model.", "vision_model.")))
@@ -111,7 +114,9 @@ def test_gradients_through_the_frozen_llm_reach_mlp1():
     ids = t(g["ids"]).long()
     yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
     gt = np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None]
-    hidden = llm_image_hidden(m, rows, ids, torch.ones_like(ids))
+    amask = t(g["attention_mask"]).long()
+    assert (fixture == "train_llm_slice_pad") == bool((amask == 0).any())
+    hidden = llm_image_hidden(m, rows, ids, amask)
     hs = hidden.detach().float().cpu().numpy().reshape(-1)[::97]
     assert np.abs(hs - g["hidden_sample"]).max() < 2e-4 * max(1.0, np.abs(g["hidden_sample"]).max()), np.abs(hs - g["hidden_sample"]).max()
     loss, bce, dice = segmentation_loss(m, hidden, t(img), (t(g["pts"]), t(g["lbl"])), t(gt))

@@ -1875,7 +1875,7 @@ static int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     const long waves = a.act == 3 ? (long)a.N / 4 : ((long)a.N + 3) / 4;
     // measured (tools/probes/skinny_probe.py, us per launch): w13 47.4 -> 45.3 with two resident workgroups per CU (45.8 with one, 46.9 with
     // three); the LM head (92553 rows) 129 -> 137: its 5785 workgroups already amortise the ramp, so it keeps the kernel above
-    if (MM == 4 && (normed || a.act == 3) && waves >= 4096 && lds <= 64 * 1024) {
+    if (MM == 4 && (normed || a.act == 3) && waves >= 4096 && lds + 256 <= 64 * 1024) {   // (+ the kernel's static nred[16]: K = 8192 would tip over the 64 KiB default)
         // one workgroup per CU; W waves each so that the units divide evenly (fewest idle wave-trips, ties to the larger W)
         static PerDeviceOnce cu_once; static int n_cu = 256;
         if (cu_once.first()) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n_cu = pr.multiProcessorCount; }
@@ -1956,7 +1956,8 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int variant = g_gemm_variant;
     // decode step: a handful of rows against the whole weight matrix
-    if (variant == 0 && (act != 4 || (M <= 4 && K % 2048 == 0)) && dtype == ULLSAM_DT_BF16 && M <= 8 && K % 512 == 0 && lda % 8 == 0 && ldw % 8 == 0 &&
+    // (the forced variants select TILE kernels; a launch with the RMSNorm prologue exists in the skinny kernels only and goes there whatever is forced)
+    if ((variant == 0 || norm) && (act != 4 || (M <= 4 && K % 2048 == 0)) && dtype == ULLSAM_DT_BF16 && M <= 8 && K % 512 == 0 && lda % 8 == 0 && ldw % 8 == 0 &&
         (size_t)(M <= 4 ? 4 : 8) * K * 2 <= 144 * 1024 && (act != 3 || N % 128 == 0))
         return launch_gemm_skinny(a, s);
     ULLSAM_CHECK(!norm, "ullsam_gemm: the RMSNorm prologue exists in the decode-step kernels only (bf16, M <= 4, K <= 4096; got M=%d K=%d)", M, K);
