@@ -115,6 +115,25 @@ __device__ __forceinline__ void halves(float x, float& lo, float& hi) {
     hi = __uint_as_float(r[1]);
 }
 
+// max of the 16 registers of an MFMA accumulator as ONE asm statement of v_max3_f32: through fmaxf hipcc puts a canonicalising v_max_f32 x, x in
+// front of every MFMA result (16 more VALU instructions per 32-key block in loops that are VALU-bound), and it pads every asm statement's boundary
+// with an s_nop, so a chain of eight statements would carry eight of them.  The caller guarantees that the MFMAs that wrote `s` are at least a few
+// instructions back (no MFMA -> VALU read hazard at this place).
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max16_raw(const f32x16& s) {
+    float mr;
+    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %0, %0, %8, %9\n\t"
+        "v_max3_f32 %0, %0, %10, %11\n\tv_max3_f32 %0, %0, %12, %13\n\tv_max3_f32 %0, %0, %14, %15\n\tv_max_f32 %0, %0, %16"
+        : "=&v"(mr)
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]), "v"(s[10]), "v"(s[11]),
+          "v"(s[12]), "v"(s[13]), "v"(s[14]), "v"(s[15]));
+    return mr;
+}
+
 template <typename T, int HD, int MODE, int NWAVES, bool FAST64>
 __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 1 : 2) void flash_attn_kernel(AttnArgs p) {  // 8 waves per CU = 2 per SIMD: at most 256 VGPR+AGPR
     constexpr int TR = ((MODE == MODE_VIT_WINDOW && NWAVES == 7) || NWAVES == 8) ? 128 : 64;  // keys per staged K/V tile
@@ -1224,12 +1243,6 @@ static int launch_causal128(const AttnArgs& a, hipStream_t s) {
 //    * workgroups are numbered so that the 16 query blocks of a (image, head) pair run on one XCD (its K / V, 1.3 MB, stay in that L2).
 //  LDS: 32 KiB K ring + 32 KiB V ring + 22 KiB rel-pos table staging + 8 x 8 KiB rel_h tables = 150 KiB, one workgroup per CU.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float max3_raw(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 __global__ __launch_bounds__(512) void vitglob_attn_kernel(AttnArgs p) {
     typedef bf16 T;
     constexpr int HD = 80, KSTEPS = 5, DT = 3, G = 64, NB = 128, STAGE = 32 * 256, NE = 2 * G - 1;
@@ -1388,14 +1401,8 @@ __global__ __launch_bounds__(512) void vitglob_attn_kernel(AttnArgs p) {
     // a grid row: its rel_h term is uniform over the block (added to the block maximum, folded into the exponent's offset)
     auto soft_block = [&](int j, f32x16& s) __attribute__((always_inline)) -> float {
         const float rh64 = relh[(j >> 1) * 32 + ql];
-        // (v_max3_f32 as asm: through fmaxf hipcc puts a canonicalising v_max_f32 x, x in front of every MFMA result -- 16 more instructions in a
-        // VALU-bound loop.  The scores were written by MFMAs at least one PV product or one barrier earlier: no MFMA -> VALU hazard at this place.)
-        float mr;   // (ONE statement: hipcc pads every asm statement's boundary with an s_nop, and a chain of eight would carry eight of them)
-        asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %0, %0, %8, %9\n\t"
-            "v_max3_f32 %0, %0, %10, %11\n\tv_max3_f32 %0, %0, %12, %13\n\tv_max3_f32 %0, %0, %14, %15\n\tv_max_f32 %0, %0, %16"
-            : "=&v"(mr)
-            : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]), "v"(s[10]), "v"(s[11]),
-              "v"(s[12]), "v"(s[13]), "v"(s[14]), "v"(s[15]));
+        // (max16_raw: the scores were written by MFMAs at least one PV product or one barrier earlier)
+        const float mr = max16_raw(s);
         float lo, hi;
         halves(mr, lo, hi);
         const float mx = __builtin_fmaf(max3_raw(lo, hi, hi), scale2, rh64);
