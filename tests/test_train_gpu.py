@@ -407,6 +407,65 @@ def test_reference_trainer_step_runs_on_the_modules_own_forwards():
         assert not m.vision_model(pixel_values).requires_grad
 
 
+def test_reference_trainer_step_under_ddp_as_the_trainer_wraps_it():
+    """train_joint_v2.py:1755-1761 wraps the MODEL: DistributedDataParallel(model, device_ids, output_device, find_unused_parameters=True) +
+    _set_static_graph(), then calls model(...) through DDP and model.module.vision_model / prompt_encoder / mask_decoder beside it
+    (:1014-1050).  Same statements here under RCCL at world size 1 (what one box offers): loss and gradients equal the fixture's, over two
+    iterations (the static graph is recorded in the first)."""
+    import os
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from torch.nn.parallel import DistributedDataParallel
+    g = U.gold("train_step")
+    m = _ullsam_tiny(torch.float32)
+    for n, p in m.named_parameters():
+        p.requires_grad_(not n.startswith("language_model."))
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    pixel_values = t(U.rand_image((1, 3, 1024, 1024), seed=int(g["seed"])))
+    input_ids = t(g["ids"]).long()
+    points, point_labels = t(g["pts"]), t(g["lbl"])
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
+    masks = t(np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29583")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        model = DistributedDataParallel(m, device_ids=[0], output_device=0, find_unused_parameters=True)
+        model._set_static_graph()
+        model.train()
+        for it in range(2):
+            for p in m.parameters():
+                p.grad = None
+            outputs = model(pixel_values=pixel_values, input_ids=input_ids, attention_mask=torch.ones_like(input_ids), image_flags=None, labels=input_ids.clone(),
+                            return_dict=True, use_cache=False, img_context_token_id=92546, output_hidden_states=True)
+            last_hidden_state = outputs.hidden_states
+            image_embeddings = model.module.vision_model(pixel_values)
+            image_pe = model.module.prompt_encoder.get_dense_pe().to(DEV)
+            bs = points.shape[0]
+            if last_hidden_state.shape[0] != bs:
+                last_hidden_state = last_hidden_state.repeat(bs, 1, 1, 1)
+            sparse_embeddings, dense_embeddings = model.module.prompt_encoder(points=(points, point_labels), boxes=None, masks=None, llm_hidden_states=last_hidden_state)
+            low_res_masks, _ = model.module.mask_decoder(image_embeddings=image_embeddings, image_pe=image_pe, sparse_prompt_embeddings=sparse_embeddings,
+                                                         dense_prompt_embeddings=dense_embeddings, multimask_output=False)
+            pred_masks = F.interpolate(low_res_masks, (1024, 1024), mode="bilinear", align_corners=False)
+            seg_loss, _, _ = _trainer_losses(pred_masks, masks)
+            loss = 0 * outputs.loss + seg_loss
+            loss.backward()
+            torch.cuda.synchronize()
+            assert abs(loss.item() - float(g["loss"])) < 2e-5 * float(g["loss"]), (it, loss.item(), float(g["loss"]))
+            params = dict(m.named_parameters())
+            for n in [str(v) for v in g["names"]]:
+                ref = g["g:" + n].astype(np.float64)
+                assert params[n].grad is not None, (it, n)
+                full = params[n].grad.float().cpu().numpy().reshape(-1).astype(np.float64)
+                got = full[::max(1, full.size // 512)]
+                assert np.abs(got - ref).max() < 1e-3 * np.abs(ref).max() + 1e-7, (it, n)
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
 def _ullsam_real_dims(dtype):
     """The composite at the bench configuration's HEAD DIMENSIONS: SAM ViT-B width (768 = 12 heads x 64; one windowed + one global block on the
     64 x 64 grid) and one 7B-shaped InternLM2 layer (hidden 4096, 32 heads / 8 KV heads x 128, intermediate 14336), filled like the fixtures."""
