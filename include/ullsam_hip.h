@@ -27,7 +27,7 @@ extern "C" {
 
 /* Bumped whenever an entry point is added or a signature changes.  The Python binding refuses a library that reports another
    version (a stale libullsam_hip.so would otherwise receive shifted arguments, e.g. a row count where the stream is expected). */
-#define ULLSAM_ABI_VERSION 7
+#define ULLSAM_ABI_VERSION 8
 
 const char* ullsam_last_error_string(void);
 int ullsam_abi_version(void); /* == ULLSAM_ABI_VERSION of the header the library was built from */
@@ -83,6 +83,13 @@ int ullsam_decode_qkv_rope(const void* a, const float* x, long ldx, const float*
  * the hypernetwork product of mask_decoder.py:146-147 and its gradients) */
 int ullsam_train_matmul(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k, long b_b,
                         long b_k, long b_n, long c_b, long c_m, long c_n, int accumulate, void* stream);
+/* the same product with its k range cut into `ksplit` pieces run by separate workgroups and added IN ORDER by a second kernel (few output tiles,
+ * long sums: rel-pos table gradients, the hypernetwork gradient over 65536 pixels); partial: ksplit * batch * M * N floats of scratch */
+int ullsam_train_matmul_splitk(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k, long b_b,
+                               long b_k, long b_n, long c_b, long c_m, long c_n, int accumulate, int ksplit, float* partial, void* stream);
+/* the product above runs on the matrix pipe (exact fp32 MFMA, 128 x 128 tiles) from M >= 64, N >= 48, K >= 16; 0 keeps every launch on the
+ * one-output-per-thread kernel (tests compare the two); returns the previous setting */
+int ullsam_train_set_matmul_mfma(int on);
 /* out[c] += sum_r x[r*ld + c] (bias gradients; gradients of parameters broadcast over the batch) */
 int ullsam_train_colsum(const float* x, float* out, long rows, int cols, long ld, void* stream);
 /* nn.LayerNorm / LayerNorm2d backward on rows of D (w NULL: no affine, prompt_encoder.py:141-144); dw / db may be NULL */

@@ -69,10 +69,12 @@ def test_bf16_model_gets_the_fp32_step_on_its_rounded_weights():
     """The trainer's default keeps the model in bf16 (train_joint_v2.py:1599,1676).  The step widens bf16 parameters and computes in fp32, so a
     bf16 model's gradients are those of the fp32 model holding the same (bf16-rounded) weights, rounded to bf16: compared tensor by tensor on
     the decoder-side slice."""
+    from ullsam_amd import training
     from ullsam_amd.training import segmentation_loss
     g = U.gold("train_slice")
     hid, img, pts, gt = _inputs(g)
     grads = []
+    old_switch, training.BF16_LINEAR = training.BF16_LINEAR, False      # this test is about the fp32-arithmetic route (the bf16 GEMM route: next test)
     for widen in (False, True):
         m = _ullsam_tiny(torch.bfloat16)
         if widen:
@@ -82,6 +84,7 @@ def test_bf16_model_gets_the_fp32_step_on_its_rounded_weights():
         loss, _, _ = segmentation_loss(m, hid, img, pts, gt)
         loss.backward()
         grads.append((float(loss.detach()), {n: p.grad for n, p in m.named_parameters() if p.grad is not None}))
+    training.BF16_LINEAR = old_switch
     (l16, g16), (l32, g32) = grads
     assert abs(l16 - l32) < 1e-5 * abs(l32)               # (sums by atomics: the two runs differ in the order of additions)
     assert set(g16) == set(g32) and len(g16) >= 125
@@ -257,6 +260,41 @@ def test_segmentation_loss_gradient_by_central_differences_on_another_prompt_sha
         assert abs(num - ana) < 5e-2 * abs(ana) + 4e-4, (tuple(p.shape), i, ana, num)   # fp32 loss: ~2e-7 of rounding over a 4e-3 step = 1e-4 on the quotient
 
 
+@pytest.mark.parametrize("M,N,K,batch,a_t,b_t", [(196, 196, 80, 7, False, True), (196, 80, 196, 7, False, False), (300, 131, 1081, 3, True, False),
+                                                     (1081, 128, 1081, 2, True, True), (64, 48, 16, 1, False, False), (257, 129, 33, 2, True, True),
+                                                     (14, 80, 5600, 14, True, False), (5, 32, 65536, 2, False, True), (100, 64, 4100, 3, False, False)])
+def test_train_matmul_on_the_matrix_pipe_equals_the_scalar_kernel(M, N, K, batch, a_t, b_t):
+    """ullsam_train_matmul's MFMA form (v_mfma_f32_32x32x2_f32, exact fp32) against its one-output-per-thread form and float64, over the operand
+    layouts the train step uses (row-major and transposed views, batch strides, ragged M / N / K tails, accumulate; the last three shapes
+    take the split-k route: few output tiles under a long sum, partials added in order)."""
+    from ullsam_amd import _lib
+    from ullsam_amd.training import _mm
+    rng = np.random.default_rng(M * 131 + N * 7 + K)
+    A = torch.from_numpy(rng.standard_normal((batch, K, M) if a_t else (batch, M, K), dtype=np.float32)).to(DEV)
+    B = torch.from_numpy(rng.standard_normal((batch, N, K) if b_t else (batch, K, N), dtype=np.float32)).to(DEV)
+    C0 = torch.from_numpy(rng.standard_normal((batch, M, N), dtype=np.float32)).to(DEV)
+    sa = (M * K, 1, M) if a_t else (M * K, K, 1)
+    sb = (N * K, 1, K) if b_t else (N * K, N, 1)
+    ref = (A.double().transpose(1, 2) if a_t else A.double()) @ (B.double().transpose(1, 2) if b_t else B.double())
+    outs = []
+    lib = _lib.load()
+    for on in (1, 0):
+        old = lib.ullsam_train_set_matmul_mfma(on)
+        try:
+            C = C0.clone()
+            _mm(A, B, C, M, N, K, sa, sb, (M * N, N, 1), batch=batch, accumulate=False)
+            Cacc = C0.clone()
+            _mm(A, B, Cacc, M, N, K, sa, sb, (M * N, N, 1), batch=batch, accumulate=True)
+            torch.cuda.synchronize()
+        finally:
+            lib.ullsam_train_set_matmul_mfma(old)
+        outs.append(C)
+        scale = float(ref.abs().max())
+        assert float((C.double() - ref).abs().max()) < 2e-6 * scale * max(1.0, K ** 0.5 / 8), (on, M, N, K)
+        assert float((Cacc.double() - ref - C0.double()).abs().max()) < 2e-6 * scale * max(1.0, K ** 0.5 / 8) + 1e-6
+    assert float((outs[0] - outs[1]).abs().max()) < 1e-5 * float(ref.abs().max())
+
+
 def test_train_step_module_under_ddp_world_1():
     """TrainStep wrapped in DistributedDataParallel (RCCL, world size 1: what one box offers): the hooks fire, the gradients equal the plain step's."""
     import os
@@ -293,6 +331,56 @@ def test_train_step_module_under_ddp_world_1():
     for n, r in ref.items():
         got = dict(m.named_parameters())[n].grad
         assert got is not None and float((got - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-7, n
+
+
+def test_bf16_model_runs_its_large_linears_on_bf16_gemms():
+    """training.BF16_LINEAR (default): the large linears of a bf16 model (>= 256 rows, dimensions % 64: the ViT's qkv / proj / lin1 / lin2, patch
+    embedding, neck, mlp1 / mlp2) run forward, dX and dW on the bf16 MFMA GEMM -- what the reference's trainer computes (bf16 model under
+    autocast(bf16), train_joint_v2.py:1665,1676).  Against the fp32-arithmetic route on the same bf16 weights: the loss within 2e-3, every
+    gradient within bf16-activation noise of its tensor's scale (and the bf16 route really is taken: LinearBf16Fn nodes in the graph)."""
+    from ullsam_amd import training
+    g = U.gold("train_step")
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    x = t(U.rand_image((1, 3, 1024, 1024), seed=int(g["seed"])))
+    ids = t(g["ids"]).long()
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
+    gt = t(np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None])
+    res = []
+    old_switch = training.BF16_LINEAR
+    try:
+        for on in (True, False):
+            training.BF16_LINEAR = on
+            m = _ullsam_tiny(torch.bfloat16)
+            for n, p in m.named_parameters():
+                p.requires_grad_(not n.startswith("language_model."))
+            loss, _, _ = training.train_step_loss(m, x, ids, torch.ones_like(ids), (t(g["pts"]), t(g["lbl"])), gt)
+            if on:
+                seen, stack, hit = set(), [loss.grad_fn], 0
+                while stack:
+                    f = stack.pop()
+                    if f is None or f in seen:
+                        continue
+                    seen.add(f)
+                    hit += "LinearBf16Fn" in type(f).__name__
+                    stack.extend(nf for nf, _ in f.next_functions)
+                assert hit >= 8, hit
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((float(loss.detach()), {n: p.grad.float() for n, p in m.named_parameters() if p.grad is not None}))
+    finally:
+        training.BF16_LINEAR = old_switch
+    (lb, gb), (lf, gf) = res
+    assert abs(lb - lf) < 2e-3 * abs(lf), (lb, lf)
+    assert set(gb) == set(gf)
+    worst = (0.0, "")
+    for n in gf:
+        scale = float(gf[n].abs().max())
+        if scale < 1e-6:
+            continue
+        e = float((gb[n] - gf[n]).abs().max()) / scale
+        worst = max(worst, (e, n))
+        assert e < 0.03, (n, e)          # measured worst: 0.011
+    print("bf16-GEMM route vs fp32-arithmetic route on the same bf16 weights: loss", lb, lf, "worst relative gradient difference", worst)
 
 
 def test_bf16_model_runs_the_frozen_llm_on_bf16_gemms():

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ULLSAM_HIP_LIB") or os.path.join(_HERE, "lib", "libullsam_hip.so")  # env: A/B a side build (developer switch)
 
-ABI_VERSION = 7  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
+ABI_VERSION = 8  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
 
 _lib = None
 
@@ -23,6 +23,7 @@ SIGNATURES = {
     "ullsam_gemm_rmsnorm": [vp, i64, vp, f32, vp, i64, vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, vp],
     "ullsam_decode_qkv_rope": [vp, vp, i64, vp, f32, vp, i64, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp],
     "ullsam_train_matmul": [vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [i32, vp],
+    "ullsam_train_matmul_splitk": [vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [i32, i32, vp, vp],
     "ullsam_train_colsum": [vp, vp, i64, i32, i64, vp],
     "ullsam_train_ln_bwd": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
     "ullsam_train_act": [vp, vp, vp, i64, i32, vp],
@@ -76,7 +77,7 @@ SIGNATURES = {
 }
 PLAIN = {"ullsam_last_error_string": ([], C.c_char_p), "ullsam_abi_version": ([], i32), "ullsam_device_count": ([], i32),
          "ullsam_set_gemm_variant": ([i32], i32), "ullsam_set_gemm_tuning": ([i32, i32], i32), "ullsam_set_attn_variant": ([i32], i32),
-         "ullsam_set_norm_variant": ([i32], i32), "ullsam_set_attn_debug": ([vp], i32)}
+         "ullsam_set_norm_variant": ([i32], i32), "ullsam_train_set_matmul_mfma": ([i32], i32), "ullsam_set_attn_debug": ([vp], i32)}
 
 
 class UllsamError(RuntimeError):

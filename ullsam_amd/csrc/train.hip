@@ -14,15 +14,19 @@ struct MmArgs {
     int M, N, K, batch;
     long a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n;
     int accumulate;
+    int ksplit, kc;      // blockIdx.z = batch index * ksplit + s: split s sums k in [s kc, min(K, (s + 1) kc)) into C + s c_s (partials, reduced in order afterwards)
+    long c_s;
 };
 __global__ __launch_bounds__(256) void matmul_f32_kernel(MmArgs p) {
     // 64 x 64 outputs per workgroup, 4 x 4 per thread, K in steps of 16 through LDS.  The element -> thread assignment of the two tile loads
     // follows the operand's unit stride (k-fastest for a row-major operand, m- / n-fastest for a transposed one), so both are coalesced.
     __shared__ float As[16][65], Bs[16][65];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, b = blockIdx.z;
-    const float* A = p.A + (long)b * p.a_b;
-    const float* B = p.B + (long)b * p.b_b;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, b = blockIdx.z / p.ksplit, ks = blockIdx.z % p.ksplit;
+    const float* A = p.A + (long)b * p.a_b + (long)ks * p.kc * p.a_k;
+    const float* B = p.B + (long)b * p.b_b + (long)ks * p.kc * p.b_k;
+    p.K = min(p.kc, p.K - ks * p.kc);
+    p.C += (long)ks * p.c_s;
     const bool a_kfast = p.a_k <= p.a_m, b_nfast = p.b_n <= p.b_k;
     float acc[4][4];
 #pragma unroll
@@ -62,11 +66,157 @@ __global__ __launch_bounds__(256) void matmul_f32_kernel(MmArgs p) {
             }
         }
 }
+// The same product on the matrix pipe (v_mfma_f32_32x32x2_f32: an exact fp32 fma chain, so the result differs from the kernel above only in the
+// order of the k sums): 128 x 128 outputs per workgroup, four waves of 64 x 64, K in steps of 32 through two LDS buffers filled from registers
+// (the global loads of step t + 1 are in flight under step t's MFMAs; one barrier per step).  Both tiles sit in LDS k-major, [k][m ^ (k >> 1)],
+// row stride 160 words: a fragment read (32 consecutive m of row k | 32 of row k + 1) touches 64 distinct banks, and so does the transposing
+// write of a k-fastest operand (32 consecutive k of one m).  This is what the matrix-form attention of the train step runs on (the score,
+// probability and gradient products of ViT-H's 4096 x 4096 global blocks: 45 % of a step's GPU time on the scalar kernel).
+constexpr int MMF_LD = 160;
+template <bool AK, bool BN>   // AK: A's unit stride is k (row-major [m][k]); BN: B's unit stride is n (row-major [k][n])
+__global__ __launch_bounds__(256, 2) void matmul_f32_mfma_kernel(MmArgs p) {
+    extern __shared__ float mmf_lds[];                     // [2 buffers][A | B][32 k][160]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128, b = blockIdx.z / p.ksplit, ks = blockIdx.z % p.ksplit;
+    p.A += (long)ks * p.kc * p.a_k;
+    p.B += (long)ks * p.kc * p.b_k;
+    p.K = min(p.kc, p.K - ks * p.kc);
+    p.C += (long)ks * p.c_s;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // element i (0..15) of a thread's share of a 128 x 32 tile: the thread index runs along the operand's unit stride
+    //   k-fastest:  row (tid >> 5) + 8 i, k = tid & 31          row-fastest:  row tid & 127, k = (tid >> 7) + 2 i
+    const int t5 = tid >> 5, k5 = tid & 31, t7 = tid >> 7, r7 = tid & 127;
+    const float* pa = p.A + (long)b * p.a_b + (AK ? (long)(m0 + t5) * p.a_m + (long)k5 * p.a_k : (long)(m0 + r7) * p.a_m + (long)t7 * p.a_k);
+    const float* pb = p.B + (long)b * p.b_b + (BN ? (long)(n0 + r7) * p.b_n + (long)t7 * p.b_k : (long)(n0 + t5) * p.b_n + (long)k5 * p.b_k);
+    const long a_inc = AK ? 8 * p.a_m : 2 * p.a_k, b_inc = BN ? 2 * p.b_k : 8 * p.b_n, a_step = 32 * p.a_k, b_step = 32 * p.b_k;
+    const bool inner = m0 + 128 <= p.M && n0 + 128 <= p.N;
+    float ra[16], rb[16];
+    auto fetch = [&](int k0) {
+        if (inner && k0 + 32 <= p.K) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ra[i] = pa[i * a_inc]; rb[i] = pb[i * b_inc]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool va = AK ? (m0 + t5 + 8 * i < p.M && k0 + k5 < p.K) : (m0 + r7 < p.M && k0 + t7 + 2 * i < p.K);
+                const bool vb = BN ? (n0 + r7 < p.N && k0 + t7 + 2 * i < p.K) : (n0 + t5 + 8 * i < p.N && k0 + k5 < p.K);
+                ra[i] = va ? pa[i * a_inc] : 0.f;
+                rb[i] = vb ? pb[i * b_inc] : 0.f;
+            }
+        }
+        pa += a_step;
+        pb += b_step;
+    };
+    auto stash = [&](int buf) {
+        float* As = mmf_lds + buf * (2 * 32 * MMF_LD);
+        float* Bs = As + 32 * MMF_LD;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (AK) As[k5 * MMF_LD + ((t5 + 8 * i) ^ (k5 >> 1))] = ra[i];
+            else    As[(t7 + 2 * i) * MMF_LD + (r7 ^ i)] = ra[i];
+            if (BN) Bs[(t7 + 2 * i) * MMF_LD + (r7 ^ i)] = rb[i];
+            else    Bs[k5 * MMF_LD + ((t5 + 8 * i) ^ (k5 >> 1))] = rb[i];
+        }
+    };
+    const int steps = (p.K + 31) / 32;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int kh = lane >> 5, l5 = lane & 31;
+    for (int t = 0; t < steps; ++t) {
+        if (t + 1 < steps) fetch(32 * (t + 1));
+        const float* As = mmf_lds + (t & 1) * (2 * 32 * MMF_LD) + kh * MMF_LD;
+        const float* Bs = As + 32 * MMF_LD;
+#pragma unroll
+        for (int kp = 0; kp < 16; ++kp) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = As[2 * kp * MMF_LD + ((wm * 64 + i * 32 + l5) ^ kp)];
+                bf[i] = Bs[2 * kp * MMF_LD + ((wn * 64 + i * 32 + l5) ^ kp)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < steps) stash((t + 1) & 1);
+        __syncthreads();
+    }
+    // accumulator element e of lane l: row 8 (e / 4) + 4 (l / 32) + e % 4, column l % 32 of the 32 x 32 tile
+    float* cb = p.C + (long)b * p.c_b;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + 8 * (e >> 2) + 4 * kh + (e & 3), n = n0 + wn * 64 + j * 32 + l5;
+                if (m < p.M && n < p.N) {
+                    float* c = cb + (long)m * p.c_m + (long)n * p.c_n;
+                    *c = p.accumulate ? *c + acc[i][j][e] : acc[i][j][e];
+                }
+            }
+}
+template <bool AK, bool BN>
+static void launch_matmul_mfma(const MmArgs& a, hipStream_t stream) {
+    constexpr int LDS = 2 * 2 * 32 * MMF_LD * 4;
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(matmul_f32_mfma_kernel<AK, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
+    matmul_f32_mfma_kernel<AK, BN><<<dim3((a.N + 127) / 128, (a.M + 127) / 128, a.batch * a.ksplit), 256, LDS, stream>>>(a);
+}
+static int g_train_matmul_mfma = 1;
+extern "C" int ullsam_train_set_matmul_mfma(int on) { const int old = g_train_matmul_mfma; g_train_matmul_mfma = on; return old; }
+// C[i] (+)= sum over splits s (in order: deterministic) of part[s][i]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, long n, int ksplit, int M, int N, int batch,
+                                                            long c_b, long c_m, long c_n, int accumulate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += part[(long)k * n + i];
+    const int nn = (int)(i % N), m = (int)((i / N) % M), b = (int)(i / ((long)M * N));
+    float* c = C + (long)b * c_b + (long)m * c_m + (long)nn * c_n;
+    *c = accumulate ? *c + s : s;
+}
+static int train_matmul_launch(MmArgs a, hipStream_t st) {
+    if (g_train_matmul_mfma && a.M >= 64 && a.N >= 48 && a.K >= 16) {
+        const bool ak = a.a_k <= a.a_m, bn = a.b_n <= a.b_k;
+        if (ak && bn) launch_matmul_mfma<true, true>(a, st);
+        else if (ak) launch_matmul_mfma<true, false>(a, st);
+        else if (bn) launch_matmul_mfma<false, true>(a, st);
+        else launch_matmul_mfma<false, false>(a, st);
+    } else {
+        matmul_f32_kernel<<<dim3((a.N + 63) / 64, (a.M + 63) / 64, a.batch * a.ksplit), 256, 0, st>>>(a);
+    }
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int ullsam_train_matmul(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k,
                                    long b_b, long b_k, long b_n, long c_b, long c_m, long c_n, int accumulate, void* stream) {
     ULLSAM_CHECK(M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "train_matmul: M=%d N=%d K=%d batch=%d", M, N, K, batch);
-    MmArgs a{A, B, C, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n, accumulate};
-    matmul_f32_kernel<<<dim3((N + 63) / 64, (M + 63) / 64, batch), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
+    MmArgs a{A, B, C, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n, accumulate, 1, K, 0};
+    return train_matmul_launch(a, reinterpret_cast<hipStream_t>(stream));
+}
+// The same product with the k range cut into `ksplit` pieces that run as separate workgroups (products with a few output tiles and a long
+// sum: the table gradients of the decomposed relative-position bias, the hypernetwork gradient over 65536 pixels).  `partial` holds
+// ksplit * batch * M * N floats; the pieces are added in order by a second kernel, so the result does not depend on scheduling.
+extern "C" int ullsam_train_matmul_splitk(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k,
+                                          long b_b, long b_k, long b_n, long c_b, long c_m, long c_n, int accumulate, int ksplit, float* partial, void* stream) {
+    ULLSAM_CHECK(M > 0 && N > 0 && K > 0 && batch > 0 && ksplit >= 1 && (long)batch * ksplit < 65536 && partial, "train_matmul_splitk: M=%d N=%d K=%d batch=%d ksplit=%d", M, N, K, batch, ksplit);
+    const int kc = ((K + ksplit - 1) / ksplit + 31) / 32 * 32;
+    const int ns = (K + kc - 1) / kc;                      // every split owns at least one k
+    const long n = (long)batch * M * N;
+    MmArgs a{A, B, partial, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, (long)M * N, (long)N, 1, 0, ns, kc, n};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rc = train_matmul_launch(a, st);
+    if (rc) return rc;
+    splitk_reduce_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(partial, C, n, ns, M, N, batch, c_b, c_m, c_n, accumulate);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }

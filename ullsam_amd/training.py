@@ -50,6 +50,13 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 
 def _mm(A, B, C, M, N, K, sa, sb, sc, batch=1, accumulate=False):
     """C[b](m,n) (+)= sum_k A[b](m,k) B[b](k,n); sa = (batch, m, k) element strides of A, sb = (batch, k, n), sc = (batch, m, n)."""
+    tile = 128 if (M >= 64 and N >= 48) else 64
+    tiles = -(-M // tile) * -(-N // tile) * batch
+    if K >= 2048 and tiles <= 128:          # a few output tiles under a long sum: cut k over workgroups (partials added in order: deterministic)
+        ks = max(2, min(K // 512, 1024 // tiles, 65535 // batch))
+        part = torch.empty((ks * batch * M * N,), dtype=F32, device=C.device)
+        _lib.call("ullsam_train_matmul_splitk", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, batch, *sa, *sb, *sc, int(accumulate), ks, part.data_ptr(), _s())
+        return
     _lib.call("ullsam_train_matmul", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, batch, *sa, *sb, *sc, int(accumulate), _s())
 
 
@@ -180,11 +187,62 @@ class FrozenLinearBf16Fn(Function):
         return ops.gemm(ops.cast(_c(dy), torch.bfloat16), _transposed_frozen(ctx.w), out_f32=True), None, None
 
 
+BF16_LINEAR = True   # a bf16 model's large linears (>= 256 rows, both dimensions % 64) run forward, dX and dW on the bf16 MFMA GEMM -- the trainer's own
+#                      semantics: train_joint_v2.py:1665,1676 puts the model in bf16 under autocast(bf16).  False: bf16 weights are widened and the
+#                      arithmetic stays fp32 (tests compare the two)
+
+
+def _pad_cols(t: torch.Tensor, mult: int = 64) -> torch.Tensor:
+    """[R, C] -> [R, C rounded up to mult], zero filled (the inner dimension of the dW GEMM is the row count of the step: 4900 for a windowed block)."""
+    R, Cn = t.shape
+    Cp = -(-Cn // mult) * mult
+    if Cp == Cn:
+        return t.contiguous()
+    out = torch.zeros((R, Cp), dtype=t.dtype, device=t.device)
+    out[:, :Cn] = t
+    return out
+
+
+class LinearBf16Fn(Function):
+    """y = x W^T (+ b) for a TRAINABLE bf16 weight on the inference path's bf16 MFMA GEMM (fp32 accumulation, fp32 results): forward with W as
+    stored; dX = dY W through a transposed copy of W; dW = dY^T X as the GEMM [N, M] x ([K, M])^T over bf16 transposes of dY and X (rows padded
+    to a multiple of 64 with zeros); db = column sums of the fp32 dY.  Activations and gradients are rounded to bf16 at each GEMM's door,
+    which is what the reference's trainer computes (bf16 model under autocast)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xb = ops.cast(_c(x), torch.bfloat16)
+        ctx.save_for_backward(xb, w)
+        ctx.has_b = b is not None
+        return ops.gemm(xb, w.detach(), None if b is None else _c(b), out_f32=True)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, w = ctx.saved_tensors
+        dy = _c(dy)
+        dyb = ops.cast(dy, torch.bfloat16)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dyb, w.detach().t().contiguous(), out_f32=True)
+        if ctx.needs_input_grad[1]:
+            dw = ops.gemm(_pad_cols(dyb.t()), _pad_cols(xb.t()), out_f32=True)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = _colsum(dy)
+        return dx, dw, db
+
+
+def _apply_linear(x, w, b):
+    """nn.Linear on rows: LinearBf16Fn for the large linears of a bf16 model, LinearFn (fp32 arithmetic) otherwise."""
+    if BF16_LINEAR and w.dtype == torch.bfloat16 and x.shape[0] >= 256 and w.shape[1] % 64 == 0 and w.shape[0] % 64 == 0:
+        return LinearBf16Fn.apply(x, w, b)
+    return LinearFn.apply(x, w, b)
+
+
 def _frozen_linear(x, w, b):
     """nn.Linear with a frozen weight inside llm_image_hidden: bf16 weights take the bf16 GEMM, fp32 weights the fp32 path."""
     if w.dtype == torch.bfloat16 and not w.requires_grad and w.shape[1] % 64 == 0 and w.shape[0] % 64 == 0:
         return FrozenLinearBf16Fn.apply(x, w, b)
-    return LinearFn.apply(x, w, b)
+    return _apply_linear(x, w, b)
 
 
 class LayerNormFn(Function):
@@ -606,7 +664,7 @@ class SegLossFn(Function):
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
 def _linear(lin, x):
-    return LinearFn.apply(x, lin.weight, lin.bias)
+    return _apply_linear(x, lin.weight, lin.bias)
 
 
 def _ln(norm, x):
@@ -652,7 +710,7 @@ def _conv_transpose_k2s2(ct, x_rows):
     cin, cout = ct.weight.shape[0], ct.weight.shape[1]
     w = ct.weight.permute(2, 3, 1, 0).reshape(4 * cout, cin)                     # data movement only (autograd routes the gradient back)
     b = BroadcastRowsFn.apply(ct.bias, 4).reshape(4 * cout)
-    return LinearFn.apply(x_rows, w, b).reshape(-1, cout)
+    return _apply_linear(x_rows, w, b).reshape(-1, cout)
 
 
 def dense_feature_rows(model, hidden: torch.Tensor) -> torch.Tensor:
@@ -794,7 +852,7 @@ def vision_feature_rows(enc, pixel_values: torch.Tensor) -> torch.Tensor:
     B = pixel_values.shape[0]
     cols = ops.patch_im2col(_c(pixel_values.float()), S, p, F32, None, None)                   # [B*N, 3*p*p], a constant
     pe = enc.patch_embed.proj
-    x = LinearFn.apply(cols, pe.weight.reshape(D, -1), pe.bias)
+    x = _apply_linear(cols, pe.weight.reshape(D, -1), pe.bias)
     if enc.pos_embed is not None:
         x = AddFn.apply(x, enc.pos_embed.reshape(N, D))
     for blk in enc.blocks:
@@ -811,7 +869,7 @@ def vision_feature_rows(enc, pixel_values: torch.Tensor) -> torch.Tensor:
         else:
             Hh = g
         Bw, T = t.shape[0], Hh * Hh
-        qkv = LinearFn.apply(t.reshape(Bw * T, D), at.qkv.weight, at.qkv.bias).reshape(Bw, T, 3, heads, hd)
+        qkv = _apply_linear(t.reshape(Bw * T, D), at.qkv.weight, at.qkv.bias).reshape(Bw, T, 3, heads, hd)
         q, k, v = (qkv[:, :, i].reshape(Bw * T, heads * hd) for i in range(3))
         if at.rel_pos_h.shape[0] != 2 * Hh - 1 or at.rel_pos_w.shape[0] != 2 * Hh - 1:
             raise NotImplementedError("get_rel_pos with interpolated tables (image_encoder.py:310-318) is not part of the training slice")
@@ -825,7 +883,7 @@ def vision_feature_rows(enc, pixel_values: torch.Tensor) -> torch.Tensor:
         rel_w = BmmNTFn.apply(q5.permute(2, 0, 1, 3, 4).reshape(Hh, Bw * Hh * heads, hd), Rw)   # [qw, (b, qh, head), kw]
         rel_w = rel_w.reshape(Hh, Bw, Hh, heads, Hh).permute(1, 3, 2, 0, 4).reshape(Bw, heads, T, Hh)
         a = AttentionFn.apply(q, k, v, Bw, heads, heads, T, T, -1, None, rel_h, rel_w, Hh)
-        a = LinearFn.apply(a, at.proj.weight, at.proj.bias)
+        a = _apply_linear(a, at.proj.weight, at.proj.bias)
         if ws > 0:                                                                             # window_unpartition :267-290
             a = a.reshape(B, gp // ws, gp // ws, ws, ws, D).permute(0, 1, 3, 2, 4, 5).contiguous().reshape(B, gp, gp, D)
             if gp > g:
@@ -834,8 +892,8 @@ def vision_feature_rows(enc, pixel_values: torch.Tensor) -> torch.Tensor:
         m = blk.mlp
         x = AddFn.apply(x, _linear(m.lin2, ActFn.apply(_linear(m.lin1, _ln(blk.norm2, x)), m.act_code)))
     n0, n1, n2, n3 = enc.neck[0], enc.neck[1], enc.neck[2], enc.neck[3]
-    y = _ln(n1, LinearFn.apply(x, n0.weight.reshape(C, D), None))
-    z = LinearFn.apply(Im2col3x3Fn.apply(y, B, g, g), n2.weight.permute(0, 2, 3, 1).reshape(C, 9 * C), None)
+    y = _ln(n1, _apply_linear(x, n0.weight.reshape(C, D), None))
+    z = _apply_linear(Im2col3x3Fn.apply(y, B, g, g), n2.weight.permute(0, 2, 3, 1).reshape(C, 9 * C), None)
     return _ln(n3, z).reshape(B, N, C)
 
 
