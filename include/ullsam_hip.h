@@ -116,6 +116,8 @@ int ullsam_train_col2im3x3(const float* dcols, float* dx, int B, int H, int W, i
  * S already holds the P the forward kept. */
 int ullsam_train_attn_rows(float* S, float* dP, const float* bias_h, const float* bias_w, float* dbias_h, float* dbias_w, const int* key_mask,
                            int B, int H, int Sq, int Sk, int kw, int causal, int have_p, void* stream);
+/* 0: keep the row pass on its three-pass form (tests compare it with the register-resident form used for Sk <= 4096); returns the previous setting */
+int ullsam_train_set_rows_reg(int on);
 /* InternLM2RMSNorm backward (modeling_internlm2.py:75-89); dw may be NULL (frozen LLM) */
 int ullsam_train_rmsnorm_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, long rows, int D, float eps, void* stream);
 /* apply_rotary_pos_emb (modeling_internlm2.py:233-247) on rows [tokens, heads, hd]; adjoint != 0: its transpose (the backward) */

@@ -295,6 +295,55 @@ def test_train_matmul_on_the_matrix_pipe_equals_the_scalar_kernel(M, N, K, batch
     assert float((outs[0] - outs[1]).abs().max()) < 1e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("B,H,Sq,Sk,kw,causal,masked", [(2, 3, 196, 196, 14, -1, False), (1, 2, 70, 1081, 0, 0, True), (1, 2, 33, 4096, 64, -1, False),
+                                                          (2, 2, 50, 300, 0, 5, True), (1, 1, 9, 2000, 0, -1, False)])
+def test_attention_row_pass_register_form_equals_the_three_pass_form(B, H, Sq, Sk, kw, causal, masked):
+    """ullsam_train_attn_rows with the row held in registers (Sk <= 4096: one wave per row up to 256 keys, four waves above) against its
+    three-pass form: forward (softmax of S + decomposed bias + causal / padding masks, incl. a fully padded batch entry) and backward (dS and the
+    bias-gradient rows), to fp32 rounding of the row sums."""
+    from ullsam_amd import _lib, ops
+    lib = _lib.load()
+    rng = np.random.default_rng(Sq * 7 + Sk)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    S0 = t(rng.standard_normal((B * H, Sq, Sk), dtype=np.float32) * 3)
+    dP0 = t(rng.standard_normal((B * H, Sq, Sk), dtype=np.float32))
+    bh = bw = None
+    if kw:
+        bh, bw = t(rng.standard_normal((B * H, Sq, Sk // kw), dtype=np.float32)), t(rng.standard_normal((B * H, Sq, kw), dtype=np.float32))
+    km = None
+    if masked:
+        km_np = np.ones((B, Sk), np.int32)
+        km_np[0, :Sk // 3] = 0
+        km = t(km_np)
+    outs = []
+    for on in (1, 0):
+        old = lib.ullsam_train_set_rows_reg(on)
+        try:
+            P = S0.clone()
+            _lib.call("ullsam_train_attn_rows", P.data_ptr(), None, ops._p(bh), ops._p(bw), None, None, ops._p(km), B, H, Sq, Sk, max(kw, 1), causal, 0,
+                      torch.cuda.current_stream().cuda_stream)
+            dS = dP0.clone()
+            dbh = torch.full_like(bh, 7.0) if kw else None
+            dbw = torch.full_like(bw, 7.0) if kw else None
+            _lib.call("ullsam_train_attn_rows", P.data_ptr(), dS.data_ptr(), ops._p(bh), ops._p(bw), ops._p(dbh), ops._p(dbw), None, B, H, Sq, Sk, max(kw, 1),
+                      causal, 1, torch.cuda.current_stream().cuda_stream)
+            # and the fused use (have_p 0 with dP): S -> P and dP -> dS in one call
+            P2, dS2 = S0.clone(), dP0.clone()
+            _lib.call("ullsam_train_attn_rows", P2.data_ptr(), dS2.data_ptr(), ops._p(bh), ops._p(bw), ops._p(dbh.clone() if kw else None), ops._p(dbw.clone() if kw else None),
+                      ops._p(km), B, H, Sq, Sk, max(kw, 1), causal, 0, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        finally:
+            lib.ullsam_train_set_rows_reg(old)
+        assert float((P2 - P).abs().max()) < 1e-6 and float((dS2 - dS).abs().max()) < 1e-5
+        outs.append((P, dS, dbh, dbw))
+    (P1, d1, h1, w1), (P0, d0, h0, w0) = outs
+    assert abs(float(P1.sum()) - B * H * Sq) < 1e-3 * B * H * Sq
+    assert float((P1 - P0).abs().max()) < 2e-6
+    assert float((d1 - d0).abs().max()) < 2e-5 * max(1.0, float(d0.abs().max()))
+    if kw:
+        assert float((h1 - h0).abs().max()) < 2e-5 * max(1.0, float(h0.abs().max())) and float((w1 - w0).abs().max()) < 2e-5 * max(1.0, float(w0.abs().max()))
+
+
 def test_train_step_module_under_ddp_world_1():
     """TrainStep wrapped in DistributedDataParallel (RCCL, world size 1: what one box offers): the hooks fire, the gradients equal the plain step's."""
     import os

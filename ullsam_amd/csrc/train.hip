@@ -540,10 +540,117 @@ __global__ __launch_bounds__(256) void attn_rows_bwd_kernel(float* __restrict__ 
         if (tid < kw) dbias_w[row * kw + tid] = dbs[128 + tid];
     }
 }
+// The same row pass with the row held in registers (Sk <= 64 NW VPT): one read and one write of S / dP instead of three of each, wave
+// reductions, 4 / NW rows per workgroup (a 196-key window row is one wave's work, a 4096-key row four waves'), and the decomposed-bias gradient rows
+// summed from an LDS copy of dS in a fixed order (no LDS atomics).  Arithmetic and its order per element are those of the kernel above
+// except for the order of the row sums.
+template <int NW, int VPT>
+__global__ __launch_bounds__(256) void attn_rows_reg_kernel(float* __restrict__ S, float* __restrict__ dP, const float* __restrict__ bias_h,
+                                                            const float* __restrict__ bias_w, float* __restrict__ dbias_h, float* __restrict__ dbias_w,
+                                                            const int* __restrict__ key_mask, int H, int Sq, int Sk, int kw, int causal, int have_p, long rows) {
+    constexpr int RPB = 4 / NW, T = 64 * NW;
+    extern __shared__ float rows_lds[];                    // [RPB][T * VPT] dS of the rows in flight (bias gradients only)
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rib = wave / NW, tix = (wave % NW) * 64 + lane;
+    const long row = (long)blockIdx.x * RPB + rib;
+    const bool live = row < rows;
+    const int qi = live ? (int)(row % Sq) : 0;
+    const long bh = live ? row / Sq : 0;
+    const int b = (int)(bh / H);
+    float* s = S + row * Sk;
+    float* g = dP + row * Sk;
+    const int kh_n = bias_h ? Sk / kw : 0;
+    const float* bhp = bias_h ? bias_h + row * kh_n : nullptr;
+    const float* bwp = bias_h ? bias_w + row * kw : nullptr;
+    auto row_reduce = [&](float v, const bool is_max) -> float {
+        v = is_max ? wave_max(v) : wave_sum(v);
+        if (NW == 1) return v;
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    const float FMIN = -3.4028234663852886e38f;
+    float p[VPT];
+    if (!have_p) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int kt = tix + T * i;
+            float v = -INFINITY;
+            if (live && kt < Sk) {
+                v = s[kt];
+                if (bhp) v += bhp[kt / kw] + bwp[kt % kw];
+                if (causal >= 0 && kt > qi + causal) v += FMIN;
+                if (key_mask && key_mask[(long)b * Sk + kt] == 0) v += FMIN;
+            }
+            p[i] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = row_reduce(mx, true);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) { p[i] = (mx == -INFINITY || p[i] == -INFINITY) ? 0.f : expf(p[i] - mx); sum += p[i]; }
+        sum = row_reduce(sum, false);
+        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            p[i] *= inv;
+            const int kt = tix + T * i;
+            if (live && kt < Sk) s[kt] = p[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) { const int kt = tix + T * i; p[i] = (live && kt < Sk) ? s[kt] : 0.f; }
+    }
+    if (!dP) return;
+    float gr[VPT], ds = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) { const int kt = tix + T * i; gr[i] = (live && kt < Sk) ? g[kt] : 0.f; ds += p[i] * gr[i]; }
+    const float D = row_reduce(ds, false);
+    float* mine = rows_lds + rib * (T * VPT);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int kt = tix + T * i;
+        const float dl = p[i] * (gr[i] - D);
+        if (live && kt < Sk) g[kt] = dl;
+        if (bhp) mine[kt] = (live && kt < Sk) ? dl : 0.f;
+    }
+    if (bhp) {
+        __syncthreads();
+        if (live)
+            for (int j = tix; j < kh_n + kw; j += T) {
+                float a = 0.f;
+                if (j < kh_n) { for (int c = 0; c < kw; ++c) a += mine[j * kw + c]; dbias_h[row * kh_n + j] = a; }
+                else { const int c = j - kh_n; for (int r = 0; r < kh_n; ++r) a += mine[r * kw + c]; dbias_w[row * kw + c] = a; }
+            }
+    }
+}
+template <int NW, int VPT>
+static void launch_attn_rows_reg(float* S, float* dP, const float* bias_h, const float* bias_w, float* dbias_h, float* dbias_w, const int* key_mask,
+                                 int B, int H, int Sq, int Sk, int kw, int causal, int have_p, hipStream_t st) {
+    constexpr int RPB = 4 / NW;
+    const long rows = (long)B * H * Sq;
+    const int lds = (bias_h && dP) ? RPB * 64 * NW * VPT * 4 : 0;
+    attn_rows_reg_kernel<NW, VPT><<<dim3((unsigned)((rows + RPB - 1) / RPB)), 256, lds, st>>>(S, dP, bias_h, bias_w, dbias_h, dbias_w, key_mask, H, Sq, Sk, kw, causal, have_p, rows);
+}
+static int g_train_rows_reg = 1;
+extern "C" int ullsam_train_set_rows_reg(int on) { const int old = g_train_rows_reg; g_train_rows_reg = on; return old; }
 extern "C" int ullsam_train_attn_rows(float* S, float* dP, const float* bias_h, const float* bias_w, float* dbias_h, float* dbias_w,
                                       const int* key_mask, int B, int H, int Sq, int Sk, int kw, int causal, int have_p, void* stream) {
     ULLSAM_CHECK(B > 0 && H > 0 && (long)B * H < 65536 && Sq > 0 && Sk > 0, "train_attn_rows: bad dims");
     ULLSAM_CHECK(!bias_h || (bias_w && (!dP || (dbias_h && dbias_w)) && kw > 0 && kw <= 128 && Sk % kw == 0 && Sk / kw <= 128), "train_attn_rows: bias needs Sk = kh * kw, kh, kw <= 128");
+    if (g_train_rows_reg && Sk <= 4096) {
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define ROWS_REG(NW, VPT) launch_attn_rows_reg<NW, VPT>(S, dP, bias_h, bias_w, dbias_h, dbias_w, key_mask, B, H, Sq, Sk, kw, causal, have_p, st)
+        if (Sk <= 256) ROWS_REG(1, 4);
+        else if (Sk <= 1024) ROWS_REG(4, 4);
+        else if (Sk <= 2048) ROWS_REG(4, 8);
+        else ROWS_REG(4, 16);
+#undef ROWS_REG
+        ULLSAM_LAUNCH_CHECK();
+        return 0;
+    }
     attn_rows_bwd_kernel<<<dim3(Sq, B * H), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(S, dP, bias_h, bias_w, dbias_h, dbias_w, key_mask, H, Sq, Sk, kw, causal, have_p);
     ULLSAM_LAUNCH_CHECK();
     return 0;
