@@ -83,6 +83,10 @@ int ullsam_decode_qkv_rope(const void* a, const float* x, long ldx, const float*
  * the hypernetwork product of mask_decoder.py:146-147 and its gradients) */
 int ullsam_train_matmul(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k, long b_b,
                         long b_k, long b_n, long c_b, long c_m, long c_n, int accumulate, void* stream);
+/* the product with both fp32 operands rounded to bf16 on load and summed on the bf16 MFMA (fp32 accumulation and result): torch.autocast(bfloat16)'s matmul,
+ * i.e. the attention products of the reference's trainer on its bf16 model (train_joint_v2.py:1665) */
+int ullsam_train_matmul_bf16(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k, long b_b,
+                             long b_k, long b_n, long c_b, long c_m, long c_n, int accumulate, void* stream);
 /* the same product with its k range cut into `ksplit` pieces run by separate workgroups and added IN ORDER by a second kernel (few output tiles,
  * long sums: rel-pos table gradients, the hypernetwork gradient over 65536 pixels); partial: ksplit * batch * M * N floats of scratch */
 int ullsam_train_matmul_splitk(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k, long b_b,
@@ -184,6 +188,8 @@ int ullsam_im2col3x3(int dtype, const void* in, void* out, int B, int H, int W, 
 int ullsam_add_cast(const void* a, int a_dtype, long a_rows, const float* b, long b_rows, void* out, int out_dtype,
                     long rows, int cols, void* stream);                                  /* transformer.py:165,181; mask_decoder.py:127 */
 int ullsam_transpose_f32(const float* in, float* out, int B, int R, int C, void* stream);  /* image_encoder.py:114 permute */
+/* in [R, C] (in_dtype: f32 or bf16) -> out bf16 [C, Rp], transposed, columns R..Rp-1 zero (training: the dW / dX GEMM operands, cast + transposed in one pass) */
+int ullsam_transpose_to_bf16(int in_dtype, const void* in, void* out, int R, int C, int Rp, void* stream);
 int ullsam_pixel_shuffle_ln(int dtype, const float* in_nhwc, void* out, const float* w, const float* b, int B, int H, int W,
                             int C, float eps, void* stream);                             /* modeling_internvl_sam.py:226-251,89 */
 int ullsam_pixel_unshuffle(const float* in, float* out_nhwc, int B, int H, int W, int C, void* stream); /* :256-268 */

@@ -293,6 +293,13 @@ def test_train_matmul_on_the_matrix_pipe_equals_the_scalar_kernel(M, N, K, batch
         assert float((C.double() - ref).abs().max()) < 2e-6 * scale * max(1.0, K ** 0.5 / 8), (on, M, N, K)
         assert float((Cacc.double() - ref - C0.double()).abs().max()) < 2e-6 * scale * max(1.0, K ** 0.5 / 8) + 1e-6
     assert float((outs[0] - outs[1]).abs().max()) < 1e-5 * float(ref.abs().max())
+    # the bf16-rounding form (autocast's matmul): equal to the fp64 product of the bf16-rounded operands up to fp32 accumulation
+    if M >= 64 and N >= 48:
+        Cb = torch.empty_like(C0)
+        _mm(A, B, Cb, M, N, K, sa, sb, (M * N, N, 1), batch=batch, bf16=True)
+        Ar, Br = A.bfloat16().double(), B.bfloat16().double()
+        refb = (Ar.transpose(1, 2) if a_t else Ar) @ (Br.transpose(1, 2) if b_t else Br)
+        assert float((Cb.double() - refb).abs().max()) < 2e-6 * float(refb.abs().max()) * max(1.0, K ** 0.5 / 8)
 
 
 @pytest.mark.parametrize("B,H,Sq,Sk,kw,causal,masked", [(2, 3, 196, 196, 14, -1, False), (1, 2, 70, 1081, 0, 0, True), (1, 2, 33, 4096, 64, -1, False),
@@ -384,8 +391,8 @@ def test_train_step_module_under_ddp_world_1():
 
 def test_bf16_model_runs_its_large_linears_on_bf16_gemms():
     """training.BF16_LINEAR (default): the large linears of a bf16 model (>= 256 rows, dimensions % 64: the ViT's qkv / proj / lin1 / lin2, patch
-    embedding, neck, mlp1 / mlp2) run forward, dX and dW on the bf16 MFMA GEMM -- what the reference's trainer computes (bf16 model under
-    autocast(bf16), train_joint_v2.py:1665,1676).  Against the fp32-arithmetic route on the same bf16 weights: the loss within 2e-3, every
+    embedding, neck, mlp1 / mlp2) run forward, dX and dW on the bf16 MFMA GEMM, and the score / probability products of the ViT's and the LLM's
+    attention round their operands to bf16 -- what the reference's trainer computes (bf16 model under autocast(bf16), train_joint_v2.py:1665,1676).  Against the fp32-arithmetic route on the same bf16 weights: the loss within 2e-3, every
     gradient within bf16-activation noise of its tensor's scale (and the bf16 route really is taken: LinearBf16Fn nodes in the graph)."""
     from ullsam_amd import training
     g = U.gold("train_step")
@@ -421,15 +428,21 @@ def test_bf16_model_runs_its_large_linears_on_bf16_gemms():
     (lb, gb), (lf, gf) = res
     assert abs(lb - lf) < 2e-3 * abs(lf), (lb, lf)
     assert set(gb) == set(gf)
-    worst = (0.0, "")
+    worst, worst_cos = (0.0, ""), (1.0, "")
     for n in gf:
         scale = float(gf[n].abs().max())
         if scale < 1e-6:
             continue
         e = float((gb[n] - gf[n]).abs().max()) / scale
+        cos = float((gb[n] * gf[n]).sum() / (gb[n].norm() * gf[n].norm()))
         worst = max(worst, (e, n))
-        assert e < 0.03, (n, e)          # measured worst: 0.011
-    print("bf16-GEMM route vs fp32-arithmetic route on the same bf16 weights: loss", lb, lf, "worst relative gradient difference", worst)
+        worst_cos = min(worst_cos, (cos, n))
+        # linears alone: worst 0.011; with the attention products in bf16 the relative-position tables, whose gradients are sums of dS = P (dP - sum P dP)
+        # over thousands of (query, key) pairs with cancellation, move by up to 0.06 of their largest entry while keeping their direction
+        # ... and a ReLU unit of the decoder's MLP whose pre-activation sits at zero may switch (one row of a lin1 gradient appears / disappears: 0.11 of the
+        # tensor's largest entry at cosine 0.99995): the bound on single entries is loose, the bound on the tensor's direction is not
+        assert e < 0.25 and cos > 0.995, (n, e, cos)
+    print("bf16-GEMM route vs fp32-arithmetic route on the same bf16 weights: loss", lb, lf, "worst relative gradient difference", worst, "worst cosine", worst_cos)
 
 
 def test_bf16_model_runs_the_frozen_llm_on_bf16_gemms():

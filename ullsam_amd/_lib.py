@@ -23,6 +23,7 @@ SIGNATURES = {
     "ullsam_gemm_rmsnorm": [vp, i64, vp, f32, vp, i64, vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, vp],
     "ullsam_decode_qkv_rope": [vp, vp, i64, vp, f32, vp, i64, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp],
     "ullsam_train_matmul": [vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [i32, vp],
+    "ullsam_train_matmul_bf16": [vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [i32, vp],
     "ullsam_train_matmul_splitk": [vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [i32, i32, vp, vp],
     "ullsam_train_colsum": [vp, vp, i64, i32, i64, vp],
     "ullsam_train_ln_bwd": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
@@ -50,6 +51,7 @@ SIGNATURES = {
     "ullsam_im2col3x3": [i32, vp, vp, i32, i32, i32, i32, vp],
     "ullsam_add_cast": [vp, i32, i64, vp, i64, vp, i32, i64, i32, vp],
     "ullsam_transpose_f32": [vp, vp, i32, i32, i32, vp],
+    "ullsam_transpose_to_bf16": [i32, vp, vp, i32, i32, i32, vp],
     "ullsam_pixel_shuffle_ln": [i32, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "ullsam_pixel_unshuffle": [vp, vp, i32, i32, i32, i32, vp],
     "ullsam_scan_image_tokens": [vp, vp, vp, i32, i32, C.c_longlong, vp],

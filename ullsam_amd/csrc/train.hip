@@ -171,6 +171,104 @@ static void launch_matmul_mfma(const MmArgs& a, hipStream_t stream) {
     if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(matmul_f32_mfma_kernel<AK, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
     matmul_f32_mfma_kernel<AK, BN><<<dim3((a.N + 127) / 128, (a.M + 127) / 128, a.batch * a.ksplit), 256, LDS, stream>>>(a);
 }
+// The same product with both operands ROUNDED TO bf16 on their way into LDS and the sums on v_mfma_f32_32x32x16_bf16 (fp32 accumulation, fp32 result):
+// what torch.autocast(bfloat16) makes of a matmul, i.e. what the reference's trainer computes for the attention products of its bf16 model
+// (train_joint_v2.py:1665).  Operands and result stay fp32 in memory, so the kernel is a drop-in for the one above; 16x fewer matrix cycles leave it
+// bound by the operand reads.  LDS image: [row][32 k] bf16 with an 80-byte row stride (a 16-lane group of a ds_read_b128 fragment read covers all 64 banks).
+constexpr int MMB_LD = 40;
+template <bool AK, bool BN>
+__global__ __launch_bounds__(256, 2) void matmul_bf16_mfma_kernel(MmArgs p) {
+    extern __shared__ bf16 mmb_lds[];                      // [2 buffers][A | B][128 rows][40]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128, b = blockIdx.z / p.ksplit, ks = blockIdx.z % p.ksplit;
+    p.A += (long)ks * p.kc * p.a_k;
+    p.B += (long)ks * p.kc * p.b_k;
+    p.K = min(p.kc, p.K - ks * p.kc);
+    p.C += (long)ks * p.c_s;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int t5 = tid >> 5, k5 = tid & 31, t7 = tid >> 7, r7 = tid & 127;
+    const float* pa = p.A + (long)b * p.a_b + (AK ? (long)(m0 + t5) * p.a_m + (long)k5 * p.a_k : (long)(m0 + r7) * p.a_m + (long)t7 * p.a_k);
+    const float* pb = p.B + (long)b * p.b_b + (BN ? (long)(n0 + r7) * p.b_n + (long)t7 * p.b_k : (long)(n0 + t5) * p.b_n + (long)k5 * p.b_k);
+    const long a_inc = AK ? 8 * p.a_m : 2 * p.a_k, b_inc = BN ? 2 * p.b_k : 8 * p.b_n, a_step = 32 * p.a_k, b_step = 32 * p.b_k;
+    const bool inner = m0 + 128 <= p.M && n0 + 128 <= p.N;
+    float ra[16], rb[16];
+    auto fetch = [&](int k0) {
+        if (inner && k0 + 32 <= p.K) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ra[i] = pa[i * a_inc]; rb[i] = pb[i * b_inc]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool va = AK ? (m0 + t5 + 8 * i < p.M && k0 + k5 < p.K) : (m0 + r7 < p.M && k0 + t7 + 2 * i < p.K);
+                const bool vb = BN ? (n0 + r7 < p.N && k0 + t7 + 2 * i < p.K) : (n0 + t5 + 8 * i < p.N && k0 + k5 < p.K);
+                ra[i] = va ? pa[i * a_inc] : 0.f;
+                rb[i] = vb ? pb[i * b_inc] : 0.f;
+            }
+        }
+        pa += a_step;
+        pb += b_step;
+    };
+    auto stash = [&](int buf) {
+        bf16* As = mmb_lds + buf * (2 * 128 * MMB_LD);
+        bf16* Bs = As + 128 * MMB_LD;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (AK) As[(t5 + 8 * i) * MMB_LD + k5] = (bf16)ra[i];
+            else    As[r7 * MMB_LD + t7 + 2 * i] = (bf16)ra[i];
+            if (BN) Bs[r7 * MMB_LD + t7 + 2 * i] = (bf16)rb[i];
+            else    Bs[(t5 + 8 * i) * MMB_LD + k5] = (bf16)rb[i];
+        }
+    };
+    const int steps = (p.K + 31) / 32;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int kh = lane >> 5, l5 = lane & 31;
+    for (int t = 0; t < steps; ++t) {
+        if (t + 1 < steps) fetch(32 * (t + 1));
+        const bf16* As = mmb_lds + (t & 1) * (2 * 128 * MMB_LD) + 8 * kh;
+        const bf16* Bs = As + 128 * MMB_LD;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * 64 + i * 32 + l5) * MMB_LD + 16 * kk);
+                bf[i] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * 64 + i * 32 + l5) * MMB_LD + 16 * kk);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < steps) stash((t + 1) & 1);
+        __syncthreads();
+    }
+    float* cb = p.C + (long)b * p.c_b;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + 8 * (e >> 2) + 4 * kh + (e & 3), n = n0 + wn * 64 + j * 32 + l5;
+                if (m < p.M && n < p.N) {
+                    float* c = cb + (long)m * p.c_m + (long)n * p.c_n;
+                    *c = p.accumulate ? *c + acc[i][j][e] : acc[i][j][e];
+                }
+            }
+}
+template <bool AK, bool BN>
+static void launch_matmul_bf16(const MmArgs& a, hipStream_t stream) {
+    constexpr int LDS = 2 * 2 * 128 * MMB_LD * 2;
+    matmul_bf16_mfma_kernel<AK, BN><<<dim3((a.N + 127) / 128, (a.M + 127) / 128, a.batch * a.ksplit), 256, LDS, stream>>>(a);
+}
 static int g_train_matmul_mfma = 1;
 extern "C" int ullsam_train_set_matmul_mfma(int on) { const int old = g_train_matmul_mfma; g_train_matmul_mfma = on; return old; }
 // C[i] (+)= sum over splits s (in order: deterministic) of part[s][i]
@@ -202,6 +300,21 @@ extern "C" int ullsam_train_matmul(const float* A, const float* B, float* C, int
     ULLSAM_CHECK(M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "train_matmul: M=%d N=%d K=%d batch=%d", M, N, K, batch);
     MmArgs a{A, B, C, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n, accumulate, 1, K, 0};
     return train_matmul_launch(a, reinterpret_cast<hipStream_t>(stream));
+}
+// fp32 operands rounded to bf16 at the product's door (see matmul_bf16_mfma_kernel); shapes below the MFMA tile fall back to the fp32 product
+extern "C" int ullsam_train_matmul_bf16(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k,
+                                        long b_b, long b_k, long b_n, long c_b, long c_m, long c_n, int accumulate, void* stream) {
+    ULLSAM_CHECK(M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "train_matmul_bf16: M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    MmArgs a{A, B, C, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n, accumulate, 1, K, 0};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!(M >= 64 && N >= 48 && K >= 16)) return train_matmul_launch(a, st);
+    const bool ak = a_k <= a_m, bn = b_n <= b_k;
+    if (ak && bn) launch_matmul_bf16<true, true>(a, st);
+    else if (ak) launch_matmul_bf16<true, false>(a, st);
+    else if (bn) launch_matmul_bf16<false, true>(a, st);
+    else launch_matmul_bf16<false, false>(a, st);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
 }
 // The same product with the k range cut into `ksplit` pieces that run as separate workgroups (products with a few output tiles and a long
 // sum: the table gradients of the decomposed relative-position bias, the hypernetwork gradient over 65536 pixels).  `partial` holds

@@ -136,6 +136,35 @@ extern "C" int ullsam_transpose_f32(const float* in, float* out, int B, int R, i
     return 0;
 }
 
+// ---- [R, C] fp32 or bf16 -> [C, Rp] bf16, transposed, columns R .. Rp - 1 zero: the operands of the training step's dW = dY^T X GEMM (inner dimension =
+// the step's row count, padded to the GEMM's K granularity) and the W^T of dX = dY W, cast and transposed in one pass -------------------------------
+template <typename Tin>
+__global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const Tin* __restrict__ in, bf16* __restrict__ out, int R, int C, int Rp) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = r0 + ty + 4 * j, c = c0 + tx;
+        tile[ty + 4 * j][tx] = (r < R && c < C) ? to_f32(in[(long)r * C + c]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = c0 + ty + 4 * j, r = r0 + tx;
+        if (c < C && r < Rp) out[(long)c * Rp + r] = from_f32<bf16>(tile[tx][ty + 4 * j]);
+    }
+}
+extern "C" int ullsam_transpose_to_bf16(int in_dtype, const void* in, void* out, int R, int C, int Rp, void* stream) {
+    ULLSAM_CHECK(R > 0 && C > 0 && Rp >= R, "transpose_to_bf16: R=%d C=%d Rp=%d", R, C, Rp);
+    const dim3 grid((C + 63) / 64, (Rp + 63) / 64);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (in_dtype == ULLSAM_DT_F32) transpose_to_bf16_kernel<float><<<grid, 256, 0, st>>>(static_cast<const float*>(in), static_cast<bf16*>(out), R, C, Rp);
+    else transpose_to_bf16_kernel<bf16><<<grid, 256, 0, st>>>(static_cast<const bf16*>(in), static_cast<bf16*>(out), R, C, Rp);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- pixel_shuffle(0.5, v2) + LayerNorm(4C)  (modeling_internvl_sam.py:226-251, mlp1[0] :89) -------------------
 // in : image embedding NHWC f32 [B, H, W, C];  out: T [B*(H/2)*(W/2), 4C]
 //      out[(h2,w2), (h&1)*2C + (w&1)*C + c] = in[2h2+(h&1), 2w2+(w&1), c]; one wave per output token

@@ -276,6 +276,16 @@ def transpose(x: torch.Tensor, B: int, R: int, C: int) -> torch.Tensor:
     return out
 
 
+def transpose_to_bf16(x: torch.Tensor, pad_to: int = 1) -> torch.Tensor:
+    """fp32 / bf16 [R, C] -> bf16 [C, R rounded up to pad_to] (zero filled), cast and transposed in one pass."""
+    _chk(x, "x")
+    R, Cn = x.shape
+    Rp = -(-R // pad_to) * pad_to
+    out = torch.empty((Cn, Rp), dtype=torch.bfloat16, device=x.device)
+    _lib.call("ullsam_transpose_to_bf16", dt_code(x.dtype), x.data_ptr(), out.data_ptr(), R, Cn, Rp, _stream())
+    return out
+
+
 def pixel_shuffle_ln(x_nhwc: torch.Tensor, w, b, B, H, W, C, eps, dtype) -> torch.Tensor:
     _chk(x_nhwc, "x", torch.float32)
     out = torch.empty((B * (H // 2) * (W // 2), 4 * C), dtype=dtype, device=x_nhwc.device)

@@ -48,8 +48,12 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _mm(A, B, C, M, N, K, sa, sb, sc, batch=1, accumulate=False):
-    """C[b](m,n) (+)= sum_k A[b](m,k) B[b](k,n); sa = (batch, m, k) element strides of A, sb = (batch, k, n), sc = (batch, m, n)."""
+def _mm(A, B, C, M, N, K, sa, sb, sc, batch=1, accumulate=False, bf16=False):
+    """C[b](m,n) (+)= sum_k A[b](m,k) B[b](k,n); sa = (batch, m, k) element strides of A, sb = (batch, k, n), sc = (batch, m, n).
+    bf16: operands rounded to bf16 on load, bf16 MFMA with fp32 accumulation (autocast's matmul; the attention products of a bf16 model)."""
+    if bf16:
+        _lib.call("ullsam_train_matmul_bf16", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, batch, *sa, *sb, *sc, int(accumulate), _s())
+        return
     tile = 128 if (M >= 64 and N >= 48) else 64
     tiles = -(-M // tile) * -(-N // tile) * batch
     if K >= 2048 and tiles <= 128:          # a few output tiles under a long sum: cut k over workgroups (partials added in order: deterministic)
@@ -141,7 +145,7 @@ class _TransposeCache:
             return e[0]
         if e is not None:
             self.bytes -= e[0].numel() * e[0].element_size()
-        t = w.detach().t().contiguous()
+        t = ops.transpose_to_bf16(w.detach()) if w.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 2 and w.is_contiguous() else w.detach().t().contiguous()
         nb = t.numel() * t.element_size()
         if self.bytes + nb > self.max_bytes:
             self.clear()
@@ -192,17 +196,6 @@ BF16_LINEAR = True   # a bf16 model's large linears (>= 256 rows, both dimension
 #                      arithmetic stays fp32 (tests compare the two)
 
 
-def _pad_cols(t: torch.Tensor, mult: int = 64) -> torch.Tensor:
-    """[R, C] -> [R, C rounded up to mult], zero filled (the inner dimension of the dW GEMM is the row count of the step: 4900 for a windowed block)."""
-    R, Cn = t.shape
-    Cp = -(-Cn // mult) * mult
-    if Cp == Cn:
-        return t.contiguous()
-    out = torch.zeros((R, Cp), dtype=t.dtype, device=t.device)
-    out[:, :Cn] = t
-    return out
-
-
 class LinearBf16Fn(Function):
     """y = x W^T (+ b) for a TRAINABLE bf16 weight on the inference path's bf16 MFMA GEMM (fp32 accumulation, fp32 results): forward with W as
     stored; dX = dY W through a transposed copy of W; dW = dY^T X as the GEMM [N, M] x ([K, M])^T over bf16 transposes of dY and X (rows padded
@@ -223,9 +216,9 @@ class LinearBf16Fn(Function):
         dyb = ops.cast(dy, torch.bfloat16)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm(dyb, w.detach().t().contiguous(), out_f32=True)
+            dx = ops.gemm(dyb, ops.transpose_to_bf16(w.detach()), out_f32=True)
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm(_pad_cols(dyb.t()), _pad_cols(xb.t()), out_f32=True)
+            dw = ops.gemm(ops.transpose_to_bf16(dy, 64), ops.transpose_to_bf16(xb, 64), out_f32=True)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = _colsum(dy)
         return dx, dw, db
@@ -358,8 +351,9 @@ class AttentionFn(Function):
     ViT's (image_encoder.py:224-240: bias_h [B, H, Sq, Sk/kw] + bias_w [B, H, Sq, kw], the decomposed relative-position terms)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, B, H, KVH, Sq, Sk, causal, key_mask, bias_h, bias_w, kw):
+    def forward(ctx, q, k, v, B, H, KVH, Sq, Sk, causal, key_mask, bias_h, bias_w, kw, bf16=False):
         q, k, v = _c(q), _c(k), _c(v)
+        ctx.bf16 = bool(bf16)     # matrix form only: the score / probability products as autocast(bfloat16) computes them (bf16 models)
         if bias_h is not None:
             bias_h, bias_w = _c(bias_h), _c(bias_w)
         hd = q.shape[-1] // H
@@ -374,11 +368,11 @@ class AttentionFn(Function):
         qs, kh, vh = AttentionFn._head_major(q, k, v, ctx.dims)
         BH = B * H
         P = torch.empty((BH, Sq, Sk), dtype=F32, device=q.device)
-        _mm(qs, kh, P, Sq, Sk, hd, (Sq * hd, hd, 1), (Sk * hd, 1, hd), (Sq * Sk, Sk, 1), batch=BH)          # S = (q scale) k^T
+        _mm(qs, kh, P, Sq, Sk, hd, (Sq * hd, hd, 1), (Sk * hd, 1, hd), (Sq * Sk, Sk, 1), batch=BH, bf16=ctx.bf16)          # S = (q scale) k^T
         _lib.call("ullsam_train_attn_rows", P.data_ptr(), None, ops._p(bias_h), ops._p(bias_w), None, None, ops._p(key_mask), B, H, Sq, Sk, kw,
                   causal, 0, _s())                                                                           # S <- P = softmax(S + bias + masks)
         oh = torch.empty_like(qs)
-        _mm(P, vh, oh, Sq, hd, Sk, (Sq * Sk, Sk, 1), (Sk * hd, hd, 1), (Sq * hd, hd, 1), batch=BH)          # out = P v
+        _mm(P, vh, oh, Sq, hd, Sk, (Sq * Sk, Sk, 1), (Sk * hd, hd, 1), (Sq * hd, hd, 1), batch=BH, bf16=ctx.bf16)          # out = P v
         ctx.save_for_backward(qs, kh, vh, P, bias_h, bias_w)
         ctx.matrix = True
         return oh.permute(0, 2, 1, 3).reshape(B * Sq, H * hd).contiguous()
@@ -423,26 +417,26 @@ class AttentionFn(Function):
             dbw = torch.empty_like(bias_w) if bias_w is not None else None
             dq, dk, dv = torch.empty_like(q), torch.zeros_like(k), torch.zeros_like(v)
             AttentionFn._launch(q, k, v, dout, None, dq, dk, dv, ctx.dims, key_mask, bias_h, bias_w, dbh, dbw)
-            return (dq, dk, dv) + nones + (dbh, dbw, None)
+            return (dq, dk, dv) + nones + (dbh, dbw, None, None)
         qs, kh, vh, P, bias_h, bias_w = ctx.saved_tensors
         dbh = torch.empty_like(bias_h) if bias_h is not None else None
         dbw = torch.empty_like(bias_w) if bias_w is not None else None
         G, BH = H // KVH, B * H
         doh = dout.reshape(B, Sq, H, hd).permute(0, 2, 1, 3).contiguous()
         dP = torch.empty_like(P)
-        _mm(doh, vh, dP, Sq, Sk, hd, (Sq * hd, hd, 1), (Sk * hd, 1, hd), (Sq * Sk, Sk, 1), batch=BH)        # dP = dO v^T
+        _mm(doh, vh, dP, Sq, Sk, hd, (Sq * hd, hd, 1), (Sk * hd, 1, hd), (Sq * Sk, Sk, 1), batch=BH, bf16=ctx.bf16)        # dP = dO v^T
         _lib.call("ullsam_train_attn_rows", P.data_ptr(), dP.data_ptr(), ops._p(bias_h), ops._p(bias_w), ops._p(dbh), ops._p(dbw), None, B, H,
                   Sq, Sk, kw, causal, 1, _s())                                                               # dP <- dS = P (dP - sum_j P_j dP_j)
         dvh, dkh, dqs = torch.empty_like(kh), torch.empty_like(kh), torch.empty_like(qs)
-        _mm(P, doh, dvh, Sk, hd, Sq, (Sq * Sk, 1, Sk), (Sq * hd, hd, 1), (Sk * hd, hd, 1), batch=BH)        # dV = P^T dO
-        _mm(dP, qs, dkh, Sk, hd, Sq, (Sq * Sk, 1, Sk), (Sq * hd, hd, 1), (Sk * hd, hd, 1), batch=BH)        # dK = dS^T (q scale)
-        _mm(dP, kh, dqs, Sq, hd, Sk, (Sq * Sk, Sk, 1), (Sk * hd, hd, 1), (Sq * hd, hd, 1), batch=BH)        # d(q scale) = dS k
+        _mm(P, doh, dvh, Sk, hd, Sq, (Sq * Sk, 1, Sk), (Sq * hd, hd, 1), (Sk * hd, hd, 1), batch=BH, bf16=ctx.bf16)        # dV = P^T dO
+        _mm(dP, qs, dkh, Sk, hd, Sq, (Sq * Sk, 1, Sk), (Sq * hd, hd, 1), (Sk * hd, hd, 1), batch=BH, bf16=ctx.bf16)        # dK = dS^T (q scale)
+        _mm(dP, kh, dqs, Sq, hd, Sk, (Sq * Sk, Sk, 1), (Sk * hd, hd, 1), (Sq * hd, hd, 1), batch=BH, bf16=ctx.bf16)        # d(q scale) = dS k
         dqh = AttentionFn._scaled(dqs, 1.0 / math.sqrt(hd))
         if G > 1:                                                                                   # the gradient of repeat_kv: sum over the group
             red = lambda t: _colsum(t.reshape(B, KVH, G, Sk * hd).permute(2, 0, 1, 3).reshape(G, -1).contiguous()).reshape(B, KVH, Sk, hd)
             dkh, dvh = red(dkh), red(dvh)
         back = lambda t, S_, Hx: t.permute(0, 2, 1, 3).reshape(B * S_, Hx * hd).contiguous()
-        return (back(dqh, Sq, H), back(dkh, Sk, KVH), back(dvh, Sk, KVH)) + nones + (dbh, dbw, None)
+        return (back(dqh, Sq, H), back(dkh, Sk, KVH), back(dvh, Sk, KVH)) + nones + (dbh, dbw, None, None)
 
 
 class GatherRowsFn(Function):
@@ -826,7 +820,7 @@ def llm_image_hidden(model, vit_feature_rows: torch.Tensor, input_ids: torch.Ten
         q = RoPEFn.apply(qkv[:, :, :G].reshape(B * S, H * hd), pos, cos, sin, H)
         k = RoPEFn.apply(qkv[:, :, G].reshape(B * S, KVH * hd), pos, cos, sin, KVH)
         v = qkv[:, :, G + 1].reshape(B * S, KVH * hd)
-        a = AttentionFn.apply(q, k, v, B, H, KVH, S, S, 0, key_mask, None, None, 0)
+        a = AttentionFn.apply(q, k, v, B, H, KVH, S, S, 0, key_mask, None, None, 0, BF16_LINEAR and at.wqkv.weight.dtype == torch.bfloat16)
         x = AddFn.apply(x, _frozen_linear(a, at.wo.weight, at.wo.bias))
         xn = RMSNormFn.apply(x, layer.ffn_norm.weight, layer.ffn_norm.variance_epsilon)
         hmid = SwiGLUFn.apply(_frozen_linear(xn, ff.w1.weight, None), _frozen_linear(xn, ff.w3.weight, None))
@@ -882,7 +876,7 @@ def vision_feature_rows(enc, pixel_values: torch.Tensor) -> torch.Tensor:
         rel_h = rel_h.reshape(Hh, Bw, Hh, heads, Hh).permute(1, 3, 0, 2, 4).reshape(Bw, heads, T, Hh)
         rel_w = BmmNTFn.apply(q5.permute(2, 0, 1, 3, 4).reshape(Hh, Bw * Hh * heads, hd), Rw)   # [qw, (b, qh, head), kw]
         rel_w = rel_w.reshape(Hh, Bw, Hh, heads, Hh).permute(1, 3, 2, 0, 4).reshape(Bw, heads, T, Hh)
-        a = AttentionFn.apply(q, k, v, Bw, heads, heads, T, T, -1, None, rel_h, rel_w, Hh)
+        a = AttentionFn.apply(q, k, v, Bw, heads, heads, T, T, -1, None, rel_h, rel_w, Hh, BF16_LINEAR and at.qkv.weight.dtype == torch.bfloat16)
         a = _apply_linear(a, at.proj.weight, at.proj.bias)
         if ws > 0:                                                                             # window_unpartition :267-290
             a = a.reshape(B, gp // ws, gp // ws, ws, ws, D).permute(0, 1, 3, 2, 4, 5).contiguous().reshape(B, gp, gp, D)
