@@ -515,6 +515,16 @@ def test_transposed_weight_cache_follows_the_weight():
     assert c.bytes <= c.max_bytes and len(c) == 1
     T.invalidate_transposed_weights()
     assert len(T._WT_CACHE) == 0
+    # the module's own cache keeps nothing unless given a budget (a 7B LLM's transposes are 13 GB): every get() is a fresh transpose
+    assert T._WT_CACHE.max_bytes == 0
+    w0 = torch.nn.Parameter(torch.randn(4, 8))
+    assert torch.equal(T._WT_CACHE.get(w0), w0.detach().t()) and len(T._WT_CACHE) == 0 and T._WT_CACHE.bytes == 0
+    T.set_transpose_cache_bytes(1 << 20)
+    try:
+        assert T._WT_CACHE.get(w0) is T._WT_CACHE.get(w0) and len(T._WT_CACHE) == 1
+    finally:
+        T.set_transpose_cache_bytes(0)
+    assert len(T._WT_CACHE) == 0
 
 
 def _gloo_uneven_worker(rank, world, port, q):

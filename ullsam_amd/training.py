@@ -77,6 +77,8 @@ def _t2d(x: torch.Tensor) -> torch.Tensor:
     return ops.transpose(x.reshape(1, R, C), 1, R, C).reshape(C, R)
 
 
+RECOMPUTE_P = True   # matrix-form attention keeps q, k, v and rebuilds the probability matrix in the backward (one more product and the softmax inside the
+#                      backward's row pass) instead of holding it from the forward: -10.8 GB on a ViT-H + 7B-shaped step for ~4 % of its time
 MATRIX_ATTN_FROM = 1 << 12   # attention through materialised score matrices from Sq * Sk >= this (below: one workgroup per query, backward by atomics)
 MFMA_LINEAR = True   # nn.Linear forward / backward on the fp32 MFMA GEMM of the inference path where its shapes allow (inner dimension % 32 == 0);
 #                     the one-output-per-thread matmul of csrc/train.hip otherwise (and always with MFMA_LINEAR = False: tests compare the two)
@@ -133,7 +135,7 @@ class _TransposeCache:
     (~13 GB), which is the budget; `clear()` (also called by `invalidate_transposed_weights`, e.g. after load_state_dict / a LoRA merge done
     through `.data` in place) frees them."""
 
-    def __init__(self, max_bytes: int = 16 << 30):
+    def __init__(self, max_bytes: int = 0):
         from torch.utils.weak import WeakIdKeyDictionary   # keyed on identity: Tensor.__eq__ is elementwise
         self._d = WeakIdKeyDictionary()
         self.max_bytes = max_bytes
@@ -147,6 +149,10 @@ class _TransposeCache:
             self.bytes -= e[0].numel() * e[0].element_size()
         t = ops.transpose_to_bf16(w.detach()) if w.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 2 and w.is_contiguous() else w.detach().t().contiguous()
         nb = t.numel() * t.element_size()
+        if nb > self.max_bytes:                 # (the default budget is 0: nothing is kept, every backward transposes its weight again)
+            if e is not None:
+                del self._d[w]
+            return t
         if self.bytes + nb > self.max_bytes:
             self.clear()
         self._d[w] = (t, w._version, w.data_ptr())
@@ -161,7 +167,13 @@ class _TransposeCache:
         return len(self._d)
 
 
-_WT_CACHE = _TransposeCache()
+_WT_CACHE = _TransposeCache()      # budget 0 by default: a 7B bf16 LLM's transposes are 13 GB, re-making them costs ~3 % of a step (set_transpose_cache_bytes)
+
+
+def set_transpose_cache_bytes(n: int) -> None:
+    """Let the frozen linears keep up to n bytes of W^T copies between steps (0: transposed again in every backward)."""
+    _WT_CACHE.clear()
+    _WT_CACHE.max_bytes = int(n)
 
 
 def invalidate_transposed_weights():
@@ -373,7 +385,11 @@ class AttentionFn(Function):
                   causal, 0, _s())                                                                           # S <- P = softmax(S + bias + masks)
         oh = torch.empty_like(qs)
         _mm(P, vh, oh, Sq, hd, Sk, (Sq * Sk, Sk, 1), (Sk * hd, hd, 1), (Sq * hd, hd, 1), batch=BH, bf16=ctx.bf16)          # out = P v
-        ctx.save_for_backward(qs, kh, vh, P, bias_h, bias_w)
+        if RECOMPUTE_P:       # keep q, k, v only; the backward rebuilds P with the same two launches (bit-equal: same kernels, same inputs)
+            ctx.save_for_backward(qs, kh, vh, key_mask, bias_h, bias_w)
+        else:
+            ctx.save_for_backward(qs, kh, vh, P, bias_h, bias_w)
+        ctx.recompute = RECOMPUTE_P
         ctx.matrix = True
         return oh.permute(0, 2, 1, 3).reshape(B * Sq, H * hd).contiguous()
 
@@ -419,14 +435,18 @@ class AttentionFn(Function):
             AttentionFn._launch(q, k, v, dout, None, dq, dk, dv, ctx.dims, key_mask, bias_h, bias_w, dbh, dbw)
             return (dq, dk, dv) + nones + (dbh, dbw, None, None)
         qs, kh, vh, P, bias_h, bias_w = ctx.saved_tensors
+        G, BH = H // KVH, B * H
+        key_mask = None
+        if ctx.recompute:     # the fourth saved tensor is the key mask: S = (q scale) k^T again, softmax inside the row pass below (have_p 0)
+            key_mask, P = P, torch.empty((BH, Sq, Sk), dtype=F32, device=qs.device)
+            _mm(qs, kh, P, Sq, Sk, hd, (Sq * hd, hd, 1), (Sk * hd, 1, hd), (Sq * Sk, Sk, 1), batch=BH, bf16=ctx.bf16)
         dbh = torch.empty_like(bias_h) if bias_h is not None else None
         dbw = torch.empty_like(bias_w) if bias_w is not None else None
-        G, BH = H // KVH, B * H
         doh = dout.reshape(B, Sq, H, hd).permute(0, 2, 1, 3).contiguous()
         dP = torch.empty_like(P)
         _mm(doh, vh, dP, Sq, Sk, hd, (Sq * hd, hd, 1), (Sk * hd, 1, hd), (Sq * Sk, Sk, 1), batch=BH, bf16=ctx.bf16)        # dP = dO v^T
-        _lib.call("ullsam_train_attn_rows", P.data_ptr(), dP.data_ptr(), ops._p(bias_h), ops._p(bias_w), ops._p(dbh), ops._p(dbw), None, B, H,
-                  Sq, Sk, kw, causal, 1, _s())                                                               # dP <- dS = P (dP - sum_j P_j dP_j)
+        _lib.call("ullsam_train_attn_rows", P.data_ptr(), dP.data_ptr(), ops._p(bias_h), ops._p(bias_w), ops._p(dbh), ops._p(dbw), ops._p(key_mask), B, H,
+                  Sq, Sk, kw, causal, 0 if ctx.recompute else 1, _s())                                       # dP <- dS = P (dP - sum_j P_j dP_j)
         dvh, dkh, dqs = torch.empty_like(kh), torch.empty_like(kh), torch.empty_like(qs)
         _mm(P, doh, dvh, Sk, hd, Sq, (Sq * Sk, 1, Sk), (Sq * hd, hd, 1), (Sk * hd, hd, 1), batch=BH, bf16=ctx.bf16)        # dV = P^T dO
         _mm(dP, qs, dkh, Sk, hd, Sq, (Sq * Sk, 1, Sk), (Sq * hd, hd, 1), (Sk * hd, hd, 1), batch=BH, bf16=ctx.bf16)        # dK = dS^T (q scale)
