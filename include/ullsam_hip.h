@@ -95,13 +95,16 @@ int ullsam_train_matmul_splitk(const float* A, const float* B, float* C, int M, 
  * one-output-per-thread kernel (tests compare the two); returns the previous setting */
 int ullsam_train_set_matmul_mfma(int on);
 /* out[c] += sum_r x[r*ld + c] (bias gradients; gradients of parameters broadcast over the batch) */
-int ullsam_train_colsum(const float* x, float* out, long rows, int cols, long ld, void* stream);
+int ullsam_train_colsum(const float* x, float* out, long rows, int cols, long ld, float* partial, void* stream);
+/* (row blocks write partial sums that are added in order -- no atomics; partial: min(64, ceil(rows / 256)) * cols floats, may be NULL for rows <= 256) */
 /* nn.LayerNorm / LayerNorm2d backward on rows of D (w NULL: no affine, prompt_encoder.py:141-144); dw / db may be NULL */
-int ullsam_train_ln_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, long rows, int D, float eps, void* stream);
+int ullsam_train_ln_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, long rows, int D, float eps, float* ws, void* stream);
+/* (ws: 2 * rows + 2 * min(64, ceil(rows / 256)) * D floats when dw or db is given: row statistics and ordered partial sums) */
 /* kind 1 exact GELU, 2 ReLU: dy NULL -> out = act(x), else out = dy * act'(x) */
 int ullsam_train_act(const float* x, const float* dy, float* out, long n, int kind, void* stream);
 /* prompt_encoder.py:148 y = x * llm_scale_factor + llm_bias (dy NULL), else out = dy * s, ds += sum dy x, dt += sum dy */
-int ullsam_train_scale_shift(const float* x, const float* s, const float* t, const float* dy, float* out, float* ds, float* dt, long n, void* stream);
+int ullsam_train_scale_shift(const float* x, const float* s, const float* t, const float* dy, float* out, float* ds, float* dt, long n, float* partial, void* stream);
+/* (backward: partial = 2 * ceil(n / 1024) floats; ds / dt += the ordered sum of the per-block partials) */
 /* softmax attention for the training path, forward (dout NULL: writes out) and backward (dout given: writes dq, adds dk / dv):
  * transformer.py:220-242 (groups 1, causal -1, no mask) and modeling_internlm2.py:383-419 with the additive finfo.min masks of :834-870
  * (groups = H / KV heads, causal = Sk - Sq, key_mask int32 [B, Sk]).  q / dq / out [B,Sq,H,hd], k, v / dk, dv [B,Sk,H/groups,hd] by
@@ -133,7 +136,8 @@ int ullsam_train_swiglu(const float* g, const float* u, const float* dy, float* 
 int ullsam_train_resize_bwd(const float* dout, float* din, long planes, int ih, int iw, int oh, int ow, void* stream);
 /* calc_instance_loss (train_joint_v2.py:774-812) with BCELoss (:638-661) + DiceLoss (:605-636): x logits / t targets [P, npix];
  * sums [P][4], losses [3] = (total, bce, dice); the backward scales by gscale[0] (the incoming gradient of the total) */
-int ullsam_train_seg_loss(const float* x, const float* t, float* sums, float* losses, int P, long npix, float smooth, void* stream);
+int ullsam_train_seg_loss(const float* x, const float* t, float* sums, float* losses, int P, long npix, float smooth, float* partial, void* stream);
+/* (partial: P * 4 * ceil(npix / 1024) floats) */
 int ullsam_train_seg_loss_bwd(const float* x, const float* t, const float* sums, const float* gscale, float* dx, int P, long npix, float smooth, void* stream);
 /* dst[idx[r]] += src[r]: gradient of the point-label embedding table (prompt_encoder.py:76-96) */
 int ullsam_train_index_add_rows(const float* src, const int* idx, float* dst, long rows, int C, int nrows_dst, void* stream);

@@ -691,3 +691,60 @@ def test_whole_train_step_gradients_at_real_head_dimensions():
         assert abs(np.sqrt((full ** 2).sum()) - nref) < 1e-3 * nref + 1e-6, (n, np.sqrt((full ** 2).sum()), nref)
     assert all(p.grad is None for n, p in params.items() if n.startswith("language_model."))
     print(len(names), "gradients at real head dimensions; worst relative error", worst)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_two_runs_of_a_train_step_are_bit_equal(dtype):
+    """No sum of the step depends on scheduling: column sums, LayerNorm parameter gradients, the loss sums and the scalar gradients go through
+    per-block partials added in a fixed order, the bilinear upsample's and the table gathers' adjoints are gathers, split-k products reduce in
+    order, and every attention runs in the matrix form (MATRIX_ATTN_FROM = 0).  Two runs of the whole step at the real head geometry give the
+    same bits: the loss and every gradient."""
+    from ullsam_amd import training
+    assert training.MATRIX_ATTN_FROM == 0
+    g = U.gold("train_step_real")
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    m = _ullsam_real_dims(dtype)
+    for n, p in m.named_parameters():
+        p.requires_grad_(not n.startswith("language_model."))
+    x = t(U.rand_image((1, 3, 1024, 1024), seed=int(g["seed"])))
+    ids = t(g["ids"]).long()
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32)
+    gt = t(np.stack([((xx - 300) ** 2 + (yy - 340) ** 2 < 150 ** 2), ((xx - 700) ** 2 + (yy - 610) ** 2 < 220 ** 2)]).astype(np.float32)[:, None])
+    runs = []
+    for it in range(2):
+        for p in m.parameters():
+            p.grad = None
+        loss, _, _ = training.train_step_loss(m, x, ids, torch.ones_like(ids), (t(g["pts"]), t(g["lbl"])), gt)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = runs
+    assert torch.equal(l0, l1)
+    assert set(g0) == set(g1) and len(g0) >= 60
+    diff = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+    assert not diff, diff[:8]
+
+
+def test_small_attention_kernel_route_equals_the_matrix_route():
+    """MATRIX_ATTN_FROM > 0 sends attentions with Sq * Sk below it to the one-workgroup-per-query kernel (backward by atomics: faster for the
+    decoder's 7-token self-attention, not bit-reproducible).  Same gradients as the matrix form to fp32 rounding."""
+    from ullsam_amd import training
+    g = U.gold("train_slice")
+    hid, img, pts, gt = _inputs(g)
+    res = []
+    old = training.MATRIX_ATTN_FROM
+    try:
+        for thr in (0, 1 << 12):
+            training.MATRIX_ATTN_FROM = thr
+            m = _ullsam_tiny(torch.float32)
+            for n, p in m.named_parameters():
+                p.requires_grad_(n.startswith(("mlp2.", "prompt_encoder.", "mask_decoder.")))
+            loss, _, _ = training.segmentation_loss(m, hid, img, pts, gt)
+            loss.backward()
+            res.append((float(loss.detach()), {n: p.grad for n, p in m.named_parameters() if p.grad is not None}))
+    finally:
+        training.MATRIX_ATTN_FROM = old
+    (l0, g0), (l1, g1) = res
+    assert abs(l0 - l1) < 1e-6 * abs(l0) and set(g0) == set(g1)
+    for n in g0:
+        assert float((g0[n] - g1[n]).abs().max()) <= 2e-5 * float(g0[n].abs().max()) + 1e-8, n

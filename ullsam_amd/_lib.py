@@ -25,10 +25,10 @@ SIGNATURES = {
     "ullsam_train_matmul": [vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [i32, vp],
     "ullsam_train_matmul_bf16": [vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [i32, vp],
     "ullsam_train_matmul_splitk": [vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [i32, i32, vp, vp],
-    "ullsam_train_colsum": [vp, vp, i64, i32, i64, vp],
-    "ullsam_train_ln_bwd": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
+    "ullsam_train_colsum": [vp, vp, i64, i32, i64, vp, vp],
+    "ullsam_train_ln_bwd": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp, vp],
     "ullsam_train_act": [vp, vp, vp, i64, i32, vp],
-    "ullsam_train_scale_shift": [vp, vp, vp, vp, vp, vp, vp, i64, vp],
+    "ullsam_train_scale_shift": [vp, vp, vp, vp, vp, vp, vp, i64, vp, vp],
     "ullsam_train_attention": [vp] * 8 + [i32] * 7 + [vp] + [i64] * 12 + [f32, vp, vp, vp, vp, i32, vp],
     "ullsam_train_col2im3x3": [vp, vp, i32, i32, i32, i32, vp],
     "ullsam_train_attn_rows": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -36,7 +36,7 @@ SIGNATURES = {
     "ullsam_train_rope": [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp],
     "ullsam_train_swiglu": [vp, vp, vp, vp, vp, vp, i64, vp],
     "ullsam_train_resize_bwd": [vp, vp, i64, i32, i32, i32, i32, vp],
-    "ullsam_train_seg_loss": [vp, vp, vp, vp, i32, i64, f32, vp],
+    "ullsam_train_seg_loss": [vp, vp, vp, vp, i32, i64, f32, vp, vp],
     "ullsam_train_seg_loss_bwd": [vp, vp, vp, vp, vp, i32, i64, f32, vp],
     "ullsam_train_index_add_rows": [vp, vp, vp, i64, i32, i32, vp],
     "ullsam_norm": [vp, i32, i64, vp, i32, i64, vp, vp, i64, i32, f32, i32, i32, vp, vp, vp],

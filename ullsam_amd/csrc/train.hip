@@ -334,27 +334,47 @@ extern "C" int ullsam_train_matmul_splitk(const float* A, const float* B, float*
     return 0;
 }
 
-// ---- out[c] += sum_r x[r][c]  (bias gradients, broadcast-parameter gradients); out is zeroed by the caller ------------------------
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int cols, long ld, long rows_per_block) {
+// ---- out[c] += sum_r x[r][c]  (bias gradients, broadcast-parameter gradients); out is zeroed by the caller.  Row blocks write partial sums
+// (partial: colsum_blocks(rows) x cols floats) that a second kernel adds in order: the result does not depend on scheduling -----------------------
+static inline int colsum_blocks(long rows) { const long b = (rows + 255) / 256; return (int)(b < 64 ? b : 64); }
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, float* __restrict__ partial, long rows, int cols,
+                                                     long ld, long rows_per_block) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cols) return;
     const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     float s = 0.f;
     for (long r = r0; r < r1; ++r) s += x[r * ld + c];
-    atomicAdd(out + c, s);
+    if (gridDim.y == 1) out[c] += s;
+    else partial[(long)blockIdx.y * cols + c] = s;
 }
-extern "C" int ullsam_train_colsum(const float* x, float* out, long rows, int cols, long ld, void* stream) {
+__global__ __launch_bounds__(256) void partial_rows_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int cols, int nb) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += partial[(long)b * cols + c];
+    out[c] += s;
+}
+extern "C" int ullsam_train_colsum(const float* x, float* out, long rows, int cols, long ld, float* partial, void* stream) {
     ULLSAM_CHECK(rows > 0 && cols > 0, "train_colsum: rows=%ld cols=%d", rows, cols);
-    const long rpb = 256;
-    colsum_kernel<<<dim3((cols + 255) / 256, (unsigned)((rows + rpb - 1) / rpb)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(x, out, rows, cols, ld, rpb);
+    const int nb = colsum_blocks(rows);
+    ULLSAM_CHECK(nb == 1 || partial, "train_colsum: %d row blocks need a partial buffer of %d x %d floats", nb, nb, cols);
+    const long rpb = (rows + nb - 1) / nb;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    colsum_kernel<<<dim3((cols + 255) / 256, nb), 256, 0, st>>>(x, out, partial, rows, cols, ld, rpb);
     ULLSAM_LAUNCH_CHECK();
+    if (nb > 1) {
+        partial_rows_reduce_kernel<<<dim3((cols + 255) / 256), 256, 0, st>>>(partial, out, cols, nb);
+        ULLSAM_LAUNCH_CHECK();
+    }
     return 0;
 }
 
 // ---- LayerNorm backward (rows of D elements, biased variance, optional affine): one wave per row -----------------------------------
-// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w;  dw += dy * xhat, db += dy (atomics; zeroed by the caller)
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w;  dw += sum_rows dy * xhat, db += sum_rows dy (zeroed by the caller): a second kernel,
+// one thread per column and row block, from the (mean, rstd) pairs the first one leaves in ws; partials added in order (no atomics).
+// ws: 2 rows + 2 colsum_blocks(rows) D floats (needed when dw or db is given)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
-                                                     float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, long rows, int D, float eps) {
+                                                     float* __restrict__ dx, float* __restrict__ stats, long rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -375,14 +395,47 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     for (int i = lane; i < D; i += 64) {
         const float xh = (xr[i] - mean) * rstd, g = gr[i] * (w ? w[i] : 1.f);
         dx[row * D + i] = rstd * (g - mg - xh * mgx);
-        if (dw) atomicAdd(dw + i, gr[i] * xh);
-        if (db) atomicAdd(db + i, gr[i]);
     }
+    if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
-extern "C" int ullsam_train_ln_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, long rows, int D, float eps, void* stream) {
+__global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
+                                                            float* __restrict__ part, long rows, int D, long rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float a = 0.f, b = 0.f;
+    for (long r = r0; r < r1; ++r) {
+        const float g = dy[r * D + c];
+        a += g * ((x[r * D + c] - stats[2 * r]) * stats[2 * r + 1]);
+        b += g;
+    }
+    part[((long)blockIdx.y * 2) * D + c] = a;
+    part[((long)blockIdx.y * 2 + 1) * D + c] = b;
+}
+__global__ __launch_bounds__(256) void ln_bwd_params_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int D, int nb) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nb; ++k) { a += part[((long)k * 2) * D + c]; b += part[((long)k * 2 + 1) * D + c]; }
+    if (dw) dw[c] += a;
+    if (db) db[c] += b;
+}
+extern "C" int ullsam_train_ln_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, long rows, int D, float eps,
+                                   float* ws, void* stream) {
     ULLSAM_CHECK(rows > 0 && D > 0, "train_ln_bwd: rows=%ld D=%d", rows, D);
-    ln_bwd_kernel<<<dim3((unsigned)((rows + 3) / 4)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(x, w, dy, dx, dw, db, rows, D, eps);
+    ULLSAM_CHECK(!(dw || db) || ws, "train_ln_bwd: parameter gradients need the workspace (2 rows + 2 * %d * D floats)", colsum_blocks(rows));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ln_bwd_kernel<<<dim3((unsigned)((rows + 3) / 4)), 256, 0, st>>>(x, w, dy, dx, (dw || db) ? ws : nullptr, rows, D, eps);
     ULLSAM_LAUNCH_CHECK();
+    if (dw || db) {
+        const int nb = colsum_blocks(rows);
+        const long rpb = (rows + nb - 1) / nb;
+        float* part = ws + 2 * rows;
+        ln_bwd_params_kernel<<<dim3((D + 255) / 256, nb), 256, 0, st>>>(x, dy, ws, part, rows, D, rpb);
+        ULLSAM_LAUNCH_CHECK();
+        ln_bwd_params_reduce_kernel<<<dim3((D + 255) / 256), 256, 0, st>>>(part, dw, db, D, nb);
+        ULLSAM_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -427,15 +480,32 @@ __global__ __launch_bounds__(256) void scale_shift_kernel(const float* __restric
     a = wave_sum(a); b = wave_sum(b);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(ds, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
-        atomicAdd(dt, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    if (threadIdx.x == 0) {   // per-block partials; ordered_sum_kernel adds them in a fixed order
+        ds[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        dt[blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
 }
-extern "C" int ullsam_train_scale_shift(const float* x, const float* s, const float* t, const float* dy, float* out, float* ds, float* dt, long n, void* stream) {
-    ULLSAM_CHECK(n > 0 && (!dy || (ds && dt)), "train_scale_shift: n=%ld", n);
-    scale_shift_kernel<<<dim3((unsigned)((n + 1023) / 1024)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(x, s, t, dy, out, ds, dt, n);
+// out[v] += sum_i in[v * stride + i], i < n, for v < nvec: one wave per vector, lane l sums the contiguous chunk l, then the fixed wave tree
+__global__ __launch_bounds__(64) void ordered_sum_kernel(const float* __restrict__ in, float* __restrict__ out, long n, long stride) {
+    const float* p = in + (long)blockIdx.x * stride;
+    const long per = (n + 63) / 64, i0 = threadIdx.x * per, i1 = min(n, i0 + per);
+    float s = 0.f;
+    for (long i = i0; i < i1; ++i) s += p[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[blockIdx.x] += s;
+}
+extern "C" int ullsam_train_scale_shift(const float* x, const float* s, const float* t, const float* dy, float* out, float* ds, float* dt, long n,
+                                        float* partial, void* stream) {
+    ULLSAM_CHECK(n > 0 && (!dy || (ds && dt && partial)), "train_scale_shift: n=%ld (the backward needs 2 * ceil(n / 1024) floats of partials)", n);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long nb = (n + 1023) / 1024;
+    scale_shift_kernel<<<dim3((unsigned)nb), 256, 0, st>>>(x, s, t, dy, out, partial, partial ? partial + nb : nullptr, n);
     ULLSAM_LAUNCH_CHECK();
+    if (dy) {
+        ordered_sum_kernel<<<1, 64, 0, st>>>(partial, ds, nb, 0);
+        ordered_sum_kernel<<<1, 64, 0, st>>>(partial + nb, dt, nb, 0);
+        ULLSAM_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -838,24 +908,37 @@ extern "C" int ullsam_train_swiglu(const float* g, const float* u, const float* 
     return 0;
 }
 
-// ---- bilinear upsample backward (F.interpolate(align_corners=False), train_joint_v2.py:1073-1078): the adjoint of resize_bilinear_kernel,
-// same taps (common.h tap_of); din is zeroed by the caller -------------------------------------------------------------------------------
+// ---- bilinear upsample backward (F.interpolate(align_corners=False), train_joint_v2.py:1073-1078): the adjoint of resize_bilinear_kernel, same taps
+// (common.h tap_of), in GATHER form: one thread per input pixel adds the output pixels whose taps touch it, rows then columns in ascending
+// order (no atomics: bit-reproducible).  An input row / column iy is touched by outputs y with tap i0 == iy or i1 == iy; for a scale s = ih / oh
+// these lie within ((iy - 1) / s - 1, (iy + 2) / s + 1) ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, long planes, int ih, int iw, int oh, int ow) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= planes * oh * ow) return;
-    const int x = (int)(i % ow), y = (int)((i / ow) % oh);
-    const long pl = i / ((long)ow * oh);
-    const Tap ty = tap_of(y, (float)ih / (float)oh, ih), tx = tap_of(x, (float)iw / (float)ow, iw);
-    const float g = dout[i];
-    float* d = din + pl * ih * iw;
-    atomicAdd(d + (long)ty.i0 * iw + tx.i0, g * (1.f - ty.l) * (1.f - tx.l));
-    atomicAdd(d + (long)ty.i0 * iw + tx.i1, g * (1.f - ty.l) * tx.l);
-    atomicAdd(d + (long)ty.i1 * iw + tx.i0, g * ty.l * (1.f - tx.l));
-    atomicAdd(d + (long)ty.i1 * iw + tx.i1, g * ty.l * tx.l);
+    if (i >= planes * ih * iw) return;
+    const int ix = (int)(i % iw), iy = (int)((i / iw) % ih);
+    const long pl = i / ((long)iw * ih);
+    const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;
+    const int y0 = max(0, (int)floorf((float)(iy - 1) / sy) - 1), y1 = min(oh - 1, (int)ceilf((float)(iy + 2) / sy) + 1);
+    const int x0 = max(0, (int)floorf((float)(ix - 1) / sx) - 1), x1 = min(ow - 1, (int)ceilf((float)(ix + 2) / sx) + 1);
+    const float* g = dout + pl * oh * ow;
+    float acc = 0.f;
+    for (int y = y0; y <= y1; ++y) {
+        const Tap ty = tap_of(y, sy, ih);
+        const float wy = (ty.i0 == iy ? 1.f - ty.l : 0.f) + (ty.i1 == iy ? ty.l : 0.f);
+        if (wy == 0.f) continue;
+        float rowacc = 0.f;
+        for (int x = x0; x <= x1; ++x) {
+            const Tap tx = tap_of(x, sx, iw);
+            const float wx = (tx.i0 == ix ? 1.f - tx.l : 0.f) + (tx.i1 == ix ? tx.l : 0.f);
+            if (wx != 0.f) rowacc += g[(long)y * ow + x] * wx;
+        }
+        acc += rowacc * wy;
+    }
+    din[i] += acc;
 }
 extern "C" int ullsam_train_resize_bwd(const float* dout, float* din, long planes, int ih, int iw, int oh, int ow, void* stream) {
     ULLSAM_CHECK(planes > 0 && ih > 0 && iw > 0 && oh > 0 && ow > 0, "train_resize_bwd: bad dims");
-    const long n = planes * oh * ow;
+    const long n = planes * ih * iw;
     resize_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(dout, din, planes, ih, iw, oh, ow);
     ULLSAM_LAUNCH_CHECK();
     return 0;
@@ -879,7 +962,8 @@ __global__ __launch_bounds__(256) void seg_loss_sums_kernel(const float* __restr
 #pragma unroll
     for (int c = 0; c < 4; ++c) { a[c] = wave_sum(a[c]); if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = a[c]; }
     __syncthreads();
-    if (threadIdx.x < 4) atomicAdd(sums + inst * 4 + threadIdx.x, (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]));
+    // per-block partials [inst][4][blocks], added in order by ordered_sum_kernel
+    if (threadIdx.x < 4) sums[((long)inst * 4 + threadIdx.x) * gridDim.x + blockIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 __global__ void seg_loss_final_kernel(const float* __restrict__ sums, float* __restrict__ losses, int P, long npix, float smooth) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -904,10 +988,13 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
     const float ddice = -(2.0f * tv * den - num) / (den * den) * pr * (1.0f - pr);
     dx[inst * npix + i] = gscale[0] * (dbce + ddice) / (float)P;
 }
-extern "C" int ullsam_train_seg_loss(const float* x, const float* t, float* sums, float* losses, int P, long npix, float smooth, void* stream) {
-    ULLSAM_CHECK(P > 0 && P < 65536 && npix > 0, "train_seg_loss: P=%d npix=%ld", P, npix);
+extern "C" int ullsam_train_seg_loss(const float* x, const float* t, float* sums, float* losses, int P, long npix, float smooth, float* partial, void* stream) {
+    ULLSAM_CHECK(P > 0 && P < 65536 && npix > 0 && partial, "train_seg_loss: P=%d npix=%ld (partial: P * 4 * ceil(npix / 1024) floats)", P, npix);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    seg_loss_sums_kernel<<<dim3((unsigned)((npix + 1023) / 1024), P), 256, 0, s>>>(x, t, sums, npix);
+    const long nb = (npix + 1023) / 1024;
+    seg_loss_sums_kernel<<<dim3((unsigned)nb, P), 256, 0, s>>>(x, t, partial, npix);
+    ULLSAM_LAUNCH_CHECK();
+    ordered_sum_kernel<<<dim3(P * 4), 64, 0, s>>>(partial, sums, nb, nb);
     ULLSAM_LAUNCH_CHECK();
     seg_loss_final_kernel<<<1, 64, 0, s>>>(sums, losses, P, npix, smooth);
     ULLSAM_LAUNCH_CHECK();
@@ -921,17 +1008,21 @@ extern "C" int ullsam_train_seg_loss_bwd(const float* x, const float* t, const f
     return 0;
 }
 
-// ---- dst[idx[r]] += src[r] (rows of C floats): gradients of the point-label embedding table (prompt_encoder.py:76-96) ----------------
+// ---- dst[idx[r]] += src[r] (rows of C floats): gradients of the point-label embedding table (prompt_encoder.py:76-96) and of the relative-position
+// tables (image_encoder.py:303-322).  Gather form: one thread per destination element walks the index list in order (tables of 5 ... 127 rows,
+// lists of a few thousand entries): no atomics, bit-reproducible ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void index_add_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, long rows, int C, int nrows_dst) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * C) return;
-    const long r = i / C;
-    const int c = (int)(i - r * C), k = idx[r];
-    if (k >= 0 && k < nrows_dst) atomicAdd(dst + (long)k * C + c, src[i]);
+    if (i >= (long)nrows_dst * C) return;
+    const int k = (int)(i / C), c = (int)(i - (long)k * C);
+    float a = 0.f;
+    for (long r = 0; r < rows; ++r)
+        if (idx[r] == k) a += src[r * C + c];
+    dst[i] += a;
 }
 extern "C" int ullsam_train_index_add_rows(const float* src, const int* idx, float* dst, long rows, int C, int nrows_dst, void* stream) {
     ULLSAM_CHECK(rows > 0 && C > 0 && nrows_dst > 0, "train_index_add_rows: bad dims");
-    index_add_rows_kernel<<<dim3((unsigned)((rows * C + 255) / 256)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(src, idx, dst, rows, C, nrows_dst);
+    index_add_rows_kernel<<<dim3((unsigned)(((long)nrows_dst * C + 255) / 256)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(src, idx, dst, rows, C, nrows_dst);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }

@@ -67,8 +67,15 @@ def _mm(A, B, C, M, N, K, sa, sb, sc, batch=1, accumulate=False, bf16=False):
 def _colsum(x2d: torch.Tensor) -> torch.Tensor:
     rows, cols = x2d.shape
     out = torch.zeros((cols,), dtype=F32, device=x2d.device)
-    _lib.call("ullsam_train_colsum", x2d.data_ptr(), out.data_ptr(), rows, cols, cols, _s())
+    nb = _row_blocks(rows)
+    part = torch.empty((nb * cols,), dtype=F32, device=x2d.device) if nb > 1 else None     # per-row-block partials, added in order (no atomics)
+    _lib.call("ullsam_train_colsum", x2d.data_ptr(), out.data_ptr(), rows, cols, cols, ops._p(part), _s())
     return out
+
+
+def _row_blocks(rows: int) -> int:
+    """Row blocks of the ordered two-stage column sums (csrc/train.hip colsum_blocks)."""
+    return min(64, -(-rows // 256))
 
 
 def _t2d(x: torch.Tensor) -> torch.Tensor:
@@ -79,7 +86,8 @@ def _t2d(x: torch.Tensor) -> torch.Tensor:
 
 RECOMPUTE_P = True   # matrix-form attention keeps q, k, v and rebuilds the probability matrix in the backward (one more product and the softmax inside the
 #                      backward's row pass) instead of holding it from the forward: -10.8 GB on a ViT-H + 7B-shaped step for ~4 % of its time
-MATRIX_ATTN_FROM = 1 << 12   # attention through materialised score matrices from Sq * Sk >= this (below: one workgroup per query, backward by atomics)
+MATRIX_ATTN_FROM = 0         # attention through materialised score matrices from Sq * Sk >= this; below it one workgroup per query, whose backward adds dk / dv by
+#                              atomics (order-dependent sums): 0 keeps every attention on the matrix form, so that two runs of a step are bit-equal
 MFMA_LINEAR = True   # nn.Linear forward / backward on the fp32 MFMA GEMM of the inference path where its shapes allow (inner dimension % 32 == 0);
 #                     the one-output-per-thread matmul of csrc/train.hip otherwise (and always with MFMA_LINEAR = False: tests compare the two)
 
@@ -271,8 +279,9 @@ class LayerNormFn(Function):
         dw = torch.zeros((D,), dtype=F32, device=x.device) if ctx.affine else None
         db = torch.zeros((D,), dtype=F32, device=x.device) if ctx.affine else None
         wf = None if w is None else _c(w)   # (a bf16 weight is widened into a temporary: it must outlive the launch)
+        ws = torch.empty((2 * rows + 2 * _row_blocks(rows) * D,), dtype=F32, device=x.device) if ctx.affine else None
         _lib.call("ullsam_train_ln_bwd", x.data_ptr(), None if wf is None else wf.data_ptr(), dy.data_ptr(), dx.data_ptr(),
-                  ops._p(dw), ops._p(db), rows, D, float(ctx.eps), _s())
+                  ops._p(dw), ops._p(db), rows, D, float(ctx.eps), ops._p(ws), _s())
         del wf
         return dx, dw, db, None
 
@@ -341,7 +350,7 @@ class ScaleShiftFn(Function):
     def forward(ctx, x, s, t):
         x, s, t = _c(x), _c(s), _c(t)
         y = torch.empty_like(x)
-        _lib.call("ullsam_train_scale_shift", x.data_ptr(), s.data_ptr(), t.data_ptr(), None, y.data_ptr(), None, None, x.numel(), _s())
+        _lib.call("ullsam_train_scale_shift", x.data_ptr(), s.data_ptr(), t.data_ptr(), None, y.data_ptr(), None, None, x.numel(), None, _s())
         ctx.save_for_backward(x, s, t)
         return y
 
@@ -352,8 +361,9 @@ class ScaleShiftFn(Function):
         dx = torch.empty_like(x)
         ds = torch.zeros_like(s)
         dt = torch.zeros_like(t)
+        part = torch.empty((2 * -(-x.numel() // 1024),), dtype=F32, device=x.device)
         _lib.call("ullsam_train_scale_shift", x.data_ptr(), s.data_ptr(), t.data_ptr(), dy.data_ptr(), dx.data_ptr(), ds.data_ptr(),
-                  dt.data_ptr(), x.numel(), _s())
+                  dt.data_ptr(), x.numel(), part.data_ptr(), _s())
         return dx, ds, dt
 
 
@@ -411,7 +421,7 @@ class AttentionFn(Function):
         sc = torch.full((1,), factor, dtype=F32, device=t.device)
         zero = torch.zeros((1,), dtype=F32, device=t.device)
         out = torch.empty_like(t)
-        _lib.call("ullsam_train_scale_shift", t.data_ptr(), sc.data_ptr(), zero.data_ptr(), None, out.data_ptr(), None, None, t.numel(), _s())
+        _lib.call("ullsam_train_scale_shift", t.data_ptr(), sc.data_ptr(), zero.data_ptr(), None, out.data_ptr(), None, None, t.numel(), None, _s())
         return out
 
     @staticmethod
@@ -661,7 +671,8 @@ class SegLossFn(Function):
         npix = pred.numel() // P
         sums = torch.zeros((P, 4), dtype=F32, device=pred.device)
         losses = torch.empty((3,), dtype=F32, device=pred.device)
-        _lib.call("ullsam_train_seg_loss", pred.data_ptr(), gt.data_ptr(), sums.data_ptr(), losses.data_ptr(), P, npix, float(smooth), _s())
+        part = torch.empty((P * 4 * -(-npix // 1024),), dtype=F32, device=pred.device)
+        _lib.call("ullsam_train_seg_loss", pred.data_ptr(), gt.data_ptr(), sums.data_ptr(), losses.data_ptr(), P, npix, float(smooth), part.data_ptr(), _s())
         ctx.save_for_backward(pred, gt, sums)
         ctx.dims = (P, npix, float(smooth))
         return losses
