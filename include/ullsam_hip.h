@@ -213,7 +213,9 @@ int ullsam_argmax(const float* logits, long long* out, int rows, long V, long ld
 int ullsam_small_linear(const float* x, long ldx, const float* W, const float* b, const float* res, long ldr, float* y,
                         long ldy, int M, int N, int K, int act, void* stream);           /* transformer.py:220-227; mask_decoder.py:171-176 */
 int ullsam_skinny_linear(const float* x, long ldx, const float* WT, const float* b, const float* res, long ldr, float* y,
-                         long ldy, int M, int N, int K, int act, void* stream); /* same layers at many prompts; WT = weight^T [K,N] */
+                         long ldy, int M, int N, int K, int act, void* stream);
+/* 0: keep ullsam_skinny_linear on its FMA kernel (tests compare it with the exact-fp32 MFMA kernel used for N % 32 == 0, K in {128 .. 2048}); returns the previous setting */
+int ullsam_set_skinny_linear_mfma(int on); /* same layers at many prompts; WT = weight^T [K,N] */
 int ullsam_sparse_embed(const float* coords, const int* labels, const float* boxes, const float* G, const float* emb,
                         float* out, int P, int Np, int pad, int C, float img_w, float img_h, void* stream); /* prompt_encoder.py:76-103 */
 int ullsam_dense_pe(const float* G, float* out_nhwc, int H, int W, int C, void* stream);  /* prompt_encoder.py:230-241 */

@@ -278,7 +278,7 @@ def test_norms(ops, D):
     assert err(yb, O.layer_norm(xb, w, b, 1e-6)) < 4e-2
 
 
-@pytest.mark.parametrize("M,N,K", [(448, 256, 256), (64, 32, 256), (17, 4, 256), (100, 2048, 256), (448, 256, 2048), (30, 130, 128)])
+@pytest.mark.parametrize("M,N,K", [(448, 256, 256), (64, 32, 256), (17, 4, 256), (100, 2048, 256), (448, 256, 2048), (30, 130, 128), (449, 128, 128), (70, 64, 1024), (33, 32, 512)])
 def test_skinny_linear(ops, M, N, K):
     rng = np.random.default_rng(M + N)
     x = rng.standard_normal((M, K), dtype=np.float32)
@@ -290,6 +290,17 @@ def test_skinny_linear(ops, M, N, K):
     assert err(ops.skinny_linear(T(x), wt, T(b), ops.ACT_RELU, T(r)).cpu().numpy(), np.maximum(x @ w.T + b, 0) + r) < 1e-5
     assert err(ops.skinny_linear(T(x), wt, None, ops.ACT_GELU).cpu().numpy(), O.gelu(x @ w.T)) < 1e-5
     assert err(ops.small_linear(T(x), T(w), T(b)).cpu().numpy(), x @ w.T + b) < 1e-5
+    # the FMA kernel behind the switch (N % 32 == 0 and K in {128 .. 2048} take the exact-fp32 MFMA kernel by default): same results to fp32 rounding of the k sum
+    from ullsam_amd import _lib
+    lib = _lib.load()
+    new = ops.skinny_linear(T(x), wt, T(b), ops.ACT_RELU, T(r))
+    old_sw = lib.ullsam_set_skinny_linear_mfma(0)
+    try:
+        fma = ops.skinny_linear(T(x), wt, T(b), ops.ACT_RELU, T(r))
+    finally:
+        lib.ullsam_set_skinny_linear_mfma(old_sw)
+    assert err(fma.cpu().numpy(), np.maximum(x @ w.T + b, 0) + r) < 1e-5
+    assert float((new - fma).abs().max()) < 1e-5 * max(1.0, float(fma.abs().max()))
 
 
 @pytest.mark.parametrize("D", [2048, 4096, 3072])

@@ -98,13 +98,75 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restr
     }
 }
 
+// ---- the same layer on the matrix pipe (exact fp32: v_mfma_f32_32x32x2_f32 is an fma chain): a 32 x 32 output tile per workgroup, its four waves
+// splitting K.  Nothing goes through LDS on the way in: a lane loads x[m][k0 + 4 h .. +3] as ONE float4 (h = lane half) and the four weight rows
+// WT[k0 + 4 h + e][n] (coalesced); MFMA e of the chunk then sums k = k0 + e (lower lanes) and k0 + 4 + e (upper lanes) -- the order of the k sum is free
+// as long as both operands agree.  All of a wave's loads (K / 4 values per lane pair) are issued before its first MFMA: one memory latency per launch.
+// The token side of the mask decoder at 64 prompts per batch (448 rows x 256 .. 2048: 68 launches per batch) ran 16.6 us per launch on the FMA kernel.
+template <int KW>   // k values per wave = K / 4
+__global__ __launch_bounds__(256) void skinny_linear_mfma_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ WT,
+                                                                 const float* __restrict__ b, const float* __restrict__ res, long ldr,
+                                                                 float* __restrict__ y, long ldy, int M, int N, int act) {
+    constexpr int NCH = KW / 8;
+    __shared__ float red[4][16][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l5 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const float* xp = x + (long)min(m0 + l5, M - 1) * ldx + wv * KW + 4 * h;
+    const float* wp = WT + (long)(wv * KW + 4 * h) * N + n0 + l5;
+    float4 a[NCH];
+    float w[NCH][4];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        a[c] = *reinterpret_cast<const float4*>(xp + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[c][e] = wp[(long)(8 * c + e) * N];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].x, w[c][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].y, w[c][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].z, w[c][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].w, w[c][3], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wv][e][lane] = acc[e];
+    __syncthreads();
+    // accumulator element e of lane l: row 8 (e / 4) + 4 (l / 32) + e % 4, column l % 32; wave wv finishes elements 4 wv .. 4 wv + 3
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = 4 * wv + j;
+        const int m = m0 + 8 * (e >> 2) + 4 * h + (e & 3), n = n0 + l5;
+        float v = (red[0][e][lane] + red[1][e][lane]) + (red[2][e][lane] + red[3][e][lane]);
+        if (m < M) {
+            if (b) v += b[n];
+            if (act == 2) v = fmaxf(v, 0.f);
+            else if (act == 1) v = gelu_erf(v);
+            if (res) v += res[(long)m * ldr + n];
+            y[(long)m * ldy + n] = v;
+        }
+    }
+}
+static int g_skinny_mfma = 1;
+extern "C" int ullsam_set_skinny_linear_mfma(int on) { const int old = g_skinny_mfma; g_skinny_mfma = on; return old; }
+
 // WT fp32 [K, N] (transposed nn.Linear weight); otherwise as ullsam_small_linear.
 extern "C" int ullsam_skinny_linear(const float* x, long ldx, const float* WT, const float* b, const float* res, long ldr, float* y,
                                     long ldy, int M, int N, int K, int act, void* stream) {
     ULLSAM_CHECK(K % 128 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0, "skinny_linear: K %% 128, ldx %% 4, 16-byte aligned x");
     if ((long)M * N == 0) return 0;
-    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 15) / 16));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (g_skinny_mfma && N % 32 == 0 && (K == 128 || K == 256 || K == 512 || K == 1024 || K == 2048)) {
+        const dim3 g32((unsigned)(N / 32), (unsigned)((M + 31) / 32));
+#define SKINNY_MFMA(KW) skinny_linear_mfma_kernel<KW><<<g32, 256, 0, s>>>(x, ldx, WT, b, res, ldr, y, ldy, M, N, act)
+        if (K == 128) SKINNY_MFMA(32); else if (K == 256) SKINNY_MFMA(64); else if (K == 512) SKINNY_MFMA(128); else if (K == 1024) SKINNY_MFMA(256); else SKINNY_MFMA(512);
+#undef SKINNY_MFMA
+        ULLSAM_LAUNCH_CHECK();
+        return 0;
+    }
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 15) / 16));
     if (K % 256 == 0) skinny_linear_kernel<64><<<grid, 256, 0, s>>>(x, ldx, WT, b, res, ldr, y, ldy, M, N, K, act);
     else skinny_linear_kernel<32><<<grid, 256, 0, s>>>(x, ldx, WT, b, res, ldr, y, ldy, M, N, K, act);
     ULLSAM_LAUNCH_CHECK();
