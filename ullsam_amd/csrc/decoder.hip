@@ -103,12 +103,12 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restr
 // WT[k0 + 4 h + e][n] (coalesced); MFMA e of the chunk then sums k = k0 + e (lower lanes) and k0 + 4 + e (upper lanes) -- the order of the k sum is free
 // as long as both operands agree.  All of a wave's loads (K / 4 values per lane pair) are issued before its first MFMA: one memory latency per launch.
 // The token side of the mask decoder at 64 prompts per batch (448 rows x 256 .. 2048: 68 launches per batch) ran 16.6 us per launch on the FMA kernel.
-template <int KW>   // k values per wave = K / 4
-__global__ __launch_bounds__(256) void skinny_linear_mfma_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ WT,
+template <int KW, int NW>   // k values per wave = K / NW; NW waves (4 or 16) split K
+__global__ __launch_bounds__(64 * NW) void skinny_linear_mfma_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ WT,
                                                                  const float* __restrict__ b, const float* __restrict__ res, long ldr,
                                                                  float* __restrict__ y, long ldy, int M, int N, int act) {
     constexpr int NCH = KW / 8;
-    __shared__ float red[4][16][64];
+    __shared__ float red[NW][16][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l5 = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
     const float* xp = x + (long)min(m0 + l5, M - 1) * ldx + wv * KW + 4 * h;
@@ -134,12 +134,15 @@ __global__ __launch_bounds__(256) void skinny_linear_mfma_kernel(const float* __
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[wv][e][lane] = acc[e];
     __syncthreads();
-    // accumulator element e of lane l: row 8 (e / 4) + 4 (l / 32) + e % 4, column l % 32; wave wv finishes elements 4 wv .. 4 wv + 3
+    // accumulator element e of lane l: row 8 (e / 4) + 4 (l / 32) + e % 4, column l % 32; wave wv finishes elements (16 / NW) wv ...
+    constexpr int EPW = 16 / NW;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int e = 4 * wv + j;
+    for (int j = 0; j < EPW; ++j) {
+        const int e = EPW * wv + j;
         const int m = m0 + 8 * (e >> 2) + 4 * h + (e & 3), n = n0 + l5;
-        float v = (red[0][e][lane] + red[1][e][lane]) + (red[2][e][lane] + red[3][e][lane]);
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < NW; q += 4) v += (red[q][e][lane] + red[q + 1][e][lane]) + (red[q + 2][e][lane] + red[q + 3][e][lane]);
         if (m < M) {
             if (b) v += b[n];
             if (act == 2) v = fmaxf(v, 0.f);
@@ -158,10 +161,11 @@ extern "C" int ullsam_skinny_linear(const float* x, long ldx, const float* WT, c
     ULLSAM_CHECK(K % 128 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0, "skinny_linear: K %% 128, ldx %% 4, 16-byte aligned x");
     if ((long)M * N == 0) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // (K >= 1024: sixteen waves split K -- with four a wave's share is a chain of 256 dependent MFMAs, 179 us per launch at K = 2048)
     if (g_skinny_mfma && N % 32 == 0 && (K == 128 || K == 256 || K == 512 || K == 1024 || K == 2048)) {
         const dim3 g32((unsigned)(N / 32), (unsigned)((M + 31) / 32));
-#define SKINNY_MFMA(KW) skinny_linear_mfma_kernel<KW><<<g32, 256, 0, s>>>(x, ldx, WT, b, res, ldr, y, ldy, M, N, act)
-        if (K == 128) SKINNY_MFMA(32); else if (K == 256) SKINNY_MFMA(64); else if (K == 512) SKINNY_MFMA(128); else if (K == 1024) SKINNY_MFMA(256); else SKINNY_MFMA(512);
+#define SKINNY_MFMA(KW, NW) skinny_linear_mfma_kernel<KW, NW><<<g32, 64 * NW, 0, s>>>(x, ldx, WT, b, res, ldr, y, ldy, M, N, act)
+        if (K == 128) SKINNY_MFMA(32, 4); else if (K == 256) SKINNY_MFMA(64, 4); else if (K == 512) SKINNY_MFMA(128, 4); else if (K == 1024) SKINNY_MFMA(64, 16); else SKINNY_MFMA(128, 16);
 #undef SKINNY_MFMA
         ULLSAM_LAUNCH_CHECK();
         return 0;
