@@ -212,6 +212,13 @@ int ullsam_argmax(const float* logits, long long* out, int rows, long V, long ld
 /* Prompt encoder / mask decoder */
 int ullsam_small_linear(const float* x, long ldx, const float* W, const float* b, const float* res, long ldr, float* y,
                         long ldy, int M, int N, int K, int act, void* stream);           /* transformer.py:220-227; mask_decoder.py:171-176 */
+/* The image -> token half of a two-way block (transformer.py:176-182) for many prompts in ONE pass over the image-side stream (bf16, embedding 256,
+ * internal 128, 8 heads): q = xin Wq^T + bq (xin = keys + pe in bf16), a = softmax_heads(q k_tok^T scale) v_tok, upd = res + a Wo^T + bo (res = keys, fp32),
+ * y = LayerNorm(upd) -> out_f32 / out_c (bf16) / out_c_pe = bf16(y + key_pe[row % pe_rows]), each optional.  xin / res have P*N rows, or in_mod / res_mod
+ * rows shared by every prompt (layer 0); ktok / vtok fp32 [P, T, 128], T <= 16. */
+int ullsam_i2t_block(const void* xin, long in_mod, const float* res, long res_mod, const void* Wq, const float* bq, const float* ktok,
+                     const float* vtok, const void* Wo, const float* bo, const float* lnw, const float* lnb, float eps, const float* key_pe,
+                     long pe_rows, float* out_f32, void* out_c, void* out_c_pe, int P, int T, int N, float scale, void* stream);
 int ullsam_skinny_linear(const float* x, long ldx, const float* WT, const float* b, const float* res, long ldr, float* y,
                          long ldy, int M, int N, int K, int act, void* stream);
 /* 0: keep ullsam_skinny_linear on its FMA kernel (tests compare it with the exact-fp32 MFMA kernel used for N % 32 == 0, K in {128 .. 2048}); returns the previous setting */

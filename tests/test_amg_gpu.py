@@ -432,3 +432,41 @@ def test_generate_batch_equals_generate_per_tile_under_rccl_world_1():
         if own:
             dist.destroy_process_group()
     assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,T,shared", [(16, 7, True), (8, 9, False), (5, 16, True)])
+def test_fused_image_to_token_block_equals_the_separate_launches(P, T, shared):
+    """transformer.FUSED_I2T (default from 16384 image-side rows, bf16): the image -> token half of a two-way block -- q projection, attention over the
+    T tokens, output projection + fp32 residual, norm4 with its three outputs -- as ONE kernel (csrc/decoder.hip i2t_block_kernel) against the five
+    launches it replaces, through TwoWayTransformer.forward_tokens on random weights: same bf16 roundings at the same places, sums in another
+    order.  Both image-side layouts: one image shared by all prompts (layer 0 broadcast) and one stream per prompt; a ragged prompt count."""
+    from ullsam_amd.modeling import transformer as TR
+    torch.manual_seed(P * 31 + T)
+    tw = TR.TwoWayTransformer(depth=2, embedding_dim=256, num_heads=8, mlp_dim=2048).to(DEV)
+    for prm in tw.parameters():
+        torch.nn.init.normal_(prm, std=0.06)
+    for n, prm in tw.named_parameters():
+        if "norm" in n and n.endswith("weight"):
+            torch.nn.init.normal_(prm, mean=1.0, std=0.1)
+    tw = tw.to(torch.bfloat16)
+    N = 4096
+    keys = torch.randn((1 if shared else P, N, 256), device=DEV)
+    key_pe = torch.randn((N, 256), device=DEV)
+    tokens = torch.randn((P, T, 256), device=DEV)
+    outs = []
+    old = TR.FUSED_I2T
+    try:
+        for on in (True, False):
+            TR.FUSED_I2T = on
+            for kc in (False, True):
+                q, k = tw.forward_tokens(keys, key_pe, tokens, keys_in_compute_dtype=kc)
+                outs.append((q.float(), k.float()))
+    finally:
+        TR.FUSED_I2T = old
+    torch.cuda.synchronize()
+    for (qa, ka), (qb, kb) in zip(outs[:2], outs[2:]):
+        assert torch.isfinite(qa).all() and torch.isfinite(ka).all()
+        assert float((qa - qb).abs().max()) < 2e-2 * max(1.0, float(qb.abs().max())), float((qa - qb).abs().max())
+        assert float((ka - kb).abs().max()) < 3e-2 * max(1.0, float(kb.abs().max())), float((ka - kb).abs().max())
+        assert float((ka - kb).abs().mean()) < 2e-3 * max(1.0, float(kb.abs().mean()))

@@ -403,3 +403,215 @@ extern "C" int ullsam_mask_iou_counts(const unsigned char* a, const unsigned cha
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The image -> token half of a two-way block (transformer.py:176-182) for MANY prompts, bf16, embedding 256 / internal 128 / 8 heads of 16:
+//     q = (keys + pe) Wq^T + bq;  a = softmax_heads(q k_tok^T / 4) v_tok;  upd = keys + a Wo^T + bo;  keys' = norm4(upd)
+// as ONE pass over the image-side stream.  The separate launches (q GEMM with fp32 output, the few-keys attention, a cast, the output GEMM with
+// its fp32 residual, the fan-out LayerNorm) move 2.1 GB per layer for 64 prompts x 4096 tokens; this kernel reads (keys + pe) in bf16 and keys in
+// fp32 and writes keys' in fp32 / bf16 / bf16 (+ pe): 0.94 GB.
+// Both weight matrices sit in LDS for the life of the workgroup (128 KiB).  A wave takes 16 rows at a time with the weights as the FIRST MFMA
+// operand (D^T = W X^T), W's rows permuted so that lane (row r, group g) ends up with the 32 consecutive q columns g 32 .. g 32 + 31 -- two whole heads --,
+// so scores, softmax and the probability-weighted sum over the <= 16 tokens are lane-local fp32 arithmetic on the accumulators (the tokens' k / v in
+// LDS, read as broadcasts); the attention output goes back into the matrix pipe from the same registers (the k order of the second product is
+// permuted to match: lane group g supplies dims g 32 + 8 ks ..), and the second product leaves the lane with 64 consecutive output columns, so the
+// LayerNorm needs two cross-lane sums over the four groups and the three outputs leave as 16-byte stores.
+// A workgroup works inside ONE prompt (its tokens' k / v); grid = prompts x workgroups per prompt.
+// ---------------------------------------------------------------------------------------------------------------
+struct I2tArgs {
+    const bf16* xin; long in_mod;          // (keys + pe) in bf16 [rows (or in_mod rows shared by every prompt), 256]
+    const float* res; long res_mod;        // keys fp32 (the residual), rows as xin
+    const bf16* Wq; const float* bq;       // [128, 256], [128]
+    const float* ktok; const float* vtok;  // fp32 [P, T, 128]
+    const bf16* Wo; const float* bo;       // [256, 128], [256]
+    const float* lnw; const float* lnb; float eps;
+    const float* key_pe; long pe_rows;     // fp32 [pe_rows, 256]
+    float* out_f32; bf16* out_c; bf16* out_c_pe;   // each optional
+    int P, T, N, wg_per_prompt;
+    float scale;
+};
+__global__ __launch_bounds__(256) void i2t_block_kernel(I2tArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WQ = 0, WO = 128 * 256 * 2, TOK = WO + 256 * 128 * 2, PAR = TOK + 2 * 16 * 128 * 4;   // Wq | Wo | k_tok, v_tok [16][128] | bq, bo, lnw, lnb
+    float* ktok = reinterpret_cast<float*>(smem + TOK);
+    float* vtok = ktok + 16 * 128;
+    float* bq = reinterpret_cast<float*>(smem + PAR);
+    float* bo = bq + 128;
+    float* lnw = bo + 256;
+    float* lnb = lnw + 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    const int prompt = blockIdx.x / p.wg_per_prompt, part = blockIdx.x % p.wg_per_prompt;
+    // Wq -> LDS: physical row n (of 128) at LDS row 16 t + 4 gq + i (gq = n / 32, t = (n % 32) / 4, i = n % 4), 32 chunks per row, chunk c at c ^ (L & 15)
+    for (int c = tid; c < 128 * 32; c += 256) {
+        const int n = c >> 5, ch = c & 31, gq = n >> 5, rem = n & 31, L = 16 * (rem >> 2) + 4 * gq + (rem & 3);
+        *reinterpret_cast<uint4*>(smem + WQ + (L * 32 + (ch ^ (L & 15))) * 16) = *reinterpret_cast<const uint4*>(p.Wq + (size_t)n * 256 + ch * 8);
+    }
+    // Wo -> LDS: physical row n (of 256) at LDS row 16 t + 4 gq + i (gq = n / 64, t = (n % 64) / 4), 16 chunks per row
+    for (int c = tid; c < 256 * 16; c += 256) {
+        const int n = c >> 4, ch = c & 15, gq = n >> 6, rem = n & 63, L = 16 * (rem >> 2) + 4 * gq + (rem & 3);
+        *reinterpret_cast<uint4*>(smem + WO + (L * 16 + (ch ^ (L & 15))) * 16) = *reinterpret_cast<const uint4*>(p.Wo + (size_t)n * 128 + ch * 8);
+    }
+    for (int c = tid; c < p.T * 128; c += 256) {
+        ktok[c] = p.ktok[(size_t)prompt * p.T * 128 + c];
+        vtok[c] = p.vtok[(size_t)prompt * p.T * 128 + c];
+    }
+    for (int c = tid; c < 256; c += 256) {
+        if (c < 128) bq[c] = p.bq ? p.bq[c] : 0.f;
+        bo[c] = p.bo ? p.bo[c] : 0.f;
+        lnw[c] = p.lnw ? p.lnw[c] : 1.f;
+        lnb[c] = p.lnb ? p.lnb[c] : 0.f;
+    }
+    __syncthreads();
+    const int groups = (p.N + 15) / 16, stride = p.wg_per_prompt * 4;
+    bf16x8_t a0[8], a1[8];
+    auto load = [&](bf16x8_t (&a)[8], int grp) {
+        const long row = (long)prompt * p.N + min(grp * 16 + l16, p.N - 1);
+        const bf16* ap = p.xin + (size_t)(p.in_mod ? row % p.in_mod : row) * 256 + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) a[ks] = *reinterpret_cast<const bf16x8_t*>(ap + ks * 32);
+    };
+    auto compute = [&](const bf16x8_t (&a)[8], int grp) {
+        // ---- q^T = Wq X^T: lane (row l16, group g) gets q[g 32 + 4 t + i], t = 0 .. 7
+        f32x4 q[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) q[t] = *reinterpret_cast<const f32x4*>(bq + g * 32 + 4 * t);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int L = 16 * t + l16;
+                const bf16x8_t w = *reinterpret_cast<const bf16x8_t*>(smem + WQ + (L * 32 + ((ks * 4 + g) ^ (L & 15))) * 16);
+                q[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a[ks], q[t], 0, 0, 0);
+                if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // (else hipcc hoists every fragment read above the first MFMA and spills)
+            }
+        }
+        // ---- two heads per lane (dims g 32 + 16 hh ..): online softmax over the tokens, as fewkeys_attn_kernel computes it
+        f32x4 o[8];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            float m = -INFINITY, l = 0.f;
+            f32x4 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < p.T; ++kt) {
+                const float* kp = ktok + kt * 128 + g * 32 + hh * 16;
+                const float* vp = vtok + kt * 128 + g * 32 + hh * 16;
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + 4 * j);
+                    const f32x4 qq = q[4 * hh + j];
+                    s += qq[0] * kv[0]; s += qq[1] * kv[1]; s += qq[2] * kv[2]; s += qq[3] * kv[3];
+                }
+                s *= p.scale;
+                const float mn = fmaxf(m, s);
+                const float al = __expf(m - mn), pv = __expf(s - mn);
+                l = l * al + pv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 vv = *reinterpret_cast<const f32x4*>(vp + 4 * j);
+                    acc[j] = acc[j] * al + pv * vv;
+                }
+                m = mn;
+            }
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[4 * hh + j] = acc[j] * inv;
+        }
+        // ---- upd^T = Wo A^T, k permuted: step ks of lane group g carries dims g 32 + 8 ks .. + 7 = o[2 ks], o[2 ks + 1] (rounded to bf16 like the cast before the output GEMM)
+        f32x4 u[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) u[t] = *reinterpret_cast<const f32x4*>(bo + g * 64 + 4 * t);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t af;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { af[e] = (__bf16)o[2 * ks][e]; af[4 + e] = (__bf16)o[2 * ks + 1][e]; }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int L = 16 * t + l16;
+                const bf16x8_t w = *reinterpret_cast<const bf16x8_t*>(smem + WO + (L * 16 + ((g * 4 + ks) ^ (L & 15))) * 16);
+                u[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, af, u[t], 0, 0, 0);
+                if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- + keys (fp32 residual), LayerNorm over the 256 columns (64 here, the rest in the lanes l16 + 16, + 32, + 48), three outputs
+        const int rin = grp * 16 + l16;
+        const bool live = rin < p.N;
+        const long row = (long)prompt * p.N + min(rin, p.N - 1);
+        const float* rp = p.res + (size_t)(p.res_mod ? row % p.res_mod : row) * 256 + g * 64;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            u[t] += *reinterpret_cast<const f32x4*>(rp + 4 * t);
+            sum += (u[t][0] + u[t][1]) + (u[t][2] + u[t][3]);
+        }
+        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / 256.0f);
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f32x4 d = u[t] - mean;
+            ss += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+        const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
+        if (!live) return;
+        const float* pe = p.out_c_pe ? p.key_pe + (size_t)(row % p.pe_rows) * 256 + g * 64 : nullptr;
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {
+            f32x4 y0 = (u[t] - mean) * rstd * *reinterpret_cast<const f32x4*>(lnw + g * 64 + 4 * t) + *reinterpret_cast<const f32x4*>(lnb + g * 64 + 4 * t);
+            f32x4 y1 = (u[t + 1] - mean) * rstd * *reinterpret_cast<const f32x4*>(lnw + g * 64 + 4 * t + 4) + *reinterpret_cast<const f32x4*>(lnb + g * 64 + 4 * t + 4);
+            const size_t off = (size_t)row * 256 + g * 64 + 4 * t;
+            if (p.out_f32) { *reinterpret_cast<f32x4*>(p.out_f32 + off) = y0; *reinterpret_cast<f32x4*>(p.out_f32 + off + 4) = y1; }
+            if (p.out_c) {
+                bf16x8_t c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { c[e] = (__bf16)y0[e]; c[4 + e] = (__bf16)y1[e]; }
+                *reinterpret_cast<bf16x8_t*>(p.out_c + off) = c;
+            }
+            if (p.out_c_pe) {
+                const f32x4 z0 = y0 + *reinterpret_cast<const f32x4*>(pe + 4 * t), z1 = y1 + *reinterpret_cast<const f32x4*>(pe + 4 * t + 4);
+                bf16x8_t c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { c[e] = (__bf16)z0[e]; c[4 + e] = (__bf16)z1[e]; }
+                *reinterpret_cast<bf16x8_t*>(p.out_c_pe + off) = c;
+            }
+        }
+    };
+    int grp = part * 4 + wave;
+    if (grp >= groups) return;
+    load(a0, grp);
+    while (true) {
+        const bool more1 = grp + stride < groups;
+        if (more1) load(a1, grp + stride);
+        compute(a0, grp);
+        if (!more1) break;
+        grp += stride;
+        const bool more0 = grp + stride < groups;
+        if (more0) load(a0, grp + stride);
+        compute(a1, grp);
+        if (!more0) break;
+        grp += stride;
+    }
+}
+// xin bf16 [P*N (or in_mod), 256]; res fp32 alike; Wq bf16 [128, 256]; ktok / vtok fp32 [P, T, 128] (T <= 16); Wo bf16 [256, 128]; key_pe fp32 [pe_rows, 256];
+// outputs [P*N, 256], each optional (NULL).  scale = 1 / sqrt(16).
+extern "C" int ullsam_i2t_block(const void* xin, long in_mod, const float* res, long res_mod, const void* Wq, const float* bq, const float* ktok,
+                                const float* vtok, const void* Wo, const float* bo, const float* lnw, const float* lnb, float eps, const float* key_pe,
+                                long pe_rows, float* out_f32, void* out_c, void* out_c_pe, int P, int T, int N, float scale, void* stream) {
+    ULLSAM_CHECK(P > 0 && N > 0 && T >= 1 && T <= 16, "i2t_block: P=%d N=%d T=%d (1..16)", P, N, T);
+    ULLSAM_CHECK(xin && res && Wq && Wo && ktok && vtok && (!out_c_pe || (key_pe && pe_rows > 0)), "i2t_block: null operand");
+    ULLSAM_CHECK(((((uintptr_t)xin | (uintptr_t)res | (uintptr_t)Wq | (uintptr_t)Wo | (uintptr_t)out_f32 | (uintptr_t)out_c | (uintptr_t)out_c_pe | (uintptr_t)key_pe)) & 15) == 0,
+                 "i2t_block: 16-byte aligned operands needed");
+    I2tArgs a{static_cast<const bf16*>(xin), in_mod, res, res_mod, static_cast<const bf16*>(Wq), bq, ktok, vtok, static_cast<const bf16*>(Wo), bo, lnw, lnb, eps,
+              key_pe, pe_rows, out_f32, static_cast<bf16*>(out_c), static_cast<bf16*>(out_c_pe), P, T, N, 1, scale};
+    const int groups = (N + 15) / 16;
+    { const int by_rows = (groups + 3) / 4, by_cus = (256 + P - 1) / P; a.wg_per_prompt = by_rows < by_cus ? by_rows : by_cus; if (a.wg_per_prompt < 1) a.wg_per_prompt = 1; }
+    constexpr int LDS = 128 * 256 * 2 + 256 * 128 * 2 + 2 * 16 * 128 * 4 + (128 + 3 * 256) * 4;
+    static PerDeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(i2t_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    i2t_block_kernel<<<dim3(P * a.wg_per_prompt), 256, LDS, reinterpret_cast<hipStream_t>(stream)>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}

@@ -75,6 +75,9 @@ def _token_to_image(at: Attention, queries, qpe, keys_pe_c, keys_c, P, T, N, dt,
     return at.tok(at.out_proj, a, res=queries)
 
 
+FUSED_I2T = True   # image -> token half of a block as one kernel from 16384 image-side rows (bf16; automatic mask generation: 64 prompts x 4096 tokens)
+
+
 class TwoWayTransformer(Packed):
     def __init__(self, depth: int, embedding_dim: int, num_heads: int, mlp_dim: int, activation: Type[nn.Module] = nn.ReLU,
                  attention_downsample_rate: int = 2) -> None:
@@ -125,15 +128,22 @@ class TwoWayTransformer(Packed):
             # image -> token: keys = norm4(keys + attn(q=keys+pe, k=queries+pe, v=queries))   (:176-182)
             ia = blk.cross_attn_image_to_token
             q_in = ops.add_cast(queries, qpe, f32)
-            Qi = ops.gemm(keys_pe_c, ia.q_proj.w(dt), ia.q_proj.b(), out_f32=True)
-            a = ops.fewkeys_attention(Qi, ia.tok(ia.k_proj, q_in), ia.tok(ia.v_proj, queries), P, ia.num_heads, ia.hd, N, T,
-                                      1.0 / math.sqrt(ia.hd), q_shared=shared)
-            upd = ops.gemm(ops.cast(a, dt), ia.out_proj.w(dt), ia.out_proj.b(), residual=keys, out_f32=True,
-                           res_row_mod=N if shared else 0)
-            # norm4 feeds the next block's residual (fp32), its v projection (model dtype) and its k / q projections (+pe, model dtype)
             last = li + 1 == len(self.layers)
-            keys, keys_c, keys_pe_c = ops.norm_fanout(upd, *blk.norm4.wb(), blk.norm4.eps, dt, key_pe,
-                                                      want_f32=not (last and keys_in_compute_dtype))
+            k_tok, v_tok = ia.tok(ia.k_proj, q_in), ia.tok(ia.v_proj, queries)
+            if (FUSED_I2T and dt == torch.bfloat16 and C == 256 and ia.internal_dim == 128 and ia.num_heads == 8 and T <= 16 and P * N >= 16384
+                    and key_pe.numel() == N * C):
+                # many prompts: q projection, attention over the T tokens, output projection + residual and norm4's fan-out in ONE pass over the stream
+                keys, keys_c, keys_pe_c = ops.i2t_block(keys_pe_c, keys, ia.q_proj.w(dt), ia.q_proj.b(), k_tok, v_tok, ia.out_proj.w(dt), ia.out_proj.b(),
+                                                        *blk.norm4.wb(), blk.norm4.eps, key_pe, P, T, N, 1.0 / math.sqrt(ia.hd), shared,
+                                                        want_f32=not (last and keys_in_compute_dtype))
+            else:
+                Qi = ops.gemm(keys_pe_c, ia.q_proj.w(dt), ia.q_proj.b(), out_f32=True)
+                a = ops.fewkeys_attention(Qi, k_tok, v_tok, P, ia.num_heads, ia.hd, N, T, 1.0 / math.sqrt(ia.hd), q_shared=shared)
+                upd = ops.gemm(ops.cast(a, dt), ia.out_proj.w(dt), ia.out_proj.b(), residual=keys, out_f32=True,
+                               res_row_mod=N if shared else 0)
+                # norm4 feeds the next block's residual (fp32), its v projection (model dtype) and its k / q projections (+pe, model dtype)
+                keys, keys_c, keys_pe_c = ops.norm_fanout(upd, *blk.norm4.wb(), blk.norm4.eps, dt, key_pe,
+                                                          want_f32=not (last and keys_in_compute_dtype))
             shared = False                               # from here on every prompt has its own image-side stream
         fa = self.final_attn_token_to_image
         queries = ops.norm(_token_to_image(fa, queries, qpe, keys_pe_c, keys_c, P, T, N, dt, shared),

@@ -150,6 +150,27 @@ def norm_fanout(x: torch.Tensor, w, b, eps: float, cdt: torch.dtype, pe: Optiona
     return out_f, (out_f if f32c else out_c), out_pe
 
 
+def i2t_block(xin: torch.Tensor, res: torch.Tensor, wq: torch.Tensor, bq, ktok: torch.Tensor, vtok: torch.Tensor, wo: torch.Tensor, bo,
+              lnw, lnb, eps: float, key_pe: Optional[torch.Tensor], P: int, T: int, N: int, scale: float, shared: bool, want_f32: bool = True,
+              want_c: bool = True):
+    """The image -> token half of a two-way block in one pass (csrc/decoder.hip i2t_block_kernel): xin = (keys + pe) bf16, res = keys fp32, both
+    [P*N, 256] or [N, 256] when `shared`; ktok / vtok fp32 [P*T, 128]; -> (keys' fp32 | None, keys' bf16 | None, (keys' + pe) bf16 | None)."""
+    _chk(xin, "xin", torch.bfloat16); _chk(res, "res", torch.float32); _chk(wq, "wq", torch.bfloat16); _chk(wo, "wo", torch.bfloat16)
+    _chk(ktok, "ktok", torch.float32); _chk(vtok, "vtok", torch.float32)
+    assert wq.shape == (128, 256) and wo.shape == (256, 128) and ktok.numel() == P * T * 128 and vtok.numel() == P * T * 128
+    assert xin.numel() == (N if shared else P * N) * 256 and res.numel() == xin.numel()
+    rows = P * N
+    out_f = torch.empty((rows, 256), dtype=torch.float32, device=xin.device) if want_f32 else None
+    out_c = torch.empty((rows, 256), dtype=torch.bfloat16, device=xin.device) if want_c else None
+    out_pe = torch.empty((rows, 256), dtype=torch.bfloat16, device=xin.device) if key_pe is not None else None
+    if key_pe is not None:
+        _chk(key_pe, "key_pe", torch.float32)
+    _lib.call("ullsam_i2t_block", xin.data_ptr(), N if shared else 0, res.data_ptr(), N if shared else 0, wq.data_ptr(), _p(bq), ktok.data_ptr(), vtok.data_ptr(),
+              wo.data_ptr(), _p(bo), _p(lnw), _p(lnb), float(eps), _p(key_pe), key_pe.numel() // 256 if key_pe is not None else 0, _p(out_f), _p(out_c), _p(out_pe),
+              P, T, N, float(scale), _stream())
+    return out_f, out_c, out_pe
+
+
 def vit_attention(qkv: torch.Tensor, rel_h: torch.Tensor, rel_w: torch.Tensor, qkv_bias: torch.Tensor, B: int, heads: int,
                   hd: int, gh: int, gw: int, window: int) -> torch.Tensor:
     _chk(qkv, "qkv"); _chk(rel_h, "rel_h", qkv.dtype); _chk(rel_w, "rel_w", qkv.dtype); _chk(qkv_bias, "qkv_bias", qkv.dtype)
