@@ -435,9 +435,9 @@ def test_generate_batch_equals_generate_per_tile_under_rccl_world_1():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("P,T,shared", [(16, 7, True), (8, 9, False), (5, 16, True)])
+@pytest.mark.parametrize("P,T,shared", [(16, 7, True), (8, 9, False), (5, 16, True), (1, 7, False)])
 def test_fused_image_to_token_block_equals_the_separate_launches(P, T, shared):
-    """transformer.FUSED_I2T (default from 16384 image-side rows, bf16): the image -> token half of a two-way block -- q projection, attention over the
+    """transformer.FUSED_I2T (default for bf16 from 1024 image tokens): the image -> token half of a two-way block -- q projection, attention over the
     T tokens, output projection + fp32 residual, norm4 with its three outputs -- as ONE kernel (csrc/decoder.hip i2t_block_kernel) against the five
     launches it replaces, through TwoWayTransformer.forward_tokens on random weights: same bf16 roundings at the same places, sums in another
     order.  Both image-side layouts: one image shared by all prompts (layer 0 broadcast) and one stream per prompt; a ragged prompt count."""

@@ -75,7 +75,8 @@ def _token_to_image(at: Attention, queries, qpe, keys_pe_c, keys_c, P, T, N, dt,
     return at.tok(at.out_proj, a, res=queries)
 
 
-FUSED_I2T = True   # image -> token half of a block as one kernel from 16384 image-side rows (bf16; automatic mask generation: 64 prompts x 4096 tokens)
+FUSED_I2T = True   # image -> token half of a block as one kernel (bf16, SAM's decoder dimensions, >= 1024 image tokens; whatever the number of prompts, so
+#                    that a record's outputs do not depend on what it is batched with)
 
 
 class TwoWayTransformer(Packed):
@@ -129,16 +130,15 @@ class TwoWayTransformer(Packed):
             ia = blk.cross_attn_image_to_token
             q_in = ops.add_cast(queries, qpe, f32)
             last = li + 1 == len(self.layers)
-            k_tok, v_tok = ia.tok(ia.k_proj, q_in), ia.tok(ia.v_proj, queries)
-            if (FUSED_I2T and dt == torch.bfloat16 and C == 256 and ia.internal_dim == 128 and ia.num_heads == 8 and T <= 16 and P * N >= 16384
+            if (FUSED_I2T and dt == torch.bfloat16 and C == 256 and ia.internal_dim == 128 and ia.num_heads == 8 and T <= 16 and N >= 1024
                     and key_pe.numel() == N * C):
                 # many prompts: q projection, attention over the T tokens, output projection + residual and norm4's fan-out in ONE pass over the stream
-                keys, keys_c, keys_pe_c = ops.i2t_block(keys_pe_c, keys, ia.q_proj.w(dt), ia.q_proj.b(), k_tok, v_tok, ia.out_proj.w(dt), ia.out_proj.b(),
+                keys, keys_c, keys_pe_c = ops.i2t_block(keys_pe_c, keys, ia.q_proj.w(dt), ia.q_proj.b(), ia.tok(ia.k_proj, q_in), ia.tok(ia.v_proj, queries), ia.out_proj.w(dt), ia.out_proj.b(),
                                                         *blk.norm4.wb(), blk.norm4.eps, key_pe, P, T, N, 1.0 / math.sqrt(ia.hd), shared,
                                                         want_f32=not (last and keys_in_compute_dtype))
             else:
                 Qi = ops.gemm(keys_pe_c, ia.q_proj.w(dt), ia.q_proj.b(), out_f32=True)
-                a = ops.fewkeys_attention(Qi, k_tok, v_tok, P, ia.num_heads, ia.hd, N, T, 1.0 / math.sqrt(ia.hd), q_shared=shared)
+                a = ops.fewkeys_attention(Qi, ia.tok(ia.k_proj, q_in), ia.tok(ia.v_proj, queries), P, ia.num_heads, ia.hd, N, T, 1.0 / math.sqrt(ia.hd), q_shared=shared)
                 upd = ops.gemm(ops.cast(a, dt), ia.out_proj.w(dt), ia.out_proj.b(), residual=keys, out_f32=True,
                                res_row_mod=N if shared else 0)
                 # norm4 feeds the next block's residual (fp32), its v projection (model dtype) and its k / q projections (+pe, model dtype)
