@@ -16,7 +16,7 @@ tile = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 vit = sys.argv[3] if len(sys.argv) > 3 else "h"
 stab = float(sys.argv[4]) if len(sys.argv) > 4 else 0.92
 off = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
-iters = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+iters = int(sys.argv[6]) if len(sys.argv) > 6 else 6
 piou = float(sys.argv[7]) if len(sys.argv) > 7 else 0.90
 nms = float(sys.argv[8]) if len(sys.argv) > 8 else 0.7
 if os.environ.get("ULLSAM_GEMM_VARIANT"):
@@ -30,7 +30,7 @@ gen = SamAutomaticMaskGenerator(sam, points_per_side=side, points_per_batch=64, 
                                 stability_score_offset=off, box_nms_thresh=nms, output_mode="uncompressed_rle")
 from ullsam_amd.utils.synthetic import microscopy_tile
 img = torch.from_numpy(microscopy_tile(7, size=tile, n_cells=40, r_range=(90.0 * tile / 2048, 260.0 * tile / 2048))[0] * 255).cuda()
-t_enc = t_all = 0.0
+encs, alls = [], []
 for it in range(iters):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     tok, _ = gen._encode(img)
@@ -38,7 +38,8 @@ for it in range(iters):
     recs = gen.generate(img)
     torch.cuda.synchronize(); t2 = time.perf_counter()
     if it:
-        t_enc += t1 - t0; t_all += t2 - t1
+        encs.append(t1 - t0); alls.append(t2 - t1)
+t_enc, t_all = sorted(encs)[len(encs) // 2] * (iters - 1), sorted(alls)[len(alls) // 2] * (iters - 1)     # medians over the timed tiles (the first tile is a warm-up)
 print(json.dumps({"workload": f"AMG {side}x{side} points on a {tile}^2 tile, SAM ViT-{vit.upper()}, {'fp8 (e4m3) qkv/lin1 + bf16' if fp8 else 'bf16'}, 64 prompts/batch, multimask",
                   "seconds_per_tile": round(t_all / (iters - 1), 4), "encoder_seconds": round(t_enc / (iters - 1), 4), "prompts_per_s": round(side * side / (t_all / (iters - 1)), 1),
                   "masks_kept": len(recs), "thresholds": {"pred_iou": piou, "stability": stab, "stability_offset": off, "box_nms": nms}}))
