@@ -6,6 +6,7 @@ prompt) uses the MFMA GEMM in the model dtype with an fp32 `keys` stream.
 from __future__ import annotations
 
 import math
+import os
 from typing import Tuple, Type
 
 import torch
@@ -75,7 +76,7 @@ def _token_to_image(at: Attention, queries, qpe, keys_pe_c, keys_c, P, T, N, dt,
     return at.tok(at.out_proj, a, res=queries)
 
 
-FUSED_I2T = True   # image -> token half of a block as one kernel (bf16, SAM's decoder dimensions, >= 1024 image tokens; whatever the number of prompts, so
+FUSED_I2T = os.environ.get("ULLSAM_FUSED_I2T", "1") != "0"   # image -> token half of a block as one kernel (bf16, SAM's decoder dimensions, >= 1024 image tokens; whatever the number of prompts, so
 #                    that a record's outputs do not depend on what it is batched with)
 
 
