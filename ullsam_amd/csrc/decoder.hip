@@ -471,6 +471,16 @@ __global__ __launch_bounds__(256) void i2t_block_kernel(I2tArgs p) {
         for (int ks = 0; ks < 8; ++ks) a[ks] = *reinterpret_cast<const bf16x8_t*>(ap + ks * 32);
     };
     auto compute = [&](const bf16x8_t (&a)[8], int grp) {
+        // the fp32 residual rows of this group are requested FIRST: their latency passes under the two products and the attention (a wave has the SIMD to itself)
+        const int rin = grp * 16 + l16;
+        const bool live = rin < p.N;
+        const long row = (long)prompt * p.N + min(rin, p.N - 1);
+        f32x4 rr[16];
+        {
+            const float* rp = p.res + (size_t)(p.res_mod ? row % p.res_mod : row) * 256 + g * 64;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) rr[t] = *reinterpret_cast<const f32x4*>(rp + 4 * t);
+        }
         // ---- q^T = Wq X^T: lane (row l16, group g) gets q[g 32 + 4 t + i], t = 0 .. 7
         f32x4 q[8];
 #pragma unroll
@@ -536,14 +546,10 @@ __global__ __launch_bounds__(256) void i2t_block_kernel(I2tArgs p) {
             }
         }
         // ---- + keys (fp32 residual), LayerNorm over the 256 columns (64 here, the rest in the lanes l16 + 16, + 32, + 48), three outputs
-        const int rin = grp * 16 + l16;
-        const bool live = rin < p.N;
-        const long row = (long)prompt * p.N + min(rin, p.N - 1);
-        const float* rp = p.res + (size_t)(p.res_mod ? row % p.res_mod : row) * 256 + g * 64;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            u[t] += *reinterpret_cast<const f32x4*>(rp + 4 * t);
+            u[t] += rr[t];
             sum += (u[t][0] + u[t][1]) + (u[t][2] + u[t][3]);
         }
         sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
