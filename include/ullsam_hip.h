@@ -219,6 +219,10 @@ int ullsam_small_linear(const float* x, long ldx, const float* W, const float* b
 int ullsam_i2t_block(const void* xin, long in_mod, const float* res, long res_mod, const void* Wq, const float* bq, const float* ktok,
                      const float* vtok, const void* Wo, const float* bo, const float* lnw, const float* lnb, float eps, const float* key_pe,
                      long pe_rows, float* out_f32, void* out_c, void* out_c_pe, int P, int T, int N, float scale, void* stream);
+/* Second transposed convolution + GELU + hypernetwork product in one pass (mask_decoder.py:136-147, bf16): u1 bf16 [NB*H*W*4, 64] (first transposed convolution
+ * after LayerNorm2d + GELU), w1 bf16 [128 = (ky2, kx2, c), 64], b1 fp32 [128] | NULL, hyper fp32 [NB, NM <= 8, 32] -> out fp32 [NB, NM, 4H, 4W]; the upscaled
+ * embedding is never written. */
+int ullsam_up2_hyper_masks(const void* u1, const void* w1, const float* b1, const float* hyper, float* out, int NB, int NM, int H, int W, void* stream);
 int ullsam_skinny_linear(const float* x, long ldx, const float* WT, const float* b, const float* res, long ldr, float* y,
                          long ldy, int M, int N, int K, int act, void* stream);
 /* 0: keep ullsam_skinny_linear on its FMA kernel (tests compare it with the exact-fp32 MFMA kernel used for N % 32 == 0, K in {128 .. 2048}); returns the previous setting */

@@ -470,3 +470,30 @@ def test_fused_image_to_token_block_equals_the_separate_launches(P, T, shared):
         assert float((qa - qb).abs().max()) < 2e-2 * max(1.0, float(qb.abs().max())), float((qa - qb).abs().max())
         assert float((ka - kb).abs().max()) < 3e-2 * max(1.0, float(kb.abs().max())), float((ka - kb).abs().max())
         assert float((ka - kb).abs().mean()) < 2e-3 * max(1.0, float(kb.abs().mean()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,nm", [(3, 4), (1, 4), (5, 1)])
+def test_fused_second_upscaling_and_hypernetwork_product_equals_the_separate_launches(P, nm):
+    """ops.up2_hyper_masks (second transposed convolution as Linear 64 -> 4 x 32, GELU, rounding to bf16, hypernetwork product: one kernel, the upscaled
+    embedding never written) against ops.gemm(act=GELU) + ops.hyper_masks on the same operands: same roundings in the same places, the k sums of the
+    product in another order (a bf16 step of a channel value now and then)."""
+    from ullsam_amd import ops
+    g = torch.Generator(device=DEV); g.manual_seed(P * 10 + nm)
+    H = W = 64
+    u1 = torch.randn(P * H * W * 4, 64, device=DEV, generator=g).bfloat16()
+    w1 = (torch.randn(128, 64, device=DEV, generator=g) * 0.15).bfloat16()
+    b1 = torch.randn(128, device=DEV, generator=g) * 0.1
+    hyper = torch.randn(P, nm, 32, device=DEV, generator=g)
+    ref = ops.hyper_masks(ops.gemm(u1, w1, b1, act=ops.ACT_GELU), hyper, P, nm, H, W, 32)
+    got = ops.up2_hyper_masks(u1, w1, b1, hyper, P, nm, H, W)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape == (P, nm, 256, 256) and torch.isfinite(got).all()
+    d = (got - ref).abs()
+    assert float(d.max()) < 2e-2 * max(1.0, float(ref.abs().max())) and float(d.mean()) < 2e-4 * max(1.0, float(ref.abs().mean())), (float(d.max()), float(d.mean()))
+    # against fp64 on the bf16-rounded operands
+    x = (u1.double() @ w1.double().T + b1.double())
+    gel = (0.5 * x * (1.0 + torch.erf(x / 2 ** 0.5))).bfloat16().double().reshape(P, H, W, 2, 2, 2, 2, 32)   # [nb, y, x, ky, kx, ky2, kx2, c]
+    full = gel.permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(P, 4 * H, 4 * W, 32)
+    want = torch.einsum("pmc,pyxc->pmyx", hyper.double(), full)
+    assert float((got.double() - want).abs().max()) < 3e-2 * max(1.0, float(want.abs().max()))

@@ -621,3 +621,105 @@ extern "C" int ullsam_i2t_block(const void* xin, long in_mod, const float* res, 
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Second transposed convolution + GELU + hypernetwork product in one pass (mask_decoder.py:136-147, bf16):
+//     masks[nb][m][Y][X] = sum_c hyper[nb][m][c] * bf16(GELU(u1[row] . w1[tap * 32 + c] + b1[tap * 32 + c]))
+// u1 bf16 [NB*H*W*4, 64] (the first transposed convolution after LayerNorm2d + GELU; row = ((nb H + y) W + x) 4 + sub1), w1 bf16 [128 = (ky2, kx2, c), 64],
+// hyper fp32 [NB, NM, 32]; out fp32 [NB, NM, 4H, 4W].  The upscaled embedding [NB*H*W*4, 128] (268 MB for 64 prompts) is never written: w1 sits in LDS
+// with its rows permuted so that, with the weights as the first MFMA operand, lane (row, g) ends up with the 32 channels of ONE tap (tap = g) -- bias, GELU,
+// the rounding to bf16 the separate launches apply, and the NM dot products with the prompt's hypernetwork vectors are lane-local.
+// A workgroup works inside one prompt (its hyper vectors in LDS).
+// ---------------------------------------------------------------------------------------------------------------
+struct Up2Args { const bf16* u1; const bf16* w1; const float* b1; const float* hyper; float* out; int NB, NM, H, W, wg_per_prompt; };
+__global__ __launch_bounds__(256, 3) void up2_hyper_kernel(Up2Args p) {
+    __shared__ __attribute__((aligned(16))) char wl[128 * 64 * 2];   // w1: physical row n at LDS row 16 t + 4 gq + i (gq = n / 32 = tap, t = (n % 32) / 4), 8 chunks per row
+    __shared__ __attribute__((aligned(16))) float hs[8 * 32];
+    __shared__ __attribute__((aligned(16))) float bs[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    const int nb = blockIdx.x / p.wg_per_prompt, part = blockIdx.x % p.wg_per_prompt;
+    for (int c = tid; c < 128 * 8; c += 256) {
+        const int n = c >> 3, ch = c & 7, gq = n >> 5, rem = n & 31, L = 16 * (rem >> 2) + 4 * gq + (rem & 3);
+        *reinterpret_cast<uint4*>(wl + (L * 8 + (ch ^ ((L >> 1) & 7))) * 16) = *reinterpret_cast<const uint4*>(p.w1 + (size_t)n * 64 + ch * 8);
+    }
+    for (int c = tid; c < p.NM * 32; c += 256) hs[c] = p.hyper[(size_t)nb * p.NM * 32 + c];
+    if (tid < 128) bs[tid] = p.b1 ? p.b1[tid] : 0.f;
+    __syncthreads();
+    const long rows = (long)p.H * p.W * 4;                 // rows of this prompt
+    const int groups = (int)((rows + 15) / 16), stride = p.wg_per_prompt * 4;
+    bf16x8_t a0[2], a1[2];
+    auto load = [&](bf16x8_t (&a)[2], int grp) {
+        const long row = (long)nb * rows + min((long)grp * 16 + l16, rows - 1);
+        const bf16* ap = p.u1 + (size_t)row * 64 + g * 8;
+        a[0] = *reinterpret_cast<const bf16x8_t*>(ap);
+        a[1] = *reinterpret_cast<const bf16x8_t*>(ap + 32);
+    };
+    auto compute = [&](const bf16x8_t (&a)[2], int grp) {
+        f32x4 acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = *reinterpret_cast<const f32x4*>(bs + g * 32 + 4 * t);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int L = 16 * t + l16;
+                const bf16x8_t w = *reinterpret_cast<const bf16x8_t*>(wl + (L * 8 + ((ks * 4 + g) ^ ((L >> 1) & 7))) * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a[ks], acc[t], 0, 0, 0);
+            }
+        {
+            const long rin = (long)grp * 16 + l16;
+            if (rin >= rows) return;
+            float sm[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) sm[m] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {              // channels 4 t .. 4 t + 3 of this lane's tap, in ascending order (the order hyper_masks_kernel sums in)
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (float)(__bf16)gelu_erfc5(acc[t][i]);   // (the upscaled embedding was a bf16 tensor between the two launches; the one-transcendental GELU of the ring GEMM's bf16 epilogues, within 1.9e-6 of the erf form: the kernel is bound by this arithmetic)
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    if (m < p.NM) {
+                        const f32x4 h4 = *reinterpret_cast<const f32x4*>(hs + m * 32 + 4 * t);   // (one broadcast ds_read_b128 instead of four b32)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sm[m] += h4[i] * v[i];
+                    }
+                __builtin_amdgcn_sched_barrier(0);     // (one GELU group at a time: interleaving all 32 evaluations costs hipcc 280 registers)
+            }
+            const int sub1 = (int)(rin & 3);
+            const long pix = rin >> 2;
+            const int y = (int)(pix / p.W), x = (int)(pix % p.W);
+            const int Y = 4 * y + 2 * (sub1 >> 1) + (g >> 1), X = 4 * x + 2 * (sub1 & 1) + (g & 1);
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                if (m < p.NM) p.out[(((size_t)nb * p.NM + m) * 4 * p.H + Y) * 4 * p.W + X] = sm[m];
+        }
+    };
+    int grp = part * 4 + wave;
+    if (grp >= groups) return;
+    load(a0, grp);
+    while (true) {
+        const bool more1 = grp + stride < groups;
+        if (more1) load(a1, grp + stride);
+        compute(a0, grp);
+        if (!more1) break;
+        grp += stride;
+        const bool more0 = grp + stride < groups;
+        if (more0) load(a0, grp + stride);
+        compute(a1, grp);
+        if (!more0) break;
+        grp += stride;
+    }
+}
+// u1 bf16 [NB*H*W*4, 64]; w1 bf16 [128, 64] = (ky2, kx2, c) x cin; b1 fp32 [128] or NULL; hyper fp32 [NB, NM, 32] (NM <= 8); out fp32 [NB, NM, 4H, 4W]
+extern "C" int ullsam_up2_hyper_masks(const void* u1, const void* w1, const float* b1, const float* hyper, float* out, int NB, int NM, int H, int W, void* stream) {
+    ULLSAM_CHECK(NB > 0 && NM >= 1 && NM <= 8 && H > 0 && W > 0, "up2_hyper_masks: NB=%d NM=%d H=%d W=%d", NB, NM, H, W);
+    ULLSAM_CHECK((((uintptr_t)u1 | (uintptr_t)w1) & 15) == 0, "up2_hyper_masks: 16-byte aligned operands needed");
+    Up2Args a{static_cast<const bf16*>(u1), static_cast<const bf16*>(w1), b1, hyper, out, NB, NM, H, W, 1};
+    const long groups = ((long)H * W * 4 + 15) / 16;
+    { const long by_rows = (groups + 15) / 16, by_cus = (2048 + NB - 1) / NB;   /* eight workgroups per CU (84 registers, 18 KB of LDS each), at least four row groups per wave */
+      a.wg_per_prompt = (int)(by_rows < by_cus ? by_rows : by_cus); if (a.wg_per_prompt < 1) a.wg_per_prompt = 1; }
+    up2_hyper_kernel<<<dim3(NB * a.wg_per_prompt), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}

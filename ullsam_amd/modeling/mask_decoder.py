@@ -3,6 +3,8 @@ from __future__ import annotations
 
 from typing import List, Tuple, Type
 
+import os
+
 import torch
 from torch import nn
 
@@ -50,6 +52,9 @@ class MLP(Packed):
         return x
 
 
+FUSED_UP2 = os.environ.get("ULLSAM_FUSED_UP2", "1") != "0"   # bf16: second transposed convolution + GELU + hypernetwork product as one kernel (any prompt count)
+
+
 class MaskDecoder(Packed):
     def __init__(self, *, transformer_dim: int, transformer: nn.Module, num_multimask_outputs: int = 3,
                  activation: Type[nn.Module] = nn.GELU, iou_head_depth: int = 3, iou_head_hidden_dim: int = 256) -> None:
@@ -92,9 +97,12 @@ class MaskDecoder(Packed):
         c4, c8 = C // 4, C // 8
         u1 = ops.gemm(src.reshape(P * N, C), w0, b0, out_f32=True)           # [P*N, (ky,kx,c4)]
         u1 = ops.norm(u1.reshape(P * N * 4, c4), *ln.wb(), ln.eps, dt, act=ops.ACT_GELU)   # LayerNorm2d + GELU per output pixel
-        u2 = ops.gemm(u1, w1, b1, act=ops.ACT_GELU)                          # [P*N*4, (ky2,kx2,c8)]
         hyper = torch.stack([self.output_hypernetworks_mlps[i](hs[:, 1 + i, :]) for i in range(nm)], dim=1).contiguous()
-        masks = ops.hyper_masks(u2, hyper, P, nm, h, w, c8)
+        if FUSED_UP2 and dt == torch.bfloat16 and c4 == 64 and c8 == 32 and nm <= 8:
+            masks = ops.up2_hyper_masks(u1, w1, b1, hyper, P, nm, h, w)      # second transposed convolution + GELU + hypernetwork product: the upscaled embedding is never written
+        else:
+            u2 = ops.gemm(u1, w1, b1, act=ops.ACT_GELU)                      # [P*N*4, (ky2,kx2,c8)]
+            masks = ops.hyper_masks(u2, hyper, P, nm, h, w, c8)
         iou = self.iou_prediction_head(hs[:, 0, :])
         return masks, iou
 

@@ -476,6 +476,16 @@ def hyper_masks(up2: torch.Tensor, hyper: torch.Tensor, NB: int, NM: int, H: int
     return out
 
 
+def up2_hyper_masks(u1: torch.Tensor, w1: torch.Tensor, b1, hyper: torch.Tensor, NB: int, NM: int, H: int, W: int) -> torch.Tensor:
+    """Second transposed convolution (as Linear 64 -> 4 x 32) + GELU + hypernetwork product in one pass (bf16): u1 [NB*H*W*4, 64], w1 [128, 64], hyper fp32
+    [NB, NM, 32] -> fp32 [NB, NM, 4H, 4W]."""
+    _chk(u1, "u1", torch.bfloat16); _chk(w1, "w1", torch.bfloat16); _chk(hyper, "hyper", torch.float32)
+    assert u1.shape == (NB * H * W * 4, 64) and w1.shape == (128, 64) and hyper.numel() == NB * NM * 32
+    out = torch.empty((NB, NM, 4 * H, 4 * W), dtype=torch.float32, device=u1.device)
+    _lib.call("ullsam_up2_hyper_masks", u1.data_ptr(), w1.data_ptr(), _p(b1), hyper.data_ptr(), out.data_ptr(), NB, NM, H, W, _stream())
+    return out
+
+
 def resize_bilinear(x: torch.Tensor, out_hw, valid_hw=None, want_float=True, threshold: Optional[float] = None):
     """x fp32 [..., IH, IW] (optionally only the top-left valid_hw region is the source image)."""
     _chk(x, "x", torch.float32)
