@@ -223,6 +223,9 @@ int ullsam_i2t_block(const void* xin, long in_mod, const float* res, long res_mo
  * after LayerNorm2d + GELU), w1 bf16 [128 = (ky2, kx2, c), 64], b1 fp32 [128] | NULL, hyper fp32 [NB, NM <= 8, 32] -> out fp32 [NB, NM, 4H, 4W]; the upscaled
  * embedding is never written. */
 int ullsam_up2_hyper_masks(const void* u1, const void* w1, const float* b1, const float* hyper, float* out, int NB, int NM, int H, int W, void* stream);
+/* First transposed convolution + LayerNorm2d + GELU in one pass (mask_decoder.py:131-138, bf16): src bf16 [rows, 256], w0 bf16 [256 = (ky, kx, c), 256],
+ * b0 fp32 [256] | NULL, lnw / lnb fp32 [64] | NULL -> out bf16 [rows * 4, 64]; the fp32 result of the convolution is never written. */
+int ullsam_up1_ln_gelu(const void* src, const void* w0, const float* b0, const float* lnw, const float* lnb, float eps, void* out, long rows, void* stream);
 int ullsam_skinny_linear(const float* x, long ldx, const float* WT, const float* b, const float* res, long ldr, float* y,
                          long ldy, int M, int N, int K, int act, void* stream);
 /* 0: keep ullsam_skinny_linear on its FMA kernel (tests compare it with the exact-fp32 MFMA kernel used for N % 32 == 0, K in {128 .. 2048}); returns the previous setting */

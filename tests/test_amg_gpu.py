@@ -497,3 +497,27 @@ def test_fused_second_upscaling_and_hypernetwork_product_equals_the_separate_lau
     full = gel.permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(P, 4 * H, 4 * W, 32)
     want = torch.einsum("pmc,pyxc->pmyx", hyper.double(), full)
     assert float((got.double() - want).abs().max()) < 3e-2 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [4096 * 3, 4096, 1000])
+def test_fused_first_upscaling_layernorm_gelu_equals_the_separate_launches(rows):
+    """ops.up1_ln_gelu (first transposed convolution as Linear 256 -> 4 x 64, LayerNorm2d over each tap's 64 channels, GELU: one kernel, the fp32
+    convolution output never written) against ops.gemm(out_f32) + ops.norm(act=GELU) on the same operands."""
+    from ullsam_amd import ops
+    g = torch.Generator(device=DEV); g.manual_seed(rows)
+    src = torch.randn(rows, 256, device=DEV, generator=g).bfloat16()
+    w0 = (torch.randn(256, 256, device=DEV, generator=g) * 0.08).bfloat16()
+    b0 = torch.randn(256, device=DEV, generator=g) * 0.1
+    lw = 1.0 + 0.1 * torch.randn(64, device=DEV, generator=g)
+    lb = 0.1 * torch.randn(64, device=DEV, generator=g)
+    ref = ops.norm(ops.gemm(src, w0, b0, out_f32=True).reshape(rows * 4, 64), lw, lb, 1e-6, torch.bfloat16, act=ops.ACT_GELU).float()
+    got = ops.up1_ln_gelu(src, w0, b0, lw, lb, 1e-6).float()
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape == (rows * 4, 64) and torch.isfinite(got).all()
+    d = (got - ref).abs()
+    assert float(d.max()) < 2e-2 * max(1.0, float(ref.abs().max())) and float(d.mean()) < 3e-4, (float(d.max()), float(d.mean()))
+    x = (src.double() @ w0.double().T + b0.double()).reshape(rows * 4, 64)
+    xn = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-6) * lw.double() + lb.double()
+    want = 0.5 * xn * (1.0 + torch.erf(xn / 2 ** 0.5))
+    assert float((got.double() - want).abs().max()) < 2e-2 * max(1.0, float(want.abs().max()))

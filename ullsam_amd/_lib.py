@@ -62,6 +62,7 @@ SIGNATURES = {
     "ullsam_small_linear": [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp],
     "ullsam_i2t_block": [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, i64, vp, vp, vp, i32, i32, i32, f32, vp],
     "ullsam_up2_hyper_masks": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "ullsam_up1_ln_gelu": [vp, vp, vp, vp, vp, f32, vp, i64, vp],
     "ullsam_skinny_linear": [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp],
     "ullsam_sparse_embed": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp],
     "ullsam_dense_pe": [vp, vp, i32, i32, i32, vp],

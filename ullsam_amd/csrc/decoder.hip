@@ -723,3 +723,105 @@ extern "C" int ullsam_up2_hyper_masks(const void* u1, const void* w1, const floa
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// First transposed convolution + LayerNorm2d + GELU in one pass (mask_decoder.py:131-138, bf16):
+//     u1[row * 4 + tap][c] = bf16(GELU(LayerNorm_c(src[row] . w0[tap * 64 + c] + b0[tap * 64 + c])))
+// src bf16 [rows, 256] (the image side of the two-way transformer), w0 bf16 [256 = (ky, kx, c), 256]; out bf16 [rows * 4, 64] = [rows, 256].
+// The fp32 result of the convolution ([rows, 256] fp32 = 268 MB for 64 prompts) used to be written by the GEMM and read back by the 64-channel
+// LayerNorm; here w0 (128 KiB) sits in LDS with its rows permuted so that lane (row, g) holds the 64 channels of ONE tap (tap = g): mean, variance, the
+// affine, GELU and the rounding are lane-local, the store is 128 contiguous bytes per lane.
+// ---------------------------------------------------------------------------------------------------------------
+struct Up1Args { const bf16* src; const bf16* w0; const float* b0; const float* lnw; const float* lnb; float eps; bf16* out; long rows; };
+__global__ __launch_bounds__(512) void up1_ln_gelu_kernel(Up1Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bs = reinterpret_cast<float*>(smem + 256 * 256 * 2);      // b0 [256] | lnw [64] | lnb [64]
+    float* lw = bs + 256;
+    float* lb = lw + 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    // w0 -> LDS: physical row n (of 256) at LDS row 16 t + 4 gq + i (gq = n / 64 = tap, t = (n % 64) / 4), 32 chunks per row, chunk c at c ^ (L & 15)
+    for (int c = tid; c < 256 * 32; c += 512) {
+        const int n = c >> 5, ch = c & 31, gq = n >> 6, rem = n & 63, L = 16 * (rem >> 2) + 4 * gq + (rem & 3);
+        *reinterpret_cast<uint4*>(smem + (L * 32 + (ch ^ (L & 15))) * 16) = *reinterpret_cast<const uint4*>(p.w0 + (size_t)n * 256 + ch * 8);
+    }
+    if (tid < 256) bs[tid] = p.b0 ? p.b0[tid] : 0.f;
+    if (tid < 64) { lw[tid] = p.lnw ? p.lnw[tid] : 1.f; lb[tid] = p.lnb ? p.lnb[tid] : 0.f; }
+    __syncthreads();
+    const long groups = (p.rows + 15) / 16;
+    const long stride = (long)gridDim.x * 8;
+    bf16x8_t a[8];
+    auto load = [&](long grp) {
+        const long row = min(grp * 16 + l16, p.rows - 1);
+        const bf16* ap = p.src + (size_t)row * 256 + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) a[ks] = *reinterpret_cast<const bf16x8_t*>(ap + ks * 32);
+    };
+    auto product = [&](f32x4 (&u)[16]) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) u[t] = *reinterpret_cast<const f32x4*>(bs + g * 64 + 4 * t);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int L = 16 * t + l16;
+                const bf16x8_t w = *reinterpret_cast<const bf16x8_t*>(smem + (L * 32 + ((ks * 4 + g) ^ (L & 15))) * 16);
+                u[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a[ks], u[t], 0, 0, 0);
+                if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // (else hipcc hoists every fragment read above the first MFMA and spills)
+            }
+        }
+    };
+    auto finish = [&](f32x4 (&u)[16], long grp) {
+        const long row = grp * 16 + l16;
+        if (row >= p.rows) return;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sum += (u[t][0] + u[t][1]) + (u[t][2] + u[t][3]);
+        const float mean = sum * (1.0f / 64.0f);
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f32x4 d = u[t] - mean;
+            ss += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        const float rstd = 1.0f / sqrtf(ss * (1.0f / 64.0f) + p.eps);
+        bf16* op = p.out + (size_t)row * 256 + g * 64;
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {
+            bf16x8_t c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                c[e] = (__bf16)gelu_erfc5((u[t][e] - mean) * rstd * lw[4 * t + e] + lb[4 * t + e]);
+                c[4 + e] = (__bf16)gelu_erfc5((u[t + 1][e] - mean) * rstd * lw[4 * t + 4 + e] + lb[4 * t + 4 + e]);
+            }
+            *reinterpret_cast<bf16x8_t*>(op + 4 * t) = c;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    long grp = (long)blockIdx.x * 8 + wave;
+    if (grp >= groups) return;
+    load(grp);
+    while (true) {
+        f32x4 u[16];
+        product(u);
+        const long nxt = grp + stride;
+        const bool more = nxt < groups;
+        if (more) load(nxt);                           // the next group's fragments land under this group's LayerNorm / GELU (one register set: two spilled)
+        finish(u, grp);
+        if (!more) break;
+        grp = nxt;
+    }
+}
+// src bf16 [rows, 256]; w0 bf16 [256, 256] = (ky, kx, c) x cin; b0 fp32 [256] | NULL; lnw / lnb fp32 [64] | NULL; out bf16 [rows * 4, 64]
+extern "C" int ullsam_up1_ln_gelu(const void* src, const void* w0, const float* b0, const float* lnw, const float* lnb, float eps, void* out, long rows, void* stream) {
+    ULLSAM_CHECK(rows > 0, "up1_ln_gelu: rows=%ld", rows);
+    ULLSAM_CHECK((((uintptr_t)src | (uintptr_t)w0 | (uintptr_t)out) & 15) == 0, "up1_ln_gelu: 16-byte aligned operands needed");
+    Up1Args a{static_cast<const bf16*>(src), static_cast<const bf16*>(w0), b0, lnw, lnb, eps, static_cast<bf16*>(out), rows};
+    constexpr int LDS = 256 * 256 * 2 + (256 + 128) * 4;
+    static PerDeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(up1_ln_gelu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    const long groups = (rows + 15) / 16;
+    const long want = (groups + 7) / 8;
+    up1_ln_gelu_kernel<<<dim3((unsigned)(want < 256 ? want : 256)), 512, LDS, reinterpret_cast<hipStream_t>(stream)>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}

@@ -95,8 +95,11 @@ class MaskDecoder(Packed):
         w0, b0 = up0.packed(dt)
         w1, b1 = up1.packed(dt)
         c4, c8 = C // 4, C // 8
-        u1 = ops.gemm(src.reshape(P * N, C), w0, b0, out_f32=True)           # [P*N, (ky,kx,c4)]
-        u1 = ops.norm(u1.reshape(P * N * 4, c4), *ln.wb(), ln.eps, dt, act=ops.ACT_GELU)   # LayerNorm2d + GELU per output pixel
+        if FUSED_UP2 and dt == torch.bfloat16 and C == 256:
+            u1 = ops.up1_ln_gelu(src.reshape(P * N, C), w0, b0, *ln.wb(), ln.eps)        # first transposed convolution + LayerNorm2d + GELU: the fp32 convolution output is never written
+        else:
+            u1 = ops.gemm(src.reshape(P * N, C), w0, b0, out_f32=True)           # [P*N, (ky,kx,c4)]
+            u1 = ops.norm(u1.reshape(P * N * 4, c4), *ln.wb(), ln.eps, dt, act=ops.ACT_GELU)   # LayerNorm2d + GELU per output pixel
         hyper = torch.stack([self.output_hypernetworks_mlps[i](hs[:, 1 + i, :]) for i in range(nm)], dim=1).contiguous()
         if FUSED_UP2 and dt == torch.bfloat16 and c4 == 64 and c8 == 32 and nm <= 8:
             masks = ops.up2_hyper_masks(u1, w1, b1, hyper, P, nm, h, w)      # second transposed convolution + GELU + hypernetwork product: the upscaled embedding is never written

@@ -476,6 +476,16 @@ def hyper_masks(up2: torch.Tensor, hyper: torch.Tensor, NB: int, NM: int, H: int
     return out
 
 
+def up1_ln_gelu(src: torch.Tensor, w0: torch.Tensor, b0, lnw, lnb, eps: float) -> torch.Tensor:
+    """First transposed convolution (as Linear 256 -> 4 x 64) + LayerNorm2d + GELU in one pass (bf16): src [rows, 256], w0 [256, 256] -> bf16 [rows * 4, 64]."""
+    _chk(src, "src", torch.bfloat16); _chk(w0, "w0", torch.bfloat16)
+    rows = src.shape[0]
+    assert src.shape == (rows, 256) and w0.shape == (256, 256)
+    out = torch.empty((rows * 4, 64), dtype=torch.bfloat16, device=src.device)
+    _lib.call("ullsam_up1_ln_gelu", src.data_ptr(), w0.data_ptr(), _p(b0), _p(lnw), _p(lnb), float(eps), out.data_ptr(), rows, _stream())
+    return out
+
+
 def up2_hyper_masks(u1: torch.Tensor, w1: torch.Tensor, b1, hyper: torch.Tensor, NB: int, NM: int, H: int, W: int) -> torch.Tensor:
     """Second transposed convolution (as Linear 64 -> 4 x 32) + GELU + hypernetwork product in one pass (bf16): u1 [NB*H*W*4, 64], w1 [128, 64], hyper fp32
     [NB, NM, 32] -> fp32 [NB, NM, 4H, 4W]."""
