@@ -248,6 +248,27 @@ def test_generator_fused_and_helper_chain_agree_with_crops():
         assert ra["stability_score"] == rb["stability_score"] and ra["predicted_iou"] == rb["predicted_iou"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_generator_reuses_the_image_side_across_point_batches(dtype):
+    """The decoder's prompt-independent image side (keys = embedding + dense prompt, their model-dtype copies, layer 0's K / V projections --
+    transformer.py:220-242 recomputes them for every call) is computed by the first point batch of a crop and reused by the others
+    (`reuse_image_side`, default): same records as recomputing it per batch, over several batches per crop and two crop layers."""
+    from ullsam_amd.automatic_mask_generator import SamAutomaticMaskGenerator
+    sam, _ = _small_sam()
+    sam = sam.to(dtype)
+    img = torch.from_numpy(U.rand_image((3, 600, 800), 23, 255.0))
+    kw = dict(points_per_side=6, points_per_batch=8, pred_iou_thresh=-1e3, stability_score_thresh=0.5, stability_score_offset=0.05,
+              crop_n_layers=1, crop_n_points_downscale_factor=2, output_mode="uncompressed_rle")
+    ga, gb = SamAutomaticMaskGenerator(sam, **kw), SamAutomaticMaskGenerator(sam, **kw)
+    gb.reuse_image_side = False
+    a, b = ga.generate(img), gb.generate(img)
+    assert len(a) == len(b) > 0
+    for ra, rb in zip(a, b):
+        assert ra["segmentation"] == rb["segmentation"] and ra["bbox"] == rb["bbox"] and ra["area"] == rb["area"]
+        assert ra["stability_score"] == rb["stability_score"] and ra["predicted_iou"] == rb["predicted_iou"] and ra["point_coords"] == rb["point_coords"]
+
+
 def test_generator_min_mask_region_area_and_coco_rle():
     """min_mask_region_area: every surviving mask has no island and no hole smaller than the threshold (remove_small_regions is
     idempotent on it), areas / boxes are recomputed for changed masks; output_mode="coco_rle" round-trips to the same masks."""

@@ -65,7 +65,7 @@ class SamAutomaticMaskGenerator:
         return sam.image_encoder.forward_tokens(x[None].contiguous(), mean, std), (nh, nw)
 
     # -- one batch of point prompts ------------------------------------------------------------------------------------
-    def _process_batch(self, points: np.ndarray, img_tok, input_size, crop_box, orig_size) -> A.MaskData:
+    def _process_batch(self, points: np.ndarray, img_tok, input_size, crop_box, orig_size, image_cache=None) -> A.MaskData:
         sam = self.model
         dev = img_tok.device
         S = sam.image_encoder.img_size
@@ -77,7 +77,7 @@ class SamAutomaticMaskGenerator:
         pe = sam.prompt_encoder
         sparse = pe.sparse_tokens((scaled[:, None, :].contiguous(), labels), None)
         dense = pe.dense_tokens(pts.shape[0], None, None)
-        low, iou = sam.mask_decoder.predict_masks_tokens(img_tok, pe.dense_pe_tokens(), sparse, dense, (g, g))
+        low, iou = sam.mask_decoder.predict_masks_tokens(img_tok, pe.dense_pe_tokens(), sparse, dense, (g, g), image_cache=image_cache)
         low, iou = low[:, 1:], iou[:, 1:]                              # multimask_output=True (mask_decoder.py:100-105)
         n, k = iou.shape
         flat_iou = iou.reshape(-1)
@@ -163,8 +163,9 @@ class SamAutomaticMaskGenerator:
         img_tok, input_size = self._encode(image[:, y0:y1, x0:x1])
         pts = self.point_grids[layer_idx] * np.array([[x1 - x0, y1 - y0]], dtype=np.float64)
         data = A.MaskData()
+        image_cache = {} if getattr(self, "reuse_image_side", True) else None      # what the decoder computes from the crop's embedding alone (keys = embedding + dense prompt, their model-dtype copies, layer 0's K / V): once per crop, not per point batch
         for (p,) in A.batch_iterator(self.points_per_batch, pts):
-            data.cat(self._process_batch(p, img_tok, input_size, crop_box, orig_size), deep=False)
+            data.cat(self._process_batch(p, img_tok, input_size, crop_box, orig_size, image_cache), deep=False)
         if len(data["rles"]):
             keep = A.batched_nms(data["boxes"].float(), data["iou_preds"], torch.zeros_like(data["boxes"][:, 0]), self.box_nms_thresh)
             data.filter(keep)

@@ -1,7 +1,7 @@
 """SAM mask decoder on HIP kernels (API + state_dict mirror of modeling/mask_decoder.py)."""
 from __future__ import annotations
 
-from typing import List, Tuple, Type
+from typing import List, Optional, Tuple, Type
 
 import os
 
@@ -75,7 +75,7 @@ class MaskDecoder(Packed):
 
     # -- token-major internals ----------------------------------------------------------------------
     def predict_masks_tokens(self, image_tokens: torch.Tensor, pe_tokens: torch.Tensor, sparse: torch.Tensor,
-                             dense_tokens: torch.Tensor, hw: Tuple[int, int]):
+                             dense_tokens: torch.Tensor, hw: Tuple[int, int], image_cache: Optional[dict] = None):
         """image_tokens fp32 [1 or P, N, C]; pe_tokens [N, C]; sparse fp32 [P, n, C]; dense_tokens fp32 [P|1, N|1, C].
         Returns (masks [P, 4, 4h, 4w] fp32, iou [P, 4] fp32) -- predict_masks, mask_decoder.py:112-149."""
         h, w = hw
@@ -88,8 +88,18 @@ class MaskDecoder(Packed):
         # src = repeat_interleave(image_embeddings, P) + dense  (:126-127); row-modular broadcast of both operands
         dense_rows = dense_tokens.numel() // C
         Pk = 1 if (image_tokens.shape[0] == 1 and dense_rows in (1, N)) else P   # one image, prompt-independent dense embedding
-        keys = ops.add_cast(image_tokens.reshape(-1, C), dense_tokens.reshape(-1, C).contiguous(), torch.float32, rows=Pk * N)
-        hs, src = self.transformer.forward_tokens(keys.reshape(Pk, N, C), pe_tokens, tokens, keys_in_compute_dtype=True)
+        # image_cache (a dict owned by the caller, e.g. one per crop of the automatic mask generator): with ONE image and a prompt-independent dense
+        # embedding the image side is the same for every batch of prompts until the first image -> token attention -- keys, their model-dtype copies
+        # and layer 0's K / V projections are computed by the first call and reused by the next ones (transformer.py:220-242 re-runs them per call).
+        # The caller guarantees that image_tokens / dense_tokens / the weights do not change while it keeps the dict.
+        cache = image_cache if (image_cache is not None and Pk == 1) else None
+        if cache is not None and "keys" in cache:
+            keys = cache["keys"]
+        else:
+            keys = ops.add_cast(image_tokens.reshape(-1, C), dense_tokens.reshape(-1, C).contiguous(), torch.float32, rows=Pk * N)
+            if cache is not None:
+                cache["keys"] = keys
+        hs, src = self.transformer.forward_tokens(keys.reshape(Pk, N, C), pe_tokens, tokens, keys_in_compute_dtype=True, cache=cache)
         nm = self.num_mask_tokens
         up0, ln, up1 = self.output_upscaling[0], self.output_upscaling[1], self.output_upscaling[3]
         w0, b0 = up0.packed(dt)

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import math
 import os
-from typing import Tuple, Type
+from typing import Optional, Tuple, Type
 
 import torch
 from torch import nn
@@ -61,12 +61,17 @@ class TwoWayAttentionBlock(Packed):
         self.skip_first_layer_pe = skip_first_layer_pe
 
 
-def _token_to_image(at: Attention, queries, qpe, keys_pe_c, keys_c, P, T, N, dt, shared=False):
+def _token_to_image(at: Attention, queries, qpe, keys_pe_c, keys_c, P, T, N, dt, shared=False, kv_cache=None):
     """queries + attn(q=queries+pe, k=keys+pe, v=keys): token side fp32, image-side K/V projections on MFMA (K/V kept in the
     model dtype), attention streamed over the image keys.  `shared`: one key set [N, C] for all P prompts."""
     q = at.tok(at.q_proj, ops.add_cast(queries, qpe, torch.float32))
-    K = ops.gemm(keys_pe_c, at.k_proj.w(dt), at.k_proj.b())
-    V = ops.gemm(keys_c, at.v_proj.w(dt), at.v_proj.b())
+    if kv_cache is not None and "K0" in kv_cache:
+        K, V = kv_cache["K0"], kv_cache["V0"]
+    else:
+        K = ops.gemm(keys_pe_c, at.k_proj.w(dt), at.k_proj.b())
+        V = ops.gemm(keys_c, at.v_proj.w(dt), at.v_proj.b())
+        if kv_cache is not None:
+            kv_cache["K0"], kv_cache["V0"] = K, V
     if at.num_heads == 8 and at.hd == 16 and T <= 8:
         a = ops.tok2img_attention(q, K, V, P, at.num_heads, at.hd, T, N, 1.0 / math.sqrt(at.hd), kv_shared=shared)
     else:
@@ -95,8 +100,8 @@ class TwoWayTransformer(Packed):
     def compute_dtype(self):
         return self.final_attn_token_to_image.k_proj.weight.dtype
 
-    def forward_tokens(self, keys: torch.Tensor, key_pe: torch.Tensor, tokens: torch.Tensor, keys_in_compute_dtype: bool = False
-                       ) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward_tokens(self, keys: torch.Tensor, key_pe: torch.Tensor, tokens: torch.Tensor, keys_in_compute_dtype: bool = False,
+                       cache: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """keys fp32 [P, N, C] (image embedding + dense prompt, token-major), key_pe fp32 [N, C], tokens fp32 [P, T, C].
         Returns (queries [P,T,C], keys [P,N,C]) as TwoWayTransformer.forward transformer.py:62-108; with `keys_in_compute_dtype`
         the returned keys are in the model dtype (what the mask decoder's upscaling consumes) and the fp32 copy is never written.
@@ -112,8 +117,14 @@ class TwoWayTransformer(Packed):
         qpe = tokens.reshape(P * T, C).contiguous()
         queries = qpe
         f32 = torch.float32
-        keys_pe_c = ops.add_cast(keys, key_pe, dt)       # keys + key_pe: k of token->image, q of image->token
-        keys_c = ops.cast(keys, dt)                      # v of token->image
+        cache = cache if shared else None                # (`cache`: see MaskDecoder.predict_masks_tokens -- the prompt-independent image side of layer 0, kept across calls)
+        if cache is not None and "keys_pe_c" in cache:
+            keys_pe_c, keys_c = cache["keys_pe_c"], cache["keys_c"]
+        else:
+            keys_pe_c = ops.add_cast(keys, key_pe, dt)   # keys + key_pe: k of token->image, q of image->token
+            keys_c = ops.cast(keys, dt)                  # v of token->image
+            if cache is not None:
+                cache["keys_pe_c"], cache["keys_c"] = keys_pe_c, keys_c
         for li, blk in enumerate(self.layers):
             sa = blk.self_attn
             if blk.skip_first_layer_pe:  # no PE and NO residual (:157-158)
@@ -122,7 +133,8 @@ class TwoWayTransformer(Packed):
                 q_in, res = ops.add_cast(queries, qpe, f32), queries
             a = sa.attend_tokens(sa.tok(sa.q_proj, q_in), sa.tok(sa.k_proj, q_in), sa.tok(sa.v_proj, queries), P, T, T)
             queries = ops.norm(sa.tok(sa.out_proj, a, res=res), *blk.norm1.wb(), blk.norm1.eps, f32)
-            queries = ops.norm(_token_to_image(blk.cross_attn_token_to_image, queries, qpe, keys_pe_c, keys_c, P, T, N, dt, shared),
+            queries = ops.norm(_token_to_image(blk.cross_attn_token_to_image, queries, qpe, keys_pe_c, keys_c, P, T, N, dt, shared,
+                                               kv_cache=cache if (shared and li == 0) else None),
                                *blk.norm2.wb(), blk.norm2.eps, f32)
             m = blk.mlp
             hmid = m.lin1.tok(queries, m.act_code)
