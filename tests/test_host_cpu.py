@@ -629,3 +629,44 @@ def test_gloo_world2_mask_generator_shards_tiles_and_gathers_ragged_records():
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)], res
+
+
+def test_sampling_distribution_equals_the_logits_warpers_of_transformers():
+    """app.py:469-477 samples captions with temperature 0.7 / top_k 50 / top_p 0.9 through transformers' generate, which is not runnable here
+    (SURVEY 8c).  The distribution `_sampling_probs` builds is compared with a numpy restatement of the three logits warpers generate applies, in
+    its order -- TemperatureLogitsWarper (scores / T), TopKLogitsWarper (scores < k-th largest -> -inf), TopPLogitsWarper (ascending sort,
+    cumulative probability <= 1 - top_p removed, the last token always kept) -- on random logits incl. ties and a peaked row."""
+    from ullsam_amd.modeling.modeling_internlm2 import _sampling_probs
+    rng = np.random.default_rng(11)
+    V = 500
+    rows = [rng.standard_normal(V) * 3, rng.standard_normal(V) * 0.1, np.concatenate([[30.0], rng.standard_normal(V - 1)]),
+            np.round(rng.standard_normal(V) * 2) / 2]                         # (the last row has many exact ties)
+    logits = np.stack(rows).astype(np.float32)
+
+    def hf(scores, T, k, p):
+        s = scores.astype(np.float64) / T
+        if k:
+            kth = np.sort(s)[-min(k, s.size)]
+            s = np.where(s < kth, -np.inf, s)
+        if p and p < 1.0:
+            order = np.argsort(s, kind="stable")                               # ascending
+            e = np.exp(s[order] - s[order][-1])
+            cum = np.cumsum(e / e.sum())
+            remove = cum <= (1.0 - p)
+            remove[-1] = False                                                 # min_tokens_to_keep = 1
+            s[order[remove]] = -np.inf
+        e = np.exp(s - s.max())
+        return e / e.sum()
+
+    for T, k, p in [(0.7, 50, 0.9), (1.0, 0, 0.9), (0.7, 50, None), (1.3, 5, 0.5), (1.0, 0, None)]:
+        got = _sampling_probs(torch.from_numpy(logits), T, k, p).numpy().astype(np.float64)
+        for r in range(logits.shape[0]):
+            want = hf(logits[r], T, k, p)
+            # compared as multisets of probabilities: WHICH members of a group of tied logits fall outside the nucleus depends on the sort's tie order (in
+            # transformers as here); a token exactly on the nucleus boundary may go either way (one token of difference allowed)
+            a, b = np.sort(got[r])[::-1], np.sort(want)[::-1]
+            na, nb = int((a > 0).sum()), int((b > 0).sum())
+            assert abs(na - nb) <= 1, (T, k, p, r, na, nb)
+            n = min(na, nb)
+            assert np.abs(a[:n] / a[:n].sum() - b[:n] / b[:n].sum()).max() < 1e-5, (T, k, p, r)
+            assert abs(got[r].sum() - 1.0) < 1e-5

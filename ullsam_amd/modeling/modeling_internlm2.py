@@ -395,8 +395,11 @@ class InternLM2ForCausalLM(Packed):
         return gen if inputs_embeds is not None else torch.cat([input_ids, gen], 1)
 
 
-def _sample(logits: torch.Tensor, temperature, top_k, top_p) -> torch.Tensor:
-    """Host-side sampling policy on the kernel-produced logits (app.py:469-477 uses T=0.7, top_p=0.9, top_k=50)."""
+def _sampling_probs(logits: torch.Tensor, temperature, top_k, top_p) -> torch.Tensor:
+    """The distribution the caption path samples from (app.py:469-477: T = 0.7, top_p = 0.9, top_k = 50 through transformers' generate): temperature,
+    then top-k (everything below the k-th logit removed), then nucleus (the smallest prefix of the descending order whose mass BEFORE a token
+    is <= top_p is kept, at least one token) -- the order and the rules of transformers' TemperatureLogitsWarper / TopKLogitsWarper /
+    TopPLogitsWarper (tests/test_host_cpu.py restates those in numpy)."""
     x = logits / max(float(temperature or 1.0), 1e-5)
     if top_k:
         kth = torch.topk(x, min(int(top_k), x.shape[-1]), dim=-1).values[..., -1:]
@@ -407,4 +410,9 @@ def _sample(logits: torch.Tensor, temperature, top_k, top_p) -> torch.Tensor:
         rm = cp - torch.softmax(sx, -1) > top_p
         sx = sx.masked_fill(rm, float("-inf"))
         x = torch.full_like(x, float("-inf")).scatter(-1, si, sx)
-    return torch.multinomial(torch.softmax(x, -1), 1).squeeze(-1)
+    return torch.softmax(x, -1)
+
+
+def _sample(logits: torch.Tensor, temperature, top_k, top_p) -> torch.Tensor:
+    """Host-side sampling policy on the kernel-produced logits."""
+    return torch.multinomial(_sampling_probs(logits, temperature, top_k, top_p), 1).squeeze(-1)
