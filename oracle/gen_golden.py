@@ -525,6 +525,137 @@ def case_full_depth():
         out[f"ac_iou_pred_{ti}"] = b["iou_pred"]
     save("full_depth", weight_seed=0, tile_seeds=np.asarray(seeds, np.int64), ids_seed=1, stride=FULL_STRIDE, lbl=lbl, **out)
 
+DECODE_7B_NEW = 16
+DECODE_7B_PAD = (0, 0, 11, 0)      # left-padding positions per prompt of the batch (one prompt is shorter and left-padded)
+
+
+def decode_7b_ids():
+    """-> (ids [4, 1081], mask [4, 1081]): four synthetic prompts around 1024 image tokens each; prompt 2 has 11 fewer text tokens
+    in front and is LEFT-padded with id 2 under attention_mask 0 (what the tokenizer's padding_side='left' produces, modeling_internvl_sam.py:356-360)."""
+    rows, masks = [], []
+    for b, pad in enumerate(DECODE_7B_PAD):
+        r = O.make_input_ids(n_text_pre=20 - pad, n_text_post=34, seed=40 + b)[0]
+        rows.append(np.concatenate([np.full(pad, 2, np.int64), r]))
+        masks.append(np.concatenate([np.zeros(pad, np.int64), np.ones(r.size, np.int64)]))
+    ids, mask = np.stack(rows), np.stack(masks)
+    assert ids.shape == (4, 1081)
+    return ids, mask
+
+
+def _ref_greedy_batched(lm, emb, mask, max_new):
+    """Greedy decoding of a BATCH through the reference's own forward and tuple KV cache, the loop HF's generate ran around
+    prepare_inputs_for_generation (modeling_internlm2.py:1112-1149: first step inputs_embeds, later steps the last id,
+    position_ids = cumsum(mask) - 1 with 1 on padding).  No eos stop: every step's raw argmax is recorded, with the second choice and
+    the top-2 logit margin (consumers cut a row at its first eos)."""
+    B = emb.shape[0]
+    pos = mask.long().cumsum(-1) - 1
+    pos.masked_fill_(mask == 0, 1)
+    o = lm(inputs_embeds=emb, attention_mask=mask, position_ids=pos, use_cache=True, return_dict=True)
+    ids = np.zeros((B, max_new), np.int64)
+    second = np.zeros((B, max_new), np.int64)
+    margin = np.zeros((B, max_new), np.float32)
+    top1 = np.zeros((B, max_new), np.float32)
+    logits0 = o.logits[:, -1].float().numpy().copy()
+    for s in range(max_new):
+        last = o.logits[:, -1].float()
+        v, i = last.topk(2, -1)
+        ids[:, s], second[:, s] = i[:, 0].numpy(), i[:, 1].numpy()
+        margin[:, s], top1[:, s] = (v[:, 0] - v[:, 1]).numpy(), v[:, 0].numpy()
+        if s + 1 == max_new:
+            break
+        past = o.past_key_values
+        mask = torch.cat([mask, torch.ones((B, 1), dtype=mask.dtype)], 1)
+        pos = (mask.long().cumsum(-1) - 1)[:, -1:]
+        o = lm(input_ids=i[:, :1].contiguous(), attention_mask=mask, position_ids=pos, past_key_values=past, use_cache=True, return_dict=True)
+    return ids, second, margin, top1, logits0
+
+
+def case_decode_7b():
+    """Greedy decode at the shape BASELINE configs[2] names: the full-depth model (ViT-H x 32 + 7B-shaped InternLM2 x 32, the weights of
+    `full_depth`), the four tiles of `full_depth` as a batch of four prompts of S = 1081 (one left-padded), 16 new tokens through
+    InternVLSAMModel.generate's embedding path (modeling_internvl_sam.py:394-431) and the reference's LLM forward with its KV cache.
+    Stores ids, the runner-up id and the top-2 logit margin of every step (random 7B-shaped weights give near-ties: a bf16 run can only be
+    held to the reference's token where the margin allows)."""
+    from ullsam_amd.utils.synthetic import microscopy_batch
+    t = time.time()
+    m = _build_full_depth()
+    fill_module_inplace(m, seed=0)
+    print(f"  built + filled in {time.time() - t:.0f}s", flush=True)
+    ids, mask = decode_7b_ids()
+    tids, tmask = torch.from_numpy(ids), torch.from_numpy(mask)
+    x_np, _ = microscopy_batch(FULL_TILE_SEEDS)
+    t = time.time()
+    vit_embeds = torch.cat([m.extract_feature(torch.from_numpy(x_np[b:b + 1]))[0] for b in range(4)])    # [4, 1024, 4096]; per tile: memory
+    print(f"  extract_feature x 4 in {time.time() - t:.0f}s", flush=True)
+    emb = m.language_model.get_input_embeddings()(tids).clone()
+    B, N, C = emb.shape
+    emb = emb.reshape(B * N, C)
+    sel = tids.reshape(-1) == 92546
+    emb[sel] = vit_embeds.reshape(-1, C)[: int(sel.sum())]                                                # :407-421
+    emb = emb.reshape(B, N, C)
+    t = time.time()
+    out_ids, second, margin, top1, logits0 = _ref_greedy_batched(m.language_model, emb, tmask, DECODE_7B_NEW)
+    print(f"  greedy x {DECODE_7B_NEW} in {time.time() - t:.0f}s")
+    print("  ids\n", out_ids, "\n  margins\n", margin.round(4), flush=True)
+    save("decode_7b", weight_seed=0, tile_seeds=np.asarray(FULL_TILE_SEEDS, np.int64), ids=ids, mask=mask, greedy_ids=out_ids, second_ids=second,
+         margin=margin, top1=top1, logits0_sample=logits0[:, ::97].copy(), vit_embeds_sample=vit_embeds.numpy().reshape(-1)[::FULL_STRIDE].copy())
+
+
+SAM_H_SEEDS = (3, 5)
+
+
+def case_sam_h_forward():
+    """BASELINE configs[1] through the reference: sam_model_registry['vit_h']() (build_sam.py:14-21: ViT-H x 32 + prompt encoder + mask
+    decoder), Sam.forward (sam.py:53-131) on two 1024^2 microscopy tiles given as 0..255 images with one positive click each, single-mask
+    output; fp32 and under torch.autocast(bfloat16) (the bound of the bf16 mode)."""
+    from build_sam import sam_model_registry
+    from ullsam_amd.utils.synthetic import microscopy_batch
+    t = time.time()
+    saved = (torch.nn.Linear.reset_parameters, torch.nn.init.trunc_normal_)
+    torch.nn.Linear.reset_parameters = lambda self: None
+    torch.nn.init.trunc_normal_ = lambda t_, *a, **k: t_
+    try:
+        sam = sam_model_registry["vit_h"]()
+    finally:
+        torch.nn.Linear.reset_parameters, torch.nn.init.trunc_normal_ = saved
+    fill_module_inplace(sam, seed=0)
+    print(f"  built + filled in {time.time() - t:.0f}s", flush=True)
+    x_np, pts = microscopy_batch(SAM_H_SEEDS)
+    lbl = np.ones((1, 1), np.int32)
+
+    def run():
+        recs = [{"image": torch.from_numpy(x_np[b] * 255.0), "original_size": (1024, 1024), "point_coords": torch.from_numpy(pts[b:b + 1]),
+                 "point_labels": torch.from_numpy(lbl)} for b in range(len(SAM_H_SEEDS))]
+        emb = {}
+        h = sam.image_encoder.register_forward_hook(lambda mod, inp, out: emb.__setitem__("e", out.detach().float().numpy().copy()))
+        res = sam(recs, multimask_output=False)
+        h.remove()
+        return emb["e"], res
+
+    t = time.time()
+    e32, r32 = run()
+    t32 = time.time() - t
+    with torch.autocast("cpu", dtype=torch.bfloat16, cache_enabled=False):
+        e16, r16 = run()
+    print(f"  fp32 {t32:.0f}s, autocast {time.time() - t - t32:.0f}s", flush=True)
+    out = {}
+    for b in range(len(SAM_H_SEEDS)):
+        low, low16 = r32[b]["low_res_logits"].float().numpy(), r16[b]["low_res_logits"].float().numpy()
+        mk, mk16 = r32[b]["masks"].numpy(), r16[b]["masks"].numpy()
+        out[f"low_{b}"] = low
+        out[f"iou_pred_{b}"] = r32[b]["iou_predictions"].float().numpy()
+        out[f"mask_bits_{b}"] = np.packbits(mk)
+        out[f"mask_fill_{b}"] = np.float64(mk.mean())
+        out[f"img_emb_{b}"] = e32[b].reshape(-1)[::37].copy()
+        out[f"img_emb_{b}_ac_mean_err"] = np.float64(np.abs(e16[b] - e32[b]).mean())
+        out[f"low_{b}_ac_mean_err"] = np.float64(np.abs(low16 - low).mean())
+        out[f"low_{b}_ac_max_err"] = np.float64(np.abs(low16 - low).max())
+        out[f"ac_mask_iou_{b}"] = np.float64(O.calc_iou(mk16, mk))
+        print(f"  tile {SAM_H_SEEDS[b]}: mask fill {mk.mean():.4f}, logits mean|x| {np.abs(low).mean():.3f}, autocast: logits mean err {out[f'low_{b}_ac_mean_err']:.5f} "
+              f"max {out[f'low_{b}_ac_max_err']:.4f}, mask IoU {out[f'ac_mask_iou_{b}']:.6f}", flush=True)
+    save("sam_h_forward", weight_seed=0, tile_seeds=np.asarray(SAM_H_SEEDS, np.int64), pts=pts, lbl=lbl, **out)
+
+
 def case_train_slice():
     """Gradients of the reference's segmentation loss (train_joint_v2.py:1026-1100: text_aware_dense_feature -> prompt encoder -> mask
     decoder -> bilinear upsample -> BCE + Dice, calc_instance_loss :774-812) with respect to every parameter downstream of the LLM's last
@@ -790,7 +921,7 @@ CASES = {"train_step": case_train_step, "train_step_real": lambda: case_train_st
          "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full,
          "vit_h_d2": case_vit_h_d2, "llm_7b_l1": case_llm_7b_l1,
          "rope_variants": case_rope_variants, "llm_tiny_bias_linear": case_llm_tiny_bias_linear,
-         "full_depth": case_full_depth}
+         "full_depth": case_full_depth, "decode_7b": case_decode_7b, "sam_h_forward": case_sam_h_forward}
 
 if __name__ == "__main__":
     for n in (sys.argv[1:] or list(CASES)):

@@ -419,6 +419,57 @@ def test_vit_global_attention_dma_kernel_against_the_tiled_kernel_and_float64(op
     assert float((got - ref).abs().mean()) <= 1.15 * float((got_old - ref).abs().mean()) + 1e-6
 
 
+@pytest.mark.parametrize("B,heads,grid,qscale", [(4, 16, 64, 1.0), (1, 3, 16, 1.0), (2, 2, 30, 1.0), (1, 5, 64, 5.0)])
+def test_vit_window_attention_row_group_kernel_against_the_block_kernel_and_float64(ops, B, heads, grid, qscale):
+    """win14r_attn_kernel (round 5: a query group and a key tile are one 14-token window row on 16x16x32 MFMAs, all 14 score tiles before ONE softmax,
+    rel_w in the MFMA's initial accumulator, rel_h in the exponent's offset, K / V gathered by LDS-DMA into plain 160-byte rows) against round 1's
+    win14_attn_kernel (attention variant 13: 32-query groups, seven 32-key blocks, online softmax) on the same operands -- the bench's shape, a grid of
+    2 x 2 windows of which three are padded (16 -> 28: pad tokens are live keys = qkv.bias, image_encoder.py:243-264), a 30 x 30 grid (3 x 3 windows, 12 pad
+    rows / columns, window rows wholly outside the image), a head count that is not a multiple of the 8 XCDs, queries scaled up -- and against a float64
+    softmax with the decomposed rel-pos bias from the UNSCALED q (image_encoder.py:325-361) on one (image, window, head) incl. a padded window."""
+    from ullsam_amd import _lib
+    lib = _lib.load()
+    hd, W, D = 80, 14, heads * 80
+    g = torch.Generator(device=DEV); g.manual_seed(B * 1000 + heads * 10 + grid)
+    qkv = torch.randn(B * grid * grid, 3 * D, device=DEV, generator=g)
+    qkv[:, :D] *= qscale
+    qkv = qkv.bfloat16()
+    rh = (torch.randn(2 * W - 1, hd, device=DEV, generator=g) * 0.1).bfloat16()
+    rw = (torch.randn(2 * W - 1, hd, device=DEV, generator=g) * 0.1).bfloat16()
+    bias = (torch.randn(3 * D, device=DEV, generator=g) * 0.3).bfloat16()
+    new = ops.vit_attention(qkv, rh, rw, bias, B, heads, hd, grid, grid, W)
+    try:
+        lib.ullsam_set_attn_variant(13)
+        old = ops.vit_attention(qkv, rh, rw, bias, B, heads, hd, grid, grid, W)
+    finally:
+        lib.ullsam_set_attn_variant(0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(new.float()).all()
+    dn = (new.float() - old.float()).abs()
+    assert float(dn.max()) <= 2.0 ** -6 * max(1.0, float(old.float().abs().max())), float(dn.max())     # within two bf16 rounding steps of the largest output
+    # float64 reference of the LAST window (bottom right: padded whenever the grid is not a multiple of 14) of the last image / head
+    nw = (grid + W - 1) // W
+    b, h, wy, wx = B - 1, heads - 1, nw - 1, nw - 1
+    t = qkv.double().reshape(B, grid, grid, 3, heads, hd)
+    win = bias.double().reshape(3, heads, hd)[:, h][None, None].repeat(W, W, 1, 1)          # pad tokens: q = k = v = qkv.bias
+    ys, xs = min(W, grid - wy * W), min(W, grid - wx * W)
+    win[:ys, :xs] = t[b, wy * W:wy * W + ys, wx * W:wx * W + xs, :, h]
+    q, k, v = (win[:, :, i].reshape(W * W, hd) for i in range(3))
+    idx = torch.arange(W, device=DEV)
+    rel = idx[:, None] - idx[None, :] + W - 1
+    Rh, Rw = rh.double()[rel], rw.double()[rel]
+    qg = q.reshape(W, W, hd)
+    bh = torch.einsum("hwc,hkc->hwk", qg, Rh)
+    bw = torch.einsum("hwc,wkc->hwk", qg, Rw)
+    sc = (q @ k.T) / math.sqrt(hd) + (bh[:, :, :, None] + bw[:, :, None, :]).reshape(W * W, W * W)
+    ref = (torch.softmax(sc, -1) @ v).reshape(W, W, hd)[:ys, :xs]
+    pick = lambda o: o.double().reshape(B, grid, grid, heads, hd)[b, wy * W:wy * W + ys, wx * W:wx * W + xs, h]
+    e_new, e_old = (pick(new) - ref).abs(), (pick(old) - ref).abs()
+    print(f"vit window attention vs float64: row-group kernel max {float(e_new.max()):.3e} mean {float(e_new.mean()):.2e}; block kernel max {float(e_old.max()):.3e} mean {float(e_old.mean()):.2e}")
+    assert float(e_new.max()) < 3e-2 * max(1.0, float(ref.abs().max()))
+    assert float(e_new.mean()) <= 1.15 * float(e_old.mean()) + 1e-6
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,S,H,KVH,pad", [(2, 70, 2, 1, 9), (1, 200, 4, 2, 0), (1, 1081, 2, 2, 0)])
 def test_rope_and_causal_attention(ops, dtype, B, S, H, KVH, pad):
