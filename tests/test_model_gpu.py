@@ -685,3 +685,125 @@ def test_full_depth_golden_fp32_and_bf16():
         assert iou16 >= float(g[f"ac_mask_iou_{ti}"]) - 0.01, (ti, iou16, float(g[f"ac_mask_iou_{ti}"]))
 
 
+
+
+def decode_7b_prompts():
+    """The four prompts of tests/golden/decode_7b.npz (oracle/gen_golden.py::decode_7b_ids restated: the generator cannot be imported on the GPU box)."""
+    rows, masks = [], []
+    for b, pad in enumerate((0, 0, 11, 0)):
+        r = O.make_input_ids(n_text_pre=20 - pad, n_text_post=34, seed=40 + b)[0]
+        rows.append(np.concatenate([np.full(pad, 2, np.int64), r]))
+        masks.append(np.concatenate([np.zeros(pad, np.int64), np.ones(r.size, np.int64)]))
+    return np.stack(rows), np.stack(masks)
+
+
+DECODE_MARGIN_FP32 = 5e-3     # a top-2 logit margin below this may flip between two fp32 implementations (summation order); above it the ids must be the reference's
+DECODE_MARGIN_BF16 = 0.3      # bf16 mode: ~3x the reference's own autocast error on the final hidden state (full_depth.npz: 0.077 - 0.09 mean), carried through the LM head
+
+
+def _check_greedy_against_fixture(toks, g, bound, tag):
+    ref, second, margin = g["greedy_ids"], g["second_ids"], g["margin"]
+    B, n = ref.shape
+    kept = 0
+    for b in range(B):
+        for s in range(n):
+            if int(toks[b, s]) == int(ref[b, s]):
+                kept += 1
+                continue
+            # first divergence of this prompt: only legitimate at a near-tie, and then onto the reference's runner-up; later steps continue from another token and are not compared
+            print(f"{tag}: prompt {b} leaves the reference's ids at step {s}: got {int(toks[b, s])}, reference {int(ref[b, s])} (runner-up {int(second[b, s])}), reference margin {float(margin[b, s]):.4f}")
+            assert float(margin[b, s]) < bound, (tag, b, s, float(margin[b, s]), bound)
+            assert int(toks[b, s]) == int(second[b, s]), (tag, b, s)
+            break
+    print(f"{tag}: {kept} of {B * n} greedy ids equal to the reference's before any divergence (smallest reference margin {float(margin.min()):.4f})")
+    return kept
+
+
+def test_decode_7b_greedy_ids_against_the_reference():
+    """Greedy decode at the shape BASELINE configs[2] names, against the reference run at that shape (tests/golden/decode_7b.npz: ViT-H x 32 + 7B-shaped InternLM2 x 32 with the
+    weights of `full_depth`, a batch of four 1081-token prompts around the four microscopy tiles, prompt 2 left-padded by 11, 16 new tokens through the reference's LLM forward with
+    its KV cache, modeling_internlm2.py:1112-1149; ids + runner-up + top-2 margin of every step).  Through InternVLSAMModel.generate, i.e. the production decode launches at batch
+    4 (fused RMSNorm + wqkv + RoPE + cache append, split-key decode attention, resident w13):
+      fp32 mode: every id equal to the reference's wherever its top-2 margin exceeds 5e-3 (a smaller margin may flip between two fp32 summation orders -- and then only onto the
+      reference's runner-up);
+      bf16 mode: the same with the bound at 0.3 logit units; the first divergence of every prompt is printed."""
+    import bench
+    from ullsam_amd.utils.synthetic import microscopy_batch
+    g = U.gold("decode_7b")
+    ids_np, mask_np = decode_7b_prompts()
+    assert np.array_equal(ids_np, g["ids"]) and np.array_equal(mask_np, g["mask"])
+    x_np, _ = microscopy_batch([int(s) for s in g["tile_seeds"]])
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    n_new = g["greedy_ids"].shape[1]
+    m32 = _fill_model_from_rule(bench.build_model("h", "7b", torch.float32, DEV, init=False), int(g["weight_seed"]))
+    x = torch.from_numpy(x_np).to(DEV)
+    vit = m32._mlp1_tokens(m32.vision_model.forward_tokens(x), 4).float().cpu().numpy().reshape(-1)[::int(U.gold("full_depth")["stride"])]
+    assert err(vit, g["vit_embeds_sample"]) < 1e-3 * max(1.0, float(np.abs(g["vit_embeds_sample"]).max()))
+    toks = m32.generate(pixel_values=x, input_ids=ids, attention_mask=mask, max_new_tokens=n_new, eos_token_id=-1).cpu().numpy()
+    assert toks.shape == g["greedy_ids"].shape
+    k32 = _check_greedy_against_fixture(toks, g, DECODE_MARGIN_FP32, "fp32 mode")
+    mb = bench.build_model("h", "7b", torch.bfloat16, DEV, init=False)
+    missing, unexpected = mb.load_state_dict({k: v.to(torch.bfloat16) for k, v in m32.state_dict().items()}, strict=False)
+    assert not missing and not unexpected
+    del m32
+    torch.cuda.empty_cache()
+    toks16 = mb.generate(pixel_values=x.bfloat16(), input_ids=ids, attention_mask=mask, max_new_tokens=n_new, eos_token_id=-1).cpu().numpy()
+    k16 = _check_greedy_against_fixture(toks16, g, DECODE_MARGIN_BF16, "bf16 mode")
+    assert k32 >= int(0.9 * toks.size) and k16 >= toks.size // 2, (k32, k16)
+
+
+SAM_H_EXTRA_SEEDS = (27, 32, 7, 11, 19, 23)
+
+
+def test_sam_h_forward_config1_against_the_reference_and_per_image():
+    """BASELINE configs[1] as written: sam_model_registry['vit_h']() (ViT-H x 32 + prompt encoder + mask decoder), Sam.forward on EIGHT 1024^2 images with one positive click each.
+    Images 0 / 1 are the tiles of tests/golden/sam_h_forward.npz (the reference's Sam.forward, sam.py:53-131, fp32 and under autocast):
+      fp32 mode: low-res logits within 1e-3 * scale, predicted IoU within 1e-3, image embedding within 1e-3, mask IoU delta < 1e-4;
+      bf16 mode: logits mean error <= 1.5 x the reference's autocast mean error, mask IoU vs the reference's fp32 mask >= its autocast IoU - 0.002;
+    and at this size the batched call (one decoder pass over the eight records) equals, bit for bit, every record run alone."""
+    from ullsam_amd.build_sam import sam_model_registry
+    from ullsam_amd.utils.synthetic import microscopy_batch
+    g = U.gold("sam_h_forward")
+    seeds = [int(s) for s in g["tile_seeds"]] + list(SAM_H_EXTRA_SEEDS)
+    x_np, pts = microscopy_batch(seeds)
+    assert np.array_equal(pts[:2], g["pts"])
+    lbl = torch.from_numpy(g["lbl"]).to(DEV)
+
+    def records(dtype):
+        return [{"image": (torch.from_numpy(x_np[b]).to(DEV) * 255.0).to(dtype), "original_size": (1024, 1024), "point_coords": torch.from_numpy(pts[b:b + 1]).to(DEV),
+                 "point_labels": lbl} for b in range(len(seeds))]
+
+    with torch.device(DEV):
+        sam = sam_model_registry["vit_h"]()
+    sam = _fill_model_from_rule(sam.to(DEV), int(g["weight_seed"]))
+    recs32 = records(torch.float32)
+    out32 = sam(recs32, multimask_output=False)
+    toks = sam.image_encoder.forward_tokens(torch.stack([r["image"] for r in recs32[:2]], 0), sam.pixel_mean.reshape(-1).float().contiguous(),
+                                            sam.pixel_std.reshape(-1).float().contiguous())            # token-major [2, 4096, 256]
+    taps = {"e": toks.float().permute(0, 2, 1).contiguous().cpu().numpy()}                               # the reference's [256, 64, 64] order
+    for b in range(2):
+        low = out32[b]["low_res_logits"].float().cpu().numpy()
+        scale = max(1.0, float(np.abs(g[f"low_{b}"]).max()))
+        ref_mask = np.unpackbits(g[f"mask_bits_{b}"])[:1024 * 1024].reshape(1, 1, 1024, 1024).astype(bool)
+        iou32 = O.calc_iou(out32[b]["masks"].cpu().numpy(), ref_mask)
+        print(f"configs[1] fp32 mode, tile {seeds[b]}: logits max err {err(low, g[f'low_{b}']):.2e} (scale {scale:.2f}), mask IoU {iou32:.6f}, fill {float(g[f'mask_fill_{b}']):.3f}")
+        assert err(low, g[f"low_{b}"]) < 1e-3 * scale
+        assert err(out32[b]["iou_predictions"].float().cpu().numpy(), g[f"iou_pred_{b}"]) < 1e-3
+        assert err(taps["e"][b].reshape(-1)[::37], g[f"img_emb_{b}"]) < 1e-3 * max(1.0, float(np.abs(g[f"img_emb_{b}"]).max()))
+        assert 1.0 - iou32 < 1e-4, iou32
+    sam = sam.to(torch.bfloat16)
+    recs = records(torch.bfloat16)
+    out16 = sam(recs, multimask_output=False)
+    for b in range(2):
+        low = out16[b]["low_res_logits"].float().cpu().numpy()
+        ref_mask = np.unpackbits(g[f"mask_bits_{b}"])[:1024 * 1024].reshape(1, 1, 1024, 1024).astype(bool)
+        iou16 = O.calc_iou(out16[b]["masks"].cpu().numpy(), ref_mask)
+        m16 = float(np.abs(low - g[f"low_{b}"]).mean())
+        print(f"configs[1] bf16 mode, tile {seeds[b]}: logits mean err {m16:.5f} (reference autocast {float(g[f'low_{b}_ac_mean_err']):.5f}), mask IoU {iou16:.6f} "
+              f"(reference autocast {float(g[f'ac_mask_iou_{b}']):.6f})")
+        assert m16 < 1.5 * float(g[f"low_{b}_ac_mean_err"]), (b, m16)
+        assert iou16 >= float(g[f"ac_mask_iou_{b}"]) - 0.002, (b, iou16)
+    for b, r in enumerate(recs):
+        alone = sam([r], multimask_output=False)[0]
+        for k in ("masks", "iou_predictions", "low_res_logits"):
+            assert torch.equal(out16[b][k], alone[k]), (b, k)

@@ -945,15 +945,23 @@ static int launch_win14(const AttnArgs& a, hipStream_t s) {
 //      per lane, the same for every tile) and enters as the MFMA's INITIAL ACCUMULATOR (divided by the scale once; the two masked rows start at -1e30, so
 //      they need no select); rel_h[q, kh] is uniform over a tile and rides in the exponent's offset (one fma per score, which the scale needs anyway);
 //    * both tables' products with the UNSCALED q (image_encoder.py:354-355) are 9 MFMAs per group on operands read straight from the L2-resident
-//      tables: rel_h's rows are picked per accumulator row (e = qh + 13 - kh: wave-uniform shift), its 4 results per lane become 14 through
-//      v_permlane16/32_swap; rel_w's shift depends on the lane's query (e = qw + 13 - kw), so its 27 products go through a 2.3 KB per-wave LDS
-//      scratch and come back by a per-lane offset;
+//      tables: rel_h's rows are picked per accumulator row (e = qh + 13 - kh: wave-uniform shift), its 4 results per lane become 14 through the
+//      wave's LDS scratch (four 16-byte broadcast reads; the v_permlane16/32_swap form compiled to copies of rows 0 .. 5 in rows 8 .. 13 -- hipcc dropped
+//      the second result of the second swap, tools/probes/win14r_debug2.py); rel_w's shift depends on the lane's query (e = qw + 13 - kw), so its 27
+//      products go through the same 2.5 KB per-wave scratch and come back by a per-lane offset;
 //    * K and V are the window's 196 head slices (160 B of every 7680-byte token, pad tokens = qkv.bias) gathered back to back by LDS-DMA with
 //      per-lane source addresses: plain 160-byte rows are conflict-free both for the 16-row ds_read_b128 of the K operand and for the 4 x 32 B
 //      ds_read_b64_tr_b16 blocks of the V^T operand, so the image needs no padding, no swizzle and no staging registers; the softmax denominator comes from
 //      a sixth O^T tile whose A operand is a register of ones (same bf16-rounded probabilities as the numerator);
-//    * window rows that lie wholly outside the image (bottom windows: 6 of 14) are skipped.
-//  63.5 KB of K / V + 15.8 KB of scratch per workgroup: two workgroups (14 waves) per CU at <= 128 registers.
+//    * window rows that lie wholly outside the image (bottom windows: 6 of 14) are skipped;
+//    * both groups of a wave are prepared before the barrier (every global load of the workgroup is issued in its first microsecond); the A fragments of the score and
+//      PV products run through register rings pinned with sched_barriers (left alone hipcc emits read -> wait -> MFMA one at a time); the outputs leave through the scratch as
+//      16-byte stores, ten consecutive lanes per token (8-byte scattered stores cost 24 of 86 us).
+//  63.5 KB of K / V + 17.9 KB of scratch per workgroup: two workgroups (14 waves) per CU at <= 128 registers, no spills.
+//  Measured (ViT-H, batch 4, cold operands): 85 - 89 -> 64 - 66 us; in the bench step 78.32 -> 77.61 ms.  A persistent form (one 14-wave workgroup per CU, K / V double
+//  buffered, next problem's pieces requested a whole problem ahead by asm LDS-DMA) was built on the same arithmetic and measured EQUAL (66 - 68 us): its problems cost 17 - 18
+//  kilo-cycles each, 9 of them arithmetic, the rest the one barrier per problem (14 waves in lockstep) and request issue against a saturated memory system (~500 cycles per
+//  1 KiB piece and wave); removed (git acf202b has it).
 // ------------------------------------------------------------------------------------------------------
 template <int ABL>   // ABL: 0 = the kernel; diagnostic builds (attention variants 20 .. 22): 1 = fetch + table phase only, 2 = no K / V fetch, 3 = no stores; 4 = s_memtime stamps (ullsam_set_attn_debug)
 __global__ __launch_bounds__(448, 4) void win14r_attn_kernel(AttnArgs p) {
@@ -1135,7 +1143,8 @@ __global__ __launch_bounds__(448, 4) void win14r_attn_kernel(AttnArgs p) {
             for (int j = 0; j < 4; ++j) {
                 const int t = 4 * a4 + j;
                 if (t < G) {
-                    const float m4 = fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3]));
+                    float m4;                  // (asm: through fmaxf hipcc canonicalises every MFMA result with a v_max_f32 x, x first -- 4 more instructions per tile)
+                    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(m4) : "v"(s[t][0]), "v"(s[t][1]), "v"(s[t][2]), "v"(s[t][3]));
                     mx = fmaxf(mx, fmaf(m4, scale2, v[j]));
                 }
             }
@@ -1238,362 +1247,6 @@ __global__ __launch_bounds__(448, 4) void win14r_attn_kernel(AttnArgs p) {
     stamp(5);
     if (live[1]) main_group(1, qf1, cinit1, thr1);
     stamp(6);
-}
-
-// ------------------------------------------------------------------------------------------------------
-//  win14p_attn_kernel (round 5, second step): win14r_attn_kernel's arithmetic in a PERSISTENT workgroup that never waits for its K / V.
-//  Stamps of win14r under load (tools/probes/win_stamps.py): half of a workgroup's 32 kilo-cycle life passes before its barrier (requests issued against a saturated
-//  memory system, then the flight), the other half is arithmetic, and with two such workgroups per CU the launch runs at 2.7 TB/s where its fetches alone run at 4.4.
-//  Here ONE 14-wave workgroup per CU walks a contiguous range of (image, window, head) problems; wave w is window row w (one query group per wave and problem); the K / V
-//  image is DOUBLE buffered, and problem i + 1's pieces are requested -- by asm LDS-DMA, which hipcc does not see: through the builtin it waits vmcnt(0) before every LDS
-//  read while a request is in flight -- right behind the one barrier of problem i, a whole problem's arithmetic ahead of their use; the next problem's query fragments are
-//  prefetched into registers the same way.  Both rel-pos tables sit in LDS for the life of the workgroup (the table products' operands cost no global load per problem).
-//  LDS: 2 x 63488 (K / V images) + 8640 (tables) + 14 x 2016 (per-wave scratch: table products, then the output image in two parts) = 163840 bytes = all of it.
-// ------------------------------------------------------------------------------------------------------
-template <int ABL>   // 0 = the kernel; 1 .. 3 = the diagnostic builds of win14r_attn_kernel (attention variants 20 .. 22)
-__global__ __launch_bounds__(896, 4) void win14p_attn_kernel(AttnArgs p) {
-    typedef bf16 T;
-    constexpr int HD = 80, G = 14, NK = 196, NW = 14;
-    constexpr int NLW = 7;                     // waves 7 .. 13 are the LOADERS: they issue every LDS-DMA request and flush their outputs one problem late, at the top; waves 0 .. 6 go
-                                               // straight from the barrier into the arithmetic and store at its end.  Two classes half a phase apart on every SIMD (waves w and w + 4 share one):
-                                               // with all 14 waves in lockstep the matrix pipe idled through everybody's flush / request / softmax (stamps: 18.3 kilo-cycles per problem, 8.8 of them
-                                               // arithmetic).  (A 15th wave that ONLY issues requests was measured too: 76 - 84 us -- one wave's request stream is ~3 bytes per clock under load.)
-    constexpr int RS = 160, NPIECE = 31, OPB = NPIECE * 1024, BUFB = 2 * OPB;
-    constexpr int TABB = 27 * RS;              // one rel-pos table: 27 rows of 160 B
-    constexpr int SCW = 28;                    // scratch row pitch in floats (112 B: 16-byte aligned; 8 consecutive rows cover all 32 banks): products with Rw rows 0 .. 27
-    constexpr int SCRB = 2016;                 // per-wave scratch bytes: [16][28] floats of table products, later 12 + 2 rows of the [14 queries][160 B] output image
-    constexpr float LOG2E = 1.4426950408889634f;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const tabh = smem + 2 * BUFB;
-    char* const tabw = tabh + TABB;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ql = lane & 15, g = lane >> 4;
-    float* scr = reinterpret_cast<float*>(smem + 2 * BUFB + 2 * TABB + wave * SCRB);
-    // ABL == 4: s_memtime stamps of the wave's THIRD problem (tools/probes/win_stamps.py p): [workgroup][wave][8]
-    int stamp_it = -1;
-    auto stamp = [&](const int i) __attribute__((always_inline)) {
-        if (ABL == 4 && stamp_it == 2) {
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            if (lane == 0) p.dbg[((size_t)blockIdx.x * NW + wave) * 8 + i] = t;
-        }
-    };
-    // ---- this workgroup's problems: workgroup ids go round robin over the 8 XCDs; an XCD's workgroups share a contiguous range of (window, head) problems (the heads of a
-    // window share 128-byte lines), cut evenly among them
-    const int nprob = p.H * p.B * p.nwin;
-    int first, last;
-    {
-        const int bid = blockIdx.x, nwg = gridDim.x, xcd = bid & 7, j = bid >> 3;
-        const int q8 = nprob >> 3, r8 = nprob & 7;
-        const int xs = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, xn = q8 + (xcd < r8 ? 1 : 0);
-        const int nx = (nwg - xcd + 7) >> 3;   // workgroups on this XCD label
-        first = xs + (int)((long)xn * j / nx);
-        last = xs + (int)((long)xn * (j + 1) / nx);
-    }
-    if (first >= last) return;
-    // rel-pos tables -> LDS (visible behind the first barrier)
-    for (int c = tid; c < 2 * 27 * 10; c += NW * 64) {
-        const int t = c >= 270, cc = c - 270 * t;
-        const T* src = reinterpret_cast<const T*>(t ? p.rel_w : p.rel_h);
-        *reinterpret_cast<uint4*>(tabh + t * TABB + cc * 16) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(src) + cc * 16);
-    }
-    const T* Qg = reinterpret_cast<const T*>(p.q);
-    const T* Kg = reinterpret_cast<const T*>(p.k);
-    const T* Vg = reinterpret_cast<const T*>(p.v);
-    // q, k and v are slices of one packed qkv tensor: one set of strides, 32-bit element offsets (the launcher checks both)
-    const int bs = (int)p.q_bs, ts = (int)p.q_ts, hs = (int)p.q_hs, obs = (int)p.o_bs, ots = (int)p.o_ts, ohs = (int)p.o_hs;
-    struct Prob { int head, b, wy, wx; };
-    auto decode = [&](const int prob) __attribute__((always_inline)) -> Prob {
-        Prob r;
-        r.head = prob % p.H;
-        const int wz = (prob / p.H) % p.nwin;
-        r.b = prob / (p.H * p.nwin);
-        r.wy = wz / p.nwin_w;
-        r.wx = wz - r.wy * p.nwin_w;
-        return r;
-    };
-    // one LDS-DMA request: 64 lanes x 16 B from per-lane addresses into 1 KiB of LDS at lds_addr.  asm, so that hipcc does not order the arithmetic's LDS reads behind it; M0 is
-    // saved and restored inside the statement (cdna guide 5.7); completion: the loop's own s_waitcnt vmcnt(0)
-    auto glds = [&](const void* src, const unsigned int lds_addr) __attribute__((always_inline)) {
-        unsigned int keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(lds_addr) : "memory");
-    };
-    // K / V of a window -> buffer `buf`: piece i of an operand = image bytes [1024 i, 1024 i + 1024), lane's chunk j = 64 i + lane = (row j / 10, chunk j % 10)
-    auto request = [&](const Prob& pr, const int buf) __attribute__((always_inline)) {
-        if (ABL == 2) return;
-        int lv = lane;                         // (opaque copy: hipcc otherwise hoists the per-lane row / chunk arithmetic of every piece out of the problem loop and spills it)
-        asm volatile("" : "+v"(lv));
-        const int base = pr.b * bs + pr.head * hs;
-        const T* bk = reinterpret_cast<const T*>(p.bias_k) + (long)pr.head * HD;
-        const T* bv = reinterpret_cast<const T*>(p.bias_v) + (long)pr.head * HD;
-        const unsigned int kl = (unsigned int)(uintptr_t)LDS_PTR(smem + buf * BUFB), vl = kl + OPB;
-#pragma unroll
-        for (int n = 0; n < (NPIECE + NLW - 1) / NLW; ++n) {
-            const int i = (wave - (NW - NLW)) + NLW * n;
-            if (i < NPIECE) {   // wave-uniform
-                const int j = i * 64 + lv;
-                const int row = j / 10, c = j - row * 10;
-                const int ky = row / G, kx = row - ky * G;
-                const int gy = pr.wy * G + ky, gx = pr.wx * G + kx;
-                const T* ks; const T* vs;
-                if (row < NK && gy < p.grid_h && gx < p.grid_w) {
-                    const int off = base + (gy * p.grid_w + gx) * ts;
-                    ks = Kg + off;
-                    vs = Vg + off;
-                } else {        // window pad token: LN output padded with zeros => k = bias_k, v = bias_v (a live key); rows >= 196 are masked: any finite bytes
-                    ks = bk;
-                    vs = bv;
-                }
-                glds(ks + 8 * c, kl + i * 1024);
-                glds(vs + 8 * c, vl + i * 1024);
-            }
-        }
-    };
-    const int dg2 = 8 * (g & 1);               // third k-step (dims 64 .. 95): lane groups 2 / 3 hold dims that do not exist -- their q is zero, the other operand re-reads dims 64 .. 79
-    Frag<T> ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones.v[j] = (bf16)1.0f;
-    const float scale2 = p.scale * LOG2E, inv_scale = 1.0f / p.scale;
-    const int qh = wave;                       // this wave's window row, in every problem
-    const bool loader = wave >= NW - NLW;      // wave-uniform
-    // the lane's query fragments of a problem: B operand, lane (q = ql, g) holds q[32 ks + 8 g .. + 7]; zero for lanes 14 / 15, pad tokens and rows outside the image
-    auto load_q = [&](const Prob& pr, Frag<T>* qf) __attribute__((always_inline)) {
-        int lv = lane;                         // (opaque copy, as in request: a hoisted and spilled lane offset is reloaded from scratch memory behind a vmcnt(0) -- in the middle of the arithmetic, where that wait is for the next problem's pieces)
-        asm volatile("" : "+v"(lv));
-        const int qlv = lv & 15, gv = lv >> 4;
-        const int qgy = pr.wy * G + qh, qgx = pr.wx * G + qlv;
-        const bool ld = qlv < G && qgx < p.grid_w && qgy < p.grid_h;
-        const T* qp = Qg + (pr.b * bs + pr.head * hs + (ld ? (qgy * p.grid_w + qgx) * ts : 0));
-        qf[0] = ld ? load_frag(qp + 8 * gv) : zero_frag<T>();
-        qf[1] = ld ? load_frag(qp + 32 + 8 * gv) : zero_frag<T>();
-        qf[2] = (ld && gv < 2) ? load_frag(qp + 64 + 8 * gv) : zero_frag<T>();
-    };
-    Prob cur = decode(first);
-    if (loader) request(cur, 0);
-    Frag<T> qf[3];
-    load_q(cur, qf);
-    // rel-pos table fragments (A operands) addresses: row m = ql of the accumulator is key row kh = m for rel_h (rel index e = qh - kh + 13, get_rel_pos,
-    // image_encoder.py:318-322) and table row e = m / 16 + m for rel_w
-    const char* rha = tabh + min(max(qh + (G - 1) - ql, 0), 2 * G - 2) * RS;
-    const char* rw0 = tabw + ql * RS;
-    const char* rw1 = tabw + min(16 + ql, 2 * G - 2) * RS;
-
-    // a finished problem's output: through the wave's scratch as [query][160 B] rows (queries 0 .. 11, then 12 / 13) and out as 16-byte stores, ten consecutive lanes per token
-    bf16x4_t opk[5];
-    bool pending = false;                      // wave-uniform
-    Prob prv = cur;
-    auto flush = [&](const Prob& prv) __attribute__((always_inline)) {
-        if (!pending || ABL == 3) return;
-        pending = false;
-        char* ob = reinterpret_cast<char*>(scr);
-        T* orow = reinterpret_cast<T*>(p.out) + (prv.b * obs + prv.head * ohs + (prv.wy * G + qh) * p.grid_w * ots);
-        int lv = lane;                         // (opaque copy: the per-lane offsets below are problem-invariant, and hoisted out of the loop they are spilled)
-        asm volatile("" : "+v"(lv));
-        const int qlv = lv & 15, gv = lv >> 4;
-#pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            const int q0 = part ? 12 : 0, nq = part ? 2 : 12;
-            if (qlv >= q0 && qlv < q0 + nq) {
-#pragma unroll
-                for (int d = 0; d < 5; ++d) *reinterpret_cast<bf16x4_t*>(ob + (qlv - q0) * 160 + 32 * d + 8 * gv) = opk[d];
-            }
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int r = 0; r < (part ? 1 : 2); ++r) {
-                const int c = lv + 64 * r;            // 16-byte chunk of the part's image: query q0 + c / 10, chunk c % 10
-                const int qq = c / 10, ch = c - 10 * qq;
-                const int gx = prv.wx * G + q0 + qq;
-                if (qq < nq && gx < p.grid_w) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(ob + 16 * c);
-                    *reinterpret_cast<uint4*>(orow + gx * ots + 8 * ch) = v;
-                }
-            }
-            asm volatile("" ::: "memory");
-        }
-    };
-    for (int prob = first, it = 0; prob < last; ++prob, ++it) {
-        stamp(7);                              // (end of the previous problem, when stamp_it still names it)
-        stamp_it = it;
-        stamp(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // (the query fragments are consumed HERE as far as hipcc can tell: otherwise it puts its own wait for their loads in front of their first use, behind the requests below)
-        asm volatile("" : "+v"(qf[0].v), "+v"(qf[1].v), "+v"(qf[2].v));
-        stamp(1);
-        __syncthreads();
-        stamp(2);
-        flush(prv);                            // (loaders) the previous problem's outputs: their stores complete under this problem's arithmetic
-        stamp(3);                       // every wave's pieces of this problem have landed, and every wave is done with the previous problem (= with the other buffer)
-        const bool more = prob + 1 < last;
-        Prob nxt = cur;
-        if (more) {
-            nxt = decode(prob + 1);
-            if (loader) request(nxt, (it + 1) & 1);
-        }
-        stamp(4);
-        const char* Ks = smem + (it & 1) * BUFB;
-        const char* Vs = Ks + OPB;
-        const int qgy = cur.wy * G + qh;
-        if (qgy < p.grid_h && ABL != 1) {      // wave-uniform: otherwise the whole window row is padding (its outputs are cropped, image_encoder.py:286-288)
-            // ---- rel-pos products with the unscaled q: th[i] = rel_h[q, kh = 4 g + i]; gwa / gwb[i] = q . Rw[e] for e = 4 g + i and 16 + 4 g + i
-            f32x4 th = {0.f, 0.f, 0.f, 0.f}, gwa = th, gwb = th;
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                const int off = ks == 2 ? 128 + 2 * dg2 : 64 * ks + 16 * g;
-                mma16(load_frag(reinterpret_cast<const T*>(rha + off)), qf[ks], th);
-                mma16(load_frag(reinterpret_cast<const T*>(rw0 + off)), qf[ks], gwa);
-                mma16(load_frag(reinterpret_cast<const T*>(rw1 + off)), qf[ks], gwb);
-            }
-            // rel_w: the lane's 4 key columns kw = 4 g + i need Rw rows e = qw + 13 - kw with qw = ql: through the wave's scratch [q][e], e < 28
-            *reinterpret_cast<f32x4*>(scr + ql * SCW + 4 * g) = gwa;
-            if (g < 3) *reinterpret_cast<f32x4*>(scr + ql * SCW + 16 + 4 * g) = gwb;
-            asm volatile("" ::: "memory");
-            f32x4 cinit;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kw = 4 * g + i;
-                const float v = scr[ql * SCW + min(max(ql + (G - 1) - kw, 0), SCW - 1)];
-                cinit[i] = kw < G ? v * inv_scale : -1e30f;      // rows 14 / 15 of a tile are not keys of this window row
-            }
-            asm volatile("" ::: "memory");
-            *reinterpret_cast<f32x4*>(scr + ql * SCW + 4 * g) = th * LOG2E;   // rel_h, log2 units: read back below, when every lane needs all 14 key rows of its query
-            asm volatile("" ::: "memory");
-            // ---- S^T tile t = key row t: 14 independent accumulation chains of 3, walked k-step by k-step; A fragments through a ring, each read NR MFMAs ahead of its use
-            const char* kbase = Ks + ql * RS + g * 16;
-            const char* kbase2 = Ks + ql * RS + 128 + dg2 * 2;
-            const char* vbase = Vs + (4 * g + (ql >> 2)) * RS + 8 * (ql & 3);
-            f32x4 s[G];
-#pragma unroll
-            for (int t = 0; t < G; ++t) s[t] = cinit;
-            {
-                constexpr int NR = 5, NI = 3 * G;
-                auto kread = [&](const int n) __attribute__((always_inline)) -> Frag<T> {
-                    const int ks = n / G, t = n - ks * G;
-                    return load_frag(reinterpret_cast<const T*>((ks == 2 ? kbase2 : kbase + 64 * ks) + t * (G * RS)));
-                };
-                Frag<T> kf[NR];
-#pragma unroll
-                for (int n = 0; n < NR; ++n) kf[n] = kread(n);
-#pragma unroll
-                for (int n = 0; n < NI; ++n) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma16(kf[n % NR], qf[n / G], s[n % G]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (n + NR < NI) kf[n % NR] = kread(n + NR);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            stamp(5);
-            // the next problem's query fragments, into the registers the score products have just finished with: two phases ahead of their use, no second register set
-            if (more) load_q(nxt, qf);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- one maximum over the whole row (log2 units), one exponential per score
-            float mx = -INFINITY;
-#pragma unroll
-            for (int a4 = 0; a4 < 4; ++a4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(scr + ql * SCW + 4 * a4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int t = 4 * a4 + j;
-                    if (t < G) {
-                        const float m4 = fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3]));
-                        mx = fmaxf(mx, fmaf(m4, scale2, v[j]));
-                    }
-                }
-            }
-            mx = fmaxf(mx, lane_xor16(mx));
-            mx = fmaxf(mx, lane_xor32(mx));
-            Frag<T> pf[G / 2];
-#pragma unroll
-            for (int a4 = 0; a4 < 4; ++a4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(scr + ql * SCW + 4 * a4);   // (read again rather than held: 14 registers)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int t = 4 * a4 + j;
-                    if (t < G) {
-                        const float off = v[j] - mx;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) pf[t >> 1].v[4 * (t & 1) + i] = (bf16)__builtin_amdgcn_exp2f(fmaf(s[t][i], scale2, off));
-                    }
-                }
-            }
-            asm volatile("" ::: "memory");
-            stamp(6);
-            // ---- O^T = V^T P^T: dim tiles 0 .. 4, tile 5 = ones^T P^T (the denominator in every row); V^T fragments (two transposed 8-byte reads each) through a ring as well
-            constexpr int NV = 8, NVI = 5 * (G / 2);
-            auto vread = [&](const int m) __attribute__((always_inline)) -> Frag<T> {
-                const int st = m / 5, d = m - 5 * st;
-                const char* a0 = vbase + st * (2 * G * RS) + d * 32;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + G * RS));
-                typedef __attribute__((ext_vector_type(8))) short s16x8;
-                s16x8 tv;
-                tv[0] = lo[0]; tv[1] = lo[1]; tv[2] = lo[2]; tv[3] = lo[3];
-                tv[4] = hi[0]; tv[5] = hi[1]; tv[6] = hi[2]; tv[7] = hi[3];
-                Frag<T> vf;
-                vf.v = __builtin_bit_cast(bf16x8_t, tv);
-                return vf;
-            };
-            Frag<T> vf[NV];
-#pragma unroll
-            for (int m = 0; m < NV; ++m) vf[m] = vread(m);
-            f32x4 o[6];
-#pragma unroll
-            for (int d = 0; d < 6; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int m = 0; m < NVI; ++m) {
-                __builtin_amdgcn_sched_barrier(0);
-                mma16(vf[m % NV], pf[m / 5], o[m % 5]);
-                if (m % 5 == 4) mma16(ones, pf[m / 5], o[5]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (m + NV < NVI) vf[m % NV] = vread(m + NV);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- normalise and pack: lane (q, g) holds dims 16 d + 4 g .. + 3 of its query, 10 registers.  They go out at the START of the next iteration (flush, below): a store
-            // issued here would be the wave's youngest memory operation when the loop's top waits for the next problem's pieces (loads, LDS-DMA and stores share vmcnt, in order)
-            {
-                const float inv_l = 1.0f / o[5][0];
-#pragma unroll
-                for (int d = 0; d < 5; ++d) {
-                    opk[d][0] = (bf16)(o[d][0] * inv_l); opk[d][1] = (bf16)(o[d][1] * inv_l); opk[d][2] = (bf16)(o[d][2] * inv_l); opk[d][3] = (bf16)(o[d][3] * inv_l);
-                }
-                pending = true;
-            }
-            if (!loader) flush(cur);            // (a store issued here is this wave's youngest memory operation at the loop's top: its acknowledgement is waited for while the other class still computes)
-        }
-        else if (more) load_q(nxt, qf);        // (a wave whose window row lies outside the image in this problem)
-        prv = cur;
-        cur = nxt;
-    }
-    flush(prv);
-    if (ABL == 1 && qf[0].v[0] == (bf16)12345.f) reinterpret_cast<T*>(p.out)[0] = qf[1].v[0];
-}
-
-static int launch_win14p(const AttnArgs& a, hipStream_t s, int abl = 0) {
-    constexpr int LDS = 4 * 31 * 1024 + 2 * 27 * 160 + 14 * 2016;
-    static_assert(LDS <= 163840, "win14p: LDS budget");
-    static PerDeviceOnce attr;
-    static int ncu = 256;
-    if (attr.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(win14p_attn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(win14p_attn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(win14p_attn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(win14p_attn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(win14p_attn_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        int dev = 0, n = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ncu = n;
-    }
-    const int nprob = a.H * a.B * a.nwin;
-    const dim3 grid(nprob < ncu ? nprob : ncu), blk(896);
-    if (a.dbg) win14p_attn_kernel<4><<<grid, blk, LDS, s>>>(a);
-    else if (abl == 1) win14p_attn_kernel<1><<<grid, blk, LDS, s>>>(a);
-    else if (abl == 2) win14p_attn_kernel<2><<<grid, blk, LDS, s>>>(a);
-    else if (abl == 3) win14p_attn_kernel<3><<<grid, blk, LDS, s>>>(a);
-    else win14p_attn_kernel<0><<<grid, blk, LDS, s>>>(a);
-    ULLSAM_LAUNCH_CHECK();
-    return 0;
 }
 
 static int launch_win14r(const AttnArgs& a, hipStream_t s, int abl = 0) {
@@ -2291,8 +1944,6 @@ extern "C" int ullsam_vit_attention(int dtype, const void* qkv, void* out, const
         if (dtype == 1 && window == 14 && hd == 80 && g_attn_variant != 1 && g_attn_variant != 2 && g_attn_variant != 13 && (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)qkv_bias) & 15) == 0) {
             a.q_pos0 = (g_attn_variant >= 3 && g_attn_variant <= 8) ? g_attn_variant - 3 : 0;
             a.dbg = g_attn_dbg;
-            const bool fits32 = (long)B * N * 3 * D < (1L << 31);   // the persistent kernel addresses with 32-bit element offsets
-            if (g_attn_variant == 15 && fits32) return launch_win14p(a, s, (g_attn_variant >= 20 && g_attn_variant <= 22) ? g_attn_variant - 19 : 0);   // variant 15: the persistent double-buffered form (measured equal, not the default: DESIGN section 4)
             return launch_win14r(a, s, (g_attn_variant >= 20 && g_attn_variant <= 22) ? g_attn_variant - 19 : 0);
         }
         if (dtype == 1 && window == 14 && hd == 80 && g_attn_variant != 1 && g_attn_variant != 2) return launch_win14(a, s);
