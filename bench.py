@@ -90,6 +90,9 @@ def make_input_ids(n_text_pre: int, n_text_post: int, n_img: int = 1024, seed: i
     return np.asarray(rows, np.int64)
 
 
+GEMM_EVENT_EVERY = 5   # timed steps between two steps whose GEMM launches carry event pairs (see main)
+
+
 class GemmTimer:
     """HIP-event pairs around every ullsam_gemm launch on the launch stream (torch's current stream)."""
 
@@ -129,6 +132,40 @@ class GemmTimer:
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec)
         fl = sum(f for _, _, f in self.rec)
         return len(self.rec), ms, fl
+
+
+class CallTimer:
+    """HIP-event pairs around EVERY C-ABI call (ullsam_amd._lib.call) of one extra, UNTIMED step: `kernel_ms_per_step` = the sum of those spans = the GPU time of
+    the library's launches of a step.  Printed next to `ms_per_step` so that kernel time and inter-launch gaps / box variance can be told apart (a span of a call that launches
+    several kernels includes the gaps between them; torch's own few elementwise launches are outside)."""
+
+    def __init__(self):
+        from ullsam_amd import _lib
+        self.lib, self.orig, self.rec = _lib, _lib.call, []
+
+    def __enter__(self):
+        def timed(name, *args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig(name, *args)
+            e1.record()
+            self.rec.append((name, e0, e1))
+        self.lib.call = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.lib.call = self.orig
+
+    def summary(self):
+        by = {}
+        for name, e0, e1 in self.rec:
+            ms = e0.elapsed_time(e1)
+            c = by.setdefault(name.replace("ullsam_", ""), [0, 0.0])
+            c[0] += 1
+            c[1] += ms
+        total = sum(v[1] for v in by.values())
+        top = sorted(by.items(), key=lambda kv: -kv[1][1])[:8]
+        return total, len(self.rec), {k: {"calls": v[0], "ms": round(v[1], 3)} for k, v in top}
 
 
 def tile_seeds(rank: int, B: int):
@@ -448,7 +485,7 @@ def dist_setup(gpus: int, stub: bool):
     return rank, world, device, ranks_seen
 
 
-def timed_steps(step, warmup: int, steps: int, world: int, device: str, on_timed=None):
+def timed_steps(step, warmup: int, steps: int, world: int, device: str, on_timed=None, on_step=None):
     """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; the last step's exchange is inside the
     timed region; -> (seconds = MAX over ranks, the last gathered result)."""
     gpu = device != "cpu"
@@ -470,7 +507,9 @@ def timed_steps(step, warmup: int, steps: int, world: int, device: str, on_timed
         if on_timed:
             on_timed(True)
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
+            if on_step:
+                on_step(i)
             step()
         gathered = step.drain()
         barrier()
@@ -544,10 +583,23 @@ def main():
     full = LLM[a.llm] is not None
     inputs = make_inputs(a.batch, a.seq, device, full)
     step = make_step(mask_path_compute(model, inputs, dtype), a.batch, world)
-    dt, gathered = timed_steps(step, a.warmup, a.steps, world, device, on_timed=lambda on: setattr(timer, "on", on))
+    # The roofline's event pairs sit inside the timed region, and they are not free: an event pair around every one of the 269 GEMM launches of EVERY timed step cost
+    # 1.5 ms of a 78 ms step (same box, same process order: 77.98 vs 76.45 ms per step with / without them).  They are therefore recorded on every GEMM_EVENT_EVERY-th timed
+    # step only (steps 0, 5, 10, ...: >= 1000 timed launches at the default 20 steps); ULLSAM_BENCH_NO_GEMM_EVENTS=1 switches them off (A/B of their cost; `roofline` is then empty).
+    ev_on = os.environ.get("ULLSAM_BENCH_NO_GEMM_EVENTS") != "1"
+    dt, gathered = timed_steps(step, a.warmup, a.steps, world, device, on_timed=lambda on: setattr(timer, "on", False),
+                               on_step=lambda i: setattr(timer, "on", ev_on and i % GEMM_EVENT_EVERY == 0))
+    event_steps = len([i for i in range(a.steps) if i % GEMM_EVENT_EVERY == 0]) if ev_on else 0
     if world > 1:
         assert gathered is not None and gathered[0].shape[0] == a.batch * world and gathered[1].shape[0] == a.batch * world
     n_launch, gemm_ms, gemm_flops = timer.summary()
+    kernel_ms = None
+    if device != "cpu":                        # one more step, OUTSIDE the timed region, with an event pair around every C-ABI call
+        with torch.no_grad(), CallTimer() as ct:
+            step()
+            step.drain()
+            torch.cuda.synchronize()
+        kernel_ms, n_calls, by_call = ct.summary()
     traffic, traffic_note = (None, "not the default workload")
     if a.vit == "h" and a.llm == "7b" and a.batch == 4 and a.dtype == "bf16":
         traffic, traffic_note = traffic_record()
@@ -559,6 +611,10 @@ def main():
         "metric": "images/s end-to-end (ViT+LLM+mask) 1024^2", "value": round(value, 4), "unit": "images/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.dtype, "data": DATA_NOTE,
+        "kernel_ms_per_step": None if kernel_ms is None else round(kernel_ms, 3),
+        "gap_ms_per_step": None if kernel_ms is None else round(dt / a.steps * 1e3 - kernel_ms, 3),
+        "kernel_ms_note": None if kernel_ms is None else {"what": "sum of HIP-event spans around every C-ABI call of ONE extra untimed step on this rank (ms_per_step - this = inter-call gaps, "
+                                                                  "torch's own launches, the exchange and box variance)", "calls": n_calls, "top": by_call},
         "config": {"workload": (f"uLLSAM mask path (app.py:580-645): SAM ViT-{a.vit.upper()} + "
                                 + (f"InternLM2-{a.llm}-shaped prefill S={a.seq} + " if full else "")
                                 + f"prompt encoder + mask decoder + x4 upsample/threshold, 1 point prompt/image, batch {a.batch}/GPU"),
@@ -569,8 +625,9 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "ullsam_gemm (every nn.Linear / conv-as-GEMM launch)", "achieved": round(ach, 2),
                      "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": traffic_note,
                      "algorithmic_bytes_per_launch": round(timer.alg_bytes / max(n_launch, 1)),
-                     "launches_per_step": n_launch // max(a.steps, 1), "avg_launch_us": round(gemm_ms * 1e3 / max(n_launch, 1), 2),
-                     "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4)},
+                     "launches_per_step": n_launch // max(event_steps, 1), "avg_launch_us": round(gemm_ms * 1e3 / max(n_launch, 1), 2),
+                     "event_timed_steps": event_steps, "event_timed_launches": n_launch,
+                     "gemm_share_of_step": round(gemm_ms / max(event_steps, 1) / (dt / a.steps * 1e3), 4)},
     }
     if rank == 0 and a.dtype == "bf16" and not a.no_iou and a.vit == "h" and a.llm == "7b" and a.seq == 1081:
         line["mask_iou_vs_reference"] = mask_iou_vs_reference(model, inputs, dtype)
