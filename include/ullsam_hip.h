@@ -27,7 +27,7 @@ extern "C" {
 
 /* Bumped whenever an entry point is added or a signature changes.  The Python binding refuses a library that reports another
    version (a stale libullsam_hip.so would otherwise receive shifted arguments, e.g. a row count where the stream is expected). */
-#define ULLSAM_ABI_VERSION 8
+#define ULLSAM_ABI_VERSION 9
 
 const char* ullsam_last_error_string(void);
 int ullsam_abi_version(void); /* == ULLSAM_ABI_VERSION of the header the library was built from */
@@ -139,6 +139,12 @@ int ullsam_train_resize_bwd(const float* dout, float* din, long planes, int ih, 
 int ullsam_train_seg_loss(const float* x, const float* t, float* sums, float* losses, int P, long npix, float smooth, float* partial, void* stream);
 /* (partial: P * 4 * ceil(npix / 1024) floats) */
 int ullsam_train_seg_loss_bwd(const float* x, const float* t, const float* sums, const float* gscale, float* dx, int P, long npix, float smooth, void* stream);
+/* The language-model loss of InternLM2ForCausalLM.forward (modeling_internlm2.py:1084-1096: CrossEntropyLoss() over the shifted logits, mean over labels != -100):
+ * fp32 logits [rows, V] with row stride ld, labels int64 [rows] (negative = ignored); lse [rows], loss_rows [rows], out2 = {mean loss, 1 / #labelled rows};
+ * the backward writes dlogits = (softmax - onehot) * gscale[0] * out2[1] (zero rows where the label is ignored).  Ordered sums: reproducible bits. */
+int ullsam_train_cross_entropy(const float* logits, long ld, const long long* labels, float* lse, float* loss_rows, float* out2, long rows, int V, void* stream);
+int ullsam_train_cross_entropy_bwd(const float* logits, long ld, const long long* labels, const float* lse, const float* out2, const float* gscale, float* dlogits,
+                                   long ldx, long rows, int V, void* stream);   /* dlogits rows of ldx >= V floats: columns V .. ldx - 1 are zeroed (GEMM padding) */
 /* dst[idx[r]] += src[r]: gradient of the point-label embedding table (prompt_encoder.py:76-96) */
 int ullsam_train_index_add_rows(const float* src, const int* idx, float* dst, long rows, int C, int nrows_dst, void* stream);
 

@@ -656,8 +656,10 @@ def case_sam_h_forward():
     save("sam_h_forward", weight_seed=0, tile_seeds=np.asarray(SAM_H_SEEDS, np.int64), pts=pts, lbl=lbl, **out)
 
 
-def case_train_slice():
-    """Gradients of the reference's segmentation loss (train_joint_v2.py:1026-1100: text_aware_dense_feature -> prompt encoder -> mask
+def case_train_slice(boxes: bool = False):
+    """(boxes=True: every instance also carries a BOX prompt, as the trainer forwards `boxes=boxes`, train_joint_v2.py:975,1038,1057 -> no pad point,
+    two corner embeddings with point_embeddings[2] / [3], prompt_encoder.py:96-103,181 -> fixture train_slice_box.)
+    Gradients of the reference's segmentation loss (train_joint_v2.py:1026-1100: text_aware_dense_feature -> prompt encoder -> mask
     decoder -> bilinear upsample -> BCE + Dice, calc_instance_loss :774-812) with respect to every parameter downstream of the LLM's last
     hidden state -- mlp2, the prompt encoder, the mask decoder -- on the `ullsam_tiny` composite (full-size decoder: 64 x 64 image tokens,
     256 channels), two instances with two clicks each.  The LLM hidden states and the image embedding are inputs (seeded), as they are
@@ -694,7 +696,8 @@ def case_train_slice():
         last = m.text_aware_dense_feature(torch.from_numpy(hid))                      # [1, 256, 64, 64]
         bs = pts.shape[0]
         last = last.repeat(bs, 1, 1, 1)                                               # train_joint_v2.py:1052-1054
-        sp, de = m.prompt_encoder(points=(torch.from_numpy(pts), torch.from_numpy(lbl)), boxes=None, masks=None, llm_hidden_states=last)
+        bxs = np.array([[150.0, 190.0, 450.0, 490.0], [480.0, 390.0, 920.0, 830.0]], np.float32) if boxes else None   # x0, y0, x1, y1 around the two discs
+        sp, de = m.prompt_encoder(points=(torch.from_numpy(pts), torch.from_numpy(lbl)), boxes=None if bxs is None else torch.from_numpy(bxs), masks=None, llm_hidden_states=last)
         low, iou = m.mask_decoder(image_embeddings=torch.from_numpy(img), image_pe=m.prompt_encoder.get_dense_pe(),
                                   sparse_prompt_embeddings=sp, dense_prompt_embeddings=de, multimask_output=False)
         pred = torch.nn.functional.interpolate(low, (1024, 1024), mode="bilinear", align_corners=False)
@@ -702,6 +705,8 @@ def case_train_slice():
         loss.backward()
     out = {"hid_sample": hid.reshape(-1)[::1009].copy(), "img_seed": 11, "pts": pts, "lbl": lbl, "loss": np.float32(loss.item()), "bce": np.float32(bce.item()),
            "dice": np.float32(dice.item()), "low_sample": low.detach().numpy().reshape(-1)[::61].copy()}
+    if boxes:
+        out["boxes"] = bxs
     names = []
     for name, p_ in m.named_parameters():
         if not name.startswith(("mlp2.", "prompt_encoder.", "mask_decoder.")) or p_.grad is None:
@@ -712,7 +717,7 @@ def case_train_slice():
         out["g:" + name] = g[::stride].copy()
         out["n:" + name] = np.float32(np.sqrt((g.astype(np.float64) ** 2).sum()))
     out["names"] = np.array(names)
-    save("train_slice", **out)
+    save("train_slice_box" if boxes else "train_slice", **out)
 
 
 def case_train_llm_slice(pad: int = 0):
@@ -917,7 +922,7 @@ def case_train_step(real_dims: bool = False):
     save("train_step_real" if real_dims else "train_step", **out)
 
 
-CASES = {"train_step": case_train_step, "train_step_real": lambda: case_train_step(real_dims=True), "train_vit_slice": case_train_vit_slice, "train_slice": case_train_slice, "train_llm_slice": case_train_llm_slice, "train_llm_slice_pad": lambda: case_train_llm_slice(pad=37), "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
+CASES = {"train_step": case_train_step, "train_step_real": lambda: case_train_step(real_dims=True), "train_vit_slice": case_train_vit_slice, "train_slice": case_train_slice, "train_slice_box": lambda: case_train_slice(boxes=True), "train_llm_slice": case_train_llm_slice, "train_llm_slice_pad": lambda: case_train_llm_slice(pad=37), "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
          "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full,
          "vit_h_d2": case_vit_h_d2, "llm_7b_l1": case_llm_7b_l1,
          "rope_variants": case_rope_variants, "llm_tiny_bias_linear": case_llm_tiny_bias_linear,

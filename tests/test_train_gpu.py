@@ -519,7 +519,7 @@ def test_reference_trainer_step_runs_on_the_modules_own_forwards():
     outputs = m(pixel_values=pixel_values, input_ids=input_ids, attention_mask=attention_mask, image_flags=None, labels=labels, return_dict=True,
                 use_cache=False, img_context_token_id=92546, output_hidden_states=True)
     loss = outputs.loss
-    assert loss is not None and torch.isfinite(loss) and not loss.requires_grad
+    assert loss is not None and torch.isfinite(loss) and loss.requires_grad      # differentiable, as the reference's (its other branch back-propagates it); here it enters as 0 * loss
     last_hidden_state = outputs.hidden_states
     assert last_hidden_state.shape == (1, 256, 64, 64) and last_hidden_state.requires_grad
     assert float((last_hidden_state.detach() - out_eval.hidden_states.float()).abs().max()) < 1e-3      # same values as the inference path
@@ -748,3 +748,101 @@ def test_small_attention_kernel_route_equals_the_matrix_route():
     assert abs(l0 - l1) < 1e-6 * abs(l0) and set(g0) == set(g1)
     for n in g0:
         assert float((g0[n] - g1[n]).abs().max()) <= 2e-5 * float(g0[n].abs().max()) + 1e-8, n
+
+
+def test_box_prompts_gradients_equal_the_reference_autograd():
+    """The trainer forwards `boxes=boxes` to the prompt encoder (train_joint_v2.py:975,1038,1057; prompt_encoder.py:96-103: two corner embeddings with
+    point_embeddings[2] / [3], no pad point).  Fixture train_slice_box.npz = the REFERENCE's autograd of the decoder-side slice with a box per instance next to
+    its clicks; here through the modules' own forwards in train() mode: loss to 1e-5 relative, every gradient within 1e-3 of the tensor's largest entry --
+    the corner embeddings' among them."""
+    import torch.nn.functional as F
+    from ullsam_amd import training
+    g = U.gold("train_slice_box")
+    m = _ullsam_tiny(torch.float32)
+    for n, p in m.named_parameters():
+        p.requires_grad_(n.startswith(("mlp2.", "prompt_encoder.", "mask_decoder.")))
+    m.train()
+    hid, img, pts, gt = _inputs(g)
+    boxes = torch.from_numpy(g["boxes"]).to(DEV)
+    last = training._rows_to_nchw(training.dense_feature_rows(m, hid), 1, 64, 64).repeat(pts[0].shape[0], 1, 1, 1)       # text_aware_dense_feature, then train_joint_v2.py:1052-1054
+    sp, de = m.prompt_encoder(points=pts, boxes=boxes, masks=None, llm_hidden_states=last)
+    assert sp.shape == (2, 2 + 2, 256) and sp.requires_grad                                                          # two clicks + two corners, no pad point
+    low, iou = m.mask_decoder(image_embeddings=img, image_pe=m.prompt_encoder.get_dense_pe(), sparse_prompt_embeddings=sp, dense_prompt_embeddings=de,
+                              multimask_output=False)
+    assert err_np(low.detach().cpu().numpy().reshape(-1)[::61], g["low_sample"]) < 1e-3 * max(1.0, float(np.abs(g["low_sample"]).max()))
+    pred = F.interpolate(low, (1024, 1024), mode="bilinear", align_corners=False)
+    loss, bce, dice = _trainer_losses(pred, gt)
+    assert abs(loss.item() - float(g["loss"])) < 2e-5 * float(g["loss"]), (loss.item(), float(g["loss"]))
+    loss.backward()
+    params = dict(m.named_parameters())
+    worst = (0.0, "")
+    for n in (str(v) for v in g["names"]):
+        ref = g["g:" + n].astype(np.float64)
+        if params[n].grad is None:
+            assert float(np.abs(ref).max()) == 0.0, n            # (the reference reports a zero gradient for not_a_point_embed: no pad point with boxes)
+            continue
+        full = params[n].grad.float().cpu().numpy().reshape(-1).astype(np.float64)
+        got = full[::max(1, full.size // 2048)]
+        scale, diff = np.abs(ref).max(), np.abs(got - ref).max()
+        assert diff < 1e-3 * scale + 1e-7, (n, diff, scale)
+        if scale > 1e-6:
+            worst = max(worst, (diff / scale, n))
+    for k in (2, 3):
+        assert float(params[f"prompt_encoder.point_embeddings.{k}.weight"].grad.abs().max()) > 0
+    print("box prompts: worst relative gradient error", worst)
+
+
+def err_np(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lm_loss_of_the_composite_is_differentiable_into_mlp1(dtype):
+    """the reference's trainer has a branch that back-propagates `outputs.loss` itself (train_joint_v2.py:1000: masks is None or
+    use_llm_hidden_states False), into mlp1 through the frozen LLM.  `.loss` of the composite's forward in train() mode is the differentiable HIP
+    cross entropy over the head's logits (training.LMLossFn): its value equals torch's cross entropy on the inference path's logits, its gradient with
+    respect to the hidden states equals torch autograd's of the same head + loss, loss.backward() alone fills mlp1's gradients, and an incoming gradient
+    of exactly zero (the segmentation branch's 0 * loss) costs no GEMM and leaves zeros."""
+    import torch.nn.functional as F
+    from ullsam_amd import training
+    g = U.gold("train_step")
+    m = _ullsam_tiny(dtype)
+    for n, p in m.named_parameters():
+        p.requires_grad_(not n.startswith("language_model."))
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    pixel_values = t(U.rand_image((1, 3, 1024, 1024), seed=int(g["seed"]))).to(dtype)
+    input_ids = t(g["ids"]).long()
+    labels = input_ids.clone()
+    labels[:, :30] = -100                                                                # ignored positions, as the trainer's prompt masking produces
+    m.train()
+    out = m(pixel_values=pixel_values, input_ids=input_ids, attention_mask=torch.ones_like(input_ids), labels=labels, return_dict=True, use_cache=False)
+    assert out.loss.requires_grad
+    # value: torch's cross entropy on the inference path's logits (fp32 accumulate either way)
+    ref_val = F.cross_entropy(out.logits[..., :-1, :].reshape(-1, out.logits.shape[-1]).float(), labels[..., 1:].reshape(-1), ignore_index=-100)
+    assert abs(out.loss.item() - ref_val.item()) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(ref_val.item()), (out.loss.item(), ref_val.item())
+    out.loss.backward()
+    g1 = {n: p.grad.float().clone() for n, p in m.named_parameters() if n.startswith("mlp1.") and p.grad is not None}
+    assert len(g1) >= 4 and all(torch.isfinite(v).all() and float(v.abs().max()) > 0 for v in g1.values()), list(g1)
+    # gradient with respect to the hidden states against torch autograd of the same head + loss
+    lm = m.language_model
+    S, D = input_ids.shape[1], lm.output.weight.shape[1]
+    gen = torch.Generator(device=DEV); gen.manual_seed(3)
+    h = (torch.randn(1, S, D, device=DEV, generator=gen) * 0.7).requires_grad_(True)
+    loss_h = training.lm_loss(lm, h, labels)
+    (3.0 * loss_h).backward()
+    h2 = h.detach().clone().requires_grad_(True)
+    W = lm.output.weight.detach().float()
+    x2 = h2[:, :-1].reshape(-1, D)
+    if dtype == torch.bfloat16:
+        x2 = x2.bfloat16().float()                                                       # the head GEMM rounds its activations to bf16 at the door
+    ref = 3.0 * F.cross_entropy(x2 @ W.T, labels[:, 1:].reshape(-1), ignore_index=-100)
+    ref.backward()
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert abs(loss_h.item() * 3.0 - ref.item()) < tol * abs(ref.item())
+    scale = float(h2.grad.abs().max())
+    assert float((h.grad - h2.grad).abs().max()) < (1e-3 if dtype == torch.float32 else 3e-2) * scale, (float((h.grad - h2.grad).abs().max()), scale)
+    assert float(h.grad[:, -1].abs().max()) == 0.0                                       # the last position's logits are never used
+    # 0 * loss: exact zeros, no GEMMs
+    h3 = h.detach().clone().requires_grad_(True)
+    (0 * training.lm_loss(lm, h3, labels)).backward()
+    assert float(h3.grad.abs().max()) == 0.0

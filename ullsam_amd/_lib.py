@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ULLSAM_HIP_LIB") or os.path.join(_HERE, "lib", "libullsam_hip.so")  # env: A/B a side build (developer switch)
 
-ABI_VERSION = 8  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
+ABI_VERSION = 9  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
 
 _lib = None
 
@@ -38,6 +38,8 @@ SIGNATURES = {
     "ullsam_train_resize_bwd": [vp, vp, i64, i32, i32, i32, i32, vp],
     "ullsam_train_seg_loss": [vp, vp, vp, vp, i32, i64, f32, vp, vp],
     "ullsam_train_seg_loss_bwd": [vp, vp, vp, vp, vp, i32, i64, f32, vp],
+    "ullsam_train_cross_entropy": [vp, i64, vp, vp, vp, vp, i64, i32, vp],
+    "ullsam_train_cross_entropy_bwd": [vp, i64, vp, vp, vp, vp, vp, i64, i64, i32, vp],
     "ullsam_train_index_add_rows": [vp, vp, vp, i64, i32, i32, vp],
     "ullsam_norm": [vp, i32, i64, vp, i32, i64, vp, vp, i64, i32, f32, i32, i32, vp, vp, vp],
     "ullsam_norm_fanout": [vp, i64, i32, vp, vp, f32, vp, vp, vp, i32, vp, i64, vp],

@@ -180,7 +180,7 @@ class SamAutomaticMaskGenerator:
         ragged record lists are exchanged once at the end (parallel.gather_sharded_lists); every rank returns all tiles' records in tile order.
         Without a process group it is a loop over `generate`."""
         from . import parallel
-        rank, ws = parallel.world()
+        rank, ws = parallel.world(group)       # rank and size IN the group the records are gathered over
         a, b = parallel.shard_range(len(images), rank, ws)
         mine = [self.generate(images[i]) for i in range(a, b)]
         return parallel.gather_sharded_lists(mine, len(images), group)

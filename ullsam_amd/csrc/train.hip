@@ -167,8 +167,9 @@ __global__ __launch_bounds__(256, 2) void matmul_f32_mfma_kernel(MmArgs p) {
 template <bool AK, bool BN>
 static void launch_matmul_mfma(const MmArgs& a, hipStream_t stream) {
     constexpr int LDS = 2 * 2 * 32 * MMF_LD * 4;
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(matmul_f32_mfma_kernel<AK, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
+    static PerDeviceOnce attr;                 // per device: the attribute belongs to the current device's function object (a process may train on several GPUs)
+    if (attr.first() && hipFuncSetAttribute(reinterpret_cast<const void*>(matmul_f32_mfma_kernel<AK, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        ullsam_set_error("train matmul: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed", LDS);   // (the launch below then fails and is reported by the caller's check)
     matmul_f32_mfma_kernel<AK, BN><<<dim3((a.N + 127) / 128, (a.M + 127) / 128, a.batch * a.ksplit), 256, LDS, stream>>>(a);
 }
 // The same product with both operands ROUNDED TO bf16 on their way into LDS and the sums on v_mfma_f32_32x32x16_bf16 (fp32 accumulation, fp32 result):
@@ -1048,6 +1049,86 @@ extern "C" int ullsam_train_col2im3x3(const float* dcols, float* dx, int B, int 
     ULLSAM_CHECK(B > 0 && H > 0 && W > 0 && C > 0, "train_col2im3x3: bad dims");
     const long n = (long)B * H * W * C;
     col2im3x3_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(dcols, dx, B, H, W, C);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+//  Cross entropy of the language-model head (InternLM2ForCausalLM.forward, modeling_internlm2.py:1084-1096: CrossEntropyLoss() over the shifted
+//  logits, mean over the labels != ignore_index = -100).  One workgroup per row of fp32 logits [R, V]; every sum in a fixed order (strided partial per
+//  thread, then a shared-memory tree): two runs give the same bits.  lse[r] = log sum exp of the row, loss_rows[r] = lse - logit[label] (0 for an ignored row).
+// ------------------------------------------------------------------------------------------------------
+template <bool MAX>
+__device__ __forceinline__ float ce_block_reduce(float v, float* red) {
+    const int t = threadIdx.x;
+    red[t] = v;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (t < s) red[t] = MAX ? fmaxf(red[t], red[t + s]) : red[t] + red[t + s];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+__global__ __launch_bounds__(1024) void ce_rows_kernel(const float* __restrict__ x, long ld, const long long* __restrict__ labels, float* __restrict__ lse,
+                                                       float* __restrict__ loss_rows, int V) {
+    __shared__ float red[1024];
+    const long r = blockIdx.x;
+    const float* row = x + r * ld;
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < V; j += blockDim.x) m = fmaxf(m, row[j]);
+    m = ce_block_reduce<true>(m, red);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < V; j += blockDim.x) s += __expf(row[j] - m);
+    s = ce_block_reduce<false>(s, red);
+    if (threadIdx.x == 0) {
+        const float l = m + __logf(s);
+        const long long lab = labels[r];
+        lse[r] = l;
+        loss_rows[r] = (lab >= 0 && lab < V) ? l - row[lab] : 0.f;
+    }
+}
+// out[0] = mean of loss_rows over the rows with a label, out[1] = 1 / (number of such rows) (0 if none): ordered sums in one workgroup
+__global__ __launch_bounds__(1024) void ce_mean_kernel(const float* __restrict__ loss_rows, const long long* __restrict__ labels, long R, int V, float* __restrict__ out) {
+    __shared__ float red[1024];
+    float s = 0.f, n = 0.f;
+    for (long r = threadIdx.x; r < R; r += blockDim.x) {
+        const long long lab = labels[r];
+        if (lab >= 0 && lab < V) { s += loss_rows[r]; n += 1.f; }
+    }
+    s = ce_block_reduce<false>(s, red);
+    n = ce_block_reduce<false>(n, red);
+    if (threadIdx.x == 0) {
+        out[0] = n > 0.f ? s / n : 0.f;
+        out[1] = n > 0.f ? 1.f / n : 0.f;
+    }
+}
+// dx[r][j] = (softmax(x[r])[j] - [j == label]) * g / n_valid   (0 for an ignored row)
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ x, long ld, const long long* __restrict__ labels, const float* __restrict__ lse,
+                                                     const float* __restrict__ mean_out, const float* __restrict__ g, float* __restrict__ dx, long ldx, int V) {
+    const long r = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ldx) return;
+    const long long lab = labels[r];
+    float d = 0.f;                              // columns V .. ldx - 1 (the padding that makes dlogits a GEMM operand) are written as zeros
+    if (j < V && lab >= 0 && lab < V) d = (__expf(x[r * ld + j] - lse[r]) - (j == lab ? 1.f : 0.f)) * (g[0] * mean_out[1]);
+    dx[r * ldx + j] = d;
+}
+
+extern "C" int ullsam_train_cross_entropy(const float* logits, long ld, const long long* labels, float* lse, float* loss_rows, float* out2, long rows, int V, void* stream) {
+    ULLSAM_CHECK(rows > 0 && rows < (1L << 31) && V > 0 && ld >= V, "train_cross_entropy: rows=%ld V=%d ld=%ld", rows, V, ld);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ce_rows_kernel<<<dim3((unsigned)rows), 1024, 0, s>>>(logits, ld, labels, lse, loss_rows, V);
+    ULLSAM_LAUNCH_CHECK();
+    ce_mean_kernel<<<1, 1024, 0, s>>>(loss_rows, labels, rows, V, out2);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ullsam_train_cross_entropy_bwd(const float* logits, long ld, const long long* labels, const float* lse, const float* out2, const float* gscale, float* dlogits,
+                                              long ldx, long rows, int V, void* stream) {
+    ULLSAM_CHECK(rows > 0 && rows < 65536 && V > 0 && ld >= V && ldx >= V, "train_cross_entropy_bwd: rows=%ld V=%d ld=%ld ldx=%ld", rows, V, ld, ldx);
+    ce_bwd_kernel<<<dim3((unsigned)((ldx + 255) / 256), (unsigned)rows), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(logits, ld, labels, lse, out2, gscale, dlogits, ldx, V);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }

@@ -91,8 +91,15 @@ class MaskDecoder(Packed):
         # image_cache (a dict owned by the caller, e.g. one per crop of the automatic mask generator): with ONE image and a prompt-independent dense
         # embedding the image side is the same for every batch of prompts until the first image -> token attention -- keys, their model-dtype copies
         # and layer 0's K / V projections are computed by the first call and reused by the next ones (transformer.py:220-242 re-runs them per call).
-        # The caller guarantees that image_tokens / dense_tokens / the weights do not change while it keeps the dict.
         cache = image_cache if (image_cache is not None and Pk == 1) else None
+        if cache is not None:
+            # what the cached tensors were computed FROM: another image / dense embedding (or an in-place update of the same storage), another dtype or token
+            # count empties the dict instead of serving the previous image's keys (weights are the caller's side of the contract: a dict lives for one crop)
+            sig = (image_tokens.data_ptr(), image_tokens._version, tuple(image_tokens.shape), dense_tokens.data_ptr(), dense_tokens._version,
+                   tuple(dense_tokens.shape), str(dt), N)
+            if cache.get("_source") != sig:
+                cache.clear()
+                cache["_source"] = sig
         if cache is not None and "keys" in cache:
             keys = cache["keys"]
         else:

@@ -20,9 +20,10 @@ import torch
 import torch.distributed as dist
 
 
-def world() -> Tuple[int, int]:
+def world(group=None) -> Tuple[int, int]:
+    """(rank, size) in `group` (default: the default process group); (0, 1) without torch.distributed."""
     if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
+        return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1
 
 
@@ -35,7 +36,7 @@ def shard_range(n_items: int, rank: int, world_size: int) -> Tuple[int, int]:
 
 def exchange_counts(n_local: int, device, group=None) -> List[int]:
     """Rows held by every rank (one tiny collective; callers that know the split pass `counts` and skip it)."""
-    _, ws = world()
+    _, ws = world(group)
     if ws == 1:
         return [n_local]
     c = torch.tensor([n_local], dtype=torch.int64, device=device)
@@ -75,7 +76,7 @@ def packed_all_gather(tensors: Sequence[Optional[torch.Tensor]], counts: Optiona
                       async_op: bool = False):
     """Gather several per-image tensors (same dim 0 on a rank) with ONE all_gather_into_tensor.  Ragged shards are padded to the
     largest shard for the collective and trimmed after.  Returns a handle (async_op) or the list of gathered tensors."""
-    rank, ws = world()
+    rank, ws = world(group)
     live = [t for t in tensors if t is not None]
     n = live[0].shape[0]
     dev = live[0].device
@@ -135,7 +136,7 @@ def gather_sharded_lists(local: list, n_items: int, group=None) -> list:
     results of ITS units (a list with one entry per local unit, each entry any picklable object -- e.g. a tile's ragged list of mask records) and
     gets back the results of all `n_items` units in unit order.  One collective (all_gather_object: sizes, then the pickled payloads as byte
     tensors over RCCL / gloo); a rank that holds zero units still takes part."""
-    rank, ws = world()
+    rank, ws = world(group)
     a, b = shard_range(n_items, rank, ws)
     assert len(local) == b - a, (len(local), a, b)
     if ws == 1:

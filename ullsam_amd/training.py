@@ -617,17 +617,27 @@ class HyperMasksFn(Function):
 
 
 class SparseEmbedFn(Function):
-    """Point prompts -> sparse embeddings (prompt_encoder.py:76-96): random-Fourier PE of the click + the label's embedding row; the
-    padding point and label -1 take not_a_point_embed alone.  table = [not_a_point, point_embeddings 0..3] (5 rows)."""
+    """Point / box prompts -> sparse embeddings (prompt_encoder.py:76-103): random-Fourier PE of the click (of the two corners of a box) + the label's
+    embedding row; the padding point (appended when there are no boxes, :84-88,181) and label -1 take not_a_point_embed alone; box corners take
+    point_embeddings[2] / [3].  table = [not_a_point, point_embeddings 0..3] (5 rows); the gradient is a row sum into that table (the PE has no parameters)."""
 
     @staticmethod
-    def forward(ctx, table, coords, labels, G, img_hw):
+    def forward(ctx, table, coords, labels, boxes, G, img_hw):
         table = _c(table)
-        P, Np = coords.shape[0], coords.shape[1]
         C = table.shape[1]
-        out = ops.sparse_embed(coords, labels, None, G, table, P, Np, 1, C, img_hw[1], img_hw[0])
-        idx = torch.cat([labels.to(torch.int32) + 1, torch.zeros((P, 1), dtype=torch.int32, device=labels.device)], 1).contiguous()
-        ctx.save_for_backward(idx)
+        P = coords.shape[0] if coords is not None else boxes.shape[0]
+        Np = coords.shape[1] if coords is not None else 0
+        pad = 1 if (coords is not None and boxes is None) else 0
+        out = ops.sparse_embed(coords, labels, boxes, G, table, P, Np, pad, C, img_hw[1], img_hw[0])
+        dev = table.device
+        cols = []
+        if coords is not None:
+            cols.append(labels.to(torch.int32) + 1)
+        if pad:
+            cols.append(torch.zeros((P, 1), dtype=torch.int32, device=dev))
+        if boxes is not None:
+            cols.append(torch.tensor([[3, 4]], dtype=torch.int32, device=dev).expand(P, 2))
+        ctx.save_for_backward(torch.cat(cols, 1).contiguous())
         ctx.C = C
         return out
 
@@ -637,7 +647,7 @@ class SparseEmbedFn(Function):
         dy = _c(dy)
         dt = torch.zeros((5, ctx.C), dtype=F32, device=dy.device)
         _lib.call("ullsam_train_index_add_rows", dy.data_ptr(), idx.data_ptr(), dt.data_ptr(), idx.numel(), ctx.C, 5, _s())
-        return dt, None, None, None, None
+        return dt, None, None, None, None, None
 
 
 class ResizeFn(Function):
@@ -685,6 +695,65 @@ class SegLossFn(Function):
         dx = torch.empty_like(pred)
         _lib.call("ullsam_train_seg_loss_bwd", pred.data_ptr(), gt.data_ptr(), sums.data_ptr(), g.data_ptr(), dx.data_ptr(), P, npix, smooth, _s())
         return dx, None, None
+
+
+class LMLossFn(Function):
+    """The language-model loss of InternLM2ForCausalLM.forward (modeling_internlm2.py:1081-1096) on hidden rows: logits = output(h).float() on the inference
+    path's GEMM (bf16 weights: bf16 MFMA, fp32 weights: exact-fp32 MFMA), CrossEntropyLoss() over them (labels == -100 ignored, mean over the others; HIP
+    kernels, ordered sums).  The [rows, 92553] logits are NOT kept (400 MB per image): the backward rebuilds them, forms (softmax - onehot) / #labelled in a
+    zero-padded [rows, V rounded up to 64] buffer and multiplies by the head's weight.  The head is frozen in every setting of the reference's trainer
+    (setup_model_params, train_joint_v2.py:1280-1359): it receives no gradient here.  The trainer's segmentation branch adds this loss as `0 * loss`
+    (:1096): an incoming gradient of exactly zero returns zeros without the two GEMMs (one scalar read back per step)."""
+
+    @staticmethod
+    def _logits(h, w):
+        if w.dtype == torch.bfloat16:
+            return ops.gemm(ops.cast(h, torch.bfloat16), w.detach(), None, out_f32=True)
+        return ops.gemm(h, w.detach(), None, out_f32=True)
+
+    @staticmethod
+    def forward(ctx, h, w, labels):
+        h = _c(h)
+        labels = labels.to(torch.int64).contiguous()
+        R, V = h.shape[0], w.shape[0]
+        logits = LMLossFn._logits(h, w)
+        lse = torch.empty((R,), dtype=F32, device=h.device)
+        rows = torch.empty((R,), dtype=F32, device=h.device)
+        out2 = torch.empty((2,), dtype=F32, device=h.device)
+        _lib.call("ullsam_train_cross_entropy", logits.data_ptr(), V, labels.data_ptr(), lse.data_ptr(), rows.data_ptr(), out2.data_ptr(), R, V, _s())
+        ctx.save_for_backward(h, w, labels, lse, out2)
+        return out2[0].clone()
+
+    @staticmethod
+    def backward(ctx, dl):
+        h, w, labels, lse, out2 = ctx.saved_tensors
+        if float(dl) == 0.0:                                  # `0 * loss + seg_loss`: the gradient is exactly zero
+            return torch.zeros_like(h), None, None
+        R, D = h.shape
+        V = w.shape[0]
+        Vp = -(-V // 64) * 64
+        logits = LMLossFn._logits(h, w)
+        g = _c(dl).reshape(1).to(F32)
+        dlog = torch.empty((R, Vp), dtype=F32, device=h.device)
+        _lib.call("ullsam_train_cross_entropy_bwd", logits.data_ptr(), V, labels.data_ptr(), lse.data_ptr(), out2.data_ptr(), g.data_ptr(), dlog.data_ptr(), Vp, R, V, _s())
+        del logits
+        if w.dtype == torch.bfloat16 and D % 64 == 0:
+            dx = ops.gemm(ops.cast(dlog, torch.bfloat16), ops.transpose_to_bf16(w.detach(), 64), out_f32=True)   # [R, Vp] x ([D, Vp])^T; W^T's pad columns are zeros
+        else:
+            dx = torch.empty((R, D), dtype=F32, device=h.device)
+            _mm(dlog, _c(w.detach()).float() if w.dtype != F32 else _c(w.detach()), dx, R, D, V, (0, Vp, 1), (0, D, 1), (0, D, 1))
+        return dx, None, None
+
+
+def lm_loss(lm, hidden_all: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """`.loss` of the reference's forward as a differentiable scalar (see LMLossFn): hidden_all [B, S, D] carries the graph (mlp1 through the frozen LLM);
+    shift_logits = logits[..., :-1, :] against labels[..., 1:]: the last position's logits are never formed."""
+    B, S, D = hidden_all.shape
+    w = lm.output.weight
+    if w.requires_grad:
+        raise NotImplementedError("a trainable LM head: the reference's trainer freezes the language model in every setting (train_joint_v2.py:1280-1359)")
+    h = hidden_all[:, :-1].reshape(B * (S - 1), D)
+    return LMLossFn.apply(h, w, labels[:, 1:].reshape(-1).to(h.device))
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
@@ -772,7 +841,7 @@ def segmentation_loss(model, llm_hidden: torch.Tensor, image_embeddings: Optiona
     dense = ScaleShiftFn.apply(LayerNormFn.apply(rows, None, None, 1e-5), pe.llm_scale_factor, pe.llm_bias)
     # sparse prompt
     table = torch.cat([pe.not_a_point_embed.weight] + [e.weight for e in pe.point_embeddings], 0)
-    sparse = SparseEmbedFn.apply(table, coords, labels, pe.pe_layer.G(), pe.input_image_size)
+    sparse = SparseEmbedFn.apply(table, coords, labels, None, pe.pe_layer.G(), pe.input_image_size)
     # mask decoder (mask_decoder.py:112-149)
     out_tok = torch.cat([md.iou_token.weight, md.mask_tokens.weight], 0)
     tokens = torch.cat([BroadcastRowsFn.apply(out_tok, P), sparse], 1)
@@ -953,19 +1022,24 @@ def vision_forward(enc, pixel_values: torch.Tensor) -> torch.Tensor:
 
 
 def prompt_encoder_forward(pe, points, boxes, masks, llm_hidden_states):
-    """PromptEncoder.forward with gradients (prompt_encoder.py:153-203) for what the reference's training step passes: point prompts (+ the
-    pad point) and the LLM dense prompt; -> (sparse [P, n + 1, C], dense [P, C, h, w]) fp32."""
-    if boxes is not None or masks is not None:
-        raise NotImplementedError("the differentiable prompt encoder covers the trainer's step: points + llm_hidden_states (train_joint_v2.py:1055-1060)")
-    if points is None:
-        raise NotImplementedError("the differentiable prompt encoder needs point prompts")
+    """PromptEncoder.forward with gradients (prompt_encoder.py:153-203): point prompts (+ the pad point), box prompts (the trainer forwards `boxes=`,
+    train_joint_v2.py:975,1038,1057) and the LLM dense prompt or the no-mask embedding; -> (sparse [P, n, C], dense [P, C, h, w]) fp32."""
+    if masks is not None:
+        raise NotImplementedError("mask prompts in the differentiable prompt encoder: the reference's trainer never passes them (train_joint_v2.py:1040-1050: masks=None); "
+                                  "call the module under torch.no_grad() / in eval() for the inference path")
+    if points is None and boxes is None:
+        raise NotImplementedError("the differentiable prompt encoder needs point or box prompts")
     h, w = pe.image_embedding_size
     C = pe.embed_dim
     dev = pe.no_mask_embed.weight.device
-    coords, labels = points[0].to(dev).float().contiguous(), points[1].to(dev).to(torch.int32).contiguous()
-    P = coords.shape[0]
+    coords = labels = bx = None
+    if points is not None:
+        coords, labels = points[0].to(dev).float().contiguous(), points[1].to(dev).to(torch.int32).contiguous()
+    if boxes is not None:
+        bx = boxes.to(dev).float().reshape(-1, 4).contiguous()                   # _embed_boxes, prompt_encoder.py:96-103
+    P = coords.shape[0] if coords is not None else bx.shape[0]
     table = torch.cat([pe.not_a_point_embed.weight] + [e.weight for e in pe.point_embeddings], 0)
-    sparse = SparseEmbedFn.apply(table, coords, labels, pe.pe_layer.G(), pe.input_image_size)
+    sparse = SparseEmbedFn.apply(table, coords, labels, bx, pe.pe_layer.G(), pe.input_image_size)
     if llm_hidden_states is not None:
         x = llm_hidden_states
         n = x.shape[0]
@@ -1021,8 +1095,8 @@ def mask_decoder_forward(md, image_embeddings, image_pe, sparse_prompt_embedding
 def composite_forward(model, pixel_values, input_ids, attention_mask=None, labels=None, output_hidden_states=None):
     """InternVLSAMModel.forward with gradients (modeling_internvl_sam.py:106-224 as train_joint_v2.py:988-998 calls it): the vision model runs
     without gradients here, as in the reference (extract_feature, :243-244); mlp1 -> frozen LLM -> mlp2 is differentiable; `.loss` is the
-    language-model loss of the reference's forward as a VALUE (the trainer multiplies it by zero, :1096; the LLM is frozen); `.hidden_states`
-    is the dense feature [B, 256, 64, 64] the segmentation branch continues from."""
+    language-model loss of the reference's forward (differentiable: `lm_loss`); `.hidden_states` is the dense feature [B, 256, 64, 64] the segmentation
+    branch continues from.  `image_flags` / `position_ids` of the reference's signature do not enter this path (the reference ignores image_flags too, :119-135)."""
     from .modeling.outputs import CausalLMOutputWithPast
     lm = model.language_model
     B, S = input_ids.shape
@@ -1034,9 +1108,9 @@ def composite_forward(model, pixel_values, input_ids, attention_mask=None, label
     loss = None
     logits_fn = lambda: lm.lm_head(hidden_all.detach())
     if labels is not None:
-        with torch.no_grad():
-            logits = logits_fn()
-            loss = torch.nn.functional.cross_entropy(logits[..., :-1, :].reshape(-1, lm.vocab_size), labels[..., 1:].reshape(-1).to(logits.device))
+        # `.loss` is differentiable, as in the reference: its trainer's other branch (train_joint_v2.py: masks is None or use_llm_hidden_states False) back-propagates
+        # `outputs.loss` into mlp1 through the frozen LLM; in the segmentation branch the loss enters as 0 * loss (:1096) and its backward costs one head GEMM pair
+        loss = lm_loss(lm, hidden_all, labels)
     hs = None
     if output_hidden_states:
         hs = _rows_to_nchw(dense_feature_rows(model, hidden_img), B, g, g)
