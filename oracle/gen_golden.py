@@ -49,6 +49,28 @@ def save(name, **kw):
 
 
 # ------------------------------------------------------------------------------------------
+RELPOS_INTERP_LEN = {"window": 9, "global": 15}     # table lengths of the interpolation fixture (what window 5 / a grid of 8 would have trained): the model needs 13 / 19
+
+
+def case_vit_tiny_relpos_interp():
+    """vit_tiny with rel_pos tables of ANOTHER length than 2 * size - 1 (a checkpoint trained at another resolution): get_rel_pos interpolates them linearly
+    (image_encoder.py:306-318).  The reference module is built as usual and its tables are replaced before the forward."""
+    from modeling.image_encoder import ImageEncoderViT
+    cfg = dict(img_size=160, patch_size=16, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4, out_chans=64,
+               qkv_bias=True, use_rel_pos=True, window_size=7, global_attn_indexes=[1])
+    m = ImageEncoderViT(norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), **cfg).eval()
+    fill_module(m, seed=0)
+    for i, blk in enumerate(m.blocks):
+        L = RELPOS_INTERP_LEN["global" if i in cfg["global_attn_indexes"] else "window"]
+        for nm in ("rel_pos_h", "rel_pos_w"):
+            t = O.fill_param(f"blocks.{i}.attn.{nm}", (L, 64), 5)          # seed 5: these replace the seed-0 tables of the usual length
+            setattr(blk.attn, nm, torch.nn.Parameter(torch.from_numpy(t)))
+    x = rand_image((2, 3, 160, 160), seed=1)
+    y = m(torch.from_numpy(x)).numpy()
+    save("vit_tiny_relpos_interp", cfg=np.array(repr(cfg)), weight_seed=0, table_seed=5, input_seed=1, len_window=RELPOS_INTERP_LEN["window"],
+         len_global=RELPOS_INTERP_LEN["global"], out=y)
+
+
 def case_vit_tiny():
     from modeling.image_encoder import ImageEncoderViT
     cfg = dict(img_size=160, patch_size=16, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4, out_chans=64,
@@ -922,7 +944,7 @@ def case_train_step(real_dims: bool = False):
     save("train_step_real" if real_dims else "train_step", **out)
 
 
-CASES = {"train_step": case_train_step, "train_step_real": lambda: case_train_step(real_dims=True), "train_vit_slice": case_train_vit_slice, "train_slice": case_train_slice, "train_slice_box": lambda: case_train_slice(boxes=True), "train_llm_slice": case_train_llm_slice, "train_llm_slice_pad": lambda: case_train_llm_slice(pad=37), "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
+CASES = {"train_step": case_train_step, "train_step_real": lambda: case_train_step(real_dims=True), "train_vit_slice": case_train_vit_slice, "train_slice": case_train_slice, "train_slice_box": lambda: case_train_slice(boxes=True), "train_llm_slice": case_train_llm_slice, "train_llm_slice_pad": lambda: case_train_llm_slice(pad=37), "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "vit_tiny_relpos_interp": case_vit_tiny_relpos_interp, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
          "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full,
          "vit_h_d2": case_vit_h_d2, "llm_7b_l1": case_llm_7b_l1,
          "rope_variants": case_rope_variants, "llm_tiny_bias_linear": case_llm_tiny_bias_linear,

@@ -297,11 +297,23 @@ def patch_embed(x: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
     return linear(cols, w.reshape(D, -1), b)
 
 
+def interp_linear_rows(t: np.ndarray, n_out: int) -> np.ndarray:
+    """F.interpolate(t[None].permute(0, 2, 1), size=n_out, mode="linear") back as rows (image_encoder.py:308-316; align_corners=False):
+    out[o] = (1 - l) t[i0] + l t[i1] with src = max((o + 0.5) L / n_out - 0.5, 0), i0 = floor(src), i1 = min(i0 + 1, L - 1), l = src - i0."""
+    L = t.shape[0]
+    src = np.maximum((np.arange(n_out, dtype=F32) + F32(0.5)) * F32(L / n_out) - F32(0.5), F32(0.0)).astype(F32)
+    i0 = np.minimum(src.astype(np.int64), L - 1)
+    i1 = np.minimum(i0 + 1, L - 1)
+    lam = (src - i0.astype(F32)).astype(F32)[:, None]
+    return (t[i0] * (F32(1.0) - lam) + t[i1] * lam).astype(F32)
+
+
 def get_rel_pos(q_size: int, k_size: int, rel_pos: np.ndarray) -> np.ndarray:
-    """image_encoder.py:292-322.  No interpolation branch: at the sizes the reference runs
-    (1024^2 input) rel_pos.shape[0] == 2*max(q,k)-1 always (:306)."""
+    """image_encoder.py:292-322, including the interpolation of a table whose length is not 2 max(q, k) - 1 (:306-318: a checkpoint whose
+    tables were trained at another resolution; at the sizes the reference builds, 1024^2 input, the lengths agree and the branch is not taken)."""
     max_rel_dist = int(2 * max(q_size, k_size) - 1)
-    assert rel_pos.shape[0] == max_rel_dist, "rel_pos interpolation is not on the hot path"
+    if rel_pos.shape[0] != max_rel_dist:
+        rel_pos = interp_linear_rows(rel_pos, max_rel_dist)
     q_coords = np.arange(q_size)[:, None] * max(k_size / q_size, 1.0)
     k_coords = np.arange(k_size)[None, :] * max(q_size / k_size, 1.0)
     rel = (q_coords - k_coords) + (k_size - 1) * max(q_size / k_size, 1.0)

@@ -46,6 +46,36 @@ def test_vit_tiny_golden(dtype, tol):
     assert err(y, g["out"]) < tol  # output is LayerNorm2d-normalised (|y| ~ 1..4)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 0.12)])
+def test_vit_with_interpolated_rel_pos_tables_golden(dtype, tol):
+    """A checkpoint whose rel-pos tables have another length than 2 * size - 1: get_rel_pos interpolates them (image_encoder.py:306-318).  The tables are
+    resized once per weight version on the resize kernel; fixture = the reference run with such tables.  The training graph takes the same tables
+    (its gradient flows back through the interpolation's adjoint): forward values equal to the inference path."""
+    from torch import nn
+    from tests.test_oracle_golden import relpos_interp_params
+    g = U.gold("vit_tiny_relpos_interp")
+    enc = make_vit(U.VIT_TINY)
+    P = relpos_interp_params(g)
+    for i, blk in enumerate(enc.blocks):
+        for nm in ("rel_pos_h", "rel_pos_w"):
+            setattr(blk.attn, nm, nn.Parameter(torch.empty(P[f"blocks.{i}.attn.{nm}"].shape)))
+    enc = load(enc, P, dtype)
+    x = torch.from_numpy(U.rand_image((2, 3, 160, 160), int(g["input_seed"]))).to(DEV)
+    y = enc(x).float().cpu().numpy()
+    assert y.shape == g["out"].shape
+    assert err(y, g["out"]) < tol
+    if dtype == torch.float32:
+        from ullsam_amd import training
+        enc.train()
+        for p in enc.parameters():
+            p.requires_grad_(True)
+        yt = enc(x)
+        assert yt.requires_grad and err(yt.detach().cpu().numpy(), g["out"]) < tol
+        yt.square().mean().backward()
+        gr = enc.blocks[0].attn.rel_pos_h.grad
+        assert gr is not None and gr.shape == (int(g["len_window"]), 64) and float(gr.abs().max()) > 0
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 0.15)])
 def test_vit_b_full_golden(dtype, tol):
     g = U.gold("vit_b_full")
@@ -647,7 +677,7 @@ def test_full_depth_golden_fp32_and_bf16():
     them with an fp32 mask fill of 0.48 - 0.60, where the mask cuts through the middle of the logits' distribution and IoU is least forgiving.
       fp32 mode: every stage within 1e-3 * max(1, |stage|_max-ish scale) of the reference, low-res logits within 1e-3 * scale, mask IoU delta < 1e-4;
       bf16 mode: mean error of every stage <= 1.5 x the reference's autocast mean error, logits max error <= 1.5 x its max error, and mask IoU
-      vs the reference's fp32 mask >= the reference's autocast IoU - 0.01 -- on every tile.
+      vs the reference's fp32 mask >= the reference's autocast IoU - 0.002 -- on every tile.
     Prints the per-stage error table DESIGN.md section 2 quotes."""
     import bench
     g = U.gold("full_depth")
@@ -682,7 +712,7 @@ def test_full_depth_golden_fp32_and_bf16():
         assert rows["low"][4] < 1.5 * rows["low"][5], (ti, rows["low"])
         assert err(f[ti]["iou_pred"], g[f"iou_pred_{ti}"]) < 1e-3
         assert 1.0 - iou32 < 1e-4, (ti, iou32)
-        assert iou16 >= float(g[f"ac_mask_iou_{ti}"]) - 0.01, (ti, iou16, float(g[f"ac_mask_iou_{ti}"]))
+        assert iou16 >= float(g[f"ac_mask_iou_{ti}"]) - 0.002, (ti, iou16, float(g[f"ac_mask_iou_{ti}"]))   # (round 4 measured: above the reference's autocast on three tiles, 2e-5 below on the fourth)
 
 
 

@@ -25,6 +25,26 @@ def test_vit_tiny_matches_reference():
     _close(y, g["out"], 2e-4, "vit_tiny output")
 
 
+def relpos_interp_params(g):
+    """vit_tiny's parameters with the rel-pos tables of tests/golden/vit_tiny_relpos_interp.npz: other lengths (9 for the 7 x 7 windows, 15 for the 10 x 10 grid)."""
+    P = U.vit_params(U.VIT_TINY, int(g["weight_seed"]))
+    hd = U.VIT_TINY["embed_dim"] // U.VIT_TINY["num_heads"]
+    for i in range(U.VIT_TINY["depth"]):
+        L = int(g["len_global"] if i in U.VIT_TINY["global_attn_indexes"] else g["len_window"])
+        for nm in ("rel_pos_h", "rel_pos_w"):
+            P[f"blocks.{i}.attn.{nm}"] = O.fill_param(f"blocks.{i}.attn.{nm}", (L, hd), int(g["table_seed"]))
+    return P
+
+
+def test_vit_with_interpolated_rel_pos_tables_matches_reference():
+    """get_rel_pos interpolates a table whose length is not 2 * size - 1 (image_encoder.py:306-318); fixture: the reference with such tables."""
+    g = U.gold("vit_tiny_relpos_interp")
+    x = U.rand_image((2, 3, 160, 160), int(g["input_seed"]))
+    y = O.vit_encoder(x, relpos_interp_params(g), **U.vit_run_cfg(U.VIT_TINY))
+    _close(y, g["out"], 2e-4, "vit_tiny with interpolated rel-pos tables")
+    _close(O.interp_linear_rows(np.arange(6, dtype=np.float32)[:, None] * 2, 6), np.arange(6, dtype=np.float32)[:, None] * 2, 0, "identity length")
+
+
 def test_decoder_matches_reference():
     g = U.gold("decoder")
     seed = int(g["weight_seed"])

@@ -58,6 +58,20 @@ class Attention(Packed):
             self.rel_pos_h = nn.Parameter(torch.zeros(2 * input_size[0] - 1, self.head_dim))
             self.rel_pos_w = nn.Parameter(torch.zeros(2 * input_size[1] - 1, self.head_dim))
 
+    def rel_table(self, name: str, p: torch.Tensor, size: int, dtype: torch.dtype) -> torch.Tensor:
+        """The table get_rel_pos indexes (image_encoder.py:292-322) in the compute dtype: `p` itself when it has the 2 * size - 1 rows the window / grid needs, otherwise
+        (:306-318, a checkpoint whose tables were trained at another resolution) its linear interpolation to that length -- F.interpolate(mode="linear"),
+        align_corners=False -- computed once per weight version on the resize kernel: [hd planes] x [1 x L] resized to [1 x n] is the same one-dimensional tap arithmetic."""
+        n = 2 * size - 1
+        if p.shape[0] == n:
+            return self.cdt(name, p, dtype)
+
+        def make():
+            t = p.detach().float().t().contiguous().reshape(p.shape[1], 1, p.shape[0])
+            out, _ = ops.resize_bilinear(t, (1, n))
+            return out.reshape(p.shape[1], n).t().contiguous().to(dtype)
+        return self.pk(f"{name}:interp{n}", p, make)
+
 
 class Block(Packed):
     """image_encoder.py:119-182."""
@@ -143,7 +157,8 @@ class ImageEncoderViT(Packed):
                 xn = ops.norm(xres, *blk.norm1.wb(), blk.norm1.eps, dt)
                 qkv = ops.gemm(xn, at.qkv.w(dt), at.qkv.b())
             qb = at.qkv.bias if at.qkv.bias is not None else torch.zeros(3 * D, device=x.device)
-            att = ops.vit_attention(qkv, at.cdt("rh", at.rel_pos_h, dt), at.cdt("rw", at.rel_pos_w, dt), at.cdt("qb", qb, dt),
+            n_rel = blk.window_size if blk.window_size > 0 else g
+            att = ops.vit_attention(qkv, at.rel_table("rh", at.rel_pos_h, n_rel, dt), at.rel_table("rw", at.rel_pos_w, n_rel, dt), at.cdt("qb", qb, dt),
                                     B, self.num_heads, at.head_dim, g, g, blk.window_size)
             ops.gemm(att, at.proj.w(dt), at.proj.b(), residual=xres, out_f32=True, out=xres)
             if fp8:

@@ -965,12 +965,14 @@ def vision_feature_rows(enc, pixel_values: torch.Tensor) -> torch.Tensor:
         Bw, T = t.shape[0], Hh * Hh
         qkv = _apply_linear(t.reshape(Bw * T, D), at.qkv.weight, at.qkv.bias).reshape(Bw, T, 3, heads, hd)
         q, k, v = (qkv[:, :, i].reshape(Bw * T, heads * hd) for i in range(3))
-        if at.rel_pos_h.shape[0] != 2 * Hh - 1 or at.rel_pos_w.shape[0] != 2 * Hh - 1:
-            raise NotImplementedError("get_rel_pos with interpolated tables (image_encoder.py:310-318) is not part of the training slice")
+        def table(p):                                                                           # get_rel_pos's interpolation (:306-318) of a table of another length:
+            if p.shape[0] == 2 * Hh - 1:                                                        # F.interpolate(mode="linear") = the resize kernel on [hd planes] x [1 x L] images;
+                return p                                                                        # its adjoint (ResizeFn.backward) carries the gradient back to the stored rows
+            return ResizeFn.apply(p.float().t().reshape(hd, 1, 1, p.shape[0]), (1, 2 * Hh - 1)).reshape(hd, 2 * Hh - 1).t()
         ar = torch.arange(Hh, device=x.device)
         idx = (ar[:, None] - ar[None, :] + (Hh - 1)).reshape(-1)                                # relative_coords :320-322
-        Rh = GatherRowsFn.apply(at.rel_pos_h, idx).reshape(Hh, Hh, hd)
-        Rw = GatherRowsFn.apply(at.rel_pos_w, idx).reshape(Hh, Hh, hd)
+        Rh = GatherRowsFn.apply(table(at.rel_pos_h), idx).reshape(Hh, Hh, hd)
+        Rw = GatherRowsFn.apply(table(at.rel_pos_w), idx).reshape(Hh, Hh, hd)
         q5 = q.reshape(Bw, Hh, Hh, heads, hd)                                                  # add_decomposed_rel_pos :325-361 (unscaled q)
         rel_h = BmmNTFn.apply(q5.permute(1, 0, 2, 3, 4).reshape(Hh, Bw * Hh * heads, hd), Rh)   # [qh, (b, qw, head), kh]
         rel_h = rel_h.reshape(Hh, Bw, Hh, heads, Hh).permute(1, 3, 0, 2, 4).reshape(Bw, heads, T, Hh)
