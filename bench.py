@@ -319,7 +319,7 @@ def mask_iou_vs_reference(model, inputs, dtype):
 
 
 def cpu_baseline(vit: str, llm: str, S: int, reps: int = 3):
-    """The reference's algorithm (numpy fp32 oracle, `kind: port`) on the host cores, on a BOUNDED sample of the workload: one
+    """The reference's algorithm (the oracle restated on torch CPU tensors for the two heavy stages, `kind: port-torch`; numpy oracle beside it) on the host cores, on a BOUNDED sample of the workload: one
     image; one windowed + one global ViT block, one LLM layer, the projectors and the whole prompt-encoder / mask-decoder /
     upsample tail are each timed `reps` times after one warm-up (median reported per stage) and the blocks / layers are
     extrapolated linearly in depth (profiles/r02_cpu_baseline_full_depth.json validates the extrapolation on a full-depth run)."""
@@ -346,20 +346,33 @@ def cpu_baseline(vit: str, llm: str, S: int, reps: int = 3):
             ts.append(time.perf_counter() - t)
         return float(np.median(ts))
 
-    t_w = timed(lambda: O.vit_block(xb, P, "blocks.0.", H, 14, 1e-6))
-    t_g = timed(lambda: O.vit_block(xb, P, "blocks.1.", H, 0, 1e-6))
+    # The two heavy stages (ViT blocks, LLM layers: 99 % of the time) run through oracle/torch_port.py = the oracle's arithmetic on torch CPU tensors, i.e. on ATen's
+    # kernels, which is what the reference's own CPU path runs on (`kind: port-torch`); the same stages through the numpy oracle are timed once each beside them
+    # (`numpy_port`: 3 - 5x slower -- chains of numpy temporaries -- and the only figure of rounds 1 - 4).
+    from oracle import torch_port as TP
+    PT = TP.to_torch(P)
+    xt = torch.from_numpy(xb)
+    torch_threads = torch.get_num_threads()
+    with torch.no_grad():
+        t_w = timed(lambda: TP.vit_block(xt, PT, "blocks.0.", H, 14, 1e-6))
+        t_g = timed(lambda: TP.vit_block(xt, PT, "blocks.1.", H, 0, 1e-6))
+    t0 = time.perf_counter(); O.vit_block(xb, P, "blocks.0.", H, 14, 1e-6); np_w = time.perf_counter() - t0
+    t0 = time.perf_counter(); O.vit_block(xb, P, "blocks.1.", H, 0, 1e-6); np_g = time.perf_counter() - t0
     img = rng.random((1, 3, 1024, 1024), dtype=np.float32)
     t_fix = timed(lambda: O.vit_encoder(img, P, depth=0, num_heads=H, global_attn_indexes=()))
     n_g = len(v["glob"])
     t_vit = t_fix + (v["depth"] - n_g) * t_w + n_g * t_g
-    t_llm = t_proj = t_layer = 0.0
+    t_llm = t_proj = t_layer = np_layer = 0.0
     if LLM[llm] is not None:
         c = LLM[llm]
         cfg = dict(hidden=c["hidden_size"], layers=1, heads=c["num_attention_heads"], kv_heads=c["num_key_value_heads"],
                    inter=c["intermediate_size"], vocab=8, rope_theta=1e6, eps=1e-5)
         PL = O.fill_state(O.internlm2_shapes(cfg["hidden"], 1, cfg["heads"], cfg["kv_heads"], cfg["inter"], 8, prefix="lm."), 0)
         emb = rng.standard_normal((1, S, cfg["hidden"]), dtype=np.float32)
-        t_layer = timed(lambda: O.internlm2_model(PL, cfg, emb, prefix="lm."))
+        PLT, embt = TP.to_torch(PL), torch.from_numpy(emb)
+        with torch.no_grad():
+            t_layer = timed(lambda: TP.internlm2_layer(embt, PLT, "lm.model.layers.0.", cfg))
+        t0 = time.perf_counter(); O.internlm2_model(PL, cfg, emb, prefix="lm."); np_layer = time.perf_counter() - t0
         t_llm = c["num_hidden_layers"] * t_layer
         PP = O.fill_state(O.projector_shapes(cfg["hidden"]), 0)
         feat = rng.standard_normal((1, 256, 64, 64), dtype=np.float32)
@@ -377,13 +390,16 @@ def cpu_baseline(vit: str, llm: str, S: int, reps: int = 3):
 
     t_dec = timed(dec)
     total = t_vit + t_llm + t_proj + t_dec
+    np_total = t_fix + (v["depth"] - n_g) * np_w + n_g * np_g + (LLM[llm]["num_hidden_layers"] * np_layer if LLM[llm] else 0.0) + t_proj + t_dec
     cores = os.cpu_count() or 1
-    return {"value": round(1.0 / total, 6), "unit": "images/s", "cores": threads or cores, "host_cores": cores, "blas_threads": threads,
-            "kind": "port", "reps": reps, "statistic": "median after 1 warm-up",
+    return {"value": round(1.0 / total, 6), "unit": "images/s", "cores": torch_threads, "host_cores": cores, "blas_threads": threads, "torch_threads": torch_threads,
+            "kind": "port-torch", "reps": reps, "statistic": "median after 1 warm-up",
+            "numpy_port": {"value": round(1.0 / np_total, 6), "vit_windowed_block_s": round(np_w, 4), "vit_global_block_s": round(np_g, 4), "llm_layer_s": round(np_layer, 4),
+                           "note": "the same stages through the numpy oracle, one run each (the figure of rounds 1 - 4: kind 'port')"},
             "stages_s": {"vit_windowed_block": round(t_w, 4), "vit_global_block": round(t_g, 4), "vit_patch_embed_neck": round(t_fix, 4),
                          "llm_layer": round(t_layer, 4), "projectors_mlp1_mlp2": round(t_proj, 4), "prompt_mask_decoder_upsample": round(t_dec, 4),
                          "vit_total_extrapolated": round(t_vit, 2), "llm_total_extrapolated": round(t_llm, 2)},
-            "sample": (f"numpy fp32 oracle, 1 image: 1 windowed + 1 global ViT-{vit.upper()} block, patch-embed+neck, "
+            "sample": (f"torch-CPU restatement of the oracle (oracle/torch_port.py; patch-embed+neck, projectors and the decoder tail through the numpy oracle), fp32, 1 image: 1 windowed + 1 global ViT-{vit.upper()} block, patch-embed+neck, "
                        f"1 InternLM2-{llm} layer at S={S}, mlp1+mlp2, prompt-encoder+mask-decoder+upsample, each the median of {reps} runs; "
                        f"extrapolated linearly to {v['depth']} blocks / {LLM[llm]['num_hidden_layers'] if LLM[llm] else 0} layers; "
                        f"sampling took {time.time() - t_all:.0f}s")}

@@ -236,3 +236,22 @@ def test_amg_oracle_and_host_helpers_match_reference_vectors():
     md.filter(torch.tensor([True, False, True]))
     assert md["a"] == [1, 3] and md["b"].tolist() == [0, 2]
     assert [x for x in H.batch_iterator(2, [1, 2, 3])] == [[[1, 2]], [[3]]]
+
+
+def test_torch_cpu_port_of_the_heavy_stages_equals_the_numpy_oracle():
+    """bench.py's cpu_baseline times oracle/torch_port.py (the oracle's ViT block and InternLM2 layer on ATen kernels = the reference's own CPU substrate):
+    the port must be the oracle's arithmetic -- windowed block with padded windows, global block, an LLM layer with grouped KV heads."""
+    from oracle import torch_port as TP
+    rng = np.random.default_rng(0)
+    D, H = 128, 2
+    P = O.fill_state(O.vit_shapes(embed_dim=D, depth=2, num_heads=H, global_attn_indexes=(1,), img_size=320, window_size=7), 0)
+    x = rng.standard_normal((2, 20, 20, D), dtype=np.float32)
+    PT = TP.to_torch(P)
+    for i, ws in ((0, 7), (1, 0)):
+        _close(TP.vit_block(torch.from_numpy(x), PT, f"blocks.{i}.", H, ws, 1e-6).numpy(), O.vit_block(x, P, f"blocks.{i}.", H, ws, 1e-6), 2e-5, f"torch port, ViT block (window {ws})")
+    cfg = dict(hidden=256, layers=1, heads=4, kv_heads=2, inter=512, vocab=8, rope_theta=1e6, eps=1e-5)
+    PL = O.fill_state(O.internlm2_shapes(256, 1, 4, 2, 512, 8, prefix="lm."), 0)
+    emb = rng.standard_normal((2, 70, 256), dtype=np.float32)
+    ref, _ = O.internlm2_model(PL, cfg, emb, prefix="lm.")
+    got = O.rms_norm(TP.internlm2_layer(torch.from_numpy(emb), TP.to_torch(PL), "lm.model.layers.0.", cfg).numpy(), PL["lm.model.norm.weight"], 1e-5)
+    _close(got, ref, 2e-5, "torch port, InternLM2 layer")
