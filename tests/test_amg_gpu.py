@@ -542,3 +542,81 @@ def test_fused_first_upscaling_layernorm_gelu_equals_the_separate_launches(rows)
     xn = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-6) * lw.double() + lb.double()
     want = 0.5 * xn * (1.0 + torch.erf(xn / 2 ** 0.5))
     assert float((got.double() - want).abs().max()) < 2e-2 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,T,shared", [(64, 7, True), (4, 7, False), (3, 16, False), (1, 6, False), (17, 9, True)])
+def test_fused_token_side_of_the_two_way_blocks_equals_the_separate_launches(P, T, shared):
+    """transformer.FUSED_TOK (default for bf16): the token side of a two-way block -- self attention with its four projections, norm1, the token -> image q
+    projection | the token -> image out projection, norm2, the MLP, norm3, the image -> token k / v projections -- as TWO launches around the token -> image
+    attention (csrc/dectok.hip: one workgroup per prompt, bf16 MFMA with fp32 accumulation, every activation as TWO bf16 terms = ~17 bits) against the ~18 fp32 launches it replaces, through TwoWayTransformer.forward_tokens on random weights.  The AMG batch shape (64 prompts on one
+    shared image), the bench's (4 images, one prompt each), the largest token count, one prompt, a prompt count that is not a multiple of anything."""
+    from ullsam_amd.modeling import transformer as TR
+    torch.manual_seed(P * 131 + T)
+    tw = TR.TwoWayTransformer(depth=2, embedding_dim=256, num_heads=8, mlp_dim=2048).to(DEV)
+    for prm in tw.parameters():
+        torch.nn.init.normal_(prm, std=0.06)
+    for n, prm in tw.named_parameters():
+        if "norm" in n and n.endswith("weight"):
+            torch.nn.init.normal_(prm, mean=1.0, std=0.1)
+    tw = tw.to(torch.bfloat16)
+    N = 4096
+    keys = torch.randn((1 if shared else P, N, 256), device=DEV)
+    key_pe = torch.randn((N, 256), device=DEV)
+    tokens = torch.randn((P, T, 256), device=DEV)
+    outs = {}
+    old = TR.FUSED_TOK
+    try:
+        for on in (True, False):
+            TR.FUSED_TOK = on
+            q, k = tw.forward_tokens(keys, key_pe, tokens, keys_in_compute_dtype=True)
+            outs[on] = (q.float(), k.float())
+    finally:
+        TR.FUSED_TOK = old
+    torch.cuda.synchronize()
+    (qa, ka), (qb, kb) = outs[True], outs[False]
+    assert torch.isfinite(qa).all() and torch.isfinite(ka).all()
+    print(f"fused token side P={P} T={T}: queries max diff {float((qa - qb).abs().max()):.4f} (scale {float(qb.abs().max()):.2f}), mean {float((qa - qb).abs().mean()):.5f}; "
+          f"keys max diff {float((ka - kb).abs().max()):.4f}, mean {float((ka - kb).abs().mean()):.5f}")
+    # (measured: queries max 4e-4 ... 2.5e-3, mean 1e-4 with two bf16 terms per activation; one term -- autocast's rounding -- gave 2e-2 / 3e-3 and cost mask IoU)
+    assert float((qa - qb).abs().max()) < 1e-2 * max(1.0, float(qb.abs().max())), float((qa - qb).abs().max())
+    assert float((qa - qb).abs().mean()) < 5e-4 * max(1.0, float(qb.abs().mean()))
+    assert float((ka - kb).abs().max()) < 4e-2 * max(1.0, float(kb.abs().max())), float((ka - kb).abs().max())      # (the keys leave in bf16: one rounding step)
+    assert float((ka - kb).abs().mean()) < 5e-4 * max(1.0, float(kb.abs().mean()))
+    # a record's outputs do not depend on what it is batched with: prompt 0 alone gives the bits it has inside the batch
+    if not shared and P > 1:
+        q1, k1 = tw.forward_tokens(keys[:1], key_pe, tokens[:1], keys_in_compute_dtype=True)
+        assert torch.equal(q1.float()[0], qa[0]) and torch.equal(k1.float()[0], ka[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [64, 4, 1, 19])
+def test_fused_hypernetwork_and_iou_heads_equal_the_separate_launches(P):
+    """mask_decoder.FUSED_HEADS (default for bf16): the four hypernetwork MLPs and the IoU head (mask_decoder.py:141-149,154-176; 15 linears) as one launch
+    (csrc/dectok.hip dec_heads_kernel) against the 15 fp32 launches: through MaskDecoder.predict_masks_tokens on random weights."""
+    from ullsam_amd.modeling import mask_decoder as MD
+    from ullsam_amd.build_sam import _build_sam
+    torch.manual_seed(P)
+    sam = _build_sam(128, 2, 2, [1]).to(DEV)
+    md = sam.mask_decoder
+    for prm in md.parameters():
+        torch.nn.init.normal_(prm, std=0.06)
+    md = md.to(torch.bfloat16)
+    img = torch.randn((1, 4096, 256), device=DEV)
+    pe = torch.randn((4096, 256), device=DEV)
+    sparse = torch.randn((P, 2, 256), device=DEV)
+    dense = torch.randn((1, 1, 256), device=DEV)
+    outs = {}
+    old = MD.FUSED_HEADS
+    try:
+        for on in (True, False):
+            MD.FUSED_HEADS = on
+            m, iou = md.predict_masks_tokens(img, pe, sparse, dense, (64, 64))
+            outs[on] = (m.float(), iou.float())
+    finally:
+        MD.FUSED_HEADS = old
+    (ma, ia), (mb, ib) = outs[True], outs[False]
+    assert ma.shape == mb.shape and ia.shape == ib.shape == (P, 4)
+    assert float((ia - ib).abs().max()) < 3e-2 * max(1.0, float(ib.abs().max())), float((ia - ib).abs().max())
+    assert float((ma - mb).abs().max()) < 3e-2 * max(1.0, float(mb.abs().max())), float((ma - mb).abs().max())
+    assert float((ma - mb).abs().mean()) < 3e-3 * max(1.0, float(mb.abs().mean()))

@@ -52,6 +52,7 @@ class MLP(Packed):
         return x
 
 
+FUSED_HEADS = os.environ.get("ULLSAM_FUSED_HEADS", "1") != "0"   # bf16: hypernetwork MLPs + IoU head as one launch (csrc/dectok.hip)
 FUSED_UP2 = os.environ.get("ULLSAM_FUSED_UP2", "1") != "0"   # bf16: second transposed convolution + GELU + hypernetwork product as one kernel (any prompt count)
 
 
@@ -117,14 +118,46 @@ class MaskDecoder(Packed):
         else:
             u1 = ops.gemm(src.reshape(P * N, C), w0, b0, out_f32=True)           # [P*N, (ky,kx,c4)]
             u1 = ops.norm(u1.reshape(P * N * 4, c4), *ln.wb(), ln.eps, dt, act=ops.ACT_GELU)   # LayerNorm2d + GELU per output pixel
-        hyper = torch.stack([self.output_hypernetworks_mlps[i](hs[:, 1 + i, :]) for i in range(nm)], dim=1).contiguous()
+        heads = self._fused_heads(dt, T_all=hs.shape[1]) if (FUSED_HEADS and dt == torch.bfloat16) else None
+        if heads is not None:                                                # the four hypernetwork MLPs + the IoU head: 15 token-side linears, one launch
+            hyper, iou_all = ops.dec_heads(hs.contiguous(), heads[0], heads[1], P, hs.shape[1], nm)
+        else:
+            hyper = torch.stack([self.output_hypernetworks_mlps[i](hs[:, 1 + i, :]) for i in range(nm)], dim=1).contiguous()
         if FUSED_UP2 and dt == torch.bfloat16 and c4 == 64 and c8 == 32 and nm <= 8:
             masks = ops.up2_hyper_masks(u1, w1, b1, hyper, P, nm, h, w)      # second transposed convolution + GELU + hypernetwork product: the upscaled embedding is never written
         else:
             u2 = ops.gemm(u1, w1, b1, act=ops.ACT_GELU)                      # [P*N*4, (ky2,kx2,c8)]
             masks = ops.hyper_masks(u2, hyper, P, nm, h, w, c8)
-        iou = self.iou_prediction_head(hs[:, 0, :])
+        iou = iou_all if heads is not None else self.iou_prediction_head(hs[:, 0, :])
         return masks, iou
+
+    def _fused_heads(self, dt, T_all: int):
+        """Host arrays of the 15 weight / bias device pointers ullsam_dec_heads takes (chain-major: hypernetwork MLP 0 .. 3, IoU head), or None when the heads
+        do not have SAM's shape (four mask tokens, three layers of width 256, 32 / <= 16 outputs, no sigmoid).  A chain's last weight is zero-padded to a
+        multiple of 16 rows once per weight version (the pack cache keeps the padded copies -- and through them the pointers -- alive)."""
+        C = self.transformer_dim
+        chains = list(self.output_hypernetworks_mlps) + [self.iou_prediction_head]
+        if self.num_mask_tokens != 4 or C != 256 or T_all < 5 or any(
+                m.num_layers != 3 or m.sigmoid_output or m.layers[0].out_features != 256 or m.layers[1].out_features != 256 for m in chains):
+            return None
+        if any(m.layers[2].out_features != 32 for m in chains[:4]) or chains[4].layers[2].out_features != 4:
+            return None
+        ws, bs, keep = [], [], []
+        for ci, m in enumerate(chains):
+            for li, l in enumerate(m.layers):
+                w = l.w(dt)
+                if li == 2 and w.shape[0] % 16:
+                    w = l.pk("w:pad16", l.weight, lambda l=l: torch.cat([l.weight.detach().to(dt), torch.zeros((-l.weight.shape[0]) % 16, l.weight.shape[1], dtype=dt, device=l.weight.device)], 0).contiguous())
+                b = l.b()
+                keep += [w, b]
+                ws.append(w.data_ptr())
+                bs.append(0 if b is None else b.data_ptr())
+        key = (tuple(ws), tuple(bs))
+        hit = getattr(self, "_heads_ptrs", None)
+        if hit is None or hit[0] != key:
+            hit = (key, torch.tensor(ws, dtype=torch.int64), torch.tensor(bs, dtype=torch.int64), keep)
+            object.__setattr__(self, "_heads_ptrs", hit)
+        return hit[1], hit[2]
 
     # -- reference API -------------------------------------------------------------------------------
     @torch.no_grad()

@@ -61,10 +61,12 @@ class TwoWayAttentionBlock(Packed):
         self.skip_first_layer_pe = skip_first_layer_pe
 
 
-def _token_to_image(at: Attention, queries, qpe, keys_pe_c, keys_c, P, T, N, dt, shared=False, kv_cache=None):
+def _token_to_image(at: Attention, queries, qpe, keys_pe_c, keys_c, P, T, N, dt, shared=False, kv_cache=None, q=None, project=True):
     """queries + attn(q=queries+pe, k=keys+pe, v=keys): token side fp32, image-side K/V projections on MFMA (K/V kept in the
-    model dtype), attention streamed over the image keys.  `shared`: one key set [N, C] for all P prompts."""
-    q = at.tok(at.q_proj, ops.add_cast(queries, qpe, torch.float32))
+    model dtype), attention streamed over the image keys.  `shared`: one key set [N, C] for all P prompts.
+    q given: the q projection was made by the fused token kernel; project False: return the attention output [P*T, internal] before the out projection."""
+    if q is None:
+        q = at.tok(at.q_proj, ops.add_cast(queries, qpe, torch.float32))
     if kv_cache is not None and "K0" in kv_cache:
         K, V = kv_cache["K0"], kv_cache["V0"]
     else:
@@ -78,7 +80,12 @@ def _token_to_image(at: Attention, queries, qpe, keys_pe_c, keys_c, P, T, N, dt,
         H, hd, C = at.num_heads, at.hd, at.internal_dim
         kst = (0 if shared else N * C, C, hd)
         a = ops.naive_attention(q, K.float(), V.float(), P, H, H, hd, T, N, (T * C, C, hd), kst, kst, (T * C, C, hd), 1.0 / math.sqrt(hd))
+    if not project:
+        return a
     return at.tok(at.out_proj, a, res=queries)
+
+
+FUSED_TOK = os.environ.get("ULLSAM_FUSED_TOK", "1") != "0"   # bf16: the token side of a block as two launches (csrc/dectok.hip) instead of ~18
 
 
 FUSED_I2T = os.environ.get("ULLSAM_FUSED_I2T", "1") != "0"   # image -> token half of a block as one kernel (bf16, SAM's decoder dimensions, >= 1024 image tokens; whatever the number of prompts, so
@@ -125,6 +132,37 @@ class TwoWayTransformer(Packed):
             keys_c = ops.cast(keys, dt)                  # v of token->image
             if cache is not None:
                 cache["keys_pe_c"], cache["keys_c"] = keys_pe_c, keys_c
+        fused_tok = (FUSED_TOK and dt == torch.bfloat16 and C == 256 and T <= 16 and all(
+            b.self_attn.num_heads == 8 and b.self_attn.internal_dim == 256 and b.cross_attn_token_to_image.internal_dim == 128
+            and b.cross_attn_image_to_token.internal_dim == 128 and b.mlp.lin1.out_features == 2048 and b.mlp.act_code == ops.ACT_RELU for b in self.layers)
+            and self.final_attn_token_to_image.internal_dim == 128)
+        for li, blk in enumerate(self.layers):
+            if not fused_tok:
+                break
+            # ---- the token side as two launches around the token -> image attention (csrc/dectok.hip; same operations, activations rounded to bf16 at each linear's door)
+            queries, q_t = ops.dec_tok_attn(queries, qpe, blk.self_attn, blk.norm1, blk.cross_attn_token_to_image.q_proj, P, T, blk.skip_first_layer_pe)
+            a = _token_to_image(blk.cross_attn_token_to_image, queries, qpe, keys_pe_c, keys_c, P, T, N, dt, shared, kv_cache=cache if (shared and li == 0) else None,
+                                q=q_t, project=False)
+            ia = blk.cross_attn_image_to_token
+            queries, k_i, v_i = ops.dec_tok_mlp(queries, a, qpe, blk.cross_attn_token_to_image.out_proj, blk.norm2, blk.mlp, blk.norm3, ia.k_proj, ia.v_proj, P, T)
+            last = li + 1 == len(self.layers)
+            if FUSED_I2T and ia.num_heads == 8 and N >= 1024 and key_pe.numel() == N * C:
+                keys, keys_c, keys_pe_c = ops.i2t_block(keys_pe_c, keys, ia.q_proj.w(dt), ia.q_proj.b(), k_i, v_i, ia.out_proj.w(dt), ia.out_proj.b(),
+                                                        *blk.norm4.wb(), blk.norm4.eps, key_pe, P, T, N, 1.0 / math.sqrt(ia.hd), shared,
+                                                        want_f32=not (last and keys_in_compute_dtype))
+            else:
+                Qi = ops.gemm(keys_pe_c, ia.q_proj.w(dt), ia.q_proj.b(), out_f32=True)
+                a = ops.fewkeys_attention(Qi, k_i, v_i, P, ia.num_heads, ia.hd, N, T, 1.0 / math.sqrt(ia.hd), q_shared=shared)
+                upd = ops.gemm(ops.cast(a, dt), ia.out_proj.w(dt), ia.out_proj.b(), residual=keys, out_f32=True, res_row_mod=N if shared else 0)
+                keys, keys_c, keys_pe_c = ops.norm_fanout(upd, *blk.norm4.wb(), blk.norm4.eps, dt, key_pe, want_f32=not (last and keys_in_compute_dtype))
+            shared = False
+        if fused_tok:
+            fa = self.final_attn_token_to_image
+            _, q_t = ops.dec_tok_attn(queries, qpe, None, None, fa.q_proj, P, T, False, mode=1)
+            a = _token_to_image(fa, queries, qpe, keys_pe_c, keys_c, P, T, N, dt, shared, q=q_t, project=False)
+            queries = ops.dec_tok_mlp(queries, a, None, fa.out_proj, self.norm_final_attn, None, None, None, None, P, T)
+            out_keys = keys_c if keys_in_compute_dtype else keys
+            return queries.reshape(P, T, C), out_keys.reshape(-1, N, C)
         for li, blk in enumerate(self.layers):
             sa = blk.self_attn
             if blk.skip_first_layer_pe:  # no PE and NO residual (:157-158)

@@ -171,6 +171,57 @@ def i2t_block(xin: torch.Tensor, res: torch.Tensor, wq: torch.Tensor, bq, ktok: 
     return out_f, out_c, out_pe
 
 
+def dec_tok_attn(queries, qpe, sa, norm, q2_lin, P: int, T: int, skip_pe: bool, mode: int = 0):
+    """Fused token-side self-attention half of a two-way block (csrc/dectok.hip): queries / qpe fp32 [P*T, 256]; sa = the block's self-attention module
+    (q / k / v / out projections, bf16), norm = norm1, q2_lin = the token -> image attention's q projection.  -> (queries' fp32 [P*T, 256], q fp32 [P*T, 128]).
+    mode 1: only the q projection of (queries + qpe) (the final attention): -> (queries, q)."""
+    _chk(queries, "queries", torch.float32); _chk(qpe, "qpe", torch.float32)
+    bf = torch.bfloat16
+    q2 = torch.empty((P * T, 128), dtype=torch.float32, device=queries.device)
+    if mode == 1:
+        _lib.call("ullsam_dec_tok_attn", queries.data_ptr(), qpe.data_ptr(), None, q2.data_ptr(), None, None, None, None, None, None, None, None, None, None, 0.0,
+                  q2_lin.w(bf).data_ptr(), _p(q2_lin.b()), P, T, 0, 1, _stream())
+        return queries, q2
+    out = torch.empty_like(queries)
+    lw, lb = norm.wb()
+    _lib.call("ullsam_dec_tok_attn", queries.data_ptr(), qpe.data_ptr(), out.data_ptr(), q2.data_ptr(), sa.q_proj.w(bf).data_ptr(), _p(sa.q_proj.b()),
+              sa.k_proj.w(bf).data_ptr(), _p(sa.k_proj.b()), sa.v_proj.w(bf).data_ptr(), _p(sa.v_proj.b()), sa.out_proj.w(bf).data_ptr(), _p(sa.out_proj.b()),
+              lw.data_ptr(), lb.data_ptr(), float(norm.eps), q2_lin.w(bf).data_ptr(), _p(q2_lin.b()), P, T, int(skip_pe), 0, _stream())
+    return out, q2
+
+
+def dec_tok_mlp(queries, attn, qpe, out_lin, norm2, mlp, norm3, k_lin, v_lin, P: int, T: int):
+    """Fused second half of a block's token side (csrc/dectok.hip): queries fp32 [P*T, 256] (after norm1), attn fp32 [P*T, 128] (token -> image attention output) ->
+    out projection + residual, norm2, MLP + residual, norm3, and the image -> token k / v projections: (queries' [P*T, 256], k [P*T, 128], v [P*T, 128]) fp32.
+    mlp None: out projection + residual + norm2 only (the final attention with norm_final_attn): -> queries'."""
+    _chk(queries, "queries", torch.float32); _chk(attn, "attn", torch.float32)
+    bf = torch.bfloat16
+    out = torch.empty_like(queries)
+    w2, b2 = norm2.wb()
+    if mlp is None:
+        _lib.call("ullsam_dec_tok_mlp", queries.data_ptr(), attn.data_ptr(), None, out.data_ptr(), None, None, out_lin.w(bf).data_ptr(), _p(out_lin.b()), w2.data_ptr(), b2.data_ptr(),
+                  float(norm2.eps), None, None, None, None, None, None, 0.0, None, None, None, None, P, T, 0, _stream())
+        return out
+    _chk(qpe, "qpe", torch.float32)
+    k = torch.empty((P * T, 128), dtype=torch.float32, device=queries.device)
+    v = torch.empty_like(k)
+    w3, b3 = norm3.wb()
+    _lib.call("ullsam_dec_tok_mlp", queries.data_ptr(), attn.data_ptr(), qpe.data_ptr(), out.data_ptr(), k.data_ptr(), v.data_ptr(), out_lin.w(bf).data_ptr(), _p(out_lin.b()),
+              w2.data_ptr(), b2.data_ptr(), float(norm2.eps), mlp.lin1.w(bf).data_ptr(), _p(mlp.lin1.b()), mlp.lin2.w(bf).data_ptr(), _p(mlp.lin2.b()), w3.data_ptr(), b3.data_ptr(),
+              float(norm3.eps), k_lin.w(bf).data_ptr(), _p(k_lin.b()), v_lin.w(bf).data_ptr(), _p(v_lin.b()), P, T, 1, _stream())
+    return out, k, v
+
+
+def dec_heads(hs: torch.Tensor, w_ptrs: torch.Tensor, b_ptrs: torch.Tensor, P: int, T: int, n_iou: int):
+    """The four hypernetwork MLPs + the IoU head in one launch (csrc/dectok.hip): hs fp32 [P, T, 256]; w_ptrs / b_ptrs = HOST int64 tensors of 15 device
+    pointers (chain-major, three layers each; built and kept alive by MaskDecoder).  -> (hyper fp32 [P, 4, 32], iou fp32 [P, n_iou])."""
+    _chk(hs, "hs", torch.float32)
+    hyper = torch.empty((P, 4, 32), dtype=torch.float32, device=hs.device)
+    iou = torch.empty((P, n_iou), dtype=torch.float32, device=hs.device)
+    _lib.call("ullsam_dec_heads", hs.data_ptr(), w_ptrs.data_ptr(), b_ptrs.data_ptr(), hyper.data_ptr(), iou.data_ptr(), P, T, n_iou, _stream())
+    return hyper, iou
+
+
 def vit_attention(qkv: torch.Tensor, rel_h: torch.Tensor, rel_w: torch.Tensor, qkv_bias: torch.Tensor, B: int, heads: int,
                   hd: int, gh: int, gw: int, window: int) -> torch.Tensor:
     _chk(qkv, "qkv"); _chk(rel_h, "rel_h", qkv.dtype); _chk(rel_w, "rel_w", qkv.dtype); _chk(qkv_bias, "qkv_bias", qkv.dtype)
