@@ -233,14 +233,17 @@ int ullsam_i2t_block(const void* xin, long in_mod, const float* res, long res_mo
  *   dec_tok_mlp: y = LayerNorm(queries + attn Wo^T + bo) (norm2; with do_mlp 0 that is all: norm_final_attn); y = LayerNorm(y + W2 relu(W1 y + b1) + b2) (norm3) -> queries_out;
  *     k_out = (y + qpe) Wk^T + bk, v_out = y Wv^T + bv: the k / v of the image -> token attention (:176-178).
  * dec_heads: the four hypernetwork MLPs on tokens 1 .. 4 and the IoU head on token 0 (mask_decoder.py:141-149,154-176; three linears, ReLU between): w / b = HOST arrays
- *   of 15 device pointers (chain-major; a chain's last weight zero-padded to a multiple of 16 rows) -> hyper [P, 4, 32], iou [P, n_iou]. */
+ *   of 15 device pointers (chain-major; a chain's last weight zero-padded to a multiple of 16 rows) -> hyper [P, nm, 32], iou [P, n_iou]. */
 int ullsam_dec_tok_attn(const float* queries, const float* qpe, float* queries_out, float* q_t2i, const void* Wq, const float* bq, const void* Wk, const float* bk,
                         const void* Wv, const float* bv, const void* Wo, const float* bo, const float* ln_w, const float* ln_b, float eps, const void* Wq2,
                         const float* bq2, int P, int T, int skip_pe, int mode, void* stream);
 int ullsam_dec_tok_mlp(const float* queries, const float* attn, const float* qpe, float* queries_out, float* k_out, float* v_out, const void* Wo, const float* bo,
                        const float* ln2_w, const float* ln2_b, float eps2, const void* W1, const float* b1, const void* W2, const float* b2, const float* ln3_w,
                        const float* ln3_b, float eps3, const void* Wk, const float* bk, const void* Wv, const float* bv, int P, int T, int do_mlp, void* stream);
-int ullsam_dec_heads(const float* hs, const void* const* w, const float* const* b, float* hyper, float* iou, int P, int T, int n_iou, void* stream);
+int ullsam_dec_heads(const float* hs, const void* const* w, const float* const* b, float* hyper, float* iou, int P, int T, int n_iou, int m0, int nm, void* stream);
+/* (hypernetwork chains m0 .. m0 + nm - 1 only -> hyper [P, nm, 32]: multimask output asks for masks 1 .. 3, mask_decoder.py:100-105) */
+/* out[p][t] = t < n0 ? prefix[t] : rows[p][t - n0], fp32 rows of C: the decoder's token matrix (mask_decoder.py:119-123) */
+int ullsam_concat_token_rows(const float* prefix, int n0, const float* rows, int n1, float* out, int P, int C, void* stream);
 /* Second transposed convolution + GELU + hypernetwork product in one pass (mask_decoder.py:136-147, bf16): u1 bf16 [NB*H*W*4, 64] (first transposed convolution
  * after LayerNorm2d + GELU), w1 bf16 [128 = (ky2, kx2, c), 64], b1 fp32 [128] | NULL, hyper fp32 [NB, NM <= 8, 32] -> out fp32 [NB, NM, 4H, 4W]; the upscaled
  * embedding is never written. */

@@ -66,7 +66,8 @@ SIGNATURES = {
     "ullsam_up2_hyper_masks": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "ullsam_dec_tok_attn": [vp] * 14 + [f32, vp, vp, i32, i32, i32, i32, vp],
     "ullsam_dec_tok_mlp": [vp] * 10 + [f32] + [vp] * 6 + [f32] + [vp] * 4 + [i32, i32, i32, vp],
-    "ullsam_dec_heads": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "ullsam_dec_heads": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "ullsam_concat_token_rows": [vp, i32, vp, i32, vp, i32, i32, vp],
     "ullsam_up1_ln_gelu": [vp, vp, vp, vp, vp, f32, vp, i64, vp],
     "ullsam_skinny_linear": [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp],
     "ullsam_sparse_embed": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp],

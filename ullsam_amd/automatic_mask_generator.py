@@ -71,18 +71,20 @@ class SamAutomaticMaskGenerator:
         S = sam.image_encoder.img_size
         g = S // sam.image_encoder.patch_size
         ch, cw = crop_box[3] - crop_box[1], crop_box[2] - crop_box[0]
-        pts = torch.from_numpy(points).to(dev).float()
-        scaled = pts * torch.tensor([input_size[1] / cw, input_size[0] / ch], device=dev)  # ResizeLongestSide.apply_coords
-        labels = torch.ones((pts.shape[0], 1), dtype=torch.int32, device=dev)
+        n = points.shape[0]
+        scaled_h = (points.astype(np.float64) * np.array([input_size[1] / cw, input_size[0] / ch])).astype(np.float32)   # ResizeLongestSide.apply_coords, on the host: one upload
+        scaled = torch.from_numpy(np.ascontiguousarray(scaled_h[:, None, :])).to(dev)
+        labels = self._ones_labels(n, dev)
         pe = sam.prompt_encoder
-        sparse = pe.sparse_tokens((scaled[:, None, :].contiguous(), labels), None)
-        dense = pe.dense_tokens(pts.shape[0], None, None)
-        low, iou = sam.mask_decoder.predict_masks_tokens(img_tok, pe.dense_pe_tokens(), sparse, dense, (g, g), image_cache=image_cache)
-        low, iou = low[:, 1:], iou[:, 1:]                              # multimask_output=True (mask_decoder.py:100-105)
-        n, k = iou.shape
-        flat_iou = iou.reshape(-1)
+        sparse = pe.sparse_tokens((scaled, labels), None)
+        dense = pe.dense_tokens(n, None, None)
+        k = sam.mask_decoder.num_mask_tokens - 1
+        low, iou = sam.mask_decoder.predict_masks_tokens(img_tok, pe.dense_pe_tokens(), sparse, dense, (g, g), image_cache=image_cache,
+                                                         mask_range=(1, 1 + k))         # multimask_output=True (mask_decoder.py:100-105): masks 1 .. 3 only are ever produced
         if self.fused_postprocess:
-            return self._finish_batch_fused(low.reshape(n * k, low.shape[-2], low.shape[-1]), flat_iou, pts, k, input_size, crop_box, orig_size)
+            return self._finish_batch_fused(low.reshape(n * k, low.shape[-2], low.shape[-1]), iou, points, k, input_size, crop_box, orig_size)
+        pts = torch.from_numpy(points).to(dev).float()
+        flat_iou = iou.reshape(-1)
         keep = flat_iou > self.pred_iou_thresh
         idx = torch.nonzero(keep).reshape(-1)
         data = A.MaskData(iou_preds=flat_iou[idx], points=pts.repeat_interleave(k, dim=0)[idx])
@@ -109,13 +111,13 @@ class SamAutomaticMaskGenerator:
         data["rles"] = A.mask_to_rle_pytorch(A.uncrop_masks(binm, crop_box, orig_h, orig_w))
         return data
 
-    def _finish_batch_fused(self, low, flat_iou, pts, k, input_size, crop_box, orig_size) -> A.MaskData:
+    def _finish_batch_fused(self, low, iou, points, k, input_size, crop_box, orig_size) -> A.MaskData:
         """The filters of `_process_batch` on host copies of the per-mask scalars, after one fused device pass over all maps."""
         sam = self.model
         dev = low.device
         pp = A.postprocess_low_res(low, sam.image_encoder.img_size, input_size, crop_box, orig_size, sam.mask_threshold,
                                    self.stability_score_offset)
-        iou_h = flat_iou.float().cpu().numpy()
+        iou_h = iou.float().cpu().numpy().reshape(-1)
         keep = (iou_h > np.float32(self.pred_iou_thresh)) & (pp.stability_score >= np.float32(self.stability_score_thresh))
         sel = np.nonzero(keep)[0]
         boxes = pp.boxes[sel]
@@ -126,12 +128,18 @@ class SamAutomaticMaskGenerator:
             near_image = np.abs(b - np.asarray([0, 0, orig_w, orig_h], np.float32)[None, :]) <= 20.0
             ok = ~np.logical_and(near_crop, ~near_image).any(axis=1)
             sel, boxes = sel[ok], boxes[ok]
-        sel_d = torch.from_numpy(sel).to(dev)
-        data = A.MaskData(iou_preds=flat_iou[sel_d], points=pts.repeat_interleave(k, dim=0)[sel_d],
-                          stability_score=torch.from_numpy(pp.stability_score[sel]).to(dev),
-                          boxes=torch.from_numpy(boxes.reshape(-1, 4)).to(dev))
+        # the batch's survivors stay HOST arrays (a few records): they are moved to the device once per crop, for the box NMS (per batch that was ~10 small launches and copies)
+        data = A.MaskData(iou_preds=iou_h[sel].astype(np.float32), points=np.repeat(points.astype(np.float32), k, axis=0)[sel],
+                          stability_score=pp.stability_score[sel].astype(np.float32), boxes=boxes.reshape(-1, 4).astype(np.int64))
         data["rles"] = pp.rles(sel, as_list=False) if len(sel) else []
         return data
+
+    def _ones_labels(self, n: int, dev) -> torch.Tensor:
+        c = getattr(self, "_labels_cache", None)
+        if c is None or c.shape[0] != n or c.device != torch.device(dev):
+            c = torch.ones((n, 1), dtype=torch.int32, device=dev)
+            self._labels_cache = c
+        return c
 
     def postprocess_small_regions(self, data: A.MaskData, min_area: int, nms_thresh: float) -> A.MaskData:
         """Remove small islands / fill small holes of every mask, then re-run box NMS preferring masks that needed no change
@@ -166,6 +174,10 @@ class SamAutomaticMaskGenerator:
         image_cache = {} if getattr(self, "reuse_image_side", True) else None      # what the decoder computes from the crop's embedding alone (keys = embedding + dense prompt, their model-dtype copies, layer 0's K / V): once per crop, not per point batch
         for (p,) in A.batch_iterator(self.points_per_batch, pts):
             data.cat(self._process_batch(p, img_tok, input_size, crop_box, orig_size, image_cache), deep=False)
+        dev = img_tok.device
+        for key in ("iou_preds", "points", "stability_score", "boxes"):      # the fused path collects host arrays: to the device once per crop
+            if key in data._stats and isinstance(data[key], np.ndarray):
+                data[key] = torch.from_numpy(data[key]).to(dev)
         if len(data["rles"]):
             keep = A.batched_nms(data["boxes"].float(), data["iou_preds"], torch.zeros_like(data["boxes"][:, 0]), self.box_nms_thresh)
             data.filter(keep)

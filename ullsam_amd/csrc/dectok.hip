@@ -285,13 +285,14 @@ __global__ __launch_bounds__(64 * NWV) void dec_tok_mlp_kernel(TokMlpArgs p) {
 struct HeadArgs {
     const float* hs;                     // [P, T, 256] decoder output tokens
     const bf16* W[5][3]; const float* b[5][3];
-    float* hyper; float* iou;            // [P, 4, 32], [P, n_iou]
-    int P, T, n_iou;
+    float* hyper; float* iou;            // [P, nm, 32] (hypernetwork chains m0 .. m0 + nm - 1), [P, n_iou]
+    int P, T, n_iou, m0, nm;
 };
 __global__ __launch_bounds__(64 * NWV) void dec_heads_kernel(HeadArgs p) {
     __shared__ __attribute__((aligned(16))) bf16 x0[16 * CP], x0_lo[16 * CP], x1[16 * CP], x1_lo[16 * CP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, chain = blockIdx.x % 5, pb = blockIdx.x / 5;
     const int m = lane & 15, g = lane >> 4, tok = chain < 4 ? 1 + chain : 0;
+    if (chain < 4 && (chain < p.m0 || chain >= p.m0 + p.nm)) return;      // a mask the caller does not ask for (multimask output: masks 1 .. 3)
     for (int e = tid; e < 16 * C / 4; e += 64 * NWV) {
         const int r = e / (C / 4), c = 4 * (e % (C / 4)), prompt = pb * 16 + r;
         const float4 v = prompt < p.P ? *reinterpret_cast<const float4*>(p.hs + ((size_t)prompt * p.T + tok) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -319,11 +320,24 @@ __global__ __launch_bounds__(64 * NWV) void dec_heads_kernel(HeadArgs p) {
             const int f = 16 * tile + 4 * g + i;
             if (f < nout) {
                 const float v = acc[i] + (bias ? bias[f] : 0.f);
-                if (chain < 4) p.hyper[((size_t)prompt * 4 + chain) * 32 + f] = v;
+                if (chain < 4) p.hyper[((size_t)prompt * p.nm + (chain - p.m0)) * 32 + f] = v;
                 else p.iou[(size_t)prompt * p.n_iou + f] = v;
             }
         }
     });
+}
+
+// out[p][t] = t < n0 ? prefix[t] : rows[p][t - n0]: the decoder's token matrix [iou token, mask tokens, sparse prompt embeddings] (mask_decoder.py:119-123)
+__global__ __launch_bounds__(256) void concat_token_rows_kernel(const float* __restrict__ prefix, int n0, const float* __restrict__ rows, int n1, float* __restrict__ out, int P, int Cc) {
+    const long total = (long)P * (n0 + n1) * (Cc / 4);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % (Cc / 4));
+        const long r = e / (Cc / 4);
+        const int t = (int)(r % (n0 + n1));
+        const long pp = r / (n0 + n1);
+        reinterpret_cast<float4*>(out)[e] = t < n0 ? reinterpret_cast<const float4*>(prefix)[(long)t * (Cc / 4) + c4]
+                                                   : reinterpret_cast<const float4*>(rows)[(pp * n1 + (t - n0)) * (Cc / 4) + c4];
+    }
 }
 
 }  // namespace
@@ -361,10 +375,10 @@ extern "C" int ullsam_dec_tok_mlp(const float* queries, const float* attn, const
 
 // w[15] / b[15]: chain-major (hypernetwork MLP 0 .. 3, then the IoU head), three layers each; the LAST layer's weight of every chain has >= 16 * ceil(n_out / 16) rows
 // (zero padded by the caller: 32 rows for the hypernetworks, 16 for the IoU head).
-extern "C" int ullsam_dec_heads(const float* hs, const void* const* w, const float* const* b, float* hyper, float* iou, int P, int T, int n_iou, void* stream) {
-    ULLSAM_CHECK(P > 0 && T >= 5 && n_iou >= 1 && n_iou <= 16 && hs && w && b && hyper && iou, "dec_heads: P=%d T=%d n_iou=%d", P, T, n_iou);
+extern "C" int ullsam_dec_heads(const float* hs, const void* const* w, const float* const* b, float* hyper, float* iou, int P, int T, int n_iou, int m0, int nm, void* stream) {
+    ULLSAM_CHECK(P > 0 && T >= 5 && n_iou >= 1 && n_iou <= 16 && hs && w && b && hyper && iou && m0 >= 0 && nm >= 1 && m0 + nm <= 4, "dec_heads: P=%d T=%d n_iou=%d masks %d..+%d", P, T, n_iou, m0, nm);
     HeadArgs a;
-    a.hs = hs; a.hyper = hyper; a.iou = iou; a.P = P; a.T = T; a.n_iou = n_iou;
+    a.hs = hs; a.hyper = hyper; a.iou = iou; a.P = P; a.T = T; a.n_iou = n_iou; a.m0 = m0; a.nm = nm;
     for (int c = 0; c < 5; ++c)
         for (int l = 0; l < 3; ++l) {
             a.W[c][l] = (const bf16*)w[c * 3 + l];
@@ -372,6 +386,16 @@ extern "C" int ullsam_dec_heads(const float* hs, const void* const* w, const flo
             ULLSAM_CHECK(a.W[c][l] && AL16(a.W[c][l]), "dec_heads: weight %d.%d null / unaligned", c, l);
         }
     dec_heads_kernel<<<dim3(5 * ((P + 15) / 16)), 64 * NWV, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ullsam_concat_token_rows(const float* prefix, int n0, const float* rows, int n1, float* out, int P, int C, void* stream) {
+    ULLSAM_CHECK(P > 0 && n0 >= 0 && n1 >= 0 && n0 + n1 > 0 && C > 0 && C % 4 == 0 && out && (n0 == 0 || prefix) && (n1 == 0 || rows), "concat_token_rows: P=%d n0=%d n1=%d C=%d", P, n0, n1, C);
+    ULLSAM_CHECK(AL16(prefix) && AL16(rows) && AL16(out), "concat_token_rows: 16-byte aligned operands needed");
+    const long total = (long)P * (n0 + n1) * (C / 4);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    concat_token_rows_kernel<<<blocks, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(prefix, n0, rows, n1, out, P, C);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }

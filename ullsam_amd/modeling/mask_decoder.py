@@ -76,16 +76,19 @@ class MaskDecoder(Packed):
 
     # -- token-major internals ----------------------------------------------------------------------
     def predict_masks_tokens(self, image_tokens: torch.Tensor, pe_tokens: torch.Tensor, sparse: torch.Tensor,
-                             dense_tokens: torch.Tensor, hw: Tuple[int, int], image_cache: Optional[dict] = None):
+                             dense_tokens: torch.Tensor, hw: Tuple[int, int], image_cache: Optional[dict] = None,
+                             mask_range: Optional[Tuple[int, int]] = None):
         """image_tokens fp32 [1 or P, N, C]; pe_tokens [N, C]; sparse fp32 [P, n, C]; dense_tokens fp32 [P|1, N|1, C].
-        Returns (masks [P, 4, 4h, 4w] fp32, iou [P, 4] fp32) -- predict_masks, mask_decoder.py:112-149."""
+        Returns (masks [P, 4, 4h, 4w] fp32, iou [P, 4] fp32) -- predict_masks, mask_decoder.py:112-149.
+        mask_range (m0, m1): only masks m0 .. m1 - 1 and their IoU predictions are produced (forward's multimask slice, :100-105, taken BEFORE the hypernetwork product
+        and the second upscaling instead of after them: the automatic mask generator keeps masks 1 .. 3 of every prompt)."""
         h, w = hw
         N, C = h * w, self.transformer_dim
         P = sparse.shape[0]
         dt = self.transformer.compute_dtype
         out_tok = self.pk("out_tokens", (self.iou_token.weight, self.mask_tokens.weight),
                           lambda: torch.cat([self.iou_token.weight.detach().float(), self.mask_tokens.weight.detach().float()], 0))
-        tokens = torch.cat([out_tok.unsqueeze(0).expand(P, -1, -1), sparse.float()], dim=1).contiguous()
+        tokens = ops.concat_token_rows(out_tok, sparse.float().contiguous())   # [iou token, mask tokens, sparse prompts] per prompt (:119-123), one launch
         # src = repeat_interleave(image_embeddings, P) + dense  (:126-127); row-modular broadcast of both operands
         dense_rows = dense_tokens.numel() // C
         Pk = 1 if (image_tokens.shape[0] == 1 and dense_rows in (1, N)) else P   # one image, prompt-independent dense embedding
@@ -108,7 +111,8 @@ class MaskDecoder(Packed):
             if cache is not None:
                 cache["keys"] = keys
         hs, src = self.transformer.forward_tokens(keys.reshape(Pk, N, C), pe_tokens, tokens, keys_in_compute_dtype=True, cache=cache)
-        nm = self.num_mask_tokens
+        m0, m1 = mask_range if mask_range is not None else (0, self.num_mask_tokens)
+        nm = m1 - m0
         up0, ln, up1 = self.output_upscaling[0], self.output_upscaling[1], self.output_upscaling[3]
         w0, b0 = up0.packed(dt)
         w1, b1 = up1.packed(dt)
@@ -120,16 +124,16 @@ class MaskDecoder(Packed):
             u1 = ops.norm(u1.reshape(P * N * 4, c4), *ln.wb(), ln.eps, dt, act=ops.ACT_GELU)   # LayerNorm2d + GELU per output pixel
         heads = self._fused_heads(dt, T_all=hs.shape[1]) if (FUSED_HEADS and dt == torch.bfloat16) else None
         if heads is not None:                                                # the four hypernetwork MLPs + the IoU head: 15 token-side linears, one launch
-            hyper, iou_all = ops.dec_heads(hs.contiguous(), heads[0], heads[1], P, hs.shape[1], nm)
+            hyper, iou_all = ops.dec_heads(hs.contiguous(), heads[0], heads[1], P, hs.shape[1], self.num_mask_tokens, m0, nm)
         else:
-            hyper = torch.stack([self.output_hypernetworks_mlps[i](hs[:, 1 + i, :]) for i in range(nm)], dim=1).contiguous()
+            hyper = torch.stack([self.output_hypernetworks_mlps[i](hs[:, 1 + i, :]) for i in range(m0, m1)], dim=1).contiguous()
         if FUSED_UP2 and dt == torch.bfloat16 and c4 == 64 and c8 == 32 and nm <= 8:
             masks = ops.up2_hyper_masks(u1, w1, b1, hyper, P, nm, h, w)      # second transposed convolution + GELU + hypernetwork product: the upscaled embedding is never written
         else:
             u2 = ops.gemm(u1, w1, b1, act=ops.ACT_GELU)                      # [P*N*4, (ky2,kx2,c8)]
             masks = ops.hyper_masks(u2, hyper, P, nm, h, w, c8)
         iou = iou_all if heads is not None else self.iou_prediction_head(hs[:, 0, :])
-        return masks, iou
+        return masks, (iou if mask_range is None else iou[:, m0:m1])
 
     def _fused_heads(self, dt, T_all: int):
         """Host arrays of the 15 weight / bias device pointers ullsam_dec_heads takes (chain-major: hypernetwork MLP 0 .. 3, IoU head), or None when the heads

@@ -212,14 +212,23 @@ def dec_tok_mlp(queries, attn, qpe, out_lin, norm2, mlp, norm3, k_lin, v_lin, P:
     return out, k, v
 
 
-def dec_heads(hs: torch.Tensor, w_ptrs: torch.Tensor, b_ptrs: torch.Tensor, P: int, T: int, n_iou: int):
-    """The four hypernetwork MLPs + the IoU head in one launch (csrc/dectok.hip): hs fp32 [P, T, 256]; w_ptrs / b_ptrs = HOST int64 tensors of 15 device
-    pointers (chain-major, three layers each; built and kept alive by MaskDecoder).  -> (hyper fp32 [P, 4, 32], iou fp32 [P, n_iou])."""
+def dec_heads(hs: torch.Tensor, w_ptrs: torch.Tensor, b_ptrs: torch.Tensor, P: int, T: int, n_iou: int, m0: int = 0, nm: int = 4):
+    """The hypernetwork MLPs of masks m0 .. m0 + nm - 1 + the IoU head in one launch (csrc/dectok.hip): hs fp32 [P, T, 256]; w_ptrs / b_ptrs = HOST int64
+    tensors of 15 device pointers (chain-major, three layers each; built and kept alive by MaskDecoder).  -> (hyper fp32 [P, nm, 32], iou fp32 [P, n_iou])."""
     _chk(hs, "hs", torch.float32)
-    hyper = torch.empty((P, 4, 32), dtype=torch.float32, device=hs.device)
+    hyper = torch.empty((P, nm, 32), dtype=torch.float32, device=hs.device)
     iou = torch.empty((P, n_iou), dtype=torch.float32, device=hs.device)
-    _lib.call("ullsam_dec_heads", hs.data_ptr(), w_ptrs.data_ptr(), b_ptrs.data_ptr(), hyper.data_ptr(), iou.data_ptr(), P, T, n_iou, _stream())
+    _lib.call("ullsam_dec_heads", hs.data_ptr(), w_ptrs.data_ptr(), b_ptrs.data_ptr(), hyper.data_ptr(), iou.data_ptr(), P, T, n_iou, m0, nm, _stream())
     return hyper, iou
+
+
+def concat_token_rows(prefix: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+    """[n0, C] fp32 shared rows in front of [P, n1, C] fp32 per-prompt rows -> [P, n0 + n1, C]: the decoder's token matrix in one launch."""
+    _chk(prefix, "prefix", torch.float32); _chk(rows, "rows", torch.float32)
+    P, n1, C = rows.shape
+    out = torch.empty((P, prefix.shape[0] + n1, C), dtype=torch.float32, device=rows.device)
+    _lib.call("ullsam_concat_token_rows", prefix.data_ptr(), prefix.shape[0], rows.data_ptr() if n1 else None, n1, out.data_ptr(), P, C, _stream())
+    return out
 
 
 def vit_attention(qkv: torch.Tensor, rel_h: torch.Tensor, rel_w: torch.Tensor, qkv_bias: torch.Tensor, B: int, heads: int,

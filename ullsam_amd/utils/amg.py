@@ -317,11 +317,15 @@ class PostprocessedMasks:
     """Result of `postprocess_low_res`: per low-res map the stability counts, the box (crop coordinates), and the RLE change words
     of the mask placed in the full frame; `rles(select)` finishes the RLE of the chosen maps."""
 
-    def __init__(self, words, rle_counts, first, boxes, stab, frame):
+    def __init__(self, words, scalars, frame):
+        """scalars: ONE int32 device buffer [8, M] = rle_counts | first (bytes in its first M) | boxes [M, 4] | stability counts [M, 2]: one device -> host copy per batch."""
         self.words, self.frame = words, frame
-        self.rle_counts, self.first = rle_counts.cpu().numpy(), first.cpu().numpy()
-        self.boxes = boxes.cpu().numpy().astype(np.int64)
-        st = stab.cpu().numpy().view(np.int32)
+        M = words.shape[0]
+        h = scalars.cpu().numpy()
+        self.rle_counts = h[0][:M].copy()
+        self.first = h[1].view(np.uint8)[:M].copy()
+        self.boxes = h[2:6].reshape(-1)[:4 * M].reshape(M, 4).astype(np.int64)
+        st = h[6:8].reshape(-1)[:2 * M].reshape(M, 2)
         with np.errstate(divide="ignore", invalid="ignore"):  # int32 / int32 true division -> fp32, as calculate_stability_score
             self.stability_score = st[:, 0].astype(np.float32) / st[:, 1].astype(np.float32)
 
@@ -335,20 +339,18 @@ def postprocess_low_res(low: torch.Tensor, img_size: int, input_size, crop_box, 
     """Generator fast path over low-res logits [M, h, w]: Sam.postprocess_masks (sam.py:154-162) + calculate_stability_score +
     batched_mask_to_box + mask_to_rle_pytorch(uncrop_masks(...)) fused in one kernel; the full-resolution logits and masks are never
     written.  Equivalent to calling those helpers one after the other (same arithmetic per pixel)."""
-    low = _chk(low.float().contiguous(), "low_res_masks", torch.float32)
+    low = _chk(low if (low.dtype == torch.float32 and low.is_contiguous()) else low.float().contiguous(), "low_res_masks", torch.float32)
     M, lh, lw = low.shape
     x0, y0, x1, y1 = (int(v) for v in crop_box)
     fh, fw = int(orig_size[0]), int(orig_size[1])
     dev = low.device
     words = torch.empty((M, (fh + 63) // 64, fw), dtype=torch.int64, device=dev)
-    rle_counts = torch.empty((M,), dtype=torch.int32, device=dev)
-    first = torch.empty((M,), dtype=torch.uint8, device=dev)
-    boxes = torch.empty((M, 4), dtype=torch.int32, device=dev)
-    stab = torch.empty((M, 2), dtype=torch.int32, device=dev)
+    sc = torch.empty((8, -(-M // 4) * 4), dtype=torch.int32, device=dev)   # rle_counts | first | boxes | stability counts: one buffer (rows 16-byte aligned), one copy back
+    rle_counts, first, boxes, stab = sc[0], sc[1], sc[2:6], sc[6:8]
     _lib.call("ullsam_amg_postprocess", low.data_ptr(), None, M, lh, lw, int(img_size), int(input_size[0]), int(input_size[1]),
               y1 - y0, x1 - x0, fh, fw, x0, y0, float(mask_threshold), float(threshold_offset), words.data_ptr(),
               rle_counts.data_ptr(), first.data_ptr(), boxes.data_ptr(), stab.data_ptr(), _stream())
-    return PostprocessedMasks(words, rle_counts, first, boxes, stab, (fh, fw))
+    return PostprocessedMasks(words, sc, (fh, fw))
 
 
 def box_nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
