@@ -9,7 +9,7 @@
 //                          ReLU, -> 256) + residual, norm3, and the k (of y + pe) / v (of y) projections the image -> token attention needs.
 //   ullsam_dec_heads     : the four hypernetwork MLPs on the mask tokens and the IoU head on the IoU token (mask_decoder.py:141-149,154-176): 15 linears, one launch.
 //
-// One workgroup (8 waves) per prompt.  A linear is Y^T = W X^T on v_mfma_f32_16x16x32_bf16: W's rows (output features) are the A operand, read straight from global
+// One workgroup (8 waves) per prompt.  A linear is Y^T = W X^T on v_mfma_f32_16x16x32_bf16: W's rows (output features, packed in fragment order) are the A operand, read straight from global
 // memory (L2-resident: every prompt's workgroup streams the same 0.6 - 2.2 MB), the prompt's <= 16 token rows the B operand from LDS -- as TWO bf16 terms (x = hi + lo,
 // ~17 bits: two MFMAs per weight fragment), so that the token side keeps the accuracy the fp32 launches had (one term, autocast's rounding, cost 0.003 of mask IoU
 // on the hard tiles of the full-depth fixture); a lane ends up with 4 consecutive features of one token.  fp32 accumulation, fp32 bias / residual / LayerNorm / softmax.  Weight fragments run through a double-buffered chunk of 8 per wave (64 KB in flight per CU covers the L2 latency at 8 waves).
@@ -22,8 +22,11 @@ constexpr int C = 256, CP = C + 8;      // embedding; LDS row pitch of a bf16 ac
 constexpr int NWV = 8;                  // waves per workgroup
 
 // Y^T tile loop: ntiles row tiles (16 output features each) of W [ntiles * 16, K] over the NWV waves; x = LDS bf16 [16][K + 8]; epi(tile, acc): acc[i] = y[token lane & 15][feature 16 tile + 4 (lane >> 4) + i]
-template <int K, bool LO, typename Epi, int LDW = K>   // LDW: row stride of W in elements (a K-slice of a wider matrix)
-__device__ __forceinline__ void lin_tiles(const bf16* __restrict__ W, int ntiles, const bf16* x, const bf16* xlo, int wave, int lane, Epi epi) {
+// W is given in FRAGMENT order (packed once per weight version by the host, ops.pack_mfma_rows): [row tile][k-step of 32][lane][8 elements], i.e. the 16 bytes lane l of the
+// A operand needs for (tile, k-step) sit at ((tile * KST + ks) * 64 + l) * 16 -- a wave's load is ONE contiguous KiB (with W as stored, [out, in], it was sixteen 64-byte
+// pieces of sixteen rows: the kernels ran 3 - 4x over their weight-traffic estimate).  KST = k-steps per packed row tile (in / 32); ks0 = first k-step of a K-slice.
+template <int K, bool LO, typename Epi, int KST = K / 32>
+__device__ __forceinline__ void lin_tiles(const bf16* __restrict__ W, int ntiles, const bf16* x, const bf16* xlo, int wave, int lane, Epi epi, int ks0 = 0) {
     constexpr int KS = K / 32, CH = KS < 8 ? KS : 8, NCH = KS / CH;
     static_assert(KS % CH == 0, "K must be a multiple of 256 (or < 256 and a multiple of 32)");
     const int m = lane & 15, g = lane >> 4;
@@ -35,9 +38,9 @@ __device__ __forceinline__ void lin_tiles(const bf16* __restrict__ W, int ntiles
     Frag<bf16> a[2][CH];
     auto fetch = [&](Frag<bf16> (&buf)[CH], int s) __attribute__((always_inline)) {
         const int tile = wave + NWV * (s / NCH), c0 = (s % NCH) * CH;
-        const bf16* wr = W + (size_t)(tile * 16 + m) * LDW + 8 * g + 32 * c0;
+        const bf16* wr = W + ((size_t)(tile * KST + ks0 + c0) * 64 + lane) * 8;
 #pragma unroll
-        for (int j = 0; j < CH; ++j) buf[j] = load_frag(wr + 32 * j);
+        for (int j = 0; j < CH; ++j) buf[j] = load_frag(wr + (size_t)j * 512);
     };
     auto run = [&](const Frag<bf16> (&buf)[CH], int s, f32x4& acc) __attribute__((always_inline)) {
         const int c0 = (s % NCH) * CH;
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(64 * NWV) void dec_tok_mlp_kernel(TokMlpArgs p) {
     __syncthreads();
     // the MLP in two halves of the hidden dimension: 1024 hidden units at a time as two bf16 terms (both halves' lin2 sums meet in yf)
     for (int half = 0; half < 2; ++half) {
-        lin_tiles<C, true>(p.W1 + (size_t)half * HH * C, HH / 16, xa, xa_lo, wave, lane, [=](int tile, const f32x4& acc) {      // lin1 + ReLU -> hidden (hi, lo)
+        lin_tiles<C, true>(p.W1 + (size_t)half * (HH / 16) * (C / 32) * 512, HH / 16, xa, xa_lo, wave, lane, [=](int tile, const f32x4& acc) {      // lin1 + ReLU -> hidden (hi, lo)
             const int f = 16 * tile + 4 * g;
             const float* bb = p.b1 ? p.b1 + half * HH + f : nullptr;
             st_split4(hid + m * HHP + f, hid_lo + m * HHP + f, fmaxf(acc[0] + (bb ? bb[0] : 0.f), 0.f), fmaxf(acc[1] + (bb ? bb[1] : 0.f), 0.f), fmaxf(acc[2] + (bb ? bb[2] : 0.f), 0.f),
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(64 * NWV) void dec_tok_mlp_kernel(TokMlpArgs p) {
             if (!half && p.b2) { r.x += p.b2[f]; r.y += p.b2[f + 1]; r.z += p.b2[f + 2]; r.w += p.b2[f + 3]; }
             *reinterpret_cast<float4*>(yf + m * C + f) = make_float4(acc[0] + r.x, acc[1] + r.y, acc[2] + r.z, acc[3] + r.w);
         };
-        lin_tiles<HH, true, decltype(epi2), HID>(p.W2 + (size_t)half * HH, C / 16, hid, hid_lo, wave, lane, epi2);
+        lin_tiles<HH, true, decltype(epi2), HID / 32>(p.W2, C / 16, hid, hid_lo, wave, lane, epi2, half * (HH / 32));
         __syncthreads();
     }
     for (int e = tid; e < 2 * 16 * CP / 8; e += 64 * NWV) reinterpret_cast<uint4*>(xb)[e] = make_uint4(0u, 0u, 0u, 0u);

@@ -149,9 +149,7 @@ class MaskDecoder(Packed):
         ws, bs, keep = [], [], []
         for ci, m in enumerate(chains):
             for li, l in enumerate(m.layers):
-                w = l.w(dt)
-                if li == 2 and w.shape[0] % 16:
-                    w = l.pk("w:pad16", l.weight, lambda l=l: torch.cat([l.weight.detach().to(dt), torch.zeros((-l.weight.shape[0]) % 16, l.weight.shape[1], dtype=dt, device=l.weight.device)], 0).contiguous())
+                w = l.pk("w:mfma_rows", l.weight, lambda l=l: ops.pack_mfma_rows(l.weight))    # fragment order, zero-padded to a multiple of 16 rows
                 b = l.b()
                 keep += [w, b]
                 ws.append(w.data_ptr())

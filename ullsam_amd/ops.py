@@ -171,6 +171,22 @@ def i2t_block(xin: torch.Tensor, res: torch.Tensor, wq: torch.Tensor, bq, ktok: 
     return out_f, out_c, out_pe
 
 
+def pack_mfma_rows(w: torch.Tensor) -> torch.Tensor:
+    """nn.Linear weight [out, in] (out padded to a multiple of 16 with zero rows; in % 32 == 0) -> bf16 in MFMA A-fragment order [out / 16][in / 32][lane = 16 g + m][8]:
+    lane (m, g) of row tile t and k-step s holds w[16 t + m][32 s + 8 g .. + 7], and a wave's fragment load is one contiguous KiB (csrc/dectok.hip lin_tiles).
+    A re-layout (reshape / permute / copy), done once per weight version by the callers' pack caches."""
+    o, i = w.shape
+    assert i % 32 == 0
+    w = w.detach().to(torch.bfloat16)
+    if o % 16:
+        w = torch.cat([w, torch.zeros(((-o) % 16, i), dtype=w.dtype, device=w.device)], 0)
+    return w.reshape(-1, 16, i // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def _fw(lin) -> torch.Tensor:
+    return lin.pk("w:mfma_rows", lin.weight, lambda: pack_mfma_rows(lin.weight))
+
+
 def dec_tok_attn(queries, qpe, sa, norm, q2_lin, P: int, T: int, skip_pe: bool, mode: int = 0):
     """Fused token-side self-attention half of a two-way block (csrc/dectok.hip): queries / qpe fp32 [P*T, 256]; sa = the block's self-attention module
     (q / k / v / out projections, bf16), norm = norm1, q2_lin = the token -> image attention's q projection.  -> (queries' fp32 [P*T, 256], q fp32 [P*T, 128]).
@@ -180,13 +196,13 @@ def dec_tok_attn(queries, qpe, sa, norm, q2_lin, P: int, T: int, skip_pe: bool, 
     q2 = torch.empty((P * T, 128), dtype=torch.float32, device=queries.device)
     if mode == 1:
         _lib.call("ullsam_dec_tok_attn", queries.data_ptr(), qpe.data_ptr(), None, q2.data_ptr(), None, None, None, None, None, None, None, None, None, None, 0.0,
-                  q2_lin.w(bf).data_ptr(), _p(q2_lin.b()), P, T, 0, 1, _stream())
+                  _fw(q2_lin).data_ptr(), _p(q2_lin.b()), P, T, 0, 1, _stream())
         return queries, q2
     out = torch.empty_like(queries)
     lw, lb = norm.wb()
-    _lib.call("ullsam_dec_tok_attn", queries.data_ptr(), qpe.data_ptr(), out.data_ptr(), q2.data_ptr(), sa.q_proj.w(bf).data_ptr(), _p(sa.q_proj.b()),
-              sa.k_proj.w(bf).data_ptr(), _p(sa.k_proj.b()), sa.v_proj.w(bf).data_ptr(), _p(sa.v_proj.b()), sa.out_proj.w(bf).data_ptr(), _p(sa.out_proj.b()),
-              lw.data_ptr(), lb.data_ptr(), float(norm.eps), q2_lin.w(bf).data_ptr(), _p(q2_lin.b()), P, T, int(skip_pe), 0, _stream())
+    _lib.call("ullsam_dec_tok_attn", queries.data_ptr(), qpe.data_ptr(), out.data_ptr(), q2.data_ptr(), _fw(sa.q_proj).data_ptr(), _p(sa.q_proj.b()),
+              _fw(sa.k_proj).data_ptr(), _p(sa.k_proj.b()), _fw(sa.v_proj).data_ptr(), _p(sa.v_proj.b()), _fw(sa.out_proj).data_ptr(), _p(sa.out_proj.b()),
+              lw.data_ptr(), lb.data_ptr(), float(norm.eps), _fw(q2_lin).data_ptr(), _p(q2_lin.b()), P, T, int(skip_pe), 0, _stream())
     return out, q2
 
 
@@ -199,16 +215,16 @@ def dec_tok_mlp(queries, attn, qpe, out_lin, norm2, mlp, norm3, k_lin, v_lin, P:
     out = torch.empty_like(queries)
     w2, b2 = norm2.wb()
     if mlp is None:
-        _lib.call("ullsam_dec_tok_mlp", queries.data_ptr(), attn.data_ptr(), None, out.data_ptr(), None, None, out_lin.w(bf).data_ptr(), _p(out_lin.b()), w2.data_ptr(), b2.data_ptr(),
+        _lib.call("ullsam_dec_tok_mlp", queries.data_ptr(), attn.data_ptr(), None, out.data_ptr(), None, None, _fw(out_lin).data_ptr(), _p(out_lin.b()), w2.data_ptr(), b2.data_ptr(),
                   float(norm2.eps), None, None, None, None, None, None, 0.0, None, None, None, None, P, T, 0, _stream())
         return out
     _chk(qpe, "qpe", torch.float32)
     k = torch.empty((P * T, 128), dtype=torch.float32, device=queries.device)
     v = torch.empty_like(k)
     w3, b3 = norm3.wb()
-    _lib.call("ullsam_dec_tok_mlp", queries.data_ptr(), attn.data_ptr(), qpe.data_ptr(), out.data_ptr(), k.data_ptr(), v.data_ptr(), out_lin.w(bf).data_ptr(), _p(out_lin.b()),
-              w2.data_ptr(), b2.data_ptr(), float(norm2.eps), mlp.lin1.w(bf).data_ptr(), _p(mlp.lin1.b()), mlp.lin2.w(bf).data_ptr(), _p(mlp.lin2.b()), w3.data_ptr(), b3.data_ptr(),
-              float(norm3.eps), k_lin.w(bf).data_ptr(), _p(k_lin.b()), v_lin.w(bf).data_ptr(), _p(v_lin.b()), P, T, 1, _stream())
+    _lib.call("ullsam_dec_tok_mlp", queries.data_ptr(), attn.data_ptr(), qpe.data_ptr(), out.data_ptr(), k.data_ptr(), v.data_ptr(), _fw(out_lin).data_ptr(), _p(out_lin.b()),
+              w2.data_ptr(), b2.data_ptr(), float(norm2.eps), _fw(mlp.lin1).data_ptr(), _p(mlp.lin1.b()), _fw(mlp.lin2).data_ptr(), _p(mlp.lin2.b()), w3.data_ptr(), b3.data_ptr(),
+              float(norm3.eps), _fw(k_lin).data_ptr(), _p(k_lin.b()), _fw(v_lin).data_ptr(), _p(v_lin.b()), P, T, 1, _stream())
     return out, k, v
 
 
