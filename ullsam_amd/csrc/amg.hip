@@ -199,18 +199,20 @@ __global__ __launch_bounds__(256) void rle_pack_kernel(const unsigned char* __re
     if (lane == 0 && cnt) atomicAdd(&counts[n], cnt);
 }
 
-// One workgroup per mask: ordered emission of the change positions from the change words (see rle_pack_kernel).
-__global__ __launch_bounds__(256) void rle_emit_kernel(const unsigned long long* __restrict__ words, int H, int W, int nyb,
-                                                       const int* __restrict__ select, const long* __restrict__ offsets,
-                                                       int* __restrict__ out) {
-    __shared__ int wsum[2][4];
+// One workgroup per mask: ordered emission of the change positions from the change words (see rle_pack_kernel).  1024 threads x 4 words per trip (a 2048^2
+// mask is 65536 words = 16 trips of scan + barrier; with 256 threads it was 64 trips and 83 us for the couple of masks an AMG batch keeps: latency, not bytes).
+constexpr int EMIT_NT = 1024, EMIT_NW = EMIT_NT / 64;
+__global__ __launch_bounds__(EMIT_NT) void rle_emit_kernel(const unsigned long long* __restrict__ words, int H, int W, int nyb,
+                                                           const int* __restrict__ select, const long* __restrict__ offsets,
+                                                           int* __restrict__ out) {
+    __shared__ int wsum[2][EMIT_NW];
     const long n = select ? select[blockIdx.x] : blockIdx.x;
     const unsigned long long* wp = words + n * (long)nyb * W;
     int* dst = out + offsets[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long total = (long)W * nyb;
     int base = 0, par = 0;
-    for (long c0 = 0; c0 < total; c0 += 1024, par ^= 1) {
+    for (long c0 = 0; c0 < total; c0 += 4 * EMIT_NT, par ^= 1) {
         unsigned long long wq[4];
         int fq[4];
         int cnt = 0;
@@ -229,9 +231,13 @@ __global__ __launch_bounds__(256) void rle_emit_kernel(const unsigned long long*
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
         if (lane == 63) wsum[par][wv] = inc;
         __syncthreads();
-        int wbase = 0;
-        for (int k = 0; k < wv; ++k) wbase += wsum[par][k];
-        const int tot = wsum[par][0] + wsum[par][1] + wsum[par][2] + wsum[par][3];
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < EMIT_NW; ++k) {
+            const int v = wsum[par][k];
+            if (k < wv) wbase += v;
+            tot += v;
+        }
         if (cnt) {
             int pos = base + wbase + inc - cnt;
 #pragma unroll
@@ -267,7 +273,7 @@ extern "C" int ullsam_rle_pack(const unsigned char* masks, long N, int H, int W,
 extern "C" int ullsam_rle_emit(const unsigned long long* words, const int* select, long N, int H, int W, const long* offsets, int* out,
                                void* stream) {
     if (N == 0) return 0;
-    rle_emit_kernel<<<(unsigned)N, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(words, H, W, (H + 63) / 64, select, offsets, out);
+    rle_emit_kernel<<<(unsigned)N, EMIT_NT, 0, reinterpret_cast<hipStream_t>(stream)>>>(words, H, W, (H + 63) / 64, select, offsets, out);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
