@@ -627,9 +627,12 @@ def test_decode_attention(ops, B, H, KVH, Sk):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("P,Tq,N", [(1, 7, 4096), (3, 8, 1000), (70, 6, 4096), (2, 1, 64), (5, 7, 130)])
+@pytest.mark.parametrize("P,Tq,N", [(1, 7, 4096), (3, 8, 1000), (70, 6, 4096), (2, 1, 64), (5, 7, 130), (4, 12, 777), (2, 16, 33)])
 def test_tok2img_attention(ops, dtype, P, Tq, N):
-    """Token -> image cross attention streamed over the keys (split-K softmax merge), per-prompt and shared K/V."""
+    """Token -> image cross attention streamed over the keys (split-K softmax merge), per-prompt and shared K/V.  bf16 K / V run on the matrix pipe
+    (tok2img_partial_mfma_kernel, up to 16 query tokens, queries and probabilities as two bf16 terms: the same 2e-5 bound as the fp32 VALU kernel)."""
+    if Tq > 8 and dtype == torch.float32:
+        pytest.skip("fp32 K / V: the VALU kernel, at most 8 query tokens")
     rng = np.random.default_rng(P * 1000 + Tq)
     H, hd = 8, 16
     q = rng.standard_normal((P, Tq, H * hd), dtype=np.float32) * 2

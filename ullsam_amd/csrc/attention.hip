@@ -2208,6 +2208,160 @@ __global__ __launch_bounds__(256) void tok2img_partial_kernel(const float* __res
     }
 }
 
+// ---- the same partial pass on the matrix pipe (bf16 K / V, T <= 16; round 5).  tok2img_partial_kernel multiplies on the VALU: ~35 instructions per (key row, query)
+// put it at 58 - 65 us per call whatever the bytes (one shared 1 MB K / V set in layer 0 or 134 MB of per-prompt keys).  Here a wave walks its keys 32 at a time:
+// K rows go straight from HBM into A fragments (lane (m, g) takes the 16 bytes of key m it multiplies: whole 64-byte pieces of a row per instruction), V rows are
+// staged coalesced into a wave-private LDS image (288-byte rows: the transposed reads are conflict-free), the NEXT 32 keys' loads of both in flight in registers.
+// Scores S^T[key, q] per head on v_mfma_f32_16x16x32_bf16 with a head PAIR's 32 dims as one k-step and the other head's half of the query fragment zeroed; the
+// fp32 queries enter as TWO bf16 terms (hi + lo, kept in LDS: two MFMAs per score tile) so that the scores carry K's rounding only, as in the VALU kernel; one
+// running maximum per (query, head) agreed over the four lane groups; P^T feeds O^T[dim, q] += V^T P^T from the accumulators.
+// Same workspace layout as tok2img_partial_kernel (the merge kernel is shared).
+__global__ __launch_bounds__(256, 2) void tok2img_partial_mfma_kernel(const float* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v, float* __restrict__ ws,
+                                                                     int T, int N, long k_bs, long v_bs, float scale, int nsplit) {
+    constexpr int C = 128, HD = 16, H = 8, RP = 288, STEP = 32;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) char stage[4][STEP * RP];         // per wave: the V image; afterwards the waves' partial outputs (so)
+    __shared__ __attribute__((aligned(16))) bf16 sq[2][H][64][8];             // query B fragments, hi and lo terms, per head, in lane order
+    __shared__ float sml[4][16][H][2];
+    float (*so)[16][C] = reinterpret_cast<float (*)[16][C]>(&stage[0][0]);     // [4][16][C] floats = 32 KB of the 36 KB
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int split = blockIdx.x, pr = blockIdx.y;
+    const int m = lane & 15, g = lane >> 4;
+    const int per = (N + nsplit - 1) / nsplit;
+    const int s0 = split * per, s1 = min(N, s0 + per);
+    const int nst = (s1 - s0 + STEP - 1) / STEP;                               // 32-key steps of this split, dealt to the 4 waves round robin (<= 0: an empty split)
+    const bf16* kb = k + (long)pr * k_bs;
+    const bf16* vb = v + (long)pr * v_bs;
+    char* Vi = stage[wv];
+    // query fragments: B operand of head h = 2 hp + (g >> 1) half: lane (q = m, g) holds q[q][32 hp + 8 g .. + 7] where that is head h's, zeros elsewhere; scaled by scale * log2(e)
+    const float sc2 = scale * 1.4426950408889634f;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int h = 2 * wv + hh, hp = wv;
+        Frag<bf16> fh, fl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = ((g >> 1) == hh && m < T) ? q[((long)pr * T + m) * C + 32 * hp + 8 * g + j] * sc2 : 0.f;
+            fh.v[j] = (bf16)x;
+            fl.v[j] = (bf16)(x - (float)fh.v[j]);
+        }
+        *reinterpret_cast<bf16x8_t*>(&sq[0][h][lane][0]) = fh.v;
+        *reinterpret_cast<bf16x8_t*>(&sq[1][h][lane][0]) = fl.v;
+    }
+    __syncthreads();
+    f32x4 o[H];
+    float mx[H], ls[H];                                                        // running maximum (log2 units of the SCALED scores), this lane's partial sum (its 4 + 4 keys per step)
+#pragma unroll
+    for (int h = 0; h < H; ++h) { o[h] = f32x4{0.f, 0.f, 0.f, 0.f}; mx[h] = -1e30f; ls[h] = 0.f; }
+    u32x4 kr[8], vr[8];
+    const bf16* kl = kb + 8 * g;                                               // K fragment j = 2 hp + half: key 16 half + m, dims 32 hp + 8 g .. + 7
+    const bf16* vl = vb + 8 * (lane & 15);                                    // 32 rows x 256 B of V per step: lane l takes 16-byte chunk l & 15 of rows (l >> 4) + 4 j
+    auto fetch = [&](const int st_) __attribute__((always_inline)) {
+        const int r0 = s0 + max(st_, 0) * STEP;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long rk = min(r0 + 16 * (j & 1) + m, N - 1), rv = min(r0 + g + 4 * j, N - 1);
+            kr[j] = *reinterpret_cast<const u32x4*>(kl + rk * C + 32 * (j >> 1));
+            vr[j] = *reinterpret_cast<const u32x4*>(vl + rv * C);
+        }
+    };
+    fetch(min(wv, nst - 1));
+    for (int st = wv; st < nst; st += 4) {
+        Frag<bf16> kf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            kf[j].v = __builtin_bit_cast(bf16x8_t, kr[j]);
+            *reinterpret_cast<u32x4*>(Vi + (g + 4 * j) * RP + 16 * (lane & 15)) = vr[j];
+        }
+        fetch(min(st + 4, nst - 1));                                           // (the last steps re-fetch a step nobody uses: no branch around the loads)
+        const int valid = min(STEP, s1 - (s0 + st * STEP));                    // keys of this step inside the split (wave-uniform)
+        int lq = lane * 8;
+        asm volatile("" : "+v"(lq));                                           // (opaque per step: otherwise the 16 query fragments are hoisted out of the loop into 64 VGPRs)
+        const bf16* sqp = &sq[0][0][0][0] + lq;
+        // ---- per head: scores S^T (16 keys x 16 queries, two key halves, two query terms), softmax bookkeeping, O^T += V^T P^T
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const int hp = h >> 1;
+            const Frag<bf16> qh = load_frag(sqp + h * 512), ql = load_frag(sqp + (H + h) * 512);
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa;
+            mma16(kf[2 * hp], ql, sa);
+            mma16(kf[2 * hp + 1], ql, sb);
+            mma16(kf[2 * hp], qh, sa);
+            mma16(kf[2 * hp + 1], qh, sb);
+            // lane (q, g) holds keys 4 g + i of both halves
+            float tm = -1e30f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sa[i] = (4 * g + i < valid) ? sa[i] : -1e30f;
+                sb[i] = (16 + 4 * g + i < valid) ? sb[i] : -1e30f;
+                tm = fmaxf(tm, fmaxf(sa[i], sb[i]));
+            }
+            tm = fmaxf(tm, lane_xor16(tm));
+            tm = fmaxf(tm, lane_xor32(tm));
+            const float mn = fmaxf(mx[h], tm);
+            const float al = __builtin_amdgcn_exp2f(mx[h] - mn);
+            mx[h] = mn;
+            float ps = 0.f;
+            Frag<bf16> pf, pl;                                                 // the probabilities as two bf16 terms too: the output carries V's rounding only
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float pa = __builtin_amdgcn_exp2f(sa[i] - mn), pb = __builtin_amdgcn_exp2f(sb[i] - mn);
+                ps += pa + pb;
+                pf.v[i] = (bf16)pa;
+                pf.v[4 + i] = (bf16)pb;
+                pl.v[i] = (bf16)(pa - (float)pf.v[i]);
+                pl.v[4 + i] = (bf16)(pb - (float)pf.v[4 + i]);
+            }
+            ls[h] = ls[h] * al + ps;
+            o[h] *= al;
+            // O^T[dim 16 h + 4 g + i, q] += V^T P^T over the 32 keys: A = V^T by transposed reads (lane 4 q' + p of a 16-lane group addresses key row q', dims 4 p .. 4 p + 3)
+            const char* a0 = Vi + (4 * g + (m >> 2)) * RP + 32 * h + 8 * (m & 3);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 16 * RP));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            s16x8 tv;
+            tv[0] = lo[0]; tv[1] = lo[1]; tv[2] = lo[2]; tv[3] = lo[3];
+            tv[4] = hi[0]; tv[5] = hi[1]; tv[6] = hi[2]; tv[7] = hi[3];
+            Frag<bf16> vf;
+            vf.v = __builtin_bit_cast(bf16x8_t, tv);
+            mma16(vf, pl, o[h]);
+            mma16(vf, pf, o[h]);
+        }
+    }
+    // ---- this wave's partial: sums over the four lane groups, then the 4 waves are merged as in tok2img_partial_kernel (natural-log units in the workspace)
+    constexpr float LN2 = 0.6931471805599453f;
+    __syncthreads();                                                           // every wave is done with its stage images: the region becomes `so`
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float l = ls[h];
+        l += lane_xor16(l);
+        l += lane_xor32(l);
+        if (m < T) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) so[wv][m][HD * h + 4 * g + i] = o[h][i];
+            if (g == 0) { sml[wv][m][h][0] = mx[h] * LN2; sml[wv][m][h][1] = l; }
+        }
+    }
+    __syncthreads();
+    float* wo = ws + ((long)pr * nsplit + split) * T * C;
+    float* wml = ws + (long)gridDim.y * nsplit * T * C + ((long)pr * nsplit + split) * T * H * 2;
+    for (int i = tid; i < T * C; i += 256) {
+        const int t = i / C, cc = i % C, hh = cc / HD;
+        float mn = sml[0][t][hh][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) mn = fmaxf(mn, sml[w][t][hh][0]);
+        float acc = 0.f, ll = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a = __expf(sml[w][t][hh][0] - mn);
+            acc += so[w][t][cc] * a;
+            ll += sml[w][t][hh][1] * a;
+        }
+        wo[i] = acc;
+        if ((cc % HD) == 0) { wml[(t * H + hh) * 2] = mn; wml[(t * H + hh) * 2 + 1] = ll; }
+    }
+}
+
 __global__ __launch_bounds__(128) void tok2img_merge_kernel(const float* __restrict__ ws, float* __restrict__ out, int P, int T, int nsplit) {
     constexpr int C = 128, HD = 16, H = 8;
     const int pt = blockIdx.x, pr = pt / T, t = pt % T, cc = threadIdx.x, hh = cc / HD;
@@ -2230,12 +2384,13 @@ extern "C" int ullsam_tok2img_attention(int kv_dtype, const float* q, const void
                                         int T, int N, long k_batch_stride, long v_batch_stride, float scale, float* workspace,
                                         int nsplit, void* stream) {
     ULLSAM_CHECK(H == 8 && hd == 16, "tok2img_attention: H=%d hd=%d (8 x 16 only)", H, hd);
-    ULLSAM_CHECK(T >= 1 && T <= 8 && N >= 1 && nsplit >= 1 && P >= 1, "tok2img_attention: T=%d (1..8) N=%d nsplit=%d P=%d", T, N, nsplit, P);
+    ULLSAM_CHECK(T >= 1 && T <= (kv_dtype == ULLSAM_DT_BF16 ? 16 : 8) && N >= 1 && nsplit >= 1 && P >= 1, "tok2img_attention: T=%d (1..8, bf16: 1..16) N=%d nsplit=%d P=%d", T, N, nsplit, P);
     ULLSAM_CHECK((((uintptr_t)k | (uintptr_t)v) & 15) == 0, "tok2img_attention: k/v must be 16-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(nsplit, P);
     if (kv_dtype == ULLSAM_DT_F32) tok2img_partial_kernel<float, 8><<<grid, 256, 0, s>>>(q, k, v, workspace, T, N, k_batch_stride, v_batch_stride, scale, nsplit);
-    else tok2img_partial_kernel<bf16, 8><<<grid, 256, 0, s>>>(q, k, v, workspace, T, N, k_batch_stride, v_batch_stride, scale, nsplit);
+    else if (g_attn_variant == 16 && T <= 8) tok2img_partial_kernel<bf16, 8><<<grid, 256, 0, s>>>(q, k, v, workspace, T, N, k_batch_stride, v_batch_stride, scale, nsplit);   // (variant 16: the VALU kernel, for A/B and the equality test)
+    else tok2img_partial_mfma_kernel<<<grid, 256, 0, s>>>(q, static_cast<const bf16*>(k), static_cast<const bf16*>(v), workspace, T, N, k_batch_stride, v_batch_stride, scale, nsplit);
     ULLSAM_LAUNCH_CHECK();
     tok2img_merge_kernel<<<P * T, 128, 0, s>>>(workspace, out, P, T, nsplit);
     ULLSAM_LAUNCH_CHECK();

@@ -74,7 +74,7 @@ def _token_to_image(at: Attention, queries, qpe, keys_pe_c, keys_c, P, T, N, dt,
         V = ops.gemm(keys_c, at.v_proj.w(dt), at.v_proj.b())
         if kv_cache is not None:
             kv_cache["K0"], kv_cache["V0"] = K, V
-    if at.num_heads == 8 and at.hd == 16 and T <= 8:
+    if at.num_heads == 8 and at.hd == 16 and T <= (16 if K.dtype == torch.bfloat16 else 8):
         a = ops.tok2img_attention(q, K, V, P, at.num_heads, at.hd, T, N, 1.0 / math.sqrt(at.hd), kv_shared=shared)
     else:
         H, hd, C = at.num_heads, at.hd, at.internal_dim
