@@ -22,6 +22,9 @@ nms = float(sys.argv[8]) if len(sys.argv) > 8 else 0.7
 if os.environ.get("ULLSAM_GEMM_VARIANT"):
     from ullsam_amd import _lib
     _lib.load().ullsam_set_gemm_variant(int(os.environ["ULLSAM_GEMM_VARIANT"]))
+if os.environ.get("ULLSAM_ATTN_VARIANT"):                                    # 16: token -> image attention on the VALU kernel (A/B of the round-5 MFMA kernel)
+    from ullsam_amd import _lib
+    _lib.load().ullsam_set_attn_variant(int(os.environ["ULLSAM_ATTN_VARIANT"]))
 from ullsam_amd.utils.synthetic import blob_decoder_init
 sam = blob_decoder_init(build_model(vit, "none", torch.bfloat16, "cuda:0"))
 fp8 = os.environ.get("ULLSAM_FP8") == "1"

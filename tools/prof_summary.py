@@ -7,7 +7,7 @@ from collections import defaultdict
 
 
 def short(n):
-    n = re.sub(r"^void ", "", n)
+    n = re.sub(r"^void ", "", n).replace("(anonymous namespace)::", "")
     m = re.match(r"_Z\d+([A-Za-z0-9_]+?)I", n)
     if n.startswith("_Z"):
         base = re.match(r"_Z(\d+)", n)

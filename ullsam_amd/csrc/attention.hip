@@ -115,18 +115,6 @@ __device__ __forceinline__ void halves(float x, float& lo, float& hi) {
     hi = __uint_as_float(r[1]);
 }
 
-// lane ^ 16 / lane ^ 32 exchanges on gfx950's row-swap instructions (see decode_attn below for the semantics)
-typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float lane_xor16(float v) {
-    const unsigned int u = __builtin_bit_cast(unsigned int, v);
-    const uint2v r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return __builtin_bit_cast(float, (threadIdx.x & 16) ? r.x : r.y);
-}
-__device__ __forceinline__ float lane_xor32(float v) {
-    const unsigned int u = __builtin_bit_cast(unsigned int, v);
-    const uint2v r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r.x : r.y);
-}
 // max of the 16 registers of an MFMA accumulator as ONE asm statement of v_max3_f32: through fmaxf hipcc puts a canonicalising v_max_f32 x, x in
 // front of every MFMA result (16 more VALU instructions per 32-key block in loops that are VALU-bound), and it pads every asm statement's boundary
 // with an s_nop, so a chain of eight statements would carry eight of them.  The caller guarantees that the MFMAs that wrote `s` are at least a few

@@ -106,6 +106,18 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// lane ^ 16 / lane ^ 32 exchanges on gfx950's row-swap instructions (VALU ops: no ds_bpermute round trip through the LDS; semantics at attention.hip decode_attn)
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float lane_xor16(float v) {
+    const unsigned int u = __builtin_bit_cast(unsigned int, v);
+    const uint2v r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 16) ? r.x : r.y);
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+    const unsigned int u = __builtin_bit_cast(unsigned int, v);
+    const uint2v r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r.x : r.y);
+}
 
 // erf by Abramowitz-Stegun 7.1.26 (branch-free: 1 rcp, 1 exp, 6 fma).  In fp32 arithmetic |erf_as - erf| <= 6.1e-7 and the
 // resulting exact-form GELU is within 4.7e-7 abs of 0.5*x*(1+erf(x/sqrt2)) over [-12, 12] (tools/check_erf.py) -- rounding-noise

@@ -410,13 +410,19 @@ extern "C" int ullsam_mask_iou_counts(const unsigned char* a, const unsigned cha
 // as ONE pass over the image-side stream.  The separate launches (q GEMM with fp32 output, the few-keys attention, a cast, the output GEMM with
 // its fp32 residual, the fan-out LayerNorm) move 2.1 GB per layer for 64 prompts x 4096 tokens; this kernel reads (keys + pe) in bf16 and keys in
 // fp32 and writes keys' in fp32 / bf16 / bf16 (+ pe): 0.94 GB.
-// Both weight matrices sit in LDS for the life of the workgroup (128 KiB).  A wave takes 16 rows at a time with the weights as the FIRST MFMA
-// operand (D^T = W X^T), W's rows permuted so that lane (row r, group g) ends up with the 32 consecutive q columns g 32 .. g 32 + 31 -- two whole heads --,
-// so scores, softmax and the probability-weighted sum over the <= 16 tokens are lane-local fp32 arithmetic on the accumulators (the tokens' k / v in
-// LDS, read as broadcasts); the attention output goes back into the matrix pipe from the same registers (the k order of the second product is
-// permuted to match: lane group g supplies dims g 32 + 8 ks ..), and the second product leaves the lane with 64 consecutive output columns, so the
-// LayerNorm needs two cross-lane sums over the four groups and the three outputs leave as 16-byte stores.
-// A workgroup works inside ONE prompt (its tokens' k / v); grid = prompts x workgroups per prompt.
+// Both weight matrices sit in LDS for the life of the workgroup (128 KiB) in MFMA A-fragment order (a wave's fragment read is one contiguous KiB).
+// A wave takes 16 rows at a time with the weights as the FIRST operand (D^T = W X^T), so a lane ends up with its row's values:
+//   1. q^T: tile h = head h; lane (row r, group g) holds q[16 h + 4 g .. + 3];
+//   2. attention on v_mfma_f32_16x16x16_bf16, whose B operand (4 k-values per lane, k = 4 g + j) IS that accumulator layout: scores S^T[token, row] =
+//      K_tok q^T per head (q as two bf16 terms, the tokens' keys pre-scaled by log2(e) / 4 as two terms: three products), softmax over the <= 16 tokens
+//      = the lane's four values and the four lane groups (round 4 ran this on the VALU as ~1000 instructions per 16 rows with one wave per SIMD: 273 us;
+//      the matrix pipe needs ~200), O^T[dim, row] = V_tok^T P^T the same way (P and V as two terms);
+//   3. upd^T = Wo A^T with a head pair's 2 x 4 dims per lane as one 32-deep k-step (Wo's fragments are packed in that k order), the fp32 residual
+//      loaded straight into the accumulators at the top; tile t covers columns 16 t + 4 g .. + 3 (the four groups' fp32 loads / stores are 64 contiguous bytes per row), the
+//      LayerNorm needs two cross-lane sums over the four groups, and for the bf16 outputs neighbouring groups trade halves of a tile pair (v_permlane16_swap) so
+//      that a lane stores 8 consecutive columns = 16 bytes.
+// 512 threads: two waves per SIMD share the weights (<= 256 registers), one wave's loads and softmax under the other's products.
+// A workgroup works inside ONE prompt (its tokens' k / v fragments); grid = prompts x workgroups per prompt.
 // ---------------------------------------------------------------------------------------------------------------
 struct I2tArgs {
     const bf16* xin; long in_mod;          // (keys + pe) in bf16 [rows (or in_mod rows shared by every prompt), 256]
@@ -430,129 +436,218 @@ struct I2tArgs {
     int P, T, N, wg_per_prompt;
     float scale;
 };
-__global__ __launch_bounds__(256) void i2t_block_kernel(I2tArgs p) {
+constexpr int I2T_WQ = 0, I2T_WO = 128 * 256 * 2, I2T_KF = I2T_WO + 256 * 128 * 2, I2T_VF = I2T_KF + 8 * 2 * 64 * 8, I2T_PAR = I2T_VF + 8 * 2 * 64 * 8;
+constexpr int I2T_LDS = I2T_PAR + (128 + 3 * 256) * 4;                       // Wq | Wo | K fragments [head][term][lane] x 8 B | V fragments | bq, bo, lnw, lnb
+constexpr int I2T_WAVES = 8;
+
+__device__ __forceinline__ f32x4 mma16k16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void split4(const f32x4 x, s16x4& hi, s16x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 h = (__bf16)x[i];
+        hi[i] = __builtin_bit_cast(short, h);
+        lo[i] = __builtin_bit_cast(short, (__bf16)(x[i] - (float)h));
+    }
+}
+
+__global__ __launch_bounds__(64 * I2T_WAVES) void i2t_block_kernel(I2tArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int WQ = 0, WO = 128 * 256 * 2, TOK = WO + 256 * 128 * 2, PAR = TOK + 2 * 16 * 128 * 4;   // Wq | Wo | k_tok, v_tok [16][128] | bq, bo, lnw, lnb
-    float* ktok = reinterpret_cast<float*>(smem + TOK);
-    float* vtok = ktok + 16 * 128;
-    float* bq = reinterpret_cast<float*>(smem + PAR);
+    float* bq = reinterpret_cast<float*>(smem + I2T_PAR);
     float* bo = bq + 128;
     float* lnw = bo + 256;
     float* lnb = lnw + 256;
+    constexpr int NT = 64 * I2T_WAVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
     const int prompt = blockIdx.x / p.wg_per_prompt, part = blockIdx.x % p.wg_per_prompt;
-    // Wq -> LDS: physical row n (of 128) at LDS row 16 t + 4 gq + i (gq = n / 32, t = (n % 32) / 4, i = n % 4), 32 chunks per row, chunk c at c ^ (L & 15)
-    for (int c = tid; c < 128 * 32; c += 256) {
-        const int n = c >> 5, ch = c & 31, gq = n >> 5, rem = n & 31, L = 16 * (rem >> 2) + 4 * gq + (rem & 3);
-        *reinterpret_cast<uint4*>(smem + WQ + (L * 32 + (ch ^ (L & 15))) * 16) = *reinterpret_cast<const uint4*>(p.Wq + (size_t)n * 256 + ch * 8);
+    // Wq fragment (tile t, k-step ks): lane (m, gg) <- Wq[16 t + m][32 ks + 8 gg .. + 7]
+    for (int c = tid; c < 8 * 8 * 64; c += NT) {
+        const int f = c >> 6, ln = c & 63, t = f >> 3, ks = f & 7, m = ln & 15, gg = ln >> 4;
+        *reinterpret_cast<uint4*>(smem + I2T_WQ + c * 16) = *reinterpret_cast<const uint4*>(p.Wq + (size_t)(16 * t + m) * 256 + 32 * ks + 8 * gg);
     }
-    // Wo -> LDS: physical row n (of 256) at LDS row 16 t + 4 gq + i (gq = n / 64, t = (n % 64) / 4), 16 chunks per row
-    for (int c = tid; c < 256 * 16; c += 256) {
-        const int n = c >> 4, ch = c & 15, gq = n >> 6, rem = n & 63, L = 16 * (rem >> 2) + 4 * gq + (rem & 3);
-        *reinterpret_cast<uint4*>(smem + WO + (L * 16 + (ch ^ (L & 15))) * 16) = *reinterpret_cast<const uint4*>(p.Wo + (size_t)n * 128 + ch * 8);
+    // Wo fragment (tile t = 2 t' + par, head pair hp): lane m = 4 gq + i <-> output column 32 t' + 16 par + 4 gq + i; its 8 k-values = dims 32 hp + 4 gg .. + 3 and 32 hp + 16 + 4 gg .. + 3
+    for (int c = tid; c < 16 * 4 * 64; c += NT) {
+        const int f = c >> 6, ln = c & 63, t = f >> 2, hp = f & 3, m = ln & 15, gg = ln >> 4;
+        const int col = 32 * (t >> 1) + 16 * (t & 1) + 4 * (m >> 2) + (m & 3);
+        const bf16* src = p.Wo + (size_t)col * 128 + 32 * hp + 4 * gg;
+        const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 16);
+        *reinterpret_cast<uint4*>(smem + I2T_WO + c * 16) = uint4{lo.x, lo.y, hi.x, hi.y};
     }
-    for (int c = tid; c < p.T * 128; c += 256) {
-        ktok[c] = p.ktok[(size_t)prompt * p.T * 128 + c];
-        vtok[c] = p.vtok[(size_t)prompt * p.T * 128 + c];
+    // the tokens' fragments (A operands of the 16-deep products), two bf16 terms each: K lane (m = token, gg): k_tok[m][16 h + 4 gg + j] * log2(e) * scale;
+    // V lane (m = dim, gg): v_tok[4 gg + j][16 h + m]; tokens >= T are zeros (their scores are masked below)
+    for (int c = tid; c < 8 * 64; c += NT) {
+        const int h = c >> 6, ln = c & 63, m = ln & 15, gg = ln >> 4;
+        const float sc2 = p.scale * 1.4426950408889634f;
+        f32x4 kx, vx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            kx[j] = m < p.T ? p.ktok[((size_t)prompt * p.T + m) * 128 + 16 * h + 4 * gg + j] * sc2 : 0.f;
+            vx[j] = 4 * gg + j < p.T ? p.vtok[((size_t)prompt * p.T + 4 * gg + j) * 128 + 16 * h + m] : 0.f;
+        }
+        s16x4 kh, kl, vh, vl;
+        split4(kx, kh, kl);
+        split4(vx, vh, vl);
+        *reinterpret_cast<s16x4*>(smem + I2T_KF + ((h * 2 + 0) * 64 + ln) * 8) = kh;
+        *reinterpret_cast<s16x4*>(smem + I2T_KF + ((h * 2 + 1) * 64 + ln) * 8) = kl;
+        *reinterpret_cast<s16x4*>(smem + I2T_VF + ((h * 2 + 0) * 64 + ln) * 8) = vh;
+        *reinterpret_cast<s16x4*>(smem + I2T_VF + ((h * 2 + 1) * 64 + ln) * 8) = vl;
     }
-    for (int c = tid; c < 256; c += 256) {
+    for (int c = tid; c < 256; c += NT) {
         if (c < 128) bq[c] = p.bq ? p.bq[c] : 0.f;
         bo[c] = p.bo ? p.bo[c] : 0.f;
         lnw[c] = p.lnw ? p.lnw[c] : 1.f;
         lnb[c] = p.lnb ? p.lnb[c] : 0.f;
     }
     __syncthreads();
-    const int groups = (p.N + 15) / 16, stride = p.wg_per_prompt * 4;
-    bf16x8_t a0[8], a1[8];
-    auto load = [&](bf16x8_t (&a)[8], int grp) {
-        const long row = (long)prompt * p.N + min(grp * 16 + l16, p.N - 1);
-        const bf16* ap = p.xin + (size_t)(p.in_mod ? row % p.in_mod : row) * 256 + g * 8;
+    const int groups = (p.N + 15) / 16, stride = p.wg_per_prompt * I2T_WAVES;
+    int grp = part * I2T_WAVES + wave;
+    if (grp >= groups) return;
+    bf16x8_t a[8];
+    auto load = [&](int gr) __attribute__((always_inline)) {
+        const int r = min(gr * 16 + l16, p.N - 1);                            // (in_mod / res_mod / pe_rows are 0 or N: a shared image's row is the row inside the prompt, no division)
+        const bf16* ap = p.xin + ((size_t)(p.in_mod ? 0 : prompt) * p.N + r) * 256 + g * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) a[ks] = *reinterpret_cast<const bf16x8_t*>(ap + ks * 32);
     };
-    auto compute = [&](const bf16x8_t (&a)[8], int grp) {
-        // the fp32 residual rows of this group are requested FIRST: their latency passes under the two products and the attention (a wave has the SIMD to itself)
+    load(grp);
+    for (; grp < groups; grp += stride) {
+        int lo_ = lane * 16;
+        asm volatile("" : "+v"(lo_));                                         // (opaque per group: the fragment addresses are not loop invariants to hoist into registers)
+        const char* wl = smem + lo_;
         const int rin = grp * 16 + l16;
         const bool live = rin < p.N;
-        const long row = (long)prompt * p.N + min(rin, p.N - 1);
-        f32x4 rr[16];
+        const int rr_ = min(rin, p.N - 1);
+        const long row = (long)prompt * p.N + rr_;
+        // ---- the fp32 residual rows go straight into the accumulators of the second product: their latency passes under the first product and the attention
+        f32x4 u[16];
         {
-            const float* rp = p.res + (size_t)(p.res_mod ? row % p.res_mod : row) * 256 + g * 64;
+            const float* rp = p.res + (p.res_mod ? (size_t)rr_ : (size_t)row) * 256 + g * 4;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) rr[t] = *reinterpret_cast<const f32x4*>(rp + 4 * t);
+            for (int t = 0; t < 16; ++t) u[t] = *reinterpret_cast<const f32x4*>(rp + 16 * t);
         }
-        // ---- q^T = Wq X^T: lane (row l16, group g) gets q[g 32 + 4 t + i], t = 0 .. 7
+        // ---- q^T = Wq X^T: lane (row l16, group g) gets q[16 h + 4 g + i]
         f32x4 q[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) q[t] = *reinterpret_cast<const f32x4*>(bq + g * 32 + 4 * t);
+        for (int h = 0; h < 8; ++h) q[h] = *reinterpret_cast<const f32x4*>(bq + 16 * h + 4 * g);
+        {   // batches of four fragment reads run ONE batch ahead of their MFMAs (two register sets pinned by the scheduling fences: hipcc's own order is read, wait, multiply)
+            bf16x8_t wr[2][4];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+            for (int i = 0; i < 4; ++i) wr[0][i] = *reinterpret_cast<const bf16x8_t*>(wl + I2T_WQ + (i * 8) * 1024);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int L = 16 * t + l16;
-                const bf16x8_t w = *reinterpret_cast<const bf16x8_t*>(smem + WQ + (L * 32 + ((ks * 4 + g) ^ (L & 15))) * 16);
-                q[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a[ks], q[t], 0, 0, 0);
-                if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // (else hipcc hoists every fragment read above the first MFMA and spills)
-            }
-        }
-        // ---- two heads per lane (dims g 32 + 16 hh ..): online softmax over the tokens, as fewkeys_attn_kernel computes it
-        f32x4 o[8];
+            for (int b = 0; b < 16; ++b) {                                    // batch b: k-step b / 2, heads 4 (b & 1) .. + 3
+                if (b + 1 < 16) {
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            float m = -INFINITY, l = 0.f;
-            f32x4 acc[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int kt = 0; kt < p.T; ++kt) {
-                const float* kp = ktok + kt * 128 + g * 32 + hh * 16;
-                const float* vp = vtok + kt * 128 + g * 32 + hh * 16;
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + 4 * j);
-                    const f32x4 qq = q[4 * hh + j];
-                    s += qq[0] * kv[0]; s += qq[1] * kv[1]; s += qq[2] * kv[2]; s += qq[3] * kv[3];
+                    for (int i = 0; i < 4; ++i) wr[(b + 1) & 1][i] = *reinterpret_cast<const bf16x8_t*>(wl + I2T_WQ + ((4 * ((b + 1) & 1) + i) * 8 + ((b + 1) >> 1)) * 1024);
                 }
-                s *= p.scale;
-                const float mn = fmaxf(m, s);
-                const float al = __expf(m - mn), pv = __expf(s - mn);
-                l = l * al + pv;
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 vv = *reinterpret_cast<const f32x4*>(vp + 4 * j);
-                    acc[j] = acc[j] * al + pv * vv;
+                for (int i = 0; i < 4; ++i) q[4 * (b & 1) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[b & 1][i], a[b >> 1], q[4 * (b & 1) + i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (grp + stride < groups) load(grp + stride);                        // the next group's rows: `a` is free from here, the loads pass under everything below
+        // ---- attention per head on the 16-deep MFMA; the outputs leave rounded to bf16 like the cast before the output GEMM
+        s16x4 ob[8];
+#pragma unroll
+        for (int h0 = 0; h0 < 8; h0 += 4) {                                   // four heads abreast: each step is four independent chains
+            f32x4 sc[4], o[4];
+            float l[4];
+            const char* fl = wl - lane * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int h = h0 + j;
+                const s16x4 kh = *reinterpret_cast<const s16x4*>(fl + I2T_KF + (h * 2 + 0) * 512);
+                const s16x4 kl = *reinterpret_cast<const s16x4*>(fl + I2T_KF + (h * 2 + 1) * 512);
+                s16x4 qh, ql;
+                split4(q[h], qh, ql);
+                sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                sc[j] = mma16k16(kl, qh, sc[j]);
+                sc[j] = mma16k16(kh, ql, sc[j]);
+                sc[j] = mma16k16(kh, qh, sc[j]);                              // S^T[token 4 g + i, row l16] in log2 units
+            }
+            float mx[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mx[j] = -1e30f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    sc[j][i] = 4 * g + i < p.T ? sc[j][i] : -1e30f;
+                    mx[j] = fmaxf(mx[j], sc[j][i]);
                 }
-                m = mn;
             }
-            const float inv = 1.0f / l;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[4 * hh + j] = acc[j] * inv;
-        }
-        // ---- upd^T = Wo A^T, k permuted: step ks of lane group g carries dims g 32 + 8 ks .. + 7 = o[2 ks], o[2 ks + 1] (rounded to bf16 like the cast before the output GEMM)
-        f32x4 u[16];
+            for (int j = 0; j < 4; ++j) mx[j] = fmaxf(mx[j], lane_xor16(mx[j]));
 #pragma unroll
-        for (int t = 0; t < 16; ++t) u[t] = *reinterpret_cast<const f32x4*>(bo + g * 64 + 4 * t);
+            for (int j = 0; j < 4; ++j) mx[j] = fmaxf(mx[j], lane_xor32(mx[j]));
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8_t af;
+            for (int j = 0; j < 4; ++j) {
+                const int h = h0 + j;
+                const s16x4 vh = *reinterpret_cast<const s16x4*>(fl + I2T_VF + (h * 2 + 0) * 512);
+                const s16x4 vl = *reinterpret_cast<const s16x4*>(fl + I2T_VF + (h * 2 + 1) * 512);
+                f32x4 pr;
+                l[j] = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { af[e] = (__bf16)o[2 * ks][e]; af[4 + e] = (__bf16)o[2 * ks + 1][e]; }
+                for (int i = 0; i < 4; ++i) { pr[i] = __builtin_amdgcn_exp2f(sc[j][i] - mx[j]); l[j] += pr[i]; }
+                s16x4 ph, pl;
+                split4(pr, ph, pl);
+                o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                o[j] = mma16k16(vl, ph, o[j]);
+                o[j] = mma16k16(vh, pl, o[j]);
+                o[j] = mma16k16(vh, ph, o[j]);                                // O^T[dim 16 h + 4 g + i, row l16]
+            }
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int L = 16 * t + l16;
-                const bf16x8_t w = *reinterpret_cast<const bf16x8_t*>(smem + WO + (L * 16 + ((g * 4 + ks) ^ (L & 15))) * 16);
-                u[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, af, u[t], 0, 0, 0);
-                if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 4; ++j) l[j] += lane_xor16(l[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) l[j] += lane_xor32(l[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float inv = 1.0f / l[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ob[h0 + j][i] = __builtin_bit_cast(short, (__bf16)(o[j][i] * inv));
             }
         }
-        // ---- + keys (fp32 residual), LayerNorm over the 256 columns (64 here, the rest in the lanes l16 + 16, + 32, + 48), three outputs
+        // ---- upd^T = keys + Wo A^T (+ bo below): k-step hp of lane group g carries dims 32 hp + 4 g .. + 3 and 32 hp + 16 + 4 g .. + 3 = ob[2 hp], ob[2 hp + 1]
+        {
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            bf16x8_t af[4];
+#pragma unroll
+            for (int hp = 0; hp < 4; ++hp) {
+                s16x8 af8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { af8[e] = ob[2 * hp][e]; af8[4 + e] = ob[2 * hp + 1][e]; }
+                af[hp] = __builtin_bit_cast(bf16x8_t, af8);
+            }
+            bf16x8_t wr[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wr[0][i] = *reinterpret_cast<const bf16x8_t*>(wl + I2T_WO + (i * 4) * 1024);
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {                                    // batch b: head pair b / 4, tiles 4 (b & 3) .. + 3
+                if (b + 1 < 16) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wr[(b + 1) & 1][i] = *reinterpret_cast<const bf16x8_t*>(wl + I2T_WO + ((4 * ((b + 1) & 3) + i) * 4 + ((b + 1) >> 2)) * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[4 * (b & 3) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[b & 1][i], af[b >> 2], u[4 * (b & 3) + i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the positional rows of the third output run two steps ahead of the stores below (three register pairs): a load issued behind a step's stores waits for them
+        // (loads and stores share one in-order counter) and the compiler cannot move a load above a store it may alias -- fetched inside its own step each pair cost
+        // its round trip AND the drain of every store before it (s_waitcnt vmcnt(0), 8 times per group)
+        f32x4 pev[3][2];
+        const float* pe = p.key_pe + (size_t)rr_ * 256 + 16 * (g & 1) + 8 * (g >> 1);
+        if (p.out_c_pe) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { pev[t][0] = *reinterpret_cast<const f32x4*>(pe + 32 * t); pev[t][1] = *reinterpret_cast<const f32x4*>(pe + 32 * t + 4); }
+        }
+        // ---- + bo, LayerNorm over the 256 columns (64 here, the rest in the lanes l16 + 16, + 32, + 48), three outputs
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            u[t] += rr[t];
+            u[t] += *reinterpret_cast<const f32x4*>(bo + 16 * t + 4 * g);
             sum += (u[t][0] + u[t][1]) + (u[t][2] + u[t][3]);
         }
-        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+        sum += lane_xor16(sum); sum += lane_xor32(sum);
         const float mean = sum * (1.0f / 256.0f);
         float ss = 0.f;
 #pragma unroll
@@ -560,45 +655,45 @@ __global__ __launch_bounds__(256) void i2t_block_kernel(I2tArgs p) {
             const f32x4 d = u[t] - mean;
             ss += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
         }
-        ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+        ss += lane_xor16(ss); ss += lane_xor32(ss);
         const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
-        if (!live) return;
-        const float* pe = p.out_c_pe ? p.key_pe + (size_t)(row % p.pe_rows) * 256 + g * 64 : nullptr;
 #pragma unroll
         for (int t = 0; t < 16; t += 2) {
-            f32x4 y0 = (u[t] - mean) * rstd * *reinterpret_cast<const f32x4*>(lnw + g * 64 + 4 * t) + *reinterpret_cast<const f32x4*>(lnb + g * 64 + 4 * t);
-            f32x4 y1 = (u[t + 1] - mean) * rstd * *reinterpret_cast<const f32x4*>(lnw + g * 64 + 4 * t + 4) + *reinterpret_cast<const f32x4*>(lnb + g * 64 + 4 * t + 4);
-            const size_t off = (size_t)row * 256 + g * 64 + 4 * t;
-            if (p.out_f32) { *reinterpret_cast<f32x4*>(p.out_f32 + off) = y0; *reinterpret_cast<f32x4*>(p.out_f32 + off + 4) = y1; }
-            if (p.out_c) {
+            if (p.out_c_pe && t + 4 < 16) {
+                pev[(t / 2 + 2) % 3][0] = *reinterpret_cast<const f32x4*>(pe + 16 * (t + 4));
+                pev[(t / 2 + 2) % 3][1] = *reinterpret_cast<const f32x4*>(pe + 16 * (t + 4) + 4);
+            }
+            // tile t holds columns 16 t + 4 g .. + 3, tile t + 1 the next sixteen: the fp32 stores of the four groups are 64 contiguous bytes per row and instruction
+            const int col = 16 * t + 4 * g;
+            f32x4 y0 = (u[t] - mean) * rstd * *reinterpret_cast<const f32x4*>(lnw + col) + *reinterpret_cast<const f32x4*>(lnb + col);
+            f32x4 y1 = (u[t + 1] - mean) * rstd * *reinterpret_cast<const f32x4*>(lnw + col + 16) + *reinterpret_cast<const f32x4*>(lnb + col + 16);
+            if (p.out_f32 && live) {
+                *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)row * 256 + col) = y0;
+                *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)row * 256 + col + 16) = y1;
+            }
+            // the bf16 outputs want 8 consecutive columns per lane (16-byte stores): groups 0 / 1 and 2 / 3 trade halves (y0 of the odd group <-> y1 of the even
+            // group), after which group g holds columns 16 t + 16 (g & 1) + 8 (g >> 1) .. + 7
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                                      // (one exchanged value per lane: hipcc miscompiles the builtin when BOTH of its results are used --
+                const float got = lane_xor16((g & 1) ? y0[e] : y1[e]);         //  it copies the first into the second)
+                if (g & 1) y0[e] = got; else y1[e] = got;
+            }
+            const size_t off = (size_t)row * 256 + 16 * t + 16 * (g & 1) + 8 * (g >> 1);
+            if (p.out_c && live) {
                 bf16x8_t c;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { c[e] = (__bf16)y0[e]; c[4 + e] = (__bf16)y1[e]; }
                 *reinterpret_cast<bf16x8_t*>(p.out_c + off) = c;
             }
-            if (p.out_c_pe) {
-                const f32x4 z0 = y0 + *reinterpret_cast<const f32x4*>(pe + 4 * t), z1 = y1 + *reinterpret_cast<const f32x4*>(pe + 4 * t + 4);
+            if (p.out_c_pe && live) {
+                const f32x4 z0 = y0 + pev[(t / 2) % 3][0], z1 = y1 + pev[(t / 2) % 3][1];
                 bf16x8_t c;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { c[e] = (__bf16)z0[e]; c[4 + e] = (__bf16)z1[e]; }
                 *reinterpret_cast<bf16x8_t*>(p.out_c_pe + off) = c;
             }
+            __builtin_amdgcn_sched_barrier(0);                                 // (else the LayerNorm parameter reads of all eight steps are hoisted: 128 more registers)
         }
-    };
-    int grp = part * 4 + wave;
-    if (grp >= groups) return;
-    load(a0, grp);
-    while (true) {
-        const bool more1 = grp + stride < groups;
-        if (more1) load(a1, grp + stride);
-        compute(a0, grp);
-        if (!more1) break;
-        grp += stride;
-        const bool more0 = grp + stride < groups;
-        if (more0) load(a0, grp + stride);
-        compute(a1, grp);
-        if (!more0) break;
-        grp += stride;
     }
 }
 // xin bf16 [P*N (or in_mod), 256]; res fp32 alike; Wq bf16 [128, 256]; ktok / vtok fp32 [P, T, 128] (T <= 16); Wo bf16 [256, 128]; key_pe fp32 [pe_rows, 256];
@@ -607,17 +702,18 @@ extern "C" int ullsam_i2t_block(const void* xin, long in_mod, const float* res, 
                                 const float* vtok, const void* Wo, const float* bo, const float* lnw, const float* lnb, float eps, const float* key_pe,
                                 long pe_rows, float* out_f32, void* out_c, void* out_c_pe, int P, int T, int N, float scale, void* stream) {
     ULLSAM_CHECK(P > 0 && N > 0 && T >= 1 && T <= 16, "i2t_block: P=%d N=%d T=%d (1..16)", P, N, T);
-    ULLSAM_CHECK(xin && res && Wq && Wo && ktok && vtok && (!out_c_pe || (key_pe && pe_rows > 0)), "i2t_block: null operand");
+    ULLSAM_CHECK(xin && res && Wq && Wo && ktok && vtok && (!out_c_pe || key_pe), "i2t_block: null operand");
+    ULLSAM_CHECK((in_mod == 0 || in_mod == N) && (res_mod == 0 || res_mod == N) && (!out_c_pe || pe_rows == N), "i2t_block: in_mod=%ld res_mod=%ld pe_rows=%ld must be 0 (per prompt) or N=%d",
+                 in_mod, res_mod, pe_rows, N);
     ULLSAM_CHECK(((((uintptr_t)xin | (uintptr_t)res | (uintptr_t)Wq | (uintptr_t)Wo | (uintptr_t)out_f32 | (uintptr_t)out_c | (uintptr_t)out_c_pe | (uintptr_t)key_pe)) & 15) == 0,
                  "i2t_block: 16-byte aligned operands needed");
     I2tArgs a{static_cast<const bf16*>(xin), in_mod, res, res_mod, static_cast<const bf16*>(Wq), bq, ktok, vtok, static_cast<const bf16*>(Wo), bo, lnw, lnb, eps,
               key_pe, pe_rows, out_f32, static_cast<bf16*>(out_c), static_cast<bf16*>(out_c_pe), P, T, N, 1, scale};
     const int groups = (N + 15) / 16;
-    { const int by_rows = (groups + 3) / 4, by_cus = (256 + P - 1) / P; a.wg_per_prompt = by_rows < by_cus ? by_rows : by_cus; if (a.wg_per_prompt < 1) a.wg_per_prompt = 1; }
-    constexpr int LDS = 128 * 256 * 2 + 256 * 128 * 2 + 2 * 16 * 128 * 4 + (128 + 3 * 256) * 4;
+    { const int by_rows = (groups + I2T_WAVES - 1) / I2T_WAVES, by_cus = (256 + P - 1) / P; a.wg_per_prompt = by_rows < by_cus ? by_rows : by_cus; if (a.wg_per_prompt < 1) a.wg_per_prompt = 1; }
     static PerDeviceOnce attr;
-    if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(i2t_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    i2t_block_kernel<<<dim3(P * a.wg_per_prompt), 256, LDS, reinterpret_cast<hipStream_t>(stream)>>>(a);
+    if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(i2t_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, I2T_LDS);
+    i2t_block_kernel<<<dim3(P * a.wg_per_prompt), 64 * I2T_WAVES, I2T_LDS, reinterpret_cast<hipStream_t>(stream)>>>(a);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
