@@ -25,7 +25,9 @@ constexpr int NWV = 8;                  // waves per workgroup
 // W is given in FRAGMENT order (packed once per weight version by the host, ops.pack_mfma_rows): [row tile][k-step of 32][lane][8 elements], i.e. the 16 bytes lane l of the
 // A operand needs for (tile, k-step) sit at ((tile * KST + ks) * 64 + l) * 16 -- a wave's load is ONE contiguous KiB (with W as stored, [out, in], it was sixteen 64-byte
 // pieces of sixteen rows: the kernels ran 3 - 4x over their weight-traffic estimate).  KST = k-steps per packed row tile (in / 32); ks0 = first k-step of a K-slice.
-template <int K, bool LO, typename Epi, int KST = K / 32>
+// D = chunks of 8 fragments (8 KiB per wave) kept in flight ahead of the MFMAs: a chunk's 16 MFMAs take ~0.1 us, an L2 round trip ~1 us, so with the two buffers of
+// the first version (D = 2) a wave moved 8 KiB per round trip and the MLP's 2 MB of weights took ~60 of the kernel's 85 us; the MLP runs D = 4.
+template <int K, bool LO, typename Epi, int KST = K / 32, int D = 2>
 __device__ __forceinline__ void lin_tiles(const bf16* __restrict__ W, int ntiles, const bf16* x, const bf16* xlo, int wave, int lane, Epi epi, int ks0 = 0) {
     constexpr int KS = K / 32, CH = KS < 8 ? KS : 8, NCH = KS / CH;
     static_assert(KS % CH == 0, "K must be a multiple of 256 (or < 256 and a multiple of 32)");
@@ -35,7 +37,7 @@ __device__ __forceinline__ void lin_tiles(const bf16* __restrict__ W, int ntiles
     const int nt = (ntiles - wave + NWV - 1) / NWV;        // this wave's tiles: wave, wave + NWV, ...
     if (nt <= 0) return;
     const int total = nt * NCH;
-    Frag<bf16> a[2][CH];
+    Frag<bf16> a[D][CH];
     auto fetch = [&](Frag<bf16> (&buf)[CH], int s) __attribute__((always_inline)) {
         const int tile = wave + NWV * (s / NCH), c0 = (s % NCH) * CH;
         const bf16* wr = W + ((size_t)(tile * KST + ks0 + c0) * 64 + lane) * 8;
@@ -51,14 +53,17 @@ __device__ __forceinline__ void lin_tiles(const bf16* __restrict__ W, int ntiles
         }
         if (s % NCH == NCH - 1) { epi(wave + NWV * (s / NCH), acc); acc = f32x4{0.f, 0.f, 0.f, 0.f}; }
     };
-    fetch(a[0], 0);
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i)
+        if (i < total) fetch(a[i], i);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < total; s += 2) {                   // two steps per trip: the buffers keep static indices
-        if (s + 1 < total) fetch(a[1], s + 1);
-        run(a[0], s, acc);
-        if (s + 1 < total) {
-            if (s + 2 < total) fetch(a[0], s + 2);
-            run(a[1], s + 1, acc);
+    for (int s = 0; s < total; s += D) {                   // D steps per trip: the buffers keep static indices
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (s + j < total) {
+                if (s + j + D - 1 < total) fetch(a[(j + D - 1) % D], s + j + D - 1);
+                run(a[j], s + j, acc);
+            }
         }
     }
 }
@@ -244,12 +249,13 @@ __global__ __launch_bounds__(64 * NWV) void dec_tok_mlp_kernel(TokMlpArgs p) {
     __syncthreads();
     // the MLP in two halves of the hidden dimension: 1024 hidden units at a time as two bf16 terms (both halves' lin2 sums meet in yf)
     for (int half = 0; half < 2; ++half) {
-        lin_tiles<C, true>(p.W1 + (size_t)half * (HH / 16) * (C / 32) * 512, HH / 16, xa, xa_lo, wave, lane, [=](int tile, const f32x4& acc) {      // lin1 + ReLU -> hidden (hi, lo)
+        auto epi1 = [=](int tile, const f32x4& acc) {      // lin1 + ReLU -> hidden (hi, lo)
             const int f = 16 * tile + 4 * g;
             const float* bb = p.b1 ? p.b1 + half * HH + f : nullptr;
             st_split4(hid + m * HHP + f, hid_lo + m * HHP + f, fmaxf(acc[0] + (bb ? bb[0] : 0.f), 0.f), fmaxf(acc[1] + (bb ? bb[1] : 0.f), 0.f), fmaxf(acc[2] + (bb ? bb[2] : 0.f), 0.f),
                       fmaxf(acc[3] + (bb ? bb[3] : 0.f), 0.f));
-        });
+        };
+        lin_tiles<C, true, decltype(epi1), C / 32, 4>(p.W1 + (size_t)half * (HH / 16) * (C / 32) * 512, HH / 16, xa, xa_lo, wave, lane, epi1);
         __syncthreads();
         auto epi2 = [=](int tile, const f32x4& acc) {                                        // lin2 (+ bias + residual = norm2's output, with the first half)
             const int f = 16 * tile + 4 * g;
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(64 * NWV) void dec_tok_mlp_kernel(TokMlpArgs p) {
             if (!half && p.b2) { r.x += p.b2[f]; r.y += p.b2[f + 1]; r.z += p.b2[f + 2]; r.w += p.b2[f + 3]; }
             *reinterpret_cast<float4*>(yf + m * C + f) = make_float4(acc[0] + r.x, acc[1] + r.y, acc[2] + r.z, acc[3] + r.w);
         };
-        lin_tiles<HH, true, decltype(epi2), HID / 32>(p.W2, C / 16, hid, hid_lo, wave, lane, epi2, half * (HH / 32));
+        lin_tiles<HH, true, decltype(epi2), HID / 32, 4>(p.W2, C / 16, hid, hid_lo, wave, lane, epi2, half * (HH / 32));
         __syncthreads();
     }
     for (int e = tid; e < 2 * 16 * CP / 8; e += 64 * NWV) reinterpret_cast<uint4*>(xb)[e] = make_uint4(0u, 0u, 0u, 0u);
