@@ -295,24 +295,19 @@ __device__ inline Tap utap_of(int o, float scale, int n_in) {  // wave-uniform a
 }
 struct PostGeom { int LH, LW, S1, nh, nw, CH, CW, FH, FW, cx0, cy0; float s1y, s1x, s2y, s2x; };
 
-__device__ inline float post_eval(const float* __restrict__ lowp, const PostGeom& g, int y, int x) {  // one pixel, no memo
+__device__ inline float post_eval(const float* __restrict__ lowp, const PostGeom& g, int y, int x) {  // one pixel, no memo (named scalars: two-element arrays here went to scratch)
     const Tap ty = tap_of(y, g.s2y, g.nh), tx = tap_of(x, g.s2x, g.nw);
-    float h[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int iy = a ? ty.i1 : ty.i0;
+    const Tap c0 = tap_of(tx.i0, g.s1x, g.LW), c1 = tap_of(tx.i1, g.s1x, g.LW);
+    auto inter = [&](int iy) {                                               // the intermediate (S1-grid) row iy at the two column taps, then along x
         const Tap r = tap_of(iy, g.s1y, g.LH);
-        float iv[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const Tap c = tap_of(b ? tx.i1 : tx.i0, g.s1x, g.LW);
-            const float top = lerp_rn(lowp[(long)r.i0 * g.LW + c.i0], lowp[(long)r.i0 * g.LW + c.i1], c.l);
-            const float bot = lerp_rn(lowp[(long)r.i1 * g.LW + c.i0], lowp[(long)r.i1 * g.LW + c.i1], c.l);
-            iv[b] = lerp_rn(top, bot, r.l);
-        }
-        h[a] = lerp_rn(iv[0], iv[1], tx.l);
-    }
-    return lerp_rn(h[0], h[1], ty.l);
+        const float* r0 = lowp + (long)r.i0 * g.LW;
+        const float* r1 = lowp + (long)r.i1 * g.LW;
+        const float iv0 = lerp_rn(lerp_rn(r0[c0.i0], r0[c0.i1], c0.l), lerp_rn(r1[c0.i0], r1[c0.i1], c0.l), r.l);
+        const float iv1 = lerp_rn(lerp_rn(r0[c1.i0], r0[c1.i1], c1.l), lerp_rn(r1[c1.i0], r1[c1.i1], c1.l), r.l);
+        return lerp_rn(iv0, iv1, tx.l);
+    };
+    const float h0 = inter(ty.i0), h1 = inter(ty.i1);
+    return lerp_rn(h0, h1, ty.l);
 }
 
 // acc = 2*acc + (v > thr): compare + add-with-carry, exact `>` semantics (false for NaN).  Rows are pushed top first, so after
@@ -331,7 +326,8 @@ __global__ __launch_bounds__(256) void amg_postprocess_kernel(const float* __res
                                                               int* __restrict__ rle_counts, unsigned char* __restrict__ first,
                                                               int* __restrict__ boxes, unsigned int* __restrict__ stab) {
     const long n = blockIdx.z;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar for the compiler too: the block's rows, the memo keys and every branch on them below are wave-uniform
     const int nyb = (g.FH + 63) >> 6;
     const int yb = blockIdx.y * 4 + wv;
     if (yb >= nyb) return;
@@ -393,56 +389,40 @@ __global__ __launch_bounds__(256) void amg_postprocess_kernel(const float* __res
                 for (int j = 0; j < NC; ++j) nb |= (unsigned int)col_in[j] << j;
         }
     } else {
+        // two memo slots per level, addressed by a SCALAR slot number (keys and slot numbers are wave-uniform: scalar branches and selects; the first form
+        // handed the slots around as array references and the compiler kept them in scratch behind lane-masked branches, 32 B per lane in the row loop)
         float ga0[NC], ga1[NC], gb0[NC], gb1[NC], ha[NC], hb[NC];
-        int gka = -1, gkb = -1, hka = -1, hkb = -1;  // memo keys (wave-uniform): low-res row / intermediate row
-        auto get_g = [&](int lr, float (&o0)[NC], float (&o1)[NC]) {
-            if (lr == gka) {
-#pragma unroll
-                for (int j = 0; j < NC; ++j) { o0[j] = ga0[j]; o1[j] = ga1[j]; }
-                return;
-            }
-            if (lr == gkb) {
-#pragma unroll
-                for (int j = 0; j < NC; ++j) { o0[j] = gb0[j]; o1[j] = gb1[j]; }
-                return;
-            }
+        int gka = -1, gkb = -1, hka = -1, hkb = -1;  // memo keys: low-res row / intermediate row
+        auto ensure_g = [&](int lr) -> int {          // -> the slot that holds low-res row lr, x-interpolated at this lane's two column taps
+            if (lr == gka) return 0;
+            if (lr == gkb) return 1;
             const float* row = lowp + (long)lr * g.LW;
-#pragma unroll
-            for (int j = 0; j < NC; ++j) {
-                o0[j] = lerp_rn(row[t0[j].i0], row[t0[j].i1], t0[j].l);
-                o1[j] = lerp_rn(row[t1[j].i0], row[t1[j].i1], t1[j].l);
-            }
-            if (gka <= gkb) {
+            const int slot = gka <= gkb ? 0 : 1;      // the older row goes (rows only move down)
+            if (slot == 0) {
                 gka = lr;
 #pragma unroll
-                for (int j = 0; j < NC; ++j) { ga0[j] = o0[j]; ga1[j] = o1[j]; }
+                for (int j = 0; j < NC; ++j) { ga0[j] = lerp_rn(row[t0[j].i0], row[t0[j].i1], t0[j].l); ga1[j] = lerp_rn(row[t1[j].i0], row[t1[j].i1], t1[j].l); }
             } else {
                 gkb = lr;
 #pragma unroll
-                for (int j = 0; j < NC; ++j) { gb0[j] = o0[j]; gb1[j] = o1[j]; }
+                for (int j = 0; j < NC; ++j) { gb0[j] = lerp_rn(row[t0[j].i0], row[t0[j].i1], t0[j].l); gb1[j] = lerp_rn(row[t1[j].i0], row[t1[j].i1], t1[j].l); }
             }
+            return slot;
         };
-        auto get_h = [&](int iy, float (&h)[NC]) {
-            if (iy == hka) {
-#pragma unroll
-                for (int j = 0; j < NC; ++j) h[j] = ha[j];
-                return;
-            }
-            if (iy == hkb) {
-#pragma unroll
-                for (int j = 0; j < NC; ++j) h[j] = hb[j];
-                return;
-            }
+        auto ensure_h = [&](int iy) -> int {          // -> the slot that holds intermediate row iy at this lane's columns
+            if (iy == hka) return 0;
+            if (iy == hkb) return 1;
             const Tap rr = utap_of(iy, g.s1y, g.LH);
-            float p0[NC], p1[NC], q0[NC], q1[NC];
-            get_g(rr.i0, p0, p1);
-            get_g(rr.i1, q0, q1);
+            const int sp = ensure_g(rr.i0), sq = ensure_g(rr.i1);   // (the second call never evicts the first's row: its key is the newest)
+            const int slot = hka <= hkb ? 0 : 1;
+            float h[NC];
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
-                const float i0 = lerp_rn(p0[j], q0[j], rr.l), i1 = lerp_rn(p1[j], q1[j], rr.l);
+                const float p0 = sp ? gb0[j] : ga0[j], p1 = sp ? gb1[j] : ga1[j], q0 = sq ? gb0[j] : ga0[j], q1 = sq ? gb1[j] : ga1[j];
+                const float i0 = lerp_rn(p0, q0, rr.l), i1 = lerp_rn(p1, q1, rr.l);
                 h[j] = lerp_rn(i0, i1, tx[j].l);
             }
-            if (hka <= hkb) {
+            if (slot == 0) {
                 hka = iy;
 #pragma unroll
                 for (int j = 0; j < NC; ++j) ha[j] = h[j];
@@ -451,14 +431,13 @@ __global__ __launch_bounds__(256) void amg_postprocess_kernel(const float* __res
 #pragma unroll
                 for (int j = 0; j < NC; ++j) hb[j] = h[j];
             }
+            return slot;
         };
         auto values = [&](int yc, float (&v)[NC]) {   // crop row yc (wave-uniform), this lane's columns
             const Tap ty = utap_of(yc, g.s2y, g.nh);
-            float h0[NC], h1[NC];
-            get_h(ty.i0, h0);
-            get_h(ty.i1, h1);
+            const int s0 = ensure_h(ty.i0), s1 = ensure_h(ty.i1);
 #pragma unroll
-            for (int j = 0; j < NC; ++j) v[j] = lerp_rn(h0[j], h1[j], ty.l);
+            for (int j = 0; j < NC; ++j) v[j] = lerp_rn(s0 ? hb[j] : ha[j], s1 ? hb[j] : ha[j], ty.l);
         };
 #pragma unroll
         for (int j = 0; j < NC; ++j) wm[j] = whi[j] = wlo[j] = 0;
