@@ -25,7 +25,14 @@ DEFAULT_LIB = os.path.join(ROOT, "ullsam_amd", "lib", "libullsam_hip.so")
 # kernels the bench step (configs[2], bf16) and the decode step spend their time in: these must compile spill-free.  Mangled-name
 # fragments: DF16b = __bf16, Li<N>E = an integer template argument, Lb<0|1>E = a bool.
 HOT_BF16 = [r"gemm_ring8_kernelILi\d+ELi\d+ELi\d+ELb0E", r"gemm256_kernelIDF16bLi0E", r"gemm128_kernelIDF16b", r"flash_attn_kernelIDF16bLi80ELi2ELi8ELb1E",
-            r"vitglob_attn_kernel", r"causal128_attn_kernel", r"win14_attn_kernel", r"norm_kernelI\w*DF16b", r"norm_block_kernel", r"gemm_skinny", r"decode_attn"]
+            r"vitglob_attn_kernel", r"causal128_attn_kernel", r"win14_attn_kernel", r"win14r_attn_kernelILi0E", r"norm_kernelI\w*DF16b", r"norm_block_kernel", r"gemm_skinny",
+            r"decode_attn"]
+# round 5: the mask decoder's and the automatic mask generator's kernels (bf16 path): the fused two-way-block kernels, the upscaling kernels, the post-processing
+# (gemm256_kernel<*, 1> -- the two-buffer kernel's LDS-staged RoPE epilogue, 16 - 28 spills -- is still dispatched, by fp32 wqkv and by bf16 operands the ring's
+# epilogue cannot take (unaligned q / k / v): not on the bench path, not in this list)
+HOT_AMG = [r"i2t_block_kernel", r"up1_ln_gelu_kernel", r"up2_hyper_kernel", r"tok2img_partial_mfma_kernel", r"tok2img_merge_kernel", r"dec_tok_attn_kernel", r"dec_tok_mlp_kernel",
+           r"dec_heads_kernel", r"amg_postprocess_kernel", r"rle_emit_kernel"]
+HOT_BF16 = HOT_BF16 + HOT_AMG
 HOT = HOT_BF16
 
 
