@@ -13,8 +13,10 @@ Default workload = BASELINE.json configs[2] per GPU (ViT-H + InternLM2-7B-shaped
 N GPUs process N x 4 images (weak scaling; configs[3] at N = 8).  Weights are random-init (no checkpoints exist offline).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the MFMA GEMM; achieved = algorithmic FLOPs of every GEMM
-launch / their HIP-event durations, measured inside the timed region on the launch stream) and `cpu_baseline` (the numpy
-oracle timed on the host cores on a bounded, depth-reduced sample of the same workload; N = 1 only).
+launch / their HIP-event durations, sampled on every 5th timed step on the launch stream: an event pair per GEMM on EVERY step cost 1.5 ms
+of a 78 ms step), `kernel_ms_per_step` / `gap_ms_per_step` (HIP-event spans around every C-ABI call of one extra untimed step: what the
+kernels take, and what lies between them) and `cpu_baseline` (the oracle restated on torch CPU tensors -- multi-threaded fp32 GEMMs, `kind:
+"port-torch"` -- timed on the host cores on a bounded, depth-reduced sample of the same workload, the numpy oracle's figure beside it; N = 1 only).
 """
 from __future__ import annotations
 
