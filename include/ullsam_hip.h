@@ -27,7 +27,7 @@ extern "C" {
 
 /* Bumped whenever an entry point is added or a signature changes.  The Python binding refuses a library that reports another
    version (a stale libullsam_hip.so would otherwise receive shifted arguments, e.g. a row count where the stream is expected). */
-#define ULLSAM_ABI_VERSION 9
+#define ULLSAM_ABI_VERSION 10
 
 const char* ullsam_last_error_string(void);
 int ullsam_abi_version(void); /* == ULLSAM_ABI_VERSION of the header the library was built from */
@@ -225,6 +225,10 @@ int ullsam_small_linear(const float* x, long ldx, const float* W, const float* b
 int ullsam_i2t_block(const void* xin, long in_mod, const float* res, long res_mod, const void* Wq, const float* bq, const float* ktok,
                      const float* vtok, const void* Wo, const float* bo, const float* lnw, const float* lnb, float eps, const float* key_pe,
                      long pe_rows, float* out_f32, void* out_c, void* out_c_pe, int P, int T, int N, float scale, void* stream);
+
+/* The token -> image attention's k / v projections of the image side in one pass (transformer.py:220-222 on the image tokens; bf16, embedding 256 -> internal 128):
+ * K = xk Wk^T + bk, V = xv Wv^T + bv; xk = (keys + pe), xv = keys, bf16 [rows, 256]; Wk / Wv bf16 [128, 256]; bk / bv fp32 [128] or NULL; K / V bf16 [rows, 128]. */
+int ullsam_kv_proj(const void* xk, const void* xv, const void* Wk, const void* Wv, const float* bk, const float* bv, void* K, void* V, long rows, void* stream);
 /* The token side of a two-way block (transformer.py:153-184; bf16 weights [out, in], embedding 256, 8 heads, T <= 16 tokens per prompt, fp32 token rows) as two launches,
  * one workgroup per prompt (csrc/dectok.hip):
  *   dec_tok_attn: q_in = queries (+ qpe unless skip_pe); self attention (q, k of q_in, v of queries; scale 1 / sqrt(32) after the product, :233-235); out projection

@@ -494,6 +494,32 @@ def test_fused_image_to_token_block_equals_the_separate_launches(P, T, shared):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows", [4096, 5 * 4096 + 7, 64 * 4096])
+def test_fused_k_and_v_projection_of_the_image_side_equals_the_two_gemms(rows):
+    """ops.kv_proj (csrc/decoder.hip kv_proj_kernel: both weight matrices resident in LDS, one pass over (keys + pe) and keys) against the two ops.gemm launches it
+    replaces (the 128x128 tile kernel): fp32 sums of 256 products in another order, then the same rounding to bf16 -- a bf16 step of a value now and then, nothing more;
+    and against float64 on the bf16-rounded operands.  A ragged row count exercises the last group's clamp."""
+    from ullsam_amd import ops
+    g = torch.Generator(device=DEV); g.manual_seed(rows)
+    xk = torch.randn(rows, 256, device=DEV, generator=g).bfloat16()
+    xv = torch.randn(rows, 256, device=DEV, generator=g).bfloat16()
+    wk = (torch.randn(128, 256, device=DEV, generator=g) * 0.08).bfloat16()
+    wv = (torch.randn(128, 256, device=DEV, generator=g) * 0.08).bfloat16()
+    bk, bv = torch.randn(128, device=DEV, generator=g) * 0.1, torch.randn(128, device=DEV, generator=g) * 0.1
+    K, V = ops.kv_proj(xk, xv, wk, bk, wv, bv)
+    Kr, Vr = ops.gemm(xk, wk, bk), ops.gemm(xv, wv, bv)
+    torch.cuda.synchronize()
+    for got, ref, x, w, b in ((K, Kr, xk, wk, bk), (V, Vr, xv, wv, bv)):
+        assert got.shape == ref.shape == (rows, 128) and torch.isfinite(got.float()).all()
+        d = (got.float() - ref.float()).abs()
+        assert float(d.max()) <= 2.0 ** -7 * max(1.0, float(ref.float().abs().max())) and float((d > 0).float().mean()) < 0.02, (float(d.max()), float((d > 0).float().mean()))
+        want = x[:4096].double() @ w.double().T + b.double()
+        assert float((got[:4096].double() - want).abs().max()) < 2.0 ** -8 * max(1.0, float(want.abs().max())) + 1e-6
+    K2, V2 = ops.kv_proj(xk, xv, wk, None, wv, None)
+    assert float((K2.float() - ops.gemm(xk, wk).float()).abs().max()) <= 2.0 ** -7 * max(1.0, float(Kr.float().abs().max()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("P,nm", [(3, 4), (1, 4), (5, 1)])
 def test_fused_second_upscaling_and_hypernetwork_product_equals_the_separate_launches(P, nm):
     """ops.up2_hyper_masks (second transposed convolution as Linear 64 -> 4 x 32, GELU, rounding to bf16, hypernetwork product: one kernel, the upscaled

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ULLSAM_HIP_LIB") or os.path.join(_HERE, "lib", "libullsam_hip.so")  # env: A/B a side build (developer switch)
 
-ABI_VERSION = 9  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
+ABI_VERSION = 10  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
 
 _lib = None
 
@@ -63,6 +63,7 @@ SIGNATURES = {
     "ullsam_argmax": [vp, vp, i32, i64, i64, vp],
     "ullsam_small_linear": [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp],
     "ullsam_i2t_block": [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, i64, vp, vp, vp, i32, i32, i32, f32, vp],
+    "ullsam_kv_proj": [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp],
     "ullsam_up2_hyper_masks": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "ullsam_dec_tok_attn": [vp] * 14 + [f32, vp, vp, i32, i32, i32, i32, vp],
     "ullsam_dec_tok_mlp": [vp] * 10 + [f32] + [vp] * 6 + [f32] + [vp] * 4 + [i32, i32, i32, vp],

@@ -631,16 +631,8 @@ __global__ __launch_bounds__(64 * I2T_WAVES) void i2t_block_kernel(I2tArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // the positional rows of the third output run two steps ahead of the stores below (three register pairs): a load issued behind a step's stores waits for them
-        // (loads and stores share one in-order counter) and the compiler cannot move a load above a store it may alias -- fetched inside its own step each pair cost
-        // its round trip AND the drain of every store before it (s_waitcnt vmcnt(0), 8 times per group)
-        f32x4 pev[3][2];
-        const float* pe = p.key_pe + (size_t)rr_ * 256 + 16 * (g & 1) + 8 * (g >> 1);
-        if (p.out_c_pe) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { pev[t][0] = *reinterpret_cast<const f32x4*>(pe + 32 * t); pev[t][1] = *reinterpret_cast<const f32x4*>(pe + 32 * t + 4); }
-        }
-        // ---- + bo, LayerNorm over the 256 columns (64 here, the rest in the lanes l16 + 16, + 32, + 48), three outputs
+        // ---- + bo, LayerNorm over the 256 columns (64 here, the rest in the lanes l16 + 16, + 32, + 48), normalised IN PLACE; then the three outputs ONE BUFFER AT A TIME
+        // (fp32, bf16, bf16 + pe): interleaved per tile pair, a wave's 32 stores walked three DRAM streams at once and the positional rows' loads sat between stores
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -658,41 +650,52 @@ __global__ __launch_bounds__(64 * I2T_WAVES) void i2t_block_kernel(I2tArgs p) {
         ss += lane_xor16(ss); ss += lane_xor32(ss);
         const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
 #pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int col = 16 * t + 4 * g;                                    // tile t holds columns 16 t + 4 g .. + 3
+            u[t] = (u[t] - mean) * rstd * *reinterpret_cast<const f32x4*>(lnw + col) + *reinterpret_cast<const f32x4*>(lnb + col);
+            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);               // (else the parameter reads of all sixteen tiles are hoisted)
+        }
+        if (p.out_f32 && live) {                                               // the four groups' stores are 64 contiguous bytes per row and instruction
+            float* of = p.out_f32 + (size_t)row * 256 + 4 * g;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(of + 16 * t) = u[t];
+        }
+        // the bf16 outputs want 8 consecutive columns per lane (16-byte stores): groups 0 / 1 and 2 / 3 trade halves of a tile pair (u[t] of the odd group <-> u[t + 1] of the even
+        // group), after which group g holds columns 16 t + 16 (g & 1) + 8 (g >> 1) .. + 7 in (u[t], u[t + 1]), t even
+#pragma unroll
         for (int t = 0; t < 16; t += 2) {
-            if (p.out_c_pe && t + 4 < 16) {
-                pev[(t / 2 + 2) % 3][0] = *reinterpret_cast<const f32x4*>(pe + 16 * (t + 4));
-                pev[(t / 2 + 2) % 3][1] = *reinterpret_cast<const f32x4*>(pe + 16 * (t + 4) + 4);
-            }
-            // tile t holds columns 16 t + 4 g .. + 3, tile t + 1 the next sixteen: the fp32 stores of the four groups are 64 contiguous bytes per row and instruction
-            const int col = 16 * t + 4 * g;
-            f32x4 y0 = (u[t] - mean) * rstd * *reinterpret_cast<const f32x4*>(lnw + col) + *reinterpret_cast<const f32x4*>(lnb + col);
-            f32x4 y1 = (u[t + 1] - mean) * rstd * *reinterpret_cast<const f32x4*>(lnw + col + 16) + *reinterpret_cast<const f32x4*>(lnb + col + 16);
-            if (p.out_f32 && live) {
-                *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)row * 256 + col) = y0;
-                *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)row * 256 + col + 16) = y1;
-            }
-            // the bf16 outputs want 8 consecutive columns per lane (16-byte stores): groups 0 / 1 and 2 / 3 trade halves (y0 of the odd group <-> y1 of the even
-            // group), after which group g holds columns 16 t + 16 (g & 1) + 8 (g >> 1) .. + 7
 #pragma unroll
             for (int e = 0; e < 4; ++e) {                                      // (one exchanged value per lane: hipcc miscompiles the builtin when BOTH of its results are used --
-                const float got = lane_xor16((g & 1) ? y0[e] : y1[e]);         //  it copies the first into the second)
-                if (g & 1) y0[e] = got; else y1[e] = got;
+                const float got = lane_xor16((g & 1) ? u[t][e] : u[t + 1][e]); //  it copies the first into the second)
+                if (g & 1) u[t][e] = got; else u[t + 1][e] = got;
             }
-            const size_t off = (size_t)row * 256 + 16 * t + 16 * (g & 1) + 8 * (g >> 1);
-            if (p.out_c && live) {
+        }
+        const size_t off0 = (size_t)row * 256 + 16 * (g & 1) + 8 * (g >> 1);
+        if (p.out_c && live) {
+#pragma unroll
+            for (int t = 0; t < 16; t += 2) {
                 bf16x8_t c;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { c[e] = (__bf16)y0[e]; c[4 + e] = (__bf16)y1[e]; }
-                *reinterpret_cast<bf16x8_t*>(p.out_c + off) = c;
+                for (int e = 0; e < 4; ++e) { c[e] = (__bf16)u[t][e]; c[4 + e] = (__bf16)u[t + 1][e]; }
+                *reinterpret_cast<bf16x8_t*>(p.out_c + off0 + 16 * t) = c;
             }
-            if (p.out_c_pe && live) {
-                const f32x4 z0 = y0 + pev[(t / 2) % 3][0], z1 = y1 + pev[(t / 2) % 3][1];
+        }
+        if (p.out_c_pe && live) {
+            // the positional rows: all sixteen loads of this pass are issued before its first store (requested before the OTHER passes' stores as well they cost
+            // 64 more live registers through those passes and the two-output form ran 147 -> 163 us)
+            const float* pe = p.key_pe + (size_t)rr_ * 256 + 16 * (g & 1) + 8 * (g >> 1);
+#pragma unroll
+            for (int t = 0; t < 16; t += 2) {
+                u[t] += *reinterpret_cast<const f32x4*>(pe + 16 * t);
+                u[t + 1] += *reinterpret_cast<const f32x4*>(pe + 16 * t + 4);
+            }
+#pragma unroll
+            for (int t = 0; t < 16; t += 2) {
                 bf16x8_t c;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { c[e] = (__bf16)z0[e]; c[4 + e] = (__bf16)z1[e]; }
-                *reinterpret_cast<bf16x8_t*>(p.out_c_pe + off) = c;
+                for (int e = 0; e < 4; ++e) { c[e] = (__bf16)u[t][e]; c[4 + e] = (__bf16)u[t + 1][e]; }
+                *reinterpret_cast<bf16x8_t*>(p.out_c_pe + off0 + 16 * t) = c;
             }
-            __builtin_amdgcn_sched_barrier(0);                                 // (else the LayerNorm parameter reads of all eight steps are hoisted: 128 more registers)
         }
     }
 }
@@ -714,6 +717,102 @@ extern "C" int ullsam_i2t_block(const void* xin, long in_mod, const float* res, 
     static PerDeviceOnce attr;
     if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(i2t_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, I2T_LDS);
     i2t_block_kernel<<<dim3(P * a.wg_per_prompt), 64 * I2T_WAVES, I2T_LDS, reinterpret_cast<hipStream_t>(stream)>>>(a);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The token -> image attention's k and v projections of the image side for MANY prompts in one pass (transformer.py:123-126 / Attention.forward :220-222, bf16):
+//     K = (keys + pe) Wk^T + bk,   V = keys Wv^T + bv          [rows, 256] x [128, 256]^T -> [rows, 128] each
+// Two launches of the 128x128 tile GEMM (2048 workgroups of 64 KB each, 61 - 77 us apiece for 203 MB) ran at 2.6 - 3.3 TB/s; here both weight matrices sit in LDS as
+// MFMA A fragments for the life of the workgroup (128 KiB) and a wave streams 16 rows at a time through both products (weights first: D^T = W X^T, tile t = features
+// 16 t .. + 15), the next group's rows requested under the other product.  For the stores neighbouring lane groups trade halves of a tile pair (as in i2t_block_kernel), so a
+// lane stores 8 consecutive features = 16 bytes.
+// ---------------------------------------------------------------------------------------------------------------
+struct KvArgs { const bf16* xk; const bf16* xv; const bf16* Wk; const bf16* Wv; const float* bk; const float* bv; bf16* K; bf16* V; long rows; };
+constexpr int KV_WAVES = 8;
+__device__ __forceinline__ void kv_load(bf16x8_t (&a)[8], const bf16* x, long gr, long rows, int l16, int g) {
+    const long row = min(gr * 16 + l16, rows - 1);
+    const bf16* ap = x + (size_t)row * 256 + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) a[ks] = *reinterpret_cast<const bf16x8_t*>(ap + ks * 32);
+}
+__device__ __forceinline__ void kv_product(f32x4 (&acc)[8], const bf16x8_t (&a)[8], const char* wl, const float* bias, int g) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = *reinterpret_cast<const f32x4*>(bias + 16 * t + 4 * g);
+    bf16x8_t wr[2][4];                                                        // batches of four fragment reads one batch ahead of their MFMAs
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wr[0][i] = *reinterpret_cast<const bf16x8_t*>(wl + (i * 8) * 1024);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {                                            // batch b: k-step b / 2, tiles 4 (b & 1) .. + 3
+        if (b + 1 < 16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wr[(b + 1) & 1][i] = *reinterpret_cast<const bf16x8_t*>(wl + ((4 * ((b + 1) & 1) + i) * 8 + ((b + 1) >> 1)) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * (b & 1) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[b & 1][i], a[b >> 1], acc[4 * (b & 1) + i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+__device__ __forceinline__ void kv_store(f32x4 (&acc)[8], bf16* out, long gr, long rows, int l16, int g) {
+    const long row = gr * 16 + l16;
+#pragma unroll
+    for (int t = 0; t < 8; t += 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                                          // groups 0 / 1 and 2 / 3 trade halves: group g then holds features 16 t + 16 (g & 1) + 8 (g >> 1) .. + 7
+            const float a0 = acc[t][e], a1 = acc[t + 1][e];                   // (selects on values: a lane-dependent choice of the ELEMENT to overwrite put the array in scratch)
+            const float got = lane_xor16((g & 1) ? a0 : a1);
+            acc[t][e] = (g & 1) ? got : a0;
+            acc[t + 1][e] = (g & 1) ? a1 : got;
+        }
+        bf16x8_t c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { c[e] = (__bf16)acc[t][e]; c[4 + e] = (__bf16)acc[t + 1][e]; }
+        if (row < rows) *reinterpret_cast<bf16x8_t*>(out + (size_t)row * 128 + 16 * t + 16 * (g & 1) + 8 * (g >> 1)) = c;
+    }
+}
+__global__ __launch_bounds__(64 * KV_WAVES) void kv_proj_kernel(KvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bs = reinterpret_cast<float*>(smem + 2 * 128 * 256 * 2);          // bk [128] | bv [128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    // fragment (matrix w, tile t, k-step ks) = one contiguous KiB: lane (m, gg) <- W[16 t + m][32 ks + 8 gg .. + 7]
+    for (int c = tid; c < 2 * 8 * 8 * 64; c += 64 * KV_WAVES) {
+        const int w = c >> 12, f = (c >> 6) & 63, ln = c & 63, t = f >> 3, ks = f & 7, m = ln & 15, gg = ln >> 4;
+        *reinterpret_cast<uint4*>(smem + c * 16) = *reinterpret_cast<const uint4*>((w ? p.Wv : p.Wk) + (size_t)(16 * t + m) * 256 + 32 * ks + 8 * gg);
+    }
+    if (tid < 128) { bs[tid] = p.bk ? p.bk[tid] : 0.f; bs[128 + tid] = p.bv ? p.bv[tid] : 0.f; }
+    __syncthreads();
+    const long groups = (p.rows + 15) / 16, stride = (long)gridDim.x * KV_WAVES;
+    long grp = (long)blockIdx.x * KV_WAVES + wave;
+    if (grp >= groups) return;
+    bf16x8_t ak[8], av[8];
+    kv_load(ak, p.xk, grp, p.rows, l16, g);
+    kv_load(av, p.xv, grp, p.rows, l16, g);
+    for (; grp < groups; grp += stride) {
+        int lo_ = lane * 16;
+        asm volatile("" : "+v"(lo_));                                         // (opaque per group: the fragment addresses are not loop invariants to hoist into registers)
+        const char* wl = smem + lo_;
+        const long nxt = min(grp + stride, groups - 1);                       // (the last trip re-requests its own rows: no branch around the loads)
+        f32x4 acc[8], acc2[8];
+        kv_product(acc, ak, wl, bs, g);
+        kv_load(ak, p.xk, nxt, p.rows, l16, g);                               // the next group's k rows pass under the v product
+        kv_store(acc, p.K, grp, p.rows, l16, g);
+        kv_product(acc2, av, wl + 8 * 8 * 1024, bs + 128, g);
+        kv_load(av, p.xv, nxt, p.rows, l16, g);                               // its v rows under the stores and the next k product
+        kv_store(acc2, p.V, grp, p.rows, l16, g);
+    }
+}
+// xk, xv bf16 [rows, 256] (keys + pe, keys); Wk, Wv bf16 [128, 256]; bk, bv fp32 [128] | NULL; K, V bf16 [rows, 128]
+extern "C" int ullsam_kv_proj(const void* xk, const void* xv, const void* Wk, const void* Wv, const float* bk, const float* bv, void* K, void* V, long rows, void* stream) {
+    ULLSAM_CHECK(rows > 0 && xk && xv && Wk && Wv && K && V, "kv_proj: rows=%ld or a null operand", rows);
+    ULLSAM_CHECK((((uintptr_t)xk | (uintptr_t)xv | (uintptr_t)Wk | (uintptr_t)Wv | (uintptr_t)K | (uintptr_t)V) & 15) == 0, "kv_proj: 16-byte aligned operands needed");
+    KvArgs a{static_cast<const bf16*>(xk), static_cast<const bf16*>(xv), static_cast<const bf16*>(Wk), static_cast<const bf16*>(Wv), bk, bv, static_cast<bf16*>(K), static_cast<bf16*>(V), rows};
+    constexpr int LDS = 2 * 128 * 256 * 2 + 256 * 4;
+    static PerDeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kv_proj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    const long groups = (rows + 15) / 16, want = (groups + KV_WAVES - 1) / KV_WAVES;
+    kv_proj_kernel<<<dim3((unsigned)(want < 256 ? want : 256)), 64 * KV_WAVES, LDS, reinterpret_cast<hipStream_t>(stream)>>>(a);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }

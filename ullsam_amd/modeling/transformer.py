@@ -70,8 +70,12 @@ def _token_to_image(at: Attention, queries, qpe, keys_pe_c, keys_c, P, T, N, dt,
     if kv_cache is not None and "K0" in kv_cache:
         K, V = kv_cache["K0"], kv_cache["V0"]
     else:
-        K = ops.gemm(keys_pe_c, at.k_proj.w(dt), at.k_proj.b())
-        V = ops.gemm(keys_c, at.v_proj.w(dt), at.v_proj.b())
+        if FUSED_KV and dt == torch.bfloat16 and at.k_proj.weight.shape == (128, 256) and keys_c.shape == keys_pe_c.shape:
+            # both projections in one pass, weights resident in LDS (any row count: a record's outputs must not depend on what it is batched with)
+            K, V = ops.kv_proj(keys_pe_c, keys_c, at.k_proj.w(dt), at.k_proj.b(), at.v_proj.w(dt), at.v_proj.b())
+        else:
+            K = ops.gemm(keys_pe_c, at.k_proj.w(dt), at.k_proj.b())
+            V = ops.gemm(keys_c, at.v_proj.w(dt), at.v_proj.b())
         if kv_cache is not None:
             kv_cache["K0"], kv_cache["V0"] = K, V
     if at.num_heads == 8 and at.hd == 16 and T <= (16 if K.dtype == torch.bfloat16 else 8):
@@ -85,6 +89,7 @@ def _token_to_image(at: Attention, queries, qpe, keys_pe_c, keys_c, P, T, N, dt,
     return at.tok(at.out_proj, a, res=queries)
 
 
+FUSED_KV = os.environ.get("ULLSAM_FUSED_KV", "1") != "0"     # bf16, SAM's decoder dimensions: the image side's k and v projections of a token -> image attention as one launch (csrc/decoder.hip kv_proj_kernel)
 FUSED_TOK = os.environ.get("ULLSAM_FUSED_TOK", "1") != "0"   # bf16: the token side of a block as two launches (csrc/dectok.hip) instead of ~18
 
 

@@ -171,6 +171,17 @@ def i2t_block(xin: torch.Tensor, res: torch.Tensor, wq: torch.Tensor, bq, ktok: 
     return out_f, out_c, out_pe
 
 
+def kv_proj(xk: torch.Tensor, xv: torch.Tensor, wk: torch.Tensor, bk, wv: torch.Tensor, bv):
+    """K = xk wk^T + bk, V = xv wv^T + bv in one pass over the image side (csrc/decoder.hip kv_proj_kernel): xk / xv bf16 [rows, 256], wk / wv bf16 [128, 256] -> bf16 [rows, 128] x 2."""
+    _chk(xk, "xk", torch.bfloat16); _chk(xv, "xv", torch.bfloat16); _chk(wk, "wk", torch.bfloat16); _chk(wv, "wv", torch.bfloat16)
+    rows = xk.numel() // 256
+    assert xk.shape[-1] == 256 and xv.shape == xk.shape and wk.shape == (128, 256) and wv.shape == (128, 256)
+    K = torch.empty((rows, 128), dtype=torch.bfloat16, device=xk.device)
+    V = torch.empty((rows, 128), dtype=torch.bfloat16, device=xk.device)
+    _lib.call("ullsam_kv_proj", xk.data_ptr(), xv.data_ptr(), wk.data_ptr(), wv.data_ptr(), _p(bk), _p(bv), K.data_ptr(), V.data_ptr(), rows, _stream())
+    return K, V
+
+
 def pack_mfma_rows(w: torch.Tensor) -> torch.Tensor:
     """nn.Linear weight [out, in] (out padded to a multiple of 16 with zero rows; in % 32 == 0) -> bf16 in MFMA A-fragment order [out / 16][in / 32][lane = 16 g + m][8]:
     lane (m, g) of row tile t and k-step s holds w[16 t + m][32 s + 8 g .. + 7], and a wave's fragment load is one contiguous KiB (csrc/dectok.hip lin_tiles).
