@@ -480,7 +480,7 @@ def test_hot_kernels_compile_without_spills():
     assert len(ks) > 100, len(ks)
     hot = {n: r for n, r in ks.items() if any(re.search(h, n) for h in KR.HOT_BF16)}
     assert len(hot) >= 12, sorted(hot)
-    for must in ("gemm_ring8_kernel", "causal128_attn_kernel", "win14_attn_kernel", "win14r_attn_kernel", "gemm_skinny", "norm_block_kernel", "i2t_block_kernel", "up1_ln_gelu_kernel",
+    for must in ("gemm_ring8_kernel", "causal128_attn_kernel", "win14_attn_kernel", "win14r_attn_kernel", "gemm_skinny", "norm_block_kernel", "i2t_block_kernel", "kv_proj_kernel", "up1_ln_gelu_kernel",
                  "up2_hyper_kernel", "tok2img_partial_mfma_kernel", "dec_tok_mlp_kernel", "dec_tok_attn_kernel", "dec_heads_kernel", "amg_postprocess_kernel", "rle_emit_kernel"):
         assert any(must in n for n in hot), must
     bad = {n: (r.get("vgpr_spill_count", 0), r.get("private_segment_fixed_size", 0)) for n, r in hot.items()

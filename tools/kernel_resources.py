@@ -30,7 +30,7 @@ HOT_BF16 = [r"gemm_ring8_kernelILi\d+ELi\d+ELi\d+ELb0E", r"gemm256_kernelIDF16bL
 # round 5: the mask decoder's and the automatic mask generator's kernels (bf16 path): the fused two-way-block kernels, the upscaling kernels, the post-processing
 # (gemm256_kernel<*, 1> -- the two-buffer kernel's LDS-staged RoPE epilogue, 16 - 28 spills -- is still dispatched, by fp32 wqkv and by bf16 operands the ring's
 # epilogue cannot take (unaligned q / k / v): not on the bench path, not in this list)
-HOT_AMG = [r"i2t_block_kernel", r"up1_ln_gelu_kernel", r"up2_hyper_kernel", r"tok2img_partial_mfma_kernel", r"tok2img_merge_kernel", r"dec_tok_attn_kernel", r"dec_tok_mlp_kernel",
+HOT_AMG = [r"i2t_block_kernel", r"kv_proj_kernel", r"up1_ln_gelu_kernel", r"up2_hyper_kernel", r"tok2img_partial_mfma_kernel", r"tok2img_merge_kernel", r"dec_tok_attn_kernel", r"dec_tok_mlp_kernel",
            r"dec_heads_kernel", r"amg_postprocess_kernel", r"rle_emit_kernel"]
 HOT_BF16 = HOT_BF16 + HOT_AMG
 HOT = HOT_BF16
