@@ -29,7 +29,7 @@ from ullsam_amd.utils.synthetic import blob_decoder_init
 sam = blob_decoder_init(build_model(vit, "none", torch.bfloat16, "cuda:0"))
 fp8 = os.environ.get("ULLSAM_FP8") == "1"
 sam.image_encoder.fp8_linears = fp8
-gen = SamAutomaticMaskGenerator(sam, points_per_side=side, points_per_batch=64, pred_iou_thresh=piou, stability_score_thresh=stab,
+gen = SamAutomaticMaskGenerator(sam, points_per_side=side, points_per_batch=int(os.environ.get("AMG_PPB", "64")), pred_iou_thresh=piou, stability_score_thresh=stab,
                                 stability_score_offset=off, box_nms_thresh=nms, output_mode="uncompressed_rle")
 from ullsam_amd.utils.synthetic import microscopy_tile
 img = torch.from_numpy(microscopy_tile(7, size=tile, n_cells=40, r_range=(90.0 * tile / 2048, 260.0 * tile / 2048))[0] * 255).cuda()
@@ -43,7 +43,7 @@ for it in range(iters):
     if it:
         encs.append(t1 - t0); alls.append(t2 - t1)
 t_enc, t_all = sorted(encs)[len(encs) // 2] * (iters - 1), sorted(alls)[len(alls) // 2] * (iters - 1)     # medians over the timed tiles (the first tile is a warm-up)
-print(json.dumps({"workload": f"AMG {side}x{side} points on a {tile}^2 tile, SAM ViT-{vit.upper()}, {'fp8 (e4m3) qkv/lin1 + bf16' if fp8 else 'bf16'}, 64 prompts/batch, multimask",
+print(json.dumps({"workload": f"AMG {side}x{side} points on a {tile}^2 tile, SAM ViT-{vit.upper()}, {'fp8 (e4m3) qkv/lin1 + bf16' if fp8 else 'bf16'}, {os.environ.get('AMG_PPB', '64')} prompts/batch, multimask",
                   "seconds_per_tile": round(t_all / (iters - 1), 4), "encoder_seconds": round(t_enc / (iters - 1), 4), "prompts_per_s": round(side * side / (t_all / (iters - 1)), 1),
                   "masks_kept": len(recs), "thresholds": {"pred_iou": piou, "stability": stab, "stability_offset": off, "box_nms": nms}}))
 assert len(recs) > 0, "every mask was filtered: the timed tile did no NMS / RLE work"
