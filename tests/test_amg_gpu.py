@@ -269,6 +269,29 @@ def test_generator_reuses_the_image_side_across_point_batches(dtype):
         assert ra["stability_score"] == rb["stability_score"] and ra["predicted_iou"] == rb["predicted_iou"] and ra["point_coords"] == rb["point_coords"]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_generator_records_do_not_depend_on_points_per_batch(dtype):
+    """SAM's `points_per_batch` is a memory knob (0.123 / 0.103 / 0.095 s per real-size tile at 64 / 128 / 256): the records of a crop must be the same
+    whichever way its point grid is cut into decoder batches -- every decoder kernel works per prompt (token kernels: a workgroup per prompt; image-side kernels:
+    rows of one prompt), and the launches whose tile shape depends on the row count keep their k order.  Masks, boxes, areas, stability scores: bit-equal; the
+    predicted IoU to its last place (see below)."""
+    from ullsam_amd.automatic_mask_generator import SamAutomaticMaskGenerator
+    sam, _ = _small_sam()
+    sam = sam.to(dtype)
+    img = torch.from_numpy(U.rand_image((3, 600, 800), 29, 255.0))
+    kw = dict(points_per_side=6, pred_iou_thresh=-1e3, stability_score_thresh=0.5, stability_score_offset=0.05, output_mode="uncompressed_rle")
+    recs = [SamAutomaticMaskGenerator(sam, points_per_batch=ppb, **kw).generate(img) for ppb in (5, 12, 36)]
+    assert len(recs[0]) > 0
+    for other in recs[1:]:
+        assert len(other) == len(recs[0])
+        for ra, rb in zip(recs[0], other):
+            assert ra["segmentation"] == rb["segmentation"] and ra["bbox"] == rb["bbox"] and ra["area"] == rb["area"]
+            assert ra["stability_score"] == rb["stability_score"] and ra["point_coords"] == rb["point_coords"]
+            # the IoU head's fp32 token-side linears pick their kernel by row count (one wave per output for a handful of rows, the row-block kernels beyond):
+            # the predicted IoU may move in its last place (measured 6e-8), the masks and everything derived from them may not
+            assert abs(ra["predicted_iou"] - rb["predicted_iou"]) <= 1e-6 * max(1.0, abs(ra["predicted_iou"]))
+
+
 def test_generator_min_mask_region_area_and_coco_rle():
     """min_mask_region_area: every surviving mask has no island and no hole smaller than the threshold (remove_small_regions is
     idempotent on it), areas / boxes are recomputed for changed masks; output_mode="coco_rle" round-trips to the same masks."""

@@ -324,7 +324,7 @@ def tok2img_attention(q, k, v, P, H, hd, T, N, scale, kv_shared: bool = False):
     """q fp32 [P*T, H*hd]; k, v [P (or 1 when kv_shared) * N, H*hd] fp32 or bf16 -> fp32 [P*T, H*hd]."""
     _chk(q, "q", torch.float32); _chk(k, "k"); _chk(v, "v", k.dtype)
     C = H * hd
-    nsplit = max(1, min(32, -(-512 // P), N // 128))
+    nsplit = max(1, min(8, N // 128))          # independent of P: the partition of the keys (and with it the order of the softmax merge) must not depend on how many prompts share the launch
     ws = torch.empty((P * nsplit * T * (C + 2 * H),), dtype=torch.float32, device=q.device)
     out = torch.empty((P * T, C), dtype=torch.float32, device=q.device)
     bs = 0 if kv_shared else N * C
