@@ -14,6 +14,8 @@ SHAPES = [  # (name, M, N, K, act)
     ("dec.kproj", 262144, 128, 256, 0), ("dec.up1", 262144, 256, 256, 0),
     # the training step's frozen-LLM products at one 1081-token sequence (M = 1081: 9 x 128-row tiles x 32 = 288 workgroups of the 128x128 kernel = 1.125 rounds)
     ("trn.wo", 1081, 4096, 4096, 0), ("trn.w2", 1081, 4096, 14336, 0), ("trn.dw13", 1081, 4096, 28672, 0), ("trn.wqkv", 1081, 6144, 4096, 0), ("trn.dw2", 1081, 14336, 4096, 0),
+    # the two shapes that trail the vendor library most, WITHOUT their epilogues (bias + GELU; SwiGLU pair): loop against loop
+    ("vit.lin1.plain", 16384, 5120, 1280, 0), ("llm.w13.plain", 4324, 28672, 4096, 0),
     ("vit.proj+r", 16384, 1280, 1280, 16), ("vit.lin2+r", 16384, 1280, 5120, 16), ("llm.wo+r", 4324, 4096, 4096, 16), ("llm.w2+r", 4324, 4096, 14336, 16),
 ]
 

@@ -5,7 +5,7 @@ import numpy as np, torch
 from ullsam_amd import ops, _lib
 from ullsam_amd.packing import pack_w13
 lib = _lib.load()
-SH = {"w13": (9, 4324, 28672, 4096, 3, 272, 256, 36 + 32), "wo": (9, 4324, 4096, 4096, 0, 272, 256, 68), "w2": (9, 4324, 4096, 14336, 0, 272, 256, 68),
+SH = {"w13": (9, 4324, 28672, 4096, 3, 272, 256, 36 + 32), "w13plain": (9, 4324, 28672, 4096, 0, 272, 256, 68), "lin1": (8, 16384, 5120, 1280, 1, 256, 320, 80), "lin1plain": (8, 16384, 5120, 1280, 0, 256, 320, 80), "wo": (9, 4324, 4096, 4096, 0, 272, 256, 68), "w2": (9, 4324, 4096, 14336, 0, 272, 256, 68),
       "qkv": (8, 16384, 3840, 1280, 0, 256, 320, 80), "lin2": (8, 16384, 1280, 5120, 0, 256, 320, 80)}
 for name in (sys.argv[1:] or ["w13", "w2", "qkv", "lin2"]):
     var, M, N, K, act, BM, BN, mf = SH[name]
