@@ -185,8 +185,10 @@ int ullsam_decode_attention(const void* q, const void* kc, const void* vc, const
 int ullsam_fewkeys_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int hd, int Sq,
                              int Sk, float scale, long q_batch_stride, void* stream);
 
-/* Token -> image cross attention (T <= 8 queries, N image keys, 8 heads x 16), K/V streamed once.  transformer.py:160-166,
-   100-106.  k/v in kv_dtype with element batch strides (0 = shared image); workspace f32 [P*nsplit*T*144]. */
+/* Token -> image cross attention (T queries, N image keys, 8 heads x 16), K/V streamed once.  transformer.py:160-166,
+   100-106.  k/v in kv_dtype with element batch strides (0 = shared image): fp32 K/V T <= 8 (VALU kernel); bf16 K/V T <= 16 (matrix-pipe kernel, queries and
+   probabilities as two bf16 terms: fp32-level accuracy on the rounded K/V).  workspace f32 [P*nsplit*T*144]; the caller chooses nsplit (ops.py: from N alone,
+   so that the softmax merge order does not depend on the prompt count). */
 int ullsam_tok2img_attention(int kv_dtype, const float* q, const void* k, const void* v, float* out, int P, int H, int hd, int T,
                              int N, long k_batch_stride, long v_batch_stride, float scale, float* workspace, int nsplit,
                              void* stream);
@@ -221,7 +223,7 @@ int ullsam_small_linear(const float* x, long ldx, const float* W, const float* b
 /* The image -> token half of a two-way block (transformer.py:176-182) for many prompts in ONE pass over the image-side stream (bf16, embedding 256,
  * internal 128, 8 heads): q = xin Wq^T + bq (xin = keys + pe in bf16), a = softmax_heads(q k_tok^T scale) v_tok, upd = res + a Wo^T + bo (res = keys, fp32),
  * y = LayerNorm(upd) -> out_f32 / out_c (bf16) / out_c_pe = bf16(y + key_pe[row % pe_rows]), each optional.  xin / res have P*N rows, or in_mod / res_mod
- * rows shared by every prompt (layer 0); ktok / vtok fp32 [P, T, 128], T <= 16. */
+ * rows shared by every prompt (layer 0: in_mod / res_mod / pe_rows are 0 or N); ktok / vtok fp32 [P, T, 128], T <= 16. */
 int ullsam_i2t_block(const void* xin, long in_mod, const float* res, long res_mod, const void* Wq, const float* bq, const float* ktok,
                      const float* vtok, const void* Wo, const float* bo, const float* lnw, const float* lnb, float eps, const float* key_pe,
                      long pe_rows, float* out_f32, void* out_c, void* out_c_pe, int P, int T, int N, float scale, void* stream);
