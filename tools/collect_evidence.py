@@ -26,7 +26,7 @@ INIT_PAT = re.compile(r"distribution_elementwise|FillFunctor|fill_kernel|copyBuf
 
 
 def short(n):
-    n = re.sub(r"^void ", "", n)
+    n = re.sub(r"^void ", "", n).replace("(anonymous namespace)::", "")
     if n.startswith("_Z"):
         base = re.match(r"_Z(\d+)", n)
         k = int(base.group(1))
@@ -127,8 +127,8 @@ def main():
     run([rp, "--kernel-trace", "--output-format", "csv", "-d", kt, "--", *bench, *args], os.path.join(scratch, "kt.log"))
     ktcsv = find(kt, "*kernel_trace.csv")
     name = "kernel_summary_HEAD" if a.mode == "mask" else "decode_summary"
-    kernel_summary(ktcsv, 6 if a.mode == "mask" else 1, os.path.join(prof, f"r{a.round}_{name}.txt"),
-                   stamp + (" -- rocprofv3 --kernel-trace -- python3 bench.py --steps 4 --warmup 2 (6 steps traced, the 5 after the first counted)" if a.mode == "mask"
+    kernel_summary(ktcsv, 7 if a.mode == "mask" else 1, os.path.join(prof, f"r{a.round}_{name}.txt"),
+                   stamp + (" -- rocprofv3 --kernel-trace -- python3 bench.py --steps 4 --warmup 2 (7 steps traced: 2 warm-up + 4 timed + the kernel_ms pass with its ~500 event pairs; the 6 after the first counted)" if a.mode == "mask"
                             else " -- rocprofv3 --kernel-trace -- python3 tools/decode_bench.py"))
     if a.skip_pmc or a.mode != "mask":
         return
