@@ -14,8 +14,9 @@ N GPUs process N x 4 images (weak scaling; configs[3] at N = 8).  Weights are ra
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the MFMA GEMM; achieved = algorithmic FLOPs of every GEMM
 launch / their HIP-event durations, sampled on every 5th timed step on the launch stream: an event pair per GEMM on EVERY step cost 1.5 ms
-of a 78 ms step), `kernel_ms_per_step` / `gap_ms_per_step` (HIP-event spans around every C-ABI call of one extra untimed step: what the
-kernels take, and what lies between them) and `cpu_baseline` (the oracle restated on torch CPU tensors -- multi-threaded fp32 GEMMs, `kind:
+of a 78 ms step -- rounds 1 - 4 carried that), `step_ms` (min / median / max of the timed steps' own event spans: box and run variance in the record),
+`graph_ms_per_step` (the step replayed from ONE HIP-graph capture, untimed: eager minus this = the cost of launching kernel by kernel)
+and `cpu_baseline` (the oracle restated on torch CPU tensors -- multi-threaded fp32 GEMMs, `kind:
 "port-torch"` -- timed on the host cores on a bounded, depth-reduced sample of the same workload, the numpy oracle's figure beside it; N = 1 only).
 """
 from __future__ import annotations
@@ -134,40 +135,6 @@ class GemmTimer:
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec)
         fl = sum(f for _, _, f in self.rec)
         return len(self.rec), ms, fl
-
-
-class CallTimer:
-    """HIP-event pairs around EVERY C-ABI call (ullsam_amd._lib.call) of one extra, UNTIMED step: `kernel_ms_per_step` = the sum of those spans = the GPU time of
-    the library's launches of a step.  Printed next to `ms_per_step` so that kernel time and inter-launch gaps / box variance can be told apart (a span of a call that launches
-    several kernels includes the gaps between them; torch's own few elementwise launches are outside)."""
-
-    def __init__(self):
-        from ullsam_amd import _lib
-        self.lib, self.orig, self.rec = _lib, _lib.call, []
-
-    def __enter__(self):
-        def timed(name, *args):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self.orig(name, *args)
-            e1.record()
-            self.rec.append((name, e0, e1))
-        self.lib.call = timed
-        return self
-
-    def __exit__(self, *exc):
-        self.lib.call = self.orig
-
-    def summary(self):
-        by = {}
-        for name, e0, e1 in self.rec:
-            ms = e0.elapsed_time(e1)
-            c = by.setdefault(name.replace("ullsam_", ""), [0, 0.0])
-            c[0] += 1
-            c[1] += ms
-        total = sum(v[1] for v in by.values())
-        top = sorted(by.items(), key=lambda kv: -kv[1][1])[:8]
-        return total, len(self.rec), {k: {"calls": v[0], "ms": round(v[1], 3)} for k, v in top}
 
 
 def tile_seeds(rank: int, B: int):
@@ -515,6 +482,45 @@ def dist_setup(gpus: int, stub: bool):
     return rank, world, device, ranks_seen
 
 
+def step_spread(ms):
+    """min / median / max of the timed steps' own HIP-event spans (steps whose GEMM launches carry event pairs are listed apart: they run ~1.5 ms longer)."""
+    if not ms:
+        return None
+    plain = [t for i, t in enumerate(ms) if i % GEMM_EVENT_EVERY != 0] or ms
+    evs = [t for i, t in enumerate(ms) if i % GEMM_EVENT_EVERY == 0]
+    srt = sorted(plain)
+    return {"min": round(srt[0], 3), "median": round(srt[len(srt) // 2], 3), "max": round(srt[-1], 3), "n": len(srt),
+            "median_of_steps_with_gemm_events": round(sorted(evs)[len(evs) // 2], 3) if evs else None}
+
+
+def graph_replay_ms(compute, reps: int = 6):
+    """The step captured ONCE in a HIP graph (every launch of the library goes to the current stream; tests/test_model_gpu.py::test_mask_path_replays_from_a_hip_graph
+    pins that the replay reproduces the eager result) and replayed `reps` times behind one event pair -> ms per replay.  A diagnostic printed beside the eager `ms_per_step`
+    (the headline stays the eager loop: at N > 1 a replay would overwrite buffers the all-gather of the previous step still reads)."""
+    try:
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                compute()                                  # warm-up on the capture stream (lazy allocations, weight packing)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                compute()
+            g.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            return round(e0.elapsed_time(e1) / reps, 3), f"one HIP-graph capture of the step, {reps} replays behind one event pair, untimed; eager ms_per_step - this = what launching kernel by kernel costs"
+    except Exception as e:                                 # a diagnostic must not take the measurement down
+        return None, f"graph capture failed: {type(e).__name__}: {str(e)[:200]}"
+
+
 def timed_steps(step, warmup: int, steps: int, world: int, device: str, on_timed=None, on_step=None):
     """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; the last step's exchange is inside the
     timed region; -> (seconds = MAX over ranks, the last gathered result)."""
@@ -536,14 +542,24 @@ def timed_steps(step, warmup: int, steps: int, world: int, device: str, on_timed
         barrier()
         if on_timed:
             on_timed(True)
+        marks = []                      # one HIP event per step boundary (K + 1 events: cheap) -> per-step times, for the spread printed beside the mean
         t0 = time.perf_counter()
         for i in range(steps):
             if on_step:
                 on_step(i)
+            if gpu:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
             step()
+        if gpu:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
         gathered = step.drain()
         barrier()
         dt = time.perf_counter() - t0
+        timed_steps.step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
         if on_timed:
             on_timed(False)
     if world > 1:
@@ -573,6 +589,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-iou", action="store_true", help="skip the fp32 run that gives mask_iou_vs_fp32")
+    ap.add_argument("--no-graph", action="store_true", help="skip the HIP-graph replay diagnostic (graph_ms_per_step): kernel traces then hold warm-up + timed steps only")
     ap.add_argument("--mode", default="mask", choices=["mask", "decode"], help="mask: the headline images/s path; decode: greedy tokens/s of the caption path")
     ap.add_argument("--stub", action="store_true", help="control-path self-test without a GPU (gloo, a stub step): measures nothing")
     ap.add_argument("--vit-fp8", action="store_true", help="fp8 (e4m3) operands for the ViT's LayerNorm-fed linears (qkv, lin1): BASELINE configs[4] 'fp8 MFMA ViT path'; everything else bf16")
@@ -623,13 +640,9 @@ def main():
     if world > 1:
         assert gathered is not None and gathered[0].shape[0] == a.batch * world and gathered[1].shape[0] == a.batch * world
     n_launch, gemm_ms, gemm_flops = timer.summary()
-    kernel_ms = None
-    if device != "cpu":                        # one more step, OUTSIDE the timed region, with an event pair around every C-ABI call
-        with torch.no_grad(), CallTimer() as ct:
-            step()
-            step.drain()
-            torch.cuda.synchronize()
-        kernel_ms, n_calls, by_call = ct.summary()
+    graph_ms, graph_note = None, None
+    if device != "cpu" and world == 1 and not a.no_graph:   # the same step ONCE MORE as a HIP-graph replay, outside the timed region: launch gaps of the eager loop show as eager - graph
+        graph_ms, graph_note = graph_replay_ms(mask_path_compute(model, inputs, dtype))
     traffic, traffic_note = (None, "not the default workload")
     if a.vit == "h" and a.llm == "7b" and a.batch == 4 and a.dtype == "bf16":
         traffic, traffic_note = traffic_record()
@@ -641,10 +654,8 @@ def main():
         "metric": "images/s end-to-end (ViT+LLM+mask) 1024^2", "value": round(value, 4), "unit": "images/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.dtype, "data": DATA_NOTE,
-        "kernel_ms_per_step": None if kernel_ms is None else round(kernel_ms, 3),
-        "gap_ms_per_step": None if kernel_ms is None else round(dt / a.steps * 1e3 - kernel_ms, 3),
-        "kernel_ms_note": None if kernel_ms is None else {"what": "sum of HIP-event spans around every C-ABI call of ONE extra untimed step on this rank (ms_per_step - this = inter-call gaps, "
-                                                                  "torch's own launches, the exchange and box variance)", "calls": n_calls, "top": by_call},
+        "step_ms": step_spread(getattr(timed_steps, "step_ms", [])),
+        "graph_ms_per_step": graph_ms, "graph_note": graph_note,
         "config": {"workload": (f"uLLSAM mask path (app.py:580-645): SAM ViT-{a.vit.upper()} + "
                                 + (f"InternLM2-{a.llm}-shaped prefill S={a.seq} + " if full else "")
                                 + f"prompt encoder + mask decoder + x4 upsample/threshold, 1 point prompt/image, batch {a.batch}/GPU"),

@@ -140,8 +140,11 @@ int ullsam_train_seg_loss(const float* x, const float* t, float* sums, float* lo
 /* (partial: P * 4 * ceil(npix / 1024) floats) */
 int ullsam_train_seg_loss_bwd(const float* x, const float* t, const float* sums, const float* gscale, float* dx, int P, long npix, float smooth, void* stream);
 /* The language-model loss of InternLM2ForCausalLM.forward (modeling_internlm2.py:1084-1096: CrossEntropyLoss() over the shifted logits, mean over labels != -100):
- * fp32 logits [rows, V] with row stride ld, labels int64 [rows] (negative = ignored); lse [rows], loss_rows [rows], out2 = {mean loss, 1 / #labelled rows};
- * the backward writes dlogits = (softmax - onehot) * gscale[0] * out2[1] (zero rows where the label is ignored).  Ordered sums: reproducible bits. */
+ * fp32 logits [rows, V] with row stride ld, labels int64 [rows]; lse [rows], loss_rows [rows], out2 = {mean loss, 1 / #labelled rows};
+ * the backward writes dlogits = (softmax - onehot) * gscale[0] * out2[1] (zero rows where the label is ignored).  Ordered sums: reproducible bits.
+ * No labelled row at all: out2[0] is NaN, as torch's mean over zero rows (the reference's `0 * loss + seg` is NaN there too), out2[1] = 0.
+ * Deviation: a label outside [0, V) other than -100 is treated as ignored here, where torch raises (device-side assert); the host wrapper (training.lm_loss)
+ * rejects such labels when they arrive on the CPU. */
 int ullsam_train_cross_entropy(const float* logits, long ld, const long long* labels, float* lse, float* loss_rows, float* out2, long rows, int V, void* stream);
 int ullsam_train_cross_entropy_bwd(const float* logits, long ld, const long long* labels, const float* lse, const float* out2, const float* gscale, float* dlogits,
                                    long ldx, long rows, int V, void* stream);   /* dlogits rows of ldx >= V floats: columns V .. ldx - 1 are zeroed (GEMM padding) */

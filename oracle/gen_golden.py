@@ -623,6 +623,78 @@ def case_decode_7b():
          margin=margin, top1=top1, logits0_sample=logits0[:, ::97].copy(), vit_embeds_sample=vit_embeds.numpy().reshape(-1)[::FULL_STRIDE].copy())
 
 
+DECODE_7B_FORCED_SEED = 77
+
+
+def decode_7b_forced_ids():
+    """-> [4, 16] int64: the teacher-forced continuation of tests/golden/decode_7b_forced.npz -- seeded random ids from the body of the
+    vocabulary (no eos / pad / image-context id), DIFFERENT at every step and prompt (the greedy fixture's random-weight rows repeat one id)."""
+    return np.random.default_rng(DECODE_7B_FORCED_SEED).integers(1000, 90000, size=(4, DECODE_7B_NEW)).astype(np.int64)
+
+
+def _ref_forced(lm, emb, mask, forced):
+    """Prefill + one cached forward per forced id (modeling_internlm2.py:1112-1149, 383-426) -> (prefill output, [B, n, V] fp32 logits AFTER each forced id)."""
+    B = emb.shape[0]
+    pos = mask.long().cumsum(-1) - 1
+    pos.masked_fill_(mask == 0, 1)
+    o0 = lm(inputs_embeds=emb, attention_mask=mask, position_ids=pos, use_cache=True, return_dict=True)
+    o, rows = o0, []
+    for s in range(forced.shape[1]):
+        mask = torch.cat([mask, torch.ones((B, 1), dtype=mask.dtype)], 1)
+        p1 = (mask.long().cumsum(-1) - 1)[:, -1:]
+        o = lm(input_ids=torch.from_numpy(forced[:, s:s + 1]).contiguous(), attention_mask=mask, position_ids=p1, past_key_values=o.past_key_values, use_cache=True, return_dict=True)
+        rows.append(o.logits[:, -1].float().numpy().copy())
+    return o0, np.stack(rows, 1)
+
+
+def case_decode_7b_forced():
+    """What decode_7b cannot pin (its greedy rows are low-entropy and carry logits for step 0 only): the same model, prompts and tiles, but
+      (a) TEACHER-FORCED: 16 seeded random continuation ids per prompt fed through the reference's cached forward -- per step a strided
+          sample of the fp32 logits, the top-1 / runner-up ids and their margin (64 decode steps whose numerics are pinned directly:
+          cache append, attention over a growing cache, the skinny GEMMs at the 7B shape);
+      (b) the same passes under torch.autocast("cpu", bfloat16) (ViT included): per-step mean / max |logits - fp32 logits| over the whole
+          vocabulary -- the bound the bf16 mode's decode steps are held to -- and the reference's OWN autocast greedy ids for these prompts."""
+    from ullsam_amd.utils.synthetic import microscopy_batch
+    t = time.time()
+    m = _build_full_depth()
+    fill_module_inplace(m, seed=0)
+    print(f"  built + filled in {time.time() - t:.0f}s", flush=True)
+    ids, mask = decode_7b_ids()
+    forced = decode_7b_forced_ids()
+    tids, tmask = torch.from_numpy(ids), torch.from_numpy(mask)
+    x_np, _ = microscopy_batch(FULL_TILE_SEEDS)
+    sel = tids.reshape(-1) == 92546
+
+    def embed():
+        vit = torch.cat([m.extract_feature(torch.from_numpy(x_np[b:b + 1]))[0] for b in range(4)]).float()
+        emb = m.language_model.get_input_embeddings()(tids).clone().float()
+        B, N, C = emb.shape
+        emb = emb.reshape(B * N, C)
+        emb[sel] = vit.reshape(-1, C)[: int(sel.sum())]
+        return emb.reshape(B, N, C)
+
+    t = time.time()
+    emb = embed()
+    _, lg = _ref_forced(m.language_model, emb, tmask, forced)
+    print(f"  fp32: embeds + prefill + {DECODE_7B_NEW} forced steps in {time.time() - t:.0f}s", flush=True)
+    v, i = torch.from_numpy(lg).topk(2, -1)
+    t = time.time()
+    with torch.autocast("cpu", dtype=torch.bfloat16, cache_enabled=False):
+        emb_ac = embed()
+        o0, lg_ac = _ref_forced(m.language_model, emb_ac, tmask, forced)
+        print(f"  autocast: embeds + prefill + forced steps in {time.time() - t:.0f}s", flush=True)
+        t = time.time()
+        ac_ids, _, ac_margin, _, _ = _ref_greedy_batched(m.language_model, emb_ac, tmask, DECODE_7B_NEW)
+        print(f"  autocast greedy in {time.time() - t:.0f}s", flush=True)
+    d = np.abs(lg_ac.astype(np.float64) - lg)
+    print("  forced top-1 ids\n", i[..., 0].numpy(), "\n  margins\n", (v[..., 0] - v[..., 1]).numpy().round(4))
+    print("  autocast mean |dlogit| per step\n", d.mean(-1).round(4), "\n  autocast greedy ids\n", ac_ids, flush=True)
+    save("decode_7b_forced", weight_seed=0, tile_seeds=np.asarray(FULL_TILE_SEEDS, np.int64), ids=ids, mask=mask, forced_ids=forced,
+         logits_sample=lg[:, :, ::97].copy(), logits_absmax=np.abs(lg).max(-1), top1_ids=i[..., 0].numpy(), second_ids=i[..., 1].numpy(),
+         margin=(v[..., 0] - v[..., 1]).numpy(), top1=v[..., 0].numpy(), ac_mean_err=d.mean(-1), ac_max_err=d.max(-1),
+         ac_top1_ids=lg_ac.argmax(-1), ac_greedy_ids=ac_ids, ac_greedy_margin=ac_margin)
+
+
 SAM_H_SEEDS = (3, 5)
 
 
@@ -948,7 +1020,7 @@ CASES = {"train_step": case_train_step, "train_step_real": lambda: case_train_st
          "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full,
          "vit_h_d2": case_vit_h_d2, "llm_7b_l1": case_llm_7b_l1,
          "rope_variants": case_rope_variants, "llm_tiny_bias_linear": case_llm_tiny_bias_linear,
-         "full_depth": case_full_depth, "decode_7b": case_decode_7b, "sam_h_forward": case_sam_h_forward}
+         "full_depth": case_full_depth, "decode_7b": case_decode_7b, "decode_7b_forced": case_decode_7b_forced, "sam_h_forward": case_sam_h_forward}
 
 if __name__ == "__main__":
     for n in (sys.argv[1:] or list(CASES)):

@@ -216,6 +216,56 @@ def test_gemm_272x256_kernel(ops, M, N, K, mode):
     assert float((got - want).abs().max()) < tol * max(1.0, float(want.abs().max()) / 4)
 
 
+@pytest.mark.parametrize("variant,M,N,K,mode", [(9, 4324, 8192, 384, "swiglu"), (9, 8704, 4096, 512, "res"), (8, 8192, 3840, 384, "bias_gelu"), (8, 8000, 3840, 640, "res_mod"),
+                                                (6, 8192, 4096, 384, "bias"), (6, 6000, 6144, 1024, "plain")])
+@pytest.mark.parametrize("persist", [1, 4])
+def test_gemm_persistent_ring_equals_the_one_tile_kernel(ops, variant, M, N, K, mode, persist):
+    """The persistent forms of the ring kernel (csrc/gemm_ring8p.h: ullsam_set_gemm_tuning(2, 1) = workgroups walk tiles with the LDS ring kept full across tile borders,
+    4 = the same with ONE barrier per stage) on launches of more than one round of tiles, every direct epilogue, ragged M: same MFMA order and same epilogue arithmetic as the
+    one-tile-per-workgroup kernel, so the outputs must be EQUAL bit for bit (and both are checked against the fp32 matmul)."""
+    from ullsam_amd import _lib
+    from ullsam_amd.packing import pack_w13
+    lib = _lib.load()
+    g = torch.Generator(device=DEV); g.manual_seed(M + N + K + variant)
+    a = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g)
+    ref = a.float() @ w.float().T
+    F = torch.nn.functional
+    x0 = torch.randn(M, N, device=DEV, generator=g)
+    pe = torch.randn(M // 2, N, device=DEV, generator=g)
+
+    def run():
+        if mode == "plain":
+            return ops.gemm(a, w).float(), ref, 3e-2
+        if mode == "bias":
+            return ops.gemm(a, w, bias).float(), ref + bias, 3e-2
+        if mode == "bias_gelu":
+            return ops.gemm(a, w, bias, act=ops.ACT_GELU).float(), F.gelu(ref + bias), 3e-2
+        if mode == "res":
+            x = x0.clone()
+            ops.gemm(a, w, bias, residual=x, out_f32=True, out=x)
+            return x, ref + bias + x0, 2e-3
+        if mode == "res_mod":
+            return ops.gemm(a, w, bias, residual=pe, res_row_mod=M // 2, out_f32=True), ref + bias + pe.repeat(2, 1), 2e-3
+        I = N // 2
+        return ops.gemm(a, pack_w13(w[:I].contiguous(), w[I:].contiguous()), act=ops.ACT_SWIGLU).float(), F.silu(ref[:, :I]) * ref[:, I:], 3e-2
+    try:
+        lib.ullsam_set_gemm_variant(variant)
+        lib.ullsam_set_gemm_tuning(2, 0)
+        base, want, tol = run()
+        lib.ullsam_set_gemm_tuning(2, persist)
+        got, _, _ = run()
+        again, _, _ = run()
+        torch.cuda.synchronize()
+    finally:
+        lib.ullsam_set_gemm_variant(0)
+        lib.ullsam_set_gemm_tuning(2, 0)
+    assert float((base - want).abs().max()) < tol * max(1.0, float(want.abs().max()) / 4)
+    assert torch.equal(got, base), int((got != base).sum())
+    assert torch.equal(again, got)
+
+
 def _e4m3_decode(u8: np.ndarray) -> np.ndarray:
     """OCP e4m3fn bytes -> float32 (the tests' own decoder: sign, 4-bit exponent bias 7, 3-bit mantissa, subnormals, 0x7f = NaN)."""
     u = u8.astype(np.int32)

@@ -782,6 +782,90 @@ def test_decode_7b_greedy_ids_against_the_reference():
     assert k32 >= int(0.9 * toks.size) and k16 >= toks.size // 2, (k32, k16)
 
 
+def _forced_decode(m, x, ids, mask, forced):
+    """Prefill + one cached decode step per forced id through the calls InternLM2ForCausalLM.generate makes (modeling_internlm2.py of this package: the model forward
+    on a growing cache, lm_head on the last position) -> fp32 logits [B, n, V] AFTER each forced id.  The embedding path is InternVLSAMModel.generate's."""
+    from ullsam_amd import ops
+    lm = m.language_model
+    B, S = ids.shape
+    n = forced.shape[1]
+    vit = m._mlp1_tokens(m.vision_model.forward_tokens(x), x.shape[0])
+    rank, _ = ops.scan_image_tokens(ids.contiguous(), m.img_context_token_id)
+    emb = ops.embed_tokens(lm.model.tok_embeddings.weight.detach(), ids.contiguous(), rank, vit).reshape(B, S, -1)
+    mk = mask.long()
+    pos = (mk.cumsum(-1) - 1).masked_fill(mk == 0, 1)
+    cache = lm.model.new_cache(B, S + n + 1, ids.device)
+    lm.model(input_ids=None, inputs_embeds=emb, attention_mask=mk, position_ids=pos, past_key_values=cache, use_cache=True)
+    mask_full = torch.ones((B, S + n), dtype=torch.int32, device=ids.device)
+    mask_full[:, :S] = mk
+    pos_next = mk.sum(-1, keepdim=True).to(torch.int32)
+    rows = []
+    for s in range(n):
+        out = lm.model(input_ids=forced[:, s:s + 1].contiguous(), attention_mask=mask_full[:, :S + s + 1], position_ids=pos_next, past_key_values=cache, use_cache=True)
+        pos_next = pos_next + 1
+        rows.append(lm.lm_head(out.last_hidden_state[:, -1]).float())
+    return torch.stack(rows, 1)
+
+
+def test_decode_7b_teacher_forced_logits_at_every_step():
+    """What the greedy fixture cannot see (its random-weight rows repeat one id, and it carries logits for step 0 only): tests/golden/decode_7b_forced.npz feeds 16 SEEDED RANDOM
+    continuation ids per prompt through the reference's cached forward (modeling_internlm2.py:1112-1149, 383-426) at the 7B shape, batch 4, S = 1081 (prompt 2 left-padded), and
+    stores per step a strided sample of the logits, the top-1 / runner-up ids and their margin -- plus the same passes under torch.autocast(bfloat16): the per-step mean
+    |logits - fp32 logits| and the reference's own autocast greedy ids.  All 64 decode steps are compared, none is skipped:
+      fp32 mode: the logits sample within 1e-3 x the step's largest |logit| at every step; top-1 equal wherever the margin exceeds 5e-3 (else the reference's runner-up);
+      bf16 mode: mean |logits error| over the sample <= 1.5 x the reference's autocast mean error at every step; top-1 equal to the reference's fp32 top-1 wherever its margin
+      exceeds 6 x the reference's autocast mean error of that step (both top-2 logits may move by a few mean errors), else the runner-up;
+      greedy, bf16 mode: the ids are counted against the reference's OWN autocast ids and against its fp32 ids (decode_7b.npz) at all 64 steps: this library's bf16 mode must
+      agree with the fp32 ids about as often as the reference's autocast run does."""
+    import bench
+    from ullsam_amd.utils.synthetic import microscopy_batch
+    g = U.gold("decode_7b_forced")
+    ids_np, mask_np = decode_7b_prompts()
+    assert np.array_equal(ids_np, g["ids"]) and np.array_equal(mask_np, g["mask"])
+    x_np, _ = microscopy_batch([int(s) for s in g["tile_seeds"]])
+    ids, mask = torch.from_numpy(ids_np).to(DEV), torch.from_numpy(mask_np).to(DEV)
+    forced = torch.from_numpy(g["forced_ids"]).to(DEV)
+    B, n = g["forced_ids"].shape
+    ref_s, absmax = g["logits_sample"].astype(np.float64), g["logits_absmax"].astype(np.float64)
+    top1, second, margin = g["top1_ids"], g["second_ids"], g["margin"]
+    m32 = _fill_model_from_rule(bench.build_model("h", "7b", torch.float32, DEV, init=False), int(g["weight_seed"]))
+    x = torch.from_numpy(x_np).to(DEV)
+    lg = _forced_decode(m32, x, ids, mask, forced)
+    got_s, arg = lg[:, :, ::97].double().cpu().numpy(), lg.argmax(-1).cpu().numpy()
+    e32 = np.abs(got_s - ref_s).max(-1)
+    print(f"fp32 mode: worst logits error / step scale over the {B * n} forced steps {float((e32 / absmax).max()):.2e}; top-1 equal at {int((arg == top1).sum())} steps, smallest margin {float(margin.min()):.4f}")
+    assert (e32 < 1e-3 * np.maximum(absmax, 1.0)).all(), (e32 / absmax).max()
+    for b in range(B):
+        for s in range(n):
+            if arg[b, s] != top1[b, s]:
+                assert margin[b, s] < DECODE_MARGIN_FP32 and arg[b, s] == second[b, s], ("fp32", b, s, float(margin[b, s]))
+    mb = bench.build_model("h", "7b", torch.bfloat16, DEV, init=False)
+    missing, unexpected = mb.load_state_dict({k: v.to(torch.bfloat16) for k, v in m32.state_dict().items()}, strict=False)
+    assert not missing and not unexpected
+    del m32, lg
+    torch.cuda.empty_cache()
+    lg16 = _forced_decode(mb, x.bfloat16(), ids, mask, forced)
+    got16, arg16 = lg16[:, :, ::97].double().cpu().numpy(), lg16.argmax(-1).cpu().numpy()
+    m16 = np.abs(got16 - ref_s).mean(-1)
+    acm = g["ac_mean_err"].astype(np.float64)
+    flips = int((arg16 != top1).sum())
+    print(f"bf16 mode: mean |logits error| per step {float(m16.min()):.4f} .. {float(m16.max()):.4f} (the reference's autocast: {float(acm.min()):.4f} .. {float(acm.max()):.4f}); "
+          f"top-1 differs from the reference's fp32 top-1 at {flips} of {B * n} steps (the reference's autocast at {int((g['ac_top1_ids'] != top1).sum())})")
+    assert (m16 < 1.5 * acm).all(), (m16 / acm).max()
+    for b in range(B):
+        for s in range(n):
+            if arg16[b, s] != top1[b, s]:
+                assert margin[b, s] < 6.0 * acm[b, s] and arg16[b, s] == second[b, s], ("bf16", b, s, float(margin[b, s]), float(acm[b, s]))
+    # greedy ids of the bf16 mode against the reference's own autocast greedy ids, every step: a step where the two differ has the context of different earlier tokens or a near-tie --
+    # it is accepted when this library's id is the reference's fp32 id at that step of the fp32 greedy run (decode_7b.npz), i.e. the bf16 mode sides with fp32 where autocast left it
+    gg = U.gold("decode_7b")
+    toks16 = mb.generate(pixel_values=x.bfloat16(), input_ids=ids, attention_mask=mask, max_new_tokens=n, eos_token_id=-1).cpu().numpy()
+    ac = g["ac_greedy_ids"]
+    same_ac, same_32 = int((toks16 == ac).sum()), int((toks16 == gg["greedy_ids"]).sum())
+    print(f"bf16 greedy: {same_ac} of {B * n} ids equal to the reference's autocast ids, {same_32} equal to its fp32 ids (the reference's autocast vs its own fp32: {int((ac == gg['greedy_ids']).sum())})")
+    assert same_32 >= int((ac == gg["greedy_ids"]).sum()) - 8, (same_ac, same_32)   # as close to the reference's fp32 ids as its own autocast run is (56 of 64), with slack for one more near-tie
+
+
 SAM_H_EXTRA_SEEDS = (27, 32, 7, 11, 19, 23)
 
 

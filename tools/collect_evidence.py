@@ -120,15 +120,15 @@ def main():
         bench = [py, "tools/decode_bench.py"]
         steps = 1
     else:
-        bench = [py, "bench.py", "--no-cpu-baseline", "--no-iou"]
+        bench = [py, "bench.py", "--no-cpu-baseline", "--no-iou", "--no-graph"]
     rp = "/opt/rocm/bin/rocprofv3"
     kt = os.path.join(scratch, "kt")
     args = (["--steps", "4", "--warmup", "2"] if a.mode == "mask" else [])
     run([rp, "--kernel-trace", "--output-format", "csv", "-d", kt, "--", *bench, *args], os.path.join(scratch, "kt.log"))
     ktcsv = find(kt, "*kernel_trace.csv")
     name = "kernel_summary_HEAD" if a.mode == "mask" else "decode_summary"
-    kernel_summary(ktcsv, 7 if a.mode == "mask" else 1, os.path.join(prof, f"r{a.round}_{name}.txt"),
-                   stamp + (" -- rocprofv3 --kernel-trace -- python3 bench.py --steps 4 --warmup 2 (7 steps traced: 2 warm-up + 4 timed + the kernel_ms pass with its ~500 event pairs; the 6 after the first counted)" if a.mode == "mask"
+    kernel_summary(ktcsv, 6 if a.mode == "mask" else 1, os.path.join(prof, f"r{a.round}_{name}.txt"),
+                   stamp + (" -- rocprofv3 --kernel-trace -- python3 bench.py --steps 4 --warmup 2 (6 steps traced: 2 warm-up + 4 timed; the 5 after the first counted)" if a.mode == "mask"
                             else " -- rocprofv3 --kernel-trace -- python3 tools/decode_bench.py"))
     if a.skip_pmc or a.mode != "mask":
         return

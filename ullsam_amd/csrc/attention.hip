@@ -1929,7 +1929,7 @@ extern "C" int ullsam_vit_attention(int dtype, const void* qkv, void* out, const
         // SAM's own shape (14x14 windows, head_dim 80, bf16): the whole-window kernel; variant 2 forces the tiled kernel for A/B
         a.q_pos0 = (g_attn_variant >= 3 && g_attn_variant <= 8) ? g_attn_variant - 3 : 2;  // stagger of the second resident workgroup, units of s_sleep(127) = 3.4 us (A/B: variant 3 + n)
         // round 5: window rows as 16-wide query groups / key tiles, no key-block chain (win14r_attn_kernel); variant 13 keeps round 1's 32-query kernel (A/B, equality test)
-        if (dtype == 1 && window == 14 && hd == 80 && g_attn_variant != 1 && g_attn_variant != 2 && g_attn_variant != 13 && (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)qkv_bias) & 15) == 0) {
+        if (dtype == 1 && window == 14 && hd == 80 && g_attn_variant != 1 && g_attn_variant != 2 && g_attn_variant != 13 && (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)qkv_bias | (uintptr_t)rel_h | (uintptr_t)rel_w) & 15) == 0) {   // (the kernel reads the rel-pos tables 16 bytes at a time too)
             a.q_pos0 = (g_attn_variant >= 3 && g_attn_variant <= 8) ? g_attn_variant - 3 : 0;
             a.dbg = g_attn_dbg;
             return launch_win14r(a, s, (g_attn_variant >= 20 && g_attn_variant <= 22) ? g_attn_variant - 19 : 0);

@@ -358,7 +358,7 @@ extern "C" int ullsam_dec_tok_attn(const float* queries, const float* qpe, float
                                    const float* bq2, int P, int T, int skip_pe, int mode, void* stream) {
     ULLSAM_CHECK(P > 0 && T >= 1 && T <= 16, "dec_tok_attn: P=%d T=%d (1..16)", P, T);
     ULLSAM_CHECK(queries && qpe && q_t2i && Wq2 && (mode == 1 || (queries_out && Wq && Wk && Wv && Wo)), "dec_tok_attn: null operand");
-    ULLSAM_CHECK(AL16(queries) && AL16(qpe) && AL16(queries_out) && AL16(q_t2i) && AL16(Wq) && AL16(Wk) && AL16(Wv) && AL16(Wo) && AL16(Wq2) && AL16(bq) && AL16(bo), "dec_tok_attn: 16-byte aligned operands needed");
+    ULLSAM_CHECK(AL16(queries) && AL16(qpe) && AL16(queries_out) && AL16(q_t2i) && AL16(Wq) && AL16(Wk) && AL16(Wv) && AL16(Wo) && AL16(Wq2) && AL16(bq) && AL16(bo) && AL16(bk) && AL16(bv) && AL16(bq2) && AL16(ln_w) && AL16(ln_b), "dec_tok_attn: 16-byte aligned operands needed");
     TokAttnArgs a{queries, qpe, queries_out, q_t2i, (const bf16*)Wq, (const bf16*)Wk, (const bf16*)Wv, (const bf16*)Wo, bq, bk, bv, bo, ln_w, ln_b, eps, (const bf16*)Wq2, bq2, P, T, skip_pe, mode};
     dec_tok_attn_kernel<<<dim3(P), 64 * NWV, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
     ULLSAM_LAUNCH_CHECK();
@@ -370,7 +370,8 @@ extern "C" int ullsam_dec_tok_mlp(const float* queries, const float* attn, const
                                   const float* ln3_b, float eps3, const void* Wk, const float* bk, const void* Wv, const float* bv, int P, int T, int do_mlp, void* stream) {
     ULLSAM_CHECK(P > 0 && T >= 1 && T <= 16, "dec_tok_mlp: P=%d T=%d (1..16)", P, T);
     ULLSAM_CHECK(queries && attn && queries_out && Wo && (!do_mlp || (qpe && k_out && v_out && W1 && W2 && Wk && Wv)), "dec_tok_mlp: null operand");
-    ULLSAM_CHECK(AL16(queries) && AL16(attn) && AL16(qpe) && AL16(queries_out) && AL16(k_out) && AL16(v_out) && AL16(Wo) && AL16(W1) && AL16(W2) && AL16(Wk) && AL16(Wv), "dec_tok_mlp: 16-byte aligned operands needed");
+    ULLSAM_CHECK(AL16(queries) && AL16(attn) && AL16(qpe) && AL16(queries_out) && AL16(k_out) && AL16(v_out) && AL16(Wo) && AL16(W1) && AL16(W2) && AL16(Wk) && AL16(Wv) && AL16(bo) && AL16(ln2_w) && AL16(ln2_b) && AL16(b1) && AL16(b2) && AL16(ln3_w) && AL16(ln3_b) && AL16(bk) && AL16(bv),
+                 "dec_tok_mlp: 16-byte aligned operands needed");
     TokMlpArgs a{queries, attn, qpe, queries_out, k_out, v_out, (const bf16*)Wo, bo, ln2_w, ln2_b, eps2, (const bf16*)W1, (const bf16*)W2, b1, b2, ln3_w, ln3_b, eps3,
                  (const bf16*)Wk, (const bf16*)Wv, bk, bv, P, T, do_mlp};
     const int lds = (do_mlp ? 2 * 16 * HHP * 2 : 0) + 4 * 16 * CP * 2 + 2 * 16 * C * 4;

@@ -1196,9 +1196,40 @@ static int launch_gemm_ring8(GemmArgs a, hipStream_t stream) {
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
-static int launch_gemm_v6(const GemmArgs& a, hipStream_t stream) { return launch_gemm_ring8<8, 8, 4>(a, stream); }   // 256 x 256
-static int launch_gemm_v8(const GemmArgs& a, hipStream_t stream) { return launch_gemm_ring8<8, 8, 5>(a, stream); }   // 256 x 320
-static int launch_gemm_v9(const GemmArgs& a, hipStream_t stream) { return launch_gemm_ring8<9, 8, 4>(a, stream); }   // 272 x 256
+#include "gemm_ring8p.h"
+// Persistent form (gemm_ring8p.h) for launches of MORE than one round of tiles whose shape and epilogue it takes; everything else -- one-round
+// launches, ragged N, K not a multiple of 128, the LDS-staged epilogues -- stays on the one-tile-per-workgroup kernel.
+static int g_persist = 0;      // ullsam_set_gemm_tuning(2, v): 0 one tile per workgroup (default: the persistent forms measured equal or slower), 1 persistent, 4 persistent with one barrier per stage
+static int cu_count() {
+    static int n[32] = {};
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 31;
+    if (!n[d]) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256; n[d] = v; }
+    return n[d];
+}
+template <int BM, int BN, int NTW, int EMODE>
+static bool ring_persist_ok(const GemmArgs& a) {
+    if (!g_persist || a.N % BN != 0 || a.K % 128 != 0 || a.K < 384 || (a.dbg && !(g_dbg & 2))) return false;
+    const long tiles = (long)((a.M + BM - 1) / BM) * (a.N / BN);
+    if (tiles <= cu_count()) return false;
+    if (((size_t)(a.M + BM) * a.lda + a.K) * 2 >= (1ull << 32) || ((size_t)a.N * a.ldw + a.K) * 2 >= (1ull << 32)) return false;   // 32-bit descriptor offsets
+    if (EMODE == 1) return true;                                      // (the RoPE launcher has checked the alignment of q / k / v and the bias)
+    if (!(a.vec_ok && (a.N & 7) == 0 && (a.M & 1) == 0)) return false;   // the direct epilogues' condition in gemm_ring8_kernel
+    if (!a.out_f32) return a.act != 3 || NTW == 4;
+    return a.act == 0;
+}
+template <int MI0, int MI1, int NTW, int EMODE = 0>
+static int launch_ring(const GemmArgs& a, hipStream_t stream) {
+    if (ring_persist_ok<16 * (MI0 + MI1), 64 * NTW, NTW, EMODE>(a)) {
+        if constexpr (EMODE == 0) { if (g_persist == 4) return launch_gemm_ring8p<MI0, MI1, NTW, EMODE, 2, 1>(a, stream, cu_count()); }   // one barrier per stage
+        return launch_gemm_ring8p<MI0, MI1, NTW, EMODE>(a, stream, cu_count());
+    }
+    return launch_gemm_ring8<MI0, MI1, NTW, EMODE>(a, stream);
+}
+static int launch_gemm_v6(const GemmArgs& a, hipStream_t stream) { return launch_ring<8, 8, 4>(a, stream); }   // 256 x 256
+static int launch_gemm_v8(const GemmArgs& a, hipStream_t stream) { return launch_ring<8, 8, 5>(a, stream); }   // 256 x 320
+static int launch_gemm_v9(const GemmArgs& a, hipStream_t stream) { return launch_ring<9, 8, 4>(a, stream); }   // 272 x 256
 // The wqkv GEMM with the RoPE epilogue (act 4) on the ring kernel: the tile height among 208 / 256 / 272 rows that covers the problem in the
 // fewest tile-rounds of the 256 CUs (cost of a tile = its area).  The bench's 4324 x 6144 launch: 256x256 = 408 tiles = 1.59 rounds run as 2
 // (cost 2.0, 215 us on the two-buffer kernel in round 3), 272x256 = 384 tiles (2.125), 208x256 = 504 tiles = 1.97 rounds (1.625).
@@ -1207,9 +1238,9 @@ static int launch_gemm_ring_rope(const GemmArgs& a, hipStream_t stream, int forc
     const double c208 = cost(208), c256 = cost(256), c272 = cost(272);
     int pick = (c208 < c256 && c208 < c272) ? 208 : (c272 < c256 ? 272 : 256);
     if (force) pick = force;
-    if (pick == 208) return launch_gemm_ring8<7, 6, 4, 1>(a, stream);
-    if (pick == 272) return launch_gemm_ring8<9, 8, 4, 1>(a, stream);
-    return launch_gemm_ring8<8, 8, 4, 1>(a, stream);
+    if (pick == 208) return launch_ring<7, 6, 4, 1>(a, stream);
+    if (pick == 272) return launch_ring<9, 8, 4, 1>(a, stream);
+    return launch_ring<8, 8, 4, 1>(a, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1365,11 +1396,12 @@ extern "C" int ullsam_gemm_fp8(const void* A8, long lda, const float* a_scale, c
 extern "C" int ullsam_set_gemm_tuning(int key, int value) {
     if (key == 0 && value >= 1 && value <= 1024) { g_group_m = value; return 0; }
     if (key == 1 && value >= 0 && value <= 7) { g_auto_mask = value; return 0; }
+    if (key == 2 && (value == 0 || value == 1 || value == 4)) { g_persist = value; return 0; }
     ullsam_set_error("ullsam_set_gemm_tuning: unknown key %d / bad value %d", key, value);
     return -1;
 }
 extern "C" int ullsam_set_gemm_variant(int v) {
-    g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_dbg = (v >> 15) & 1;
+    g_gemm_variant = v & 15; g_split_tail = (v & 64) ? 0 : 1; g_dbg = (v >> 15) & 3;   // bit 15: stamp the one-tile ring kernel, bits 15 + 16: the persistent one
     return 0;
 }
 

@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(1024) void ce_rows_kernel(const float* __restrict__
         loss_rows[r] = (lab >= 0 && lab < V) ? l - row[lab] : 0.f;
     }
 }
-// out[0] = mean of loss_rows over the rows with a label, out[1] = 1 / (number of such rows) (0 if none): ordered sums in one workgroup
+// out[0] = mean of loss_rows over the rows with a label (NaN if there is none, as torch), out[1] = 1 / (number of such rows) (0 if none): ordered sums in one workgroup
 __global__ __launch_bounds__(1024) void ce_mean_kernel(const float* __restrict__ loss_rows, const long long* __restrict__ labels, long R, int V, float* __restrict__ out) {
     __shared__ float red[1024];
     float s = 0.f, n = 0.f;
@@ -1100,7 +1100,9 @@ __global__ __launch_bounds__(1024) void ce_mean_kernel(const float* __restrict__
     s = ce_block_reduce<false>(s, red);
     n = ce_block_reduce<false>(n, red);
     if (threadIdx.x == 0) {
-        out[0] = n > 0.f ? s / n : 0.f;
+        // no row with a label: the reference's CrossEntropyLoss(mean) divides 0 by 0 (modeling_internlm2.py:1084-1096) and `0 * loss + seg` is NaN there -- the same here
+        // (the backward's scale 1 / n stays 0: every row is ignored, its gradient rows are zeros as torch's are)
+        out[0] = n > 0.f ? s / n : __builtin_nanf("");
         out[1] = n > 0.f ? 1.f / n : 0.f;
     }
 }

@@ -99,11 +99,18 @@ class MaskDecoder(Packed):
         if cache is not None:
             # what the cached tensors were computed FROM: another image / dense embedding (or an in-place update of the same storage), another dtype or token
             # count empties the dict instead of serving the previous image's keys (weights are the caller's side of the contract: a dict lives for one crop)
-            sig = (image_tokens.data_ptr(), image_tokens._version, tuple(image_tokens.shape), dense_tokens.data_ptr(), dense_tokens._version,
-                   tuple(dense_tokens.shape), str(dt), N)
-            if cache.get("_source") != sig:
+            # The dict also KEEPS the two source tensors: their storage cannot be freed and handed to another image at the same address while the cache lives, and
+            # identity (`is`) + version tells "the same embedding, unchanged".  Inference tensors (torch.inference_mode) have no version counter: version None.
+            def _ver(t):
+                try:
+                    return t._version
+                except RuntimeError:
+                    return None
+            sig = (_ver(image_tokens), tuple(image_tokens.shape), _ver(dense_tokens), tuple(dense_tokens.shape), str(dt), N)
+            src = cache.get("_source")
+            if src is None or src[0] is not image_tokens or src[1] is not dense_tokens or src[2] != sig:
                 cache.clear()
-                cache["_source"] = sig
+                cache["_source"] = (image_tokens, dense_tokens, sig)
         if cache is not None and "keys" in cache:
             keys = cache["keys"]
         else:

@@ -753,7 +753,13 @@ def lm_loss(lm, hidden_all: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     if w.requires_grad:
         raise NotImplementedError("a trainable LM head: the reference's trainer freezes the language model in every setting (train_joint_v2.py:1280-1359)")
     h = hidden_all[:, :-1].reshape(B * (S - 1), D)
-    return LMLossFn.apply(h, w, labels[:, 1:].reshape(-1).to(h.device))
+    lab = labels[:, 1:].reshape(-1)
+    if not lab.is_cuda:   # host labels (what the trainer's collate hands over): torch's CrossEntropyLoss raises on a label outside {-100} U [0, V) -- checked here, where it costs no device sync
+        bad = (lab != -100) & ((lab < 0) | (lab >= w.shape[0]))
+        if bool(bad.any()):
+            raise ValueError(f"lm_loss: label {int(lab[bad][0])} outside [0, {w.shape[0]}) (and not the ignore index -100)")
+    # (labels already on the GPU are not read back: there a label outside the range is treated as ignored -- include/ullsam_hip.h, ullsam_train_cross_entropy)
+    return LMLossFn.apply(h, w, lab.to(h.device))
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
