@@ -728,6 +728,8 @@ def decode_7b_prompts():
 
 
 DECODE_MARGIN_FP32 = 5e-3     # a top-2 logit margin below this may flip between two fp32 implementations (summation order); above it the ids must be the reference's
+DECODE_TOP1_BAND = 4.0        # teacher-forced steps, bf16 mode: the reference's top-1 token must lie within this many of the reference's own autocast MEAN logit errors (0.012 - 0.013) of this run's top logit: the
+                              # largest error over 92553 logits is several mean errors, and two logits move independently
 DECODE_MARGIN_BF16 = 0.3      # bf16 mode: ~3x the reference's own autocast error on the final hidden state (full_depth.npz: 0.077 - 0.09 mean), carried through the LM head
 
 
@@ -813,8 +815,8 @@ def test_decode_7b_teacher_forced_logits_at_every_step():
     stores per step a strided sample of the logits, the top-1 / runner-up ids and their margin -- plus the same passes under torch.autocast(bfloat16): the per-step mean
     |logits - fp32 logits| and the reference's own autocast greedy ids.  All 64 decode steps are compared, none is skipped:
       fp32 mode: the logits sample within 1e-3 x the step's largest |logit| at every step; top-1 equal wherever the margin exceeds 5e-3 (else the reference's runner-up);
-      bf16 mode: mean |logits error| over the sample <= 1.5 x the reference's autocast mean error at every step; top-1 equal to the reference's fp32 top-1 wherever its margin
-      exceeds 6 x the reference's autocast mean error of that step (both top-2 logits may move by a few mean errors), else the runner-up;
+      bf16 mode: mean |logits error| over the sample <= 1.5 x the reference's autocast mean error at every step; the reference's fp32 top-1 token within 4 of the reference's autocast
+      mean errors of this run's top logit at every step (so: the same id wherever the reference's margin exceeds twice that band);
       greedy, bf16 mode: the ids are counted against the reference's OWN autocast ids and against its fp32 ids (decode_7b.npz) at all 64 steps: this library's bf16 mode must
       agree with the fp32 ids about as often as the reference's autocast run does."""
     import bench
@@ -835,10 +837,8 @@ def test_decode_7b_teacher_forced_logits_at_every_step():
     e32 = np.abs(got_s - ref_s).max(-1)
     print(f"fp32 mode: worst logits error / step scale over the {B * n} forced steps {float((e32 / absmax).max()):.2e}; top-1 equal at {int((arg == top1).sum())} steps, smallest margin {float(margin.min()):.4f}")
     assert (e32 < 1e-3 * np.maximum(absmax, 1.0)).all(), (e32 / absmax).max()
-    for b in range(B):
-        for s in range(n):
-            if arg[b, s] != top1[b, s]:
-                assert margin[b, s] < DECODE_MARGIN_FP32 and arg[b, s] == second[b, s], ("fp32", b, s, float(margin[b, s]))
+    deficit32 = (lg.max(-1).values - lg.gather(-1, torch.from_numpy(top1).to(DEV)[..., None])[..., 0]).cpu().numpy()   # how far below this run's top logit the reference's top-1 token sits (0 where the ids agree)
+    assert (deficit32 <= DECODE_MARGIN_FP32).all() and ((arg == top1) | (margin < DECODE_MARGIN_FP32)).all(), (float(deficit32.max()), int((arg != top1).sum()))
     mb = bench.build_model("h", "7b", torch.bfloat16, DEV, init=False)
     missing, unexpected = mb.load_state_dict({k: v.to(torch.bfloat16) for k, v in m32.state_dict().items()}, strict=False)
     assert not missing and not unexpected
@@ -852,10 +852,13 @@ def test_decode_7b_teacher_forced_logits_at_every_step():
     print(f"bf16 mode: mean |logits error| per step {float(m16.min()):.4f} .. {float(m16.max()):.4f} (the reference's autocast: {float(acm.min()):.4f} .. {float(acm.max()):.4f}); "
           f"top-1 differs from the reference's fp32 top-1 at {flips} of {B * n} steps (the reference's autocast at {int((g['ac_top1_ids'] != top1).sum())})")
     assert (m16 < 1.5 * acm).all(), (m16 / acm).max()
-    for b in range(B):
-        for s in range(n):
-            if arg16[b, s] != top1[b, s]:
-                assert margin[b, s] < 6.0 * acm[b, s] and arg16[b, s] == second[b, s], ("bf16", b, s, float(margin[b, s]), float(acm[b, s]))
+    # top-1 at EVERY step: wherever the reference's margin exceeds the bound the ids must agree; elsewhere the reference's top-1 token must still be within the bound of this
+    # run's top logit (a near-tie may resolve to the runner-up or to a third candidate inside the same band: step (0, 2) has three tokens within 0.04)
+    bound16 = DECODE_TOP1_BAND * acm
+    deficit16 = (lg16.max(-1).values - lg16.gather(-1, torch.from_numpy(top1).to(DEV)[..., None])[..., 0]).cpu().numpy()
+    print(f"bf16 mode: largest (top logit - logit of the reference's top-1 token) / the reference's autocast mean error over the steps: {float((deficit16 / acm).max()):.2f} (bound {DECODE_TOP1_BAND})")
+    assert (deficit16 <= bound16).all(), (deficit16 / acm).max()
+    assert ((arg16 == top1) | (margin < 2.0 * bound16)).all(), [(b, s, float(margin[b, s])) for b in range(B) for s in range(n) if arg16[b, s] != top1[b, s]]
     # greedy ids of the bf16 mode against the reference's own autocast greedy ids, every step: a step where the two differ has the context of different earlier tokens or a near-tie --
     # it is accepted when this library's id is the reference's fp32 id at that step of the fp32 greedy run (decode_7b.npz), i.e. the bf16 mode sides with fp32 where autocast left it
     gg = U.gold("decode_7b")

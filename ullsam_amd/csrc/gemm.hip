@@ -1440,6 +1440,20 @@ static int launch_gemm(GemmArgs a, hipStream_t stream) {
     return 0;
 }
 
+// A weight row piece of the decode-step kernels: every byte of W is read once per token by ONE wave, so the load carries the non-temporal hint (nt: the line is not kept
+// in the L2 / Infinity Cache at the expense of the activations, the KV cache and the next kernel's weights).  -DULLSAM_SKINNY_NT=0 builds the plain-load form for A/B.
+#ifndef ULLSAM_SKINNY_NT
+#define ULLSAM_SKINNY_NT 1
+#endif
+__device__ __forceinline__ uint4 load_w16(const bf16* ptr) {
+#if ULLSAM_SKINNY_NT
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+    return *reinterpret_cast<const uint4*>(ptr);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Skinny GEMM for the decode step (M <= 8 rows, bf16): every weight byte is needed once and nothing is reused across rows of W, so
 // this is a weight stream, not a tile problem -- the 128x128 kernel launches N/128 workgroups (32 for wo) and reads W at 0.27 TB/s.
@@ -1570,7 +1584,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     uint4 b0[4], b1[4], b2[4];
     auto fill = [&](uint4 (&b)[4], const int k) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) b[r] = *reinterpret_cast<const uint4*>(wr[r] + k);
+        for (int r = 0; r < 4; ++r) b[r] = load_w16(wr[r] + k);
     };
     if constexpr (NORM) {
         // Order pinned by the sched_barriers: the rows' loads, one step of weight loads, only then the arithmetic on the rows -- whose wait
@@ -1678,7 +1692,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_persist_kernel(GemmArgs p, in
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long row = swiglu ? r0 + (r & 1) + (r >> 1) * 64 : r0 + r;
-            b[r] = *reinterpret_cast<const uint4*>(Wl + (size_t)(on ? min(row, (long)p.N - 1) : 0) * p.ldw + (on ? fk : 0));
+            b[r] = load_w16(Wl + (size_t)(on ? min(row, (long)p.N - 1) : 0) * p.ldw + (on ? fk : 0));
         }
         fk += 512;
         if (fk >= K) { fk = 0; fu += stride; }
@@ -1795,7 +1809,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_ksplit_kernel(GemmArgs p) {
     struct Buf { uint4 w[R], a[NORM ? 1 : MM]; };
     auto fill = [&](Buf& b, const int k) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) b.w[r] = *reinterpret_cast<const uint4*>(wr[r] + k);
+        for (int r = 0; r < R; ++r) b.w[r] = load_w16(wr[r] + k);
         if constexpr (!NORM) {
 #pragma unroll
             for (int m = 0; m < MM; ++m) b.a[m] = *reinterpret_cast<const uint4*>(ar[m] + k);
