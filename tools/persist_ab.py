@@ -38,7 +38,7 @@ for name, M, N, K, act, hb, res in SHAPES:
             outs[pz] = ops.gemm(As[0], Ws[0], bias, act=act)
     torch.cuda.synchronize()
     ref = As[0].float() @ Ws[0].float().T
-    eq = {pz: (torch.equal(outs[0], outs[pz]), int((outs[0] != outs[pz]).sum().item())) for pz in MODES[1:]}
+    eq = {pz: (torch.equal(outs[0], outs[pz]), int((outs[0] != outs[pz]).sum().item())) for pz in MODES[1:]}   # (modes 5 - 7 are ablations: they differ by construction)
     Cs = [torch.zeros(M, n_out, device=dev, dtype=torch.float32 if res else torch.bfloat16) for _ in range(ncopy)]
     times = {pz: [] for pz in MODES}
     for r in range(rounds):

@@ -1223,6 +1223,11 @@ template <int MI0, int MI1, int NTW, int EMODE = 0>
 static int launch_ring(const GemmArgs& a, hipStream_t stream) {
     if (ring_persist_ok<16 * (MI0 + MI1), 64 * NTW, NTW, EMODE>(a)) {
         if constexpr (EMODE == 0) { if (g_persist == 4) return launch_gemm_ring8p<MI0, MI1, NTW, EMODE, 2, 1>(a, stream, cu_count()); }   // one barrier per stage
+        if constexpr (EMODE == 0 && MI0 == 9) {   // ablations of the 272x256 loop (wrong results: timing only)
+            if (g_persist == 5) return launch_gemm_ring8p<MI0, MI1, NTW, EMODE, 2, 0, 1>(a, stream, cu_count());
+            if (g_persist == 6) return launch_gemm_ring8p<MI0, MI1, NTW, EMODE, 2, 0, 2>(a, stream, cu_count());
+            if (g_persist == 7) return launch_gemm_ring8p<MI0, MI1, NTW, EMODE, 2, 0, 3>(a, stream, cu_count());
+        }
         return launch_gemm_ring8p<MI0, MI1, NTW, EMODE>(a, stream, cu_count());
     }
     return launch_gemm_ring8<MI0, MI1, NTW, EMODE>(a, stream);
@@ -1396,7 +1401,7 @@ extern "C" int ullsam_gemm_fp8(const void* A8, long lda, const float* a_scale, c
 extern "C" int ullsam_set_gemm_tuning(int key, int value) {
     if (key == 0 && value >= 1 && value <= 1024) { g_group_m = value; return 0; }
     if (key == 1 && value >= 0 && value <= 7) { g_auto_mask = value; return 0; }
-    if (key == 2 && (value == 0 || value == 1 || value == 4)) { g_persist = value; return 0; }
+    if (key == 2 && value >= 0 && value <= 7 && value != 2 && value != 3) { g_persist = value; return 0; }
     ullsam_set_error("ullsam_set_gemm_tuning: unknown key %d / bad value %d", key, value);
     return -1;
 }

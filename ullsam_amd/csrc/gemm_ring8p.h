@@ -91,7 +91,9 @@ __device__ __forceinline__ u32x4 raw_desc(const void* base, unsigned int bytes) 
 //   two barriers).  Safety with the four-slot ring: a stage is read by group 0 in the interval BEFORE the barrier after which group 1 reads it, so group 1's pieces
 //   must have landed one barrier earlier than in SCHED 0 -- group 1 requests THREE stages ahead (its slot was last read, by itself, two intervals earlier, and by
 //   group 0 three), group 0 two; every wave's counted wait still leaves exactly one stage of its own pieces in flight.
-template <int MI0, int MI1, int NTW, int EMODE = 0, bool STAMP = false, int DIST = 2, int SCHED = 0>
+// ABL (diagnostic, wrong results): 1 = the K loop issues no LDS-DMA request, 2 = no fragment read (the MFMAs run on whatever the registers hold), 3 = neither -- what a
+// stage costs without each ingredient (tools/persist_ab.py modes 5 / 6 / 7).
+template <int MI0, int MI1, int NTW, int EMODE = 0, bool STAMP = false, int DIST = 2, int SCHED = 0, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef bf16 T;
@@ -242,15 +244,19 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
             {
                 auto request = [&](auto QI_c) __attribute__((always_inline)) {   // request QI of this wave: A0 B0 A1 B1 A2 B2
                     constexpr int qi = decltype(QI_c)::value, i = qi >> 1;
-                    if constexpr (KIND != 0 && !(qi & 1) && i < NA) blds16_imm<RS * STG + i * 8192>(a_desc, a_off[i], rq_a, wbase);
-                    if constexpr (KIND != 0 && (qi & 1) && i < NB) blds16_imm<RS * STG + ASZ + i * 8192>(b_desc, b_off[i], rq_b, wbase);
+                    if constexpr (!(ABL & 1) && KIND != 0 && !(qi & 1) && i < NA) blds16_imm<RS * STG + i * 8192>(a_desc, a_off[i], rq_a, wbase);
+                    if constexpr (!(ABL & 1) && KIND != 0 && (qi & 1) && i < NB) blds16_imm<RS * STG + ASZ + i * 8192>(b_desc, b_off[i], rq_b, wbase);
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 auto rd = [&](auto R_c) __attribute__((always_inline)) {
                     constexpr int r = decltype(R_c)::value;
                     if constexpr (r < NTW + MIW) {
-                        if constexpr (r < NTW) b[r] = frag_at(t_b + r * 1024);
-                        else a8[r - NTW] = frag_at(t_a + (r - NTW) * 1024);
+                        if constexpr (ABL & 2) {   // no read: an opaque "definition" so that the MFMAs keep their operands
+                            if constexpr (r < NTW) asm volatile("" : "=v"(b[r].v)); else asm volatile("" : "=v"(a8[r - NTW].v));
+                        } else {
+                            if constexpr (r < NTW) b[r] = frag_at(t_b + r * 1024);
+                            else a8[r - NTW] = frag_at(t_a + (r - NTW) * 1024);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };
@@ -270,6 +276,7 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
             tstamp(1);
             auto counted_wait = [&]() __attribute__((always_inline)) {
                 if constexpr (KIND == 0) { /* nothing of this wave is in flight (the border's vmcnt(0)) */ }
+                else if constexpr (ABL & 1) { /* nothing was requested */ }
                 else if constexpr (SCHED == 1) wait_vmcnt<NA + NB>();
                 else wait_vmcnt<(DIST - 1) * (NA + NB)>();   // the stage read NEXT has landed: only the youngest stages' pieces may be in flight
             };
@@ -596,16 +603,16 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();
 }
 
-template <int MI0, int MI1, int NTW, int EMODE = 0, int DIST = 2, int SCHED = 0>
+template <int MI0, int MI1, int NTW, int EMODE = 0, int DIST = 2, int SCHED = 0, int ABL = 0>
 static int launch_gemm_ring8p(GemmArgs a, hipStream_t stream, int max_wgs) {
     constexpr int BM = 16 * (MI0 + MI1), BN = 64 * NTW;
     constexpr int LDS = 4 * (BM + BN) * 64 + 4096;   // the ring + two bias rows
     static_assert(LDS <= 163840, "160 KiB of LDS per CU");
-    constexpr bool HAS_STAMP = DIST == 2;
+    constexpr bool HAS_STAMP = DIST == 2 && ABL == 0;
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8p_kernel<MI0, MI1, NTW, EMODE, false, DIST, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if constexpr (HAS_STAMP) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8p_kernel<MI0, MI1, NTW, EMODE, true, DIST, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8p_kernel<MI0, MI1, NTW, EMODE, false, DIST, SCHED, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if constexpr (HAS_STAMP) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8p_kernel<MI0, MI1, NTW, EMODE, true, DIST, SCHED, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     }
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = a.N / BN;
@@ -614,12 +621,12 @@ static int launch_gemm_ring8p(GemmArgs a, hipStream_t stream, int max_wgs) {
     const int grid = a.full_tiles < max_wgs ? a.full_tiles : max_wgs;
     if constexpr (HAS_STAMP) {
         if (a.dbg) {
-            gemm_ring8p_kernel<MI0, MI1, NTW, EMODE, true, DIST, SCHED><<<dim3(grid), dim3(512), LDS, stream>>>(a);
+            gemm_ring8p_kernel<MI0, MI1, NTW, EMODE, true, DIST, SCHED, ABL><<<dim3(grid), dim3(512), LDS, stream>>>(a);
             ULLSAM_LAUNCH_CHECK();
             return 0;
         }
     }
-    gemm_ring8p_kernel<MI0, MI1, NTW, EMODE, false, DIST, SCHED><<<dim3(grid), dim3(512), LDS, stream>>>(a);
+    gemm_ring8p_kernel<MI0, MI1, NTW, EMODE, false, DIST, SCHED, ABL><<<dim3(grid), dim3(512), LDS, stream>>>(a);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
