@@ -31,6 +31,7 @@ fp8 = os.environ.get("ULLSAM_FP8") == "1"
 sam.image_encoder.fp8_linears = fp8
 gen = SamAutomaticMaskGenerator(sam, points_per_side=side, points_per_batch=int(os.environ.get("AMG_PPB", "64")), pred_iou_thresh=piou, stability_score_thresh=stab,
                                 stability_score_offset=off, box_nms_thresh=nms, output_mode="uncompressed_rle")
+gen.pipelined = os.environ.get("AMG_PIPE", "1") != "0"    # AMG_PIPE=0: round 5's per-batch loop (three stream synchronisations per batch), for A/B
 from ullsam_amd.utils.synthetic import microscopy_tile
 img = torch.from_numpy(microscopy_tile(7, size=tile, n_cells=40, r_range=(90.0 * tile / 2048, 260.0 * tile / 2048))[0] * 255).cuda()
 encs, alls = [], []

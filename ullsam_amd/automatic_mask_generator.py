@@ -134,6 +134,89 @@ class SamAutomaticMaskGenerator:
         data["rles"] = pp.rles(sel, as_list=False) if len(sel) else []
         return data
 
+    # -- the fused path's batches as a three-deep software pipeline ----------------------------------------------------------
+    def _run_batches_pipelined(self, pts: np.ndarray, img_tok, input_size, crop_box, orig_size, image_cache) -> A.MaskData:
+        """Every batch of `_process_batch` + `_finish_batch_fused`, in the same order and with the same arithmetic, but with the host never waiting on the
+        stream between batches: while batch i's prompt encoder / mask decoder / post-processing launches are queued, batch i - 1's per-mask scalars (copied back
+        asynchronously into pinned buffers) are filtered on the host and its RLE emission is launched, and batch i - 2's change positions (copied back the same
+        way) are turned into run lengths.  The per-batch loop of round 5 synchronised three times per batch (scalars, predicted IoUs, positions) and uploaded
+        four small arrays from pageable memory: at 64 prompts per batch a quarter of a 2048^2 tile's time was the GPU waiting for the host."""
+        sam = self.model
+        dev = img_tok.device
+        S = sam.image_encoder.img_size
+        g = S // sam.image_encoder.patch_size
+        ch, cw = crop_box[3] - crop_box[1], crop_box[2] - crop_box[0]
+        k = sam.mask_decoder.num_mask_tokens - 1
+        pe = sam.prompt_encoder
+        # ResizeLongestSide.apply_coords for ALL points of the crop on the host, one upload
+        scaled_all = torch.from_numpy(np.ascontiguousarray((pts.astype(np.float64) * np.array([input_size[1] / cw, input_size[0] / ch])).astype(np.float32)[:, None, :])).to(dev)
+        starts = list(range(0, pts.shape[0], self.points_per_batch))
+        slots = getattr(self, "_pipe_slots", None)
+        if slots is None:
+            slots = self._pipe_slots = [dict() for _ in range(3)]
+        data = A.MaskData()
+        issued, selected = {}, {}
+
+        def issue(i):
+            i0 = starts[i]
+            p = pts[i0:i0 + self.points_per_batch]
+            n = p.shape[0]
+            sparse = pe.sparse_tokens((scaled_all[i0:i0 + n], self._ones_labels(n, dev)), None)
+            dense = pe.dense_tokens(n, None, None)
+            low, iou = sam.mask_decoder.predict_masks_tokens(img_tok, pe.dense_pe_tokens(), sparse, dense, (g, g), image_cache=image_cache, mask_range=(1, 1 + k))
+            words, sc, frame = A.postprocess_low_res(low.reshape(n * k, low.shape[-2], low.shape[-1]), S, input_size, crop_box, orig_size, sam.mask_threshold,
+                                                     self.stability_score_offset, defer=True)
+            st = slots[i % 3]
+            sc_h = A._pinned(st, "sc", sc.numel(), torch.int32)[:sc.numel()].view(sc.shape)
+            iou_h = A._pinned(st, "iou", n * k, torch.float32)[:n * k]
+            sc_h.copy_(sc, non_blocking=True)
+            iou_h.copy_(iou.float().reshape(-1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            issued[i] = (p, words, frame, sc_h, iou_h, ev)
+
+        def select(i):
+            p, words, frame, sc_h, iou_h, ev = issued.pop(i)
+            ev.synchronize()
+            pp = A.PostprocessedMasks(words, sc_h.numpy(), frame)
+            iou_np = iou_h.numpy().copy()
+            keep = (iou_np > np.float32(self.pred_iou_thresh)) & (pp.stability_score >= np.float32(self.stability_score_thresh))
+            sel = np.nonzero(keep)[0]
+            boxes = pp.boxes[sel]
+            if len(sel):
+                orig_h, orig_w = orig_size
+                b = (boxes + np.asarray([crop_box[0], crop_box[1], crop_box[0], crop_box[1]])).astype(np.float32)
+                near_crop = np.abs(b - np.asarray(crop_box, np.float32)[None, :]) <= 20.0                      # is_box_near_crop_edge
+                near_image = np.abs(b - np.asarray([0, 0, orig_w, orig_h], np.float32)[None, :]) <= 20.0
+                ok = ~np.logical_and(near_crop, ~near_image).any(axis=1)
+                sel, boxes = sel[ok], boxes[ok]
+            rec = A.MaskData(iou_preds=iou_np[sel].astype(np.float32), points=np.repeat(p.astype(np.float32), k, axis=0)[sel],
+                             stability_score=pp.stability_score[sel].astype(np.float32), boxes=boxes.reshape(-1, 4).astype(np.int64))
+            emit = None
+            if len(sel):
+                emit = (*A._rle_emit_launch(words, sel, pp.rle_counts[sel], frame[0], frame[1], slots[i % 3]), pp.first[sel].copy(), frame)
+            selected[i] = (rec, emit)
+
+        def finalize(i):
+            rec, emit = selected.pop(i)
+            if emit is None:
+                rec["rles"] = []
+            else:
+                pos_h, offs, ev, first, frame = emit
+                ev.synchronize()
+                rec["rles"] = A._rle_records(pos_h.numpy().astype(np.int64), offs, first, frame[0], frame[1], as_list=False)
+            data.cat(rec, deep=False)
+
+        nb = len(starts)
+        for i in range(nb + 2):
+            if i < nb:
+                issue(i)
+            if 0 <= i - 1 < nb:
+                select(i - 1)
+            if 0 <= i - 2 < nb:
+                finalize(i - 2)
+        return data
+
     def _ones_labels(self, n: int, dev) -> torch.Tensor:
         c = getattr(self, "_labels_cache", None)
         if c is None or c.shape[0] != n or c.device != torch.device(dev):
@@ -172,8 +255,11 @@ class SamAutomaticMaskGenerator:
         pts = self.point_grids[layer_idx] * np.array([[x1 - x0, y1 - y0]], dtype=np.float64)
         data = A.MaskData()
         image_cache = {} if getattr(self, "reuse_image_side", True) else None      # what the decoder computes from the crop's embedding alone (keys = embedding + dense prompt, their model-dtype copies, layer 0's K / V): once per crop, not per point batch
-        for (p,) in A.batch_iterator(self.points_per_batch, pts):
-            data.cat(self._process_batch(p, img_tok, input_size, crop_box, orig_size, image_cache), deep=False)
+        if self.fused_postprocess and getattr(self, "pipelined", True):
+            data = self._run_batches_pipelined(pts, img_tok, input_size, crop_box, orig_size, image_cache)
+        else:
+            for (p,) in A.batch_iterator(self.points_per_batch, pts):
+                data.cat(self._process_batch(p, img_tok, input_size, crop_box, orig_size, image_cache), deep=False)
         dev = img_tok.device
         for key in ("iou_preds", "points", "stability_score", "boxes"):      # the fused path collects host arrays: to the device once per crop
             if key in data._stats and isinstance(data[key], np.ndarray):

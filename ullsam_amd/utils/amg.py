@@ -275,6 +275,39 @@ def batched_mask_to_box(masks: torch.Tensor) -> torch.Tensor:
     return out.reshape(*masks.shape[:-2], 4) if masks.dim() > 2 else out[0]
 
 
+def _rle_emit_launch(words: torch.Tensor, select, counts: np.ndarray, h: int, w: int, stage: dict):
+    """First half of `_rles_from_words` for the generator's pipelined loop: launch the emission of the ordered change positions of the masks `select` and
+    their copy back, all asynchronous -- offsets / selection go up from, and the positions come back into, the reusable PINNED buffers of `stage` (one dict
+    per batch in flight).  -> (positions as a pinned int32 view, offsets, event to wait on before reading them)."""
+    dev = words.device
+    c = np.asarray(counts, dtype=np.int64)
+    b = len(c)
+    offs = np.concatenate([[0], np.cumsum(c)])
+    n = max(int(offs[-1]), 1)
+    up64 = _pinned(stage, "up64", b, torch.int64)
+    up32 = _pinned(stage, "up32", b, torch.int32)
+    up64[:b] = torch.from_numpy(offs[:-1].copy())
+    up32[:b] = torch.from_numpy(np.asarray(select, dtype=np.int32))
+    offs_d = up64[:b].to(dev, non_blocking=True)
+    sel_d = up32[:b].to(dev, non_blocking=True)
+    pos = torch.empty((n,), dtype=torch.int32, device=dev)
+    _lib.call("ullsam_rle_emit", words.data_ptr(), sel_d.data_ptr(), b, h, w, offs_d.data_ptr(), pos.data_ptr(), _stream())
+    pos_h = _pinned(stage, "pos", n, torch.int32)[:n]
+    pos_h.copy_(pos, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    stage["_keep"] = (offs_d, sel_d, pos)     # the device buffers live until the slot is reused (their kernels have long run by then)
+    return pos_h, offs, ev
+
+
+def _pinned(stage: dict, key: str, n: int, dtype) -> torch.Tensor:
+    t = stage.get(key)
+    if t is None or t.numel() < n or t.dtype != dtype:
+        t = torch.empty((max(n, 1024),), dtype=dtype, pin_memory=True)
+        stage[key] = t
+    return t
+
+
 def _rles_from_words(words: torch.Tensor, select, counts: np.ndarray, first: np.ndarray, h: int, w: int,
                      as_list: bool = True) -> List[Dict[str, Any]]:
     """Change words [M, ceil(h/64), w] -> RLE dicts of the masks `select` (None = all), given their change counts / first bits.
@@ -290,9 +323,13 @@ def _rles_from_words(words: torch.Tensor, select, counts: np.ndarray, first: np.
     sel_d = None if select is None else torch.as_tensor(np.asarray(select, dtype=np.int32), device=dev)
     _lib.call("ullsam_rle_emit", words.data_ptr(), None if sel_d is None else sel_d.data_ptr(), b, h, w, offs_d.data_ptr(),
               pos.data_ptr(), _stream())
-    pos_h = pos.cpu().numpy().astype(np.int64)
+    return _rle_records(pos.cpu().numpy().astype(np.int64), offs, first, h, w, as_list)
+
+
+def _rle_records(pos_h: np.ndarray, offs: np.ndarray, first: np.ndarray, h: int, w: int, as_list: bool = True) -> List[Dict[str, Any]]:
+    """Second half of `_rles_from_words`: run lengths = differences of the ordered change positions (host)."""
     out = []
-    for i in range(b):
+    for i in range(len(offs) - 1):
         edges = np.concatenate([[0, 0] if first[i] else [0], pos_h[offs[i]:offs[i + 1]] + 1, [h * w]])
         runs = edges[1:] - edges[:-1]
         out.append({"size": [h, w], "counts": runs.tolist() if as_list else runs})
@@ -321,7 +358,7 @@ class PostprocessedMasks:
         """scalars: ONE int32 device buffer [8, M] = rle_counts | first (bytes in its first M) | boxes [M, 4] | stability counts [M, 2]: one device -> host copy per batch."""
         self.words, self.frame = words, frame
         M = words.shape[0]
-        h = scalars.cpu().numpy()
+        h = scalars if isinstance(scalars, np.ndarray) else scalars.cpu().numpy()   # (a host array: the generator's pipelined loop copied the buffer back asynchronously)
         self.rle_counts = h[0][:M].copy()
         self.first = h[1].view(np.uint8)[:M].copy()
         self.boxes = h[2:6].reshape(-1)[:4 * M].reshape(M, 4).astype(np.int64)
@@ -335,7 +372,7 @@ class PostprocessedMasks:
 
 
 def postprocess_low_res(low: torch.Tensor, img_size: int, input_size, crop_box, orig_size, mask_threshold: float,
-                        threshold_offset: float) -> PostprocessedMasks:
+                        threshold_offset: float, defer: bool = False) -> PostprocessedMasks:
     """Generator fast path over low-res logits [M, h, w]: Sam.postprocess_masks (sam.py:154-162) + calculate_stability_score +
     batched_mask_to_box + mask_to_rle_pytorch(uncrop_masks(...)) fused in one kernel; the full-resolution logits and masks are never
     written.  Equivalent to calling those helpers one after the other (same arithmetic per pixel)."""
@@ -350,6 +387,8 @@ def postprocess_low_res(low: torch.Tensor, img_size: int, input_size, crop_box, 
     _lib.call("ullsam_amg_postprocess", low.data_ptr(), None, M, lh, lw, int(img_size), int(input_size[0]), int(input_size[1]),
               y1 - y0, x1 - x0, fh, fw, x0, y0, float(mask_threshold), float(threshold_offset), words.data_ptr(),
               rle_counts.data_ptr(), first.data_ptr(), boxes.data_ptr(), stab.data_ptr(), _stream())
+    if defer:
+        return words, sc, (fh, fw)          # nothing read back yet: PostprocessedMasks(words, <host copy of sc>, frame) finishes it
     return PostprocessedMasks(words, sc, (fh, fw))
 
 
