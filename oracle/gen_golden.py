@@ -1016,7 +1016,45 @@ def case_train_step(real_dims: bool = False):
     save("train_step_real" if real_dims else "train_step", **out)
 
 
-CASES = {"train_step": case_train_step, "train_step_real": lambda: case_train_step(real_dims=True), "train_vit_slice": case_train_vit_slice, "train_slice": case_train_slice, "train_slice_box": lambda: case_train_slice(boxes=True), "train_llm_slice": case_train_llm_slice, "train_llm_slice_pad": lambda: case_train_llm_slice(pad=37), "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "vit_tiny_relpos_interp": case_vit_tiny_relpos_interp, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
+def mask_prompt_inputs():
+    """-> (masks [2, 1, 256, 256] fp32, weights R [2, 256, 64, 64] fp32 of the scalar the gradients are taken of, points, labels): seed-derived, restated by tests/test_train_gpu.py."""
+    rng = np.random.default_rng(21)
+    masks = (rng.standard_normal((2, 1, 256, 256), dtype=np.float32) * 2.0 + 0.25).astype(np.float32)
+    R = rng.standard_normal((2, 256, 64, 64), dtype=np.float32)
+    pts = np.array([[[300.0, 340.0]], [[700.0, 610.0]]], np.float32)
+    lbl = np.array([[1], [0]], np.int32)
+    return masks, R, pts, lbl
+
+
+def case_train_mask_prompt():
+    """Gradients THROUGH A MASK PROMPT (prompt_encoder.py:54-62 mask_downscaling, :105-108 _embed_masks, :187-188): the reference's PromptEncoder with a point and a mask
+    per prompt, the scalar sum(dense_embeddings * R) / numel for a seeded R; its autograd gradients with respect to every parameter of mask_downscaling and to the masks."""
+    sam = _sam_small()
+    pe = sam.prompt_encoder
+    fill_module(pe, seed=0, prefix="prompt_encoder.")
+    pe.train()
+    for p_ in pe.parameters():
+        p_.requires_grad_(True)
+    masks_np, R, pts, lbl = mask_prompt_inputs()
+    masks = torch.from_numpy(masks_np).requires_grad_(True)
+    with torch.enable_grad():
+        sparse, dense = pe(points=(torch.from_numpy(pts), torch.from_numpy(lbl)), boxes=None, masks=masks, llm_hidden_states=None)
+        loss = (dense * torch.from_numpy(R)).sum() / dense.numel()
+        loss.backward()
+    out = {"loss": np.float64(loss.item()), "dense_sample": dense.detach().numpy().reshape(-1)[::997].copy(), "sparse": sparse.detach().numpy().copy(),
+           "g_masks_sample": masks.grad.numpy().reshape(-1)[::61].copy(), "g_masks_absmax": np.float64(masks.grad.abs().max().item())}
+    names = []
+    for name, p_ in pe.named_parameters():
+        if name.startswith("mask_downscaling"):
+            assert p_.grad is not None, name
+            names.append("prompt_encoder." + name)
+            out["g:prompt_encoder." + name] = p_.grad.numpy().reshape(-1).copy()
+    out["names"] = np.array(names)
+    print("  loss", loss.item(), "; gradients of", len(names), "tensors; |d masks| max", float(masks.grad.abs().max()))
+    save("train_mask_prompt", **out)
+
+
+CASES = {"train_step": case_train_step, "train_step_real": lambda: case_train_step(real_dims=True), "train_vit_slice": case_train_vit_slice, "train_slice": case_train_slice, "train_slice_box": lambda: case_train_slice(boxes=True), "train_mask_prompt": case_train_mask_prompt, "train_llm_slice": case_train_llm_slice, "train_llm_slice_pad": lambda: case_train_llm_slice(pad=37), "chat_prompt": case_chat_prompt, "amg": case_amg, "vit_tiny": case_vit_tiny, "vit_tiny_relpos_interp": case_vit_tiny_relpos_interp, "decoder": case_decoder, "llm_tiny": case_llm_tiny,
          "ullsam_tiny": case_ullsam_tiny, "sam_forward": case_sam_forward, "vit_b_full": case_vit_b_full,
          "vit_h_d2": case_vit_h_d2, "llm_7b_l1": case_llm_7b_l1,
          "rope_variants": case_rope_variants, "llm_tiny_bias_linear": case_llm_tiny_bias_linear,

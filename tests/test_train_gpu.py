@@ -792,6 +792,48 @@ def test_box_prompts_gradients_equal_the_reference_autograd():
     print("box prompts: worst relative gradient error", worst)
 
 
+def test_mask_prompt_gradients_equal_the_reference_autograd():
+    """The last prompt kind: masks (prompt_encoder.py:54-62 mask_downscaling, :105-108 _embed_masks; the dense embedding IS the downscaled mask, :187-188).  Fixture
+    train_mask_prompt.npz = the REFERENCE's PromptEncoder with a point and a mask per prompt, the scalar sum(dense * R) / numel for a seeded R, its autograd gradients with respect
+    to every parameter of mask_downscaling and to the masks.  Here through PromptEncoder.forward in train() mode (training.mask_downscaling_forward: the two stride-2
+    convolutions as Linears over 2x2 pixel blocks, LayerNorm2d and GELU on NHWC rows, the 1x1 convolution): forward to 1e-5, every gradient within 1e-3 of its tensor's largest entry."""
+    g = U.gold("train_mask_prompt")
+    m = _ullsam_tiny(torch.float32)
+    pe = m.prompt_encoder
+    for n, p in m.named_parameters():
+        p.requires_grad_(n.startswith("prompt_encoder."))
+    m.train()
+    rng = np.random.default_rng(21)                                     # oracle/gen_golden.py::mask_prompt_inputs restated
+    masks_np = (rng.standard_normal((2, 1, 256, 256), dtype=np.float32) * 2.0 + 0.25).astype(np.float32)
+    R = rng.standard_normal((2, 256, 64, 64), dtype=np.float32)
+    pts = torch.tensor([[[300.0, 340.0]], [[700.0, 610.0]]], device=DEV)
+    lbl = torch.tensor([[1], [0]], dtype=torch.int32, device=DEV)
+    masks = torch.from_numpy(masks_np).to(DEV).requires_grad_(True)
+    sparse, dense = pe(points=(pts, lbl), boxes=None, masks=masks, llm_hidden_states=None)
+    assert dense.shape == (2, 256, 64, 64) and dense.requires_grad
+    assert err_np(dense.detach().cpu().numpy().reshape(-1)[::997], g["dense_sample"]) < 1e-5 * max(1.0, float(np.abs(g["dense_sample"]).max()))
+    assert err_np(sparse.detach().cpu().numpy(), g["sparse"]) < 1e-5
+    loss = (dense * torch.from_numpy(R).to(DEV)).sum() / dense.numel()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * abs(float(g["loss"])) + 1e-9, (loss.item(), float(g["loss"]))
+    loss.backward()
+    params = dict(m.named_parameters())
+    worst = (0.0, "")
+    for n in (str(v) for v in g["names"]):
+        ref = g["g:" + n].astype(np.float64)
+        got = params[n].grad.float().cpu().numpy().reshape(-1).astype(np.float64)
+        scale, diff = np.abs(ref).max(), np.abs(got - ref).max()
+        assert diff < 1e-3 * scale + 1e-10, (n, diff, scale)
+        worst = max(worst, (diff / scale, n))
+    gm = masks.grad.cpu().numpy().reshape(-1)[::61].astype(np.float64)
+    assert np.abs(gm - g["g_masks_sample"]).max() < 1e-3 * float(g["g_masks_absmax"]), np.abs(gm - g["g_masks_sample"]).max()
+    print("mask prompts: worst relative gradient error", worst)
+    # the inference path (eval mode, ops.mask_downscale) gives the same dense embedding
+    m.eval()
+    with torch.no_grad():
+        _, dense_inf = pe(points=(pts, lbl), boxes=None, masks=masks.detach(), llm_hidden_states=None)
+    assert float((dense_inf.float() - dense.detach()).abs().max()) < 1e-4 * max(1.0, float(dense.detach().abs().max()))
+
+
 def err_np(a, b):
     return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
 

@@ -1032,14 +1032,15 @@ def vision_forward(enc, pixel_values: torch.Tensor) -> torch.Tensor:
 def prompt_encoder_forward(pe, points, boxes, masks, llm_hidden_states):
     """PromptEncoder.forward with gradients (prompt_encoder.py:153-203): point prompts (+ the pad point), box prompts (the trainer forwards `boxes=`,
     train_joint_v2.py:975,1038,1057) and the LLM dense prompt or the no-mask embedding; -> (sparse [P, n, C], dense [P, C, h, w]) fp32."""
-    if masks is not None:
-        raise NotImplementedError("mask prompts in the differentiable prompt encoder: the reference's trainer never passes them (train_joint_v2.py:1040-1050: masks=None); "
-                                  "call the module under torch.no_grad() / in eval() for the inference path")
-    if points is None and boxes is None:
-        raise NotImplementedError("the differentiable prompt encoder needs point or box prompts")
+    if points is None and boxes is None and masks is None:
+        raise NotImplementedError("the differentiable prompt encoder needs point, box or mask prompts")
     h, w = pe.image_embedding_size
     C = pe.embed_dim
     dev = pe.no_mask_embed.weight.device
+    if masks is not None:                                                        # _embed_masks (prompt_encoder.py:105-108, 187-188): the dense prompt IS the downscaled mask
+        dense = mask_downscaling_forward(pe, masks.to(dev))
+        if points is None and boxes is None:
+            return torch.empty((dense.shape[0], 0, C), dtype=F32, device=dev), dense
     coords = labels = bx = None
     if points is not None:
         coords, labels = points[0].to(dev).float().contiguous(), points[1].to(dev).to(torch.int32).contiguous()
@@ -1048,7 +1049,9 @@ def prompt_encoder_forward(pe, points, boxes, masks, llm_hidden_states):
     P = coords.shape[0] if coords is not None else bx.shape[0]
     table = torch.cat([pe.not_a_point_embed.weight] + [e.weight for e in pe.point_embeddings], 0)
     sparse = SparseEmbedFn.apply(table, coords, labels, bx, pe.pe_layer.G(), pe.input_image_size)
-    if llm_hidden_states is not None:
+    if masks is not None:
+        pass                                                                     # (dense computed above: masks take precedence over the LLM dense prompt, as in the reference's if / else)
+    elif llm_hidden_states is not None:
         x = llm_hidden_states
         n = x.shape[0]
         rows = _nchw_to_rows(_c(x) if not x.requires_grad else x.float())
@@ -1059,6 +1062,30 @@ def prompt_encoder_forward(pe, points, boxes, masks, llm_hidden_states):
     else:
         dense = _rows_to_nchw(BroadcastRowsFn.apply(pe.no_mask_embed.weight.reshape(1, C), P * h * w).reshape(P * h * w, C), P, h, w)
     return sparse, dense
+
+
+def _conv_k2s2_rows(conv, x_nhwc: torch.Tensor) -> torch.Tensor:
+    """nn.Conv2d(kernel 2, stride 2) on an NHWC tensor: every 2x2 block of input pixels is one row (ky, kx, cin) of a Linear whose weight is the
+    conv's viewed as [cout, (ky, kx, cin)] -> NHWC [P, H/2, W/2, cout].  The regrouping is torch data movement; autograd routes the gradients back."""
+    P, H, W, Cin = x_nhwc.shape
+    rows = x_nhwc.reshape(P, H // 2, 2, W // 2, 2, Cin).permute(0, 1, 3, 2, 4, 5).reshape(P * (H // 2) * (W // 2), 4 * Cin)
+    wmat = conv.weight.permute(0, 2, 3, 1).reshape(conv.weight.shape[0], 4 * Cin)
+    return _apply_linear(rows, wmat, conv.bias).reshape(P, H // 2, W // 2, -1)
+
+
+def mask_downscaling_forward(pe, masks: torch.Tensor) -> torch.Tensor:
+    """PromptEncoder._embed_masks with gradients (prompt_encoder.py:54-62, 105-108): Conv2d(1, c/4, 2, 2) -> LayerNorm2d -> GELU -> Conv2d(c/4, c, 2, 2) -> LayerNorm2d
+    -> GELU -> Conv2d(c, embed_dim, 1) on masks [P, 1, 4h, 4w] -> [P, embed_dim, h, w] fp32; gradients reach every parameter of mask_downscaling (and the masks)."""
+    md = pe.mask_downscaling
+    x = masks.float().permute(0, 2, 3, 1)                                        # NHWC
+    x = _conv_k2s2_rows(md[0], x)
+    P, H, W, c1 = x.shape
+    x = ActFn.apply(LayerNormFn.apply(x.reshape(-1, c1), md[1].weight, md[1].bias, md[1].eps), 1).reshape(P, H, W, c1)
+    x = _conv_k2s2_rows(md[3], x)
+    P, H, W, c2 = x.shape
+    rows = ActFn.apply(LayerNormFn.apply(x.reshape(-1, c2), md[4].weight, md[4].bias, md[4].eps), 1)
+    rows = _apply_linear(rows, md[6].weight.reshape(md[6].weight.shape[0], c2), md[6].bias)     # 1x1 convolution
+    return _rows_to_nchw(rows, P, H, W)
 
 
 def mask_decoder_forward(md, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output: bool):
