@@ -516,9 +516,11 @@ def test_transposed_weight_cache_follows_the_weight():
     assert c.bytes <= c.max_bytes and len(c) == 1
     T.invalidate_transposed_weights()
     assert len(T._WT_CACHE) == 0
-    # the module's own cache keeps nothing unless given a budget (a 7B LLM's transposes are 13 GB): every get() is a fresh transpose
-    assert T._WT_CACHE.max_bytes == 0
+    # the module's own cache decides its budget at first use: min(16 GiB, 1 / 8 of the device's memory) for a weight on the GPU, NOTHING for a CPU tensor (every get() a fresh transpose)
+    T._WT_CACHE.max_bytes = -1
     w0 = torch.nn.Parameter(torch.randn(4, 8))
+    T._WT_CACHE.get(w0)
+    assert T._WT_CACHE.max_bytes == 0
     assert torch.equal(T._WT_CACHE.get(w0), w0.detach().t()) and len(T._WT_CACHE) == 0 and T._WT_CACHE.bytes == 0
     T.set_transpose_cache_bytes(1 << 20)
     try:
@@ -526,6 +528,7 @@ def test_transposed_weight_cache_follows_the_weight():
     finally:
         T.set_transpose_cache_bytes(0)
     assert len(T._WT_CACHE) == 0
+    T._WT_CACHE.max_bytes = -1                        # (back to "not decided yet" for whatever runs after this test)
 
 
 def _gloo_uneven_worker(rank, world, port, q):

@@ -150,6 +150,8 @@ class _TransposeCache:
         self.bytes = 0
 
     def get(self, w: torch.Tensor) -> torch.Tensor:
+        if self.max_bytes < 0:
+            self.max_bytes = _default_transpose_budget(w.device) if w.is_cuda else 0
         e = self._d.get(w)
         if e is not None and e[1] == w._version and e[2] == w.data_ptr() and e[0].shape == (w.shape[1], w.shape[0]) and e[0].dtype == w.dtype:
             return e[0]
@@ -157,7 +159,7 @@ class _TransposeCache:
             self.bytes -= e[0].numel() * e[0].element_size()
         t = ops.transpose_to_bf16(w.detach()) if w.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 2 and w.is_contiguous() else w.detach().t().contiguous()
         nb = t.numel() * t.element_size()
-        if nb > self.max_bytes:                 # (the default budget is 0: nothing is kept, every backward transposes its weight again)
+        if nb > self.max_bytes:                 # (budget 0: nothing is kept, every backward transposes its weight again)
             if e is not None:
                 del self._d[w]
             return t
@@ -175,7 +177,16 @@ class _TransposeCache:
         return len(self._d)
 
 
-_WT_CACHE = _TransposeCache()      # budget 0 by default: a 7B bf16 LLM's transposes are 13 GB, re-making them costs ~3 % of a step (set_transpose_cache_bytes)
+_WT_CACHE = _TransposeCache(-1)    # budget -1 = not decided yet: the first use sets min(16 GiB, 1/8 of the device's memory) -- on a 288 GB MI355X the 13 GB of a 7B bf16 LLM's W^T copies
+#                                    fit, and re-making them in every backward cost ~3 % of a step (round 4 kept 0 when the step still needed 60 GB); set_transpose_cache_bytes(0) switches it off
+
+
+def _default_transpose_budget(dev) -> int:
+    try:
+        total = torch.cuda.get_device_properties(dev).total_memory
+    except Exception:
+        return 0
+    return int(min(16 << 30, total // 8))
 
 
 def set_transpose_cache_bytes(n: int) -> None:
