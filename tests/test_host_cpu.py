@@ -486,6 +486,10 @@ def test_hot_kernels_compile_without_spills():
     bad = {n: (r.get("vgpr_spill_count", 0), r.get("private_segment_fixed_size", 0)) for n, r in hot.items()
            if r.get("vgpr_spill_count", 0) or r.get("sgpr_spill_count", 0) or r.get("private_segment_fixed_size", 0)}
     assert not bad, bad
+    pers = {n: r for n, r in ks.items() if any(re.search(h, n) for h in KR.HOT_PERSISTENT)}      # round 6: the default GEMM of multi-round launches
+    assert len(pers) >= 6, sorted(pers)
+    bad = {n: (r.get("vgpr_spill_count", 0), r.get("private_segment_fixed_size", 0)) for n, r in pers.items() if r.get("vgpr_spill_count", 0) or r.get("private_segment_fixed_size", 0)}
+    assert not bad, bad
     assert all(r.get("vgpr_count", 0) <= 512 for r in ks.values())
 
 

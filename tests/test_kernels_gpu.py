@@ -15,6 +15,8 @@ pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
 
+GEMM_PERSIST_DEFAULT = 2   # ullsam_set_gemm_tuning(2, v): the library's default (csrc/gemm.hip g_persist); tests that switch it put it back
+
 
 def T(x, dtype=torch.float32):
     return torch.from_numpy(np.ascontiguousarray(x)).to(DEV).to(dtype).contiguous()
@@ -218,7 +220,7 @@ def test_gemm_272x256_kernel(ops, M, N, K, mode):
 
 @pytest.mark.parametrize("variant,M,N,K,mode", [(9, 4324, 8192, 384, "swiglu"), (9, 8704, 4096, 512, "res"), (8, 8192, 3840, 384, "bias_gelu"), (8, 8000, 3840, 640, "res_mod"),
                                                 (6, 8192, 4096, 384, "bias"), (6, 6000, 6144, 1024, "plain")])
-@pytest.mark.parametrize("persist", [1, 4])
+@pytest.mark.parametrize("persist", [1, 2, 4])
 def test_gemm_persistent_ring_equals_the_one_tile_kernel(ops, variant, M, N, K, mode, persist):
     """The persistent forms of the ring kernel (csrc/gemm_ring8p.h: ullsam_set_gemm_tuning(2, 1) = workgroups walk tiles with the LDS ring kept full across tile borders,
     4 = the same with ONE barrier per stage) on launches of more than one round of tiles, every direct epilogue, ragged M: same MFMA order and same epilogue arithmetic as the
@@ -260,10 +262,42 @@ def test_gemm_persistent_ring_equals_the_one_tile_kernel(ops, variant, M, N, K, 
         torch.cuda.synchronize()
     finally:
         lib.ullsam_set_gemm_variant(0)
-        lib.ullsam_set_gemm_tuning(2, 0)
+        lib.ullsam_set_gemm_tuning(2, GEMM_PERSIST_DEFAULT)
     assert float((base - want).abs().max()) < tol * max(1.0, float(want.abs().max()) / 4)
     assert torch.equal(got, base), int((got != base).sum())
     assert torch.equal(again, got)
+
+
+@pytest.mark.parametrize("persist", [1, 2])
+@pytest.mark.parametrize("B,S,KVH,G,K,variant", [(4, 1081, 8, 4, 4096, 0), (2, 1500, 8, 4, 512, 9), (3, 1200, 8, 4, 1024, 6)])
+def test_rope_gemm_persistent_ring_equals_the_one_tile_kernel(ops, B, S, KVH, G, K, variant, persist):
+    """The wqkv GEMM with the head split + RoPE + KV-cache append in its epilogue (modeling_internlm2.py:359-388) on the persistent ring kernel (EMODE 1: 208- / 272- / 256-row
+    tiles; the first case is the bench's launch: 504 tiles of 208x256) against the one-tile kernel: q, the appended K / V rows and the untouched cache rows EQUAL bit for bit."""
+    from ullsam_amd import _lib
+    lib = _lib.load()
+    hd = 128
+    g = torch.Generator(device=DEV); g.manual_seed(B * S + K)
+    x = torch.randn(B * S, K, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(KVH * (G + 2) * hd, K, device=DEV, generator=g) * K ** -0.5).bfloat16()
+    pos = ((torch.arange(S, device=DEV, dtype=torch.int32)[None] + 3 * torch.arange(B, device=DEV, dtype=torch.int32)[:, None]) % (S + 5)).contiguous()
+    cos, sin = O.rope_tables(hd, S + 8, 1e6)
+    cos, sin = T(cos), T(sin)
+    cap, p0 = S + 6, 2
+    res = {}
+    try:
+        lib.ullsam_set_gemm_variant(variant)
+        for pz in (0, persist):
+            lib.ullsam_set_gemm_tuning(2, pz)
+            kc = torch.full((B, KVH, cap, hd), 0.25, dtype=torch.bfloat16, device=DEV); vc = torch.full_like(kc, -0.5)
+            q = ops.gemm_qkv_rope(x, w, None, kc, vc, pos, cos, sin, B, S, KVH, G, p0)
+            res[pz] = (q, kc, vc)
+        torch.cuda.synchronize()
+    finally:
+        lib.ullsam_set_gemm_variant(0)
+        lib.ullsam_set_gemm_tuning(2, GEMM_PERSIST_DEFAULT)
+    for a, b in zip(res[0], res[persist]):
+        assert torch.equal(a, b), int((a != b).sum())
+    assert float((res[0][1][:, :, :p0] - 0.25).abs().max()) == 0 and float(res[0][0].float().abs().max()) > 0
 
 
 def _e4m3_decode(u8: np.ndarray) -> np.ndarray:

@@ -59,4 +59,4 @@ for name, M, N, K, act, hb, res in SHAPES:
         line += f" | mode {pz}: {t1 * 1e3:8.1f} us {fl / t1 / 1e9:7.1f} TF/s {100 * (t1 / t0 - 1):+5.1f} % bit-equal {eq[pz][0]} ({eq[pz][1]} differ)"
     print(line, flush=True)
     del As, Ws, Cs
-lib.ullsam_set_gemm_tuning(2, 1)
+lib.ullsam_set_gemm_tuning(2, 2)

@@ -14,7 +14,7 @@ for name in (sys.argv[1:] or ["w13", "qkv", "lin1"]):
     bias = torch.randn(N, device="cuda") if act in (0, 1) and name in ("lin1", "qkv") else None
     tiles = ((M + BM - 1) // BM) * (N // BN)
     ns = K // 32
-    for mode, bits, tune in (("persistent", 3 << 15, 1), ("one-barrier", 3 << 15, 4), ("one-tile", 1 << 15, 1)):
+    for mode, bits, tune in (("persistent (default: uniform trips, epilogues together)", 3 << 15, 2), ("persistent, first form", 3 << 15, 1), ("one-barrier", 3 << 15, 4), ("one-tile", 1 << 15, 2)):
         lib.ullsam_set_gemm_tuning(2, tune)
         lib.ullsam_set_gemm_variant(var | bits)
         ws = ops._gemm_workspace(a.device); ws[48 << 20:56 << 20].zero_()
@@ -24,7 +24,7 @@ for name in (sys.argv[1:] or ["w13", "qkv", "lin1"]):
         for _ in range(10): ops.gemm(a, w, bias, act=act)
         e1.record(); torch.cuda.synchronize()
         lib.ullsam_set_gemm_variant(0)
-        lib.ullsam_set_gemm_tuning(2, 1)
+        lib.ullsam_set_gemm_tuning(2, 2)
         raw = ws[48 << 20:56 << 20].view(torch.int64).cpu().numpy().astype(np.int64)
         us = e0.elapsed_time(e1) * 100
         if mode == "one-tile":

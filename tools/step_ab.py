@@ -24,8 +24,8 @@ def main():
         times = {v: [] for v in variants}
         for r in range(rounds):
             for v in (variants if r % 2 == 0 else variants[::-1]):   # ABBA: the variant measured second in a round comes out ~0.5 % faster
-                head, _, pz = str(v).partition("p")     # "7p1" = dispatch mask 7 with the persistent ring kernel (ullsam_set_gemm_tuning key 2: 1 persistent, 4 one barrier per stage)
-                lib.ullsam_set_gemm_tuning(2, int(pz) if pz else 0)
+                head, _, pz = str(v).partition("p")     # "7p0" = dispatch mask 7 with the one-tile ring kernel (ullsam_set_gemm_tuning key 2: 0 one tile per workgroup, 2 persistent = the default, 1 / 4 the earlier persistent forms)
+                lib.ullsam_set_gemm_tuning(2, int(pz) if pz else 2)   # (2 = the library's default)
                 head, _, gm = head.partition("g")       # "7g8" = dispatch mask 7 with raster groups of 8 tile rows
                 lib.ullsam_set_gemm_tuning(0, int(gm) if gm else 4)
                 head, _, av = head.partition("a")        # "7a9" = dispatch mask 7 with ullsam_set_attn_variant(9)
@@ -45,7 +45,7 @@ def main():
     lib.ullsam_set_gemm_variant(0)
     lib.ullsam_set_attn_variant(0)
     lib.ullsam_set_gemm_tuning(0, 4)
-    lib.ullsam_set_gemm_tuning(2, 0)
+    lib.ullsam_set_gemm_tuning(2, 2)
     for v in variants:
         t = sorted(times[v])
         print(f"dispatch mask {v}: median {t[len(t) // 2]:.3f} ms/step  (min {t[0]:.3f}, max {t[-1]:.3f})  = {4e3 / t[len(t) // 2]:.2f} images/s")

@@ -85,6 +85,10 @@ __device__ __forceinline__ u32x4 raw_desc(const void* base, unsigned int bytes) 
 
 // DIST: stages between a request and its use in the two-barrier schedule (2: the one-tile kernel's; 3: an experiment).
 // SCHED 0: the one-tile kernel's schedule -- two barriers per stage, the groups' load and matrix slots strictly alternating.
+// SCHED 2: SCHED 0's stage (two barriers), but (a) every stage of every trip requests (the border requests nothing: the next tile's first load slot requests its stage 2 behind the border's
+//   vmcnt(0)), so the K loop is ONE loop of identical trips -- the last trip's stages 2 / 3 take the next tile's scalar offsets through two selects per TRIP -- with no peeled copies (the peeled
+//   first / last trips of SCHED 0 are where the 256x320 instantiation spilled); (b) the two wave groups run their epilogues AT THE SAME TIME, as in the one-tile kernel: group 0 waits one
+//   barrier at the border's start (for group 1's last matrix slot), group 1 one at its end (for group 0's first load slot) -- SCHED 0 ran them one after the other and gave back the prologue it saved.
 // SCHED 1: ONE barrier per stage.  Between two barriers group 0 runs [matrix slot of stage s, load slot of stage s + 1] and group 1 [load slot of stage s, matrix slot
 //   of stage s, counted wait]: the matrix pipe always has one group's instructions to run and a barrier's latency is paid once per stage, not twice (in-stage
 //   stamps of SCHED 0: a load slot's own work ends ~340 cycles into a slot of ~680 whose length is the partner's 512 - 576 matrix cycles plus ~120 cycles around the
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
     bias_dma(tn0 * BN, 0);
     request_stage(tm0 * a_tile, tn0 * b_tile, 0);
     request_stage(tm0 * a_tile + 64, tn0 * b_tile + 64, 1);
-    if (SCHED == 0 || grp == 1) request_stage(tm0 * a_tile + 128, tn0 * b_tile + 128, 2);
+    if (SCHED == 0 || (SCHED == 1 && grp == 1)) request_stage(tm0 * a_tile + 128, tn0 * b_tile + 128, 2);
     if constexpr (SCHED == 0 && DIST >= 3) request_stage(tm0 * a_tile + 192, tn0 * b_tile + 192, 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
     // ---- everything from here on per wave ROW (MIW sub-tile rows: compile-time) -- the tile loop, its K loop, the epilogue
     auto core = [&](auto MIW_c, auto ROWW_c, auto GRP_c) __attribute__((always_inline)) {
         constexpr int MIW = decltype(MIW_c)::value, GRP = decltype(GRP_c)::value;   // GRP: the wave group (SCHED 1 only; -1: both groups run this instantiation)
-        constexpr int DG = SCHED == 1 ? (GRP == 0 ? 2 : 3) : DIST;                  // request distance of this group
+        constexpr int DG = SCHED == 1 ? (GRP == 0 ? 2 : 3) : (SCHED == 2 ? 2 : DIST);                  // request distance of this group
         const int row_w = decltype(ROWW_c)::value >= 0 ? decltype(ROWW_c)::value : wm * (MI0 * 16);   // first tile row of this wave's row (run time when both rows share one instantiation)
         f32x4 acc[MIW][NTW];
 #pragma unroll
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
             constexpr int NA = decltype(NA_c)::value, NB = decltype(NB_c)::value;
             constexpr int RS = (J + DG) & 3, KOFF = KIND == 2 ? 64 * (J - (4 - DG)) : 64 * (J + DG);
             static_assert(KIND != 2 || J >= 4 - DG, "only the last DG stages of a tile request the next tile");
-            static_assert(SCHED == 0 || KIND != 0, "SCHED 1: every stage requests");
+            static_assert(SCHED == 0 || KIND != 0, "SCHED 1 / 2: every stage requests");
             const unsigned int rq_a = so_a + KOFF, rq_b = so_b + KOFF;   // (two scalar adds per stage)
             // this stage's read bases: the wave's per-lane bases (rd_a / rd_b, below) + the slot's offset, ONE add each, pinned here -- left to itself
             // hipcc keeps a base register per slot and (where it cannot see that the swizzle depends on the lane only) per fragment: 20 registers and
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
             auto counted_wait = [&]() __attribute__((always_inline)) {
                 if constexpr (KIND == 0) { /* nothing of this wave is in flight (the border's vmcnt(0)) */ }
                 else if constexpr (ABL & 1) { /* nothing was requested */ }
-                else if constexpr (SCHED == 1) wait_vmcnt<NA + NB>();
+                else if constexpr (SCHED == 1 || SCHED == 2) wait_vmcnt<NA + NB>();
                 else wait_vmcnt<(DIST - 1) * (NA + NB)>();   // the stage read NEXT has landed: only the youngest stages' pieces may be in flight
             };
             auto matrix_slot = [&]() __attribute__((always_inline)) {
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
                     for (int j = 0; j < NTW; ++j) mma16(b[j], a8[i], acc[i][j]);
                 __builtin_amdgcn_s_setprio(0);
             };
-            if constexpr (SCHED == 0) {
+            if constexpr (SCHED == 0 || SCHED == 2) {
                 counted_wait();
                 tstamp(2);
                 __builtin_amdgcn_sched_barrier(0);
@@ -331,6 +335,20 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
         int tile_kk = 0;
         auto run_tile = [&](auto NA_c, auto NB_c, unsigned int sa, unsigned int sb, unsigned int san, unsigned int sbn) __attribute__((always_inline)) {
             using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+            if constexpr (SCHED == 2) {
+                const int ntrip = st1 >> 2;
+                unsigned int ra = sa, rb = sb;
+                for (int t = 0; t < ntrip; ++t) {
+                    if constexpr (STAMP) stamp_on = p.dbg && tile_kk == 1 && t == 4;
+                    const bool last = t == ntrip - 1;
+                    const unsigned int ha = last ? san - 256u : ra, hb = last ? sbn - 256u : rb;   // stages 2 / 3 of the last trip request stages 0 / 1 of the next tile: (san - 256) + 64 (J + 2)
+                    stage(I0{}, I1{}, ra, rb, NA_c, NB_c);
+                    stage(I1{}, I1{}, ra, rb, NA_c, NB_c);
+                    stage(I2{}, I1{}, ha, hb, NA_c, NB_c);
+                    stage(I3{}, I1{}, ha, hb, NA_c, NB_c);
+                    ra += 256; rb += 256;
+                }
+            } else {
             using K0 = std::integral_constant<int, SCHED == 1 ? 1 : 0>;        // stage 0 of a tile: SCHED 0 requests nothing there (its stage DIST went out at the border)
             using KL0 = std::integral_constant<int, DG >= 4 ? 2 : 1>;
             using KL1 = std::integral_constant<int, DG >= 3 ? 2 : 1>;          // the kinds of the last trip's stages: stage J requests the next tile when J + DG >= 4
@@ -353,6 +371,7 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
             if constexpr (KL1::value == 2) stage(I1{}, KL1{}, san, sbn, NA_c, NB_c); else stage(I1{}, KL1{}, ra, rb, NA_c, NB_c);
             if constexpr (KL2::value == 2) stage(I2{}, KL2{}, san, sbn, NA_c, NB_c); else stage(I2{}, KL2{}, ra, rb, NA_c, NB_c);
             stage(I3{}, I2{}, san, sbn, NA_c, NB_c);
+            }
         };
 
         int v = blockIdx.x, tm = tm0, tn = tn0, par = 0, tile_k = 0;
@@ -376,6 +395,7 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
             }
             stamp(tile_k, 1);
             // ---- tile border.  Stage DIST of the next tile goes out before anything else (DIST 2: ring slot 2 was last read two stages ago by both groups).
+            if constexpr (SCHED == 2) { if (grp == 0) __builtin_amdgcn_s_barrier(); }   // group 0 waits for group 1's last matrix slot: both epilogues then run together
             if constexpr (SCHED == 0) request_stage(san + 64 * DIST, sbn + 64 * DIST, DIST);   // (SCHED 1: the next tile's first load slot requests as every other one; it starts behind this border's vmcnt(0))
             const int m0 = tm * BM, n0 = tn * BN;
             // The epilogue's per-lane quantities come from an OPAQUE copy of the lane id made in every trip (see the compiler notes above).
@@ -586,6 +606,7 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0x0F70);   // the same wait where hipcc's wait-count pass can see it: otherwise it protects the epilogue's loads / stores with waits of its own INSIDE the K loop
             stamp(tile_k, 3);
+            if constexpr (SCHED == 2) { if (grp == 1) __builtin_amdgcn_s_barrier(); }   // ... and group 1 falls back one slot behind group 0 (pairs with the barrier that ends group 0's next load slot, or the kernel's last one)
             if (!has_next) break;
 #pragma unroll
             for (int i = 0; i < MIW; ++i)
@@ -595,7 +616,7 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
             par ^= 1; ++tile_k; tile_kk = tile_k;
         }
     };
-    if constexpr (SCHED == 0 && MI0 == MI1) core(std::integral_constant<int, MI0>{}, std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
+    if constexpr ((SCHED == 0 || SCHED == 2) && MI0 == MI1) core(std::integral_constant<int, MI0>{}, std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
     else {
         if (wm == 0) core(std::integral_constant<int, MI0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         else core(std::integral_constant<int, MI1>{}, std::integral_constant<int, MI0 * 16>{}, std::integral_constant<int, 1>{});
