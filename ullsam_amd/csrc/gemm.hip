@@ -988,7 +988,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
                 if (rotate) {   // q_embed = q cos + rotate_half(q) sin, rotate_half = cat(-x2, x1)  (same fp32 products and sums as rope_split_kernel / epilogue_rows)
                     const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { lo[e] = x[e] * cv[e] - y[e] * sv[e]; hi[e] = y[e] * cv[e] + x[e] * sv[e]; }
+                    for (int e = 0; e < 8; ++e) { lo[e] = fmaf(x[e], cv[e], -(y[e] * sv[e])); hi[e] = fmaf(y[e], cv[e], x[e] * sv[e]); }   // one rounded product + one fma, spelled out: left to -ffp-contract the one-tile and the persistent instantiations contracted differently (1 bf16 ulp in 3 of 10^6 outputs)
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { lo[e] = x[e]; hi[e] = y[e]; }
