@@ -16,6 +16,8 @@
 //                       4324 prompt rows) so that the tile count is a whole number of rounds of the 256 CUs; requests and fragment reads
 //                       alternated in the load slot, the slot's control flow resolved at compile time per wave class; epilogues straight
 //                       from the accumulators (swapped operands, permuted weight rows, lane-pair swap).
+//   gemm_ring8p_kernel  (gemm_ring8p.h, round 6) the ring kernel as a persistent grid -- workgroups walk tiles with the LDS ring kept full across tile borders: launches of more
+//                       than one round of tiles with a direct epilogue (llm.w13, llm.wqkv + RoPE, vit.qkv, vit.lin1 of the bench step); outputs bit-equal to gemm_ring8_kernel.
 //   gemm256_kernel      256x256 tile, two 64 KiB stages, staggered two-group schedule (L0|C0|L1|C1), split-K tail + gemm256_tail_reduce_kernel,
 //                       LDS-staged epilogue.  fp32 (parity mode), the wqkv GEMM with its RoPE epilogue, and bf16 launches whose 256x256
 //                       tile count leaves a sliver that a split-K tail absorbs.

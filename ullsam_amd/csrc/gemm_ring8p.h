@@ -3,15 +3,16 @@
 //
 //   * a grid of at most one workgroup per CU; workgroup b walks the tiles b, b + G, b + 2 G, ... (G = gridDim.x) in the dispatch order the
 //     one-tile-per-workgroup kernel has, so the sets of tiles that run together (and share an XCD's L2) are the same;
-//   * the LDS ring NEVER drains at a tile border: the last two load slots of a tile request stages 0 and 1 of the NEXT tile (in the one-tile
-//     kernel they request nothing), and the epilogue opens by requesting its stage 2 -- three of the four ring slots are in flight or landed
-//     while the accumulators are converted and stored;
-//   * loads and stores share `vmcnt` on gfx950 and complete in issue order, which is what sank the persistent kernels of rounds 2 and 3 (the
-//     next tile's counted waits sat behind the previous tile's 16 - 40 store acknowledgements).  Here no counted wait ever has a store in front
-//     of it: the epilogue ends with ONE `s_waitcnt vmcnt(0)` -- by then stages 1' and 2' have long landed and only the youngest stores are still
-//     on their way -- the next tile's first load slot requests nothing, and its second one requests stage 3' behind the steady-state wait;
-//   * the two wave groups keep their one-slot stagger across tiles: group 0 converts and stores while group 1 runs its last matrix slot, group 1
-//     does so under group 0's first matrix slot of the next tile; the epilogue contains no barrier;
+//   * the LDS ring NEVER drains at a tile border: the last two load slots of a tile request stages 0 and 1 of the NEXT tile (in the one-tile kernel they request
+//     nothing); in the DEFAULT schedule (SCHED 2) that is all -- every trip of the K loop is the same code, the next tile's first load slot requests its stage 2 as
+//     every load slot requests the stage two ahead; the first schedule (SCHED 0) also requested stage 2 at the border and had a request-free first stage, which cost it
+//     peeled first / last trips;
+//   * loads and stores share `vmcnt` on gfx950 and complete in issue order, which is what sank the persistent kernels of rounds 2 and 3 (the next tile's counted
+//     waits sat behind the previous tile's 16 - 40 store acknowledgements).  Here the border ends with ONE `s_waitcnt vmcnt(0)` -- stages 0' and 1' have long landed,
+//     only the youngest stores are still on their way (330 - 670 cycles by the stamps) -- and no counted wait of the next tile has a store in front of it;
+//   * the two wave groups keep their one-slot stagger inside a tile; at the border (SCHED 2) group 0 waits one extra barrier for group 1's last matrix slot, both
+//     groups convert and store their accumulators AT THE SAME TIME (as in the one-tile kernel), and group 1 takes one extra barrier behind its vmcnt(0) to fall one
+//     slot behind again (SCHED 0 ran the two epilogues one after the other and so gave back the prologue it saved);
 //   * requests go through BUFFER descriptors (`buffer_load_dwordx4 ... offen lds`: descriptor + per-lane offset + scalar offset): the per-lane
 //     offsets are the same in every tile, a tile switch is one scalar per operand, and rows past M are out of the descriptor's range (no fetch, no
 //     clamp) -- so ONE copy of the load slot serves every stage of every tile, with the request's scalar offset switched two stages before a border;
