@@ -33,10 +33,13 @@ const char* ullsam_last_error_string(void);
 int ullsam_abi_version(void); /* == ULLSAM_ABI_VERSION of the header the library was built from */
 int ullsam_device_count(void);
 /* GEMM kernel selection for A/B measurements and the kernel tests: 0 = auto (by shape), 1 = 128x128 tile, 3 = 256x256 two-buffer kernel,
-   6 / 8 / 9 = ring kernel with 256x256 / 256x320 / 272x256 tiles; +64 = no split-K tail; +32768 = stamped diagnostic launch of the ring kernel. */
+   6 / 8 / 9 = ring kernel with 256x256 / 256x320 / 272x256 tiles; +64 = no split-K tail; +32768 = stamped diagnostic launch of the ring kernel (+65536 as well: of its persistent form). */
 int ullsam_set_gemm_variant(int variant);
 /* measurement knob, not part of the reference's interface: key 0 = tile rows per raster group of the 256-row-tile GEMM kernels (default 4);
-   key 1 = ring tile shapes the automatic dispatch may use (bit 0 256x256, bit 1 256x320, bit 2 272x256; default 7) */
+   key 1 = ring tile shapes the automatic dispatch may use (bit 0 256x256, bit 1 256x320, bit 2 272x256; default 7);
+   key 2 = how ring launches of MORE than one round of tiles run (csrc/gemm_ring8p.h; every value gives bit-equal outputs except the ablations): 2 (default) = persistent grid,
+   identical trips, both wave groups' epilogues together; 0 = one tile per workgroup (the kernel of rounds 2 - 5); 1 / 4 = the first persistent schedule / one barrier per stage;
+   5 - 7 = timing-only ablations of the 272x256 loop (no LDS-DMA requests / no fragment reads / neither: WRONG results) */
 int ullsam_set_gemm_tuning(int key, int value);
 /* Attention kernel selection for A/B measurements and the kernel tests: 0 = production; 1 / 2 = windowed attention on the tiled kernel (7-wave /
    4-wave workgroups) instead of the whole-window kernel; 3..8 = start stagger of the whole-window kernel's second resident workgroup; 9 = global
