@@ -395,7 +395,12 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
             }
             stamp(tile_k, 1);
             // ---- tile border.  Stage DIST of the next tile goes out before anything else (DIST 2: ring slot 2 was last read two stages ago by both groups).
-            if constexpr (SCHED == 2) { if (grp == 0) __builtin_amdgcn_s_barrier(); }   // group 0 waits for group 1's last matrix slot: both epilogues then run together
+            // SCHED 2: group 0, one slot ahead, takes ONE extra barrier inside its epilogue (it pairs with the barrier that ends group 1's last matrix slot), so that group 1's epilogue starts
+            // beside group 0's instead of behind it; placed after the first sub-tile row's conversions and stores (border_sync(1) at the top of the loops' second trip), not at the
+            // border's start: group 0 then works through group 1's last matrix slot instead of idling at the barrier for it.  Exactly one call with i == 1 (i == 2 in the two-row loop) per epilogue path.
+            auto border_sync = [&](int i, int at) __attribute__((always_inline)) {
+                if constexpr (SCHED == 2) { if (i == at && grp == 0) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } }
+            };
             if constexpr (SCHED == 0) request_stage(san + 64 * DIST, sbn + 64 * DIST, DIST);   // (SCHED 1: the next tile's first load slot requests as every other one; it starts behind this border's vmcnt(0))
             const int m0 = tm * BM, n0 = tn * BN;
             // The epilogue's per-lane quantities come from an OPAQUE copy of the lane id made in every trip (see the compiler notes above).
@@ -447,6 +452,7 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
                     if (rotate) load_cs(0, cn, sn);
     #pragma unroll
                     for (int i = 0; i < MIW; ++i) {
+                        border_sync(i, 1);
                         const float4 c0 = cn[0], c1 = cn[1], s0 = sn[0], s1 = sn[1];
                         if (rotate && i + 1 < MIW) load_cs(i + 1, cn, sn);
                         const int gm = row0 + 16 * i;
@@ -486,6 +492,7 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
                         };
     #pragma unroll
                         for (int i = 0; i < MIW; ++i) {
+                            border_sync(i, 1);
                             unsigned int o[8];
     #pragma unroll
                             for (int h = 0; h < 2; ++h)
@@ -527,6 +534,7 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
                     T* cp = reinterpret_cast<T*>(p.C) + (size_t)row0 * p.ldc + (n0 >> 1) + (wn >> 1) * 64 + (wn & 1) * 32 + 8 * g4;
     #pragma unroll
                     for (int i = 0; i < MIW; ++i) {
+                        border_sync(i, 1);
                         unsigned int o[4];
     #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -590,6 +598,7 @@ __global__ __launch_bounds__(512) void gemm_ring8p_kernel(GemmArgs p) {
                         if constexpr (decltype(RES)::value) load_res(0, ra);
     #pragma unroll
                         for (int i = 0; i < MIW; i += 2) {
+                            border_sync(i, 2);
                             if constexpr (decltype(RES)::value) { if (i + 1 < MIW) load_res(i + 1, rb); __builtin_amdgcn_sched_barrier(0); }
                             put(i, ra);
                             if constexpr (decltype(RES)::value) { if (i + 2 < MIW) load_res(i + 2, ra); __builtin_amdgcn_sched_barrier(0); }
