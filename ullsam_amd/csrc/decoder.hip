@@ -725,9 +725,8 @@ extern "C" int ullsam_i2t_block(const void* xin, long in_mod, const float* res, 
 // The token -> image attention's k and v projections of the image side for MANY prompts in one pass (transformer.py:123-126 / Attention.forward :220-222, bf16):
 //     K = (keys + pe) Wk^T + bk,   V = keys Wv^T + bv          [rows, 256] x [128, 256]^T -> [rows, 128] each
 // Two launches of the 128x128 tile GEMM (2048 workgroups of 64 KB each, 61 - 77 us apiece for 203 MB) ran at 2.6 - 3.3 TB/s; here both weight matrices sit in LDS as
-// MFMA A fragments for the life of the workgroup (128 KiB) and a wave streams 16 rows at a time through both products (weights first: D^T = W X^T, tile t = features
-// 16 t .. + 15), the next group's rows requested under the other product.  For the stores neighbouring lane groups trade halves of a tile pair (as in i2t_block_kernel), so a
-// lane stores 8 consecutive features = 16 bytes.
+// MFMA B fragments for the life of the workgroup (128 KiB) and a wave streams 16 rows at a time through both products (rows first: D = X W^T), the next group's rows
+// requested under the other product; the weight rows are permuted so that a lane's eight tiles are 8 consecutive features and a store instruction writes whole rows (kv_store).
 // ---------------------------------------------------------------------------------------------------------------
 struct KvArgs { const bf16* xk; const bf16* xv; const bf16* Wk; const bf16* Wv; const float* bk; const float* bv; bf16* K; bf16* V; long rows; };
 constexpr int KV_WAVES = 8;
@@ -737,9 +736,12 @@ __device__ __forceinline__ void kv_load(bf16x8_t (&a)[8], const bf16* x, long gr
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) a[ks] = *reinterpret_cast<const bf16x8_t*>(ap + ks * 32);
 }
-__device__ __forceinline__ void kv_product(f32x4 (&acc)[8], const bf16x8_t (&a)[8], const char* wl, const float* bias, int g) {
+__device__ __forceinline__ void kv_product(f32x4 (&acc)[8], const bf16x8_t (&a)[8], const char* wl, const float* bias, int l16) {
+    {   // the lane's 8 features 64 (l16 >> 3) + 8 (l16 & 7) .. + 7 (tile t = offset t): the same bias for its four rows
+        const f32x4 b0v = *reinterpret_cast<const f32x4*>(bias + 8 * l16), b1v = *reinterpret_cast<const f32x4*>(bias + 8 * l16 + 4);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = *reinterpret_cast<const f32x4*>(bias + 16 * t + 4 * g);
+        for (int t = 0; t < 4; ++t) { acc[t] = f32x4{b0v[t], b0v[t], b0v[t], b0v[t]}; acc[4 + t] = f32x4{b1v[t], b1v[t], b1v[t], b1v[t]}; }
+    }
     bf16x8_t wr[2][4];                                                        // batches of four fragment reads one batch ahead of their MFMAs
 #pragma unroll
     for (int i = 0; i < 4; ++i) wr[0][i] = *reinterpret_cast<const bf16x8_t*>(wl + (i * 8) * 1024);
@@ -751,35 +753,31 @@ __device__ __forceinline__ void kv_product(f32x4 (&acc)[8], const bf16x8_t (&a)[
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[4 * (b & 1) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[b & 1][i], a[b >> 1], acc[4 * (b & 1) + i], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[4 * (b & 1) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[b >> 1], wr[b & 1][i], acc[4 * (b & 1) + i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
-__device__ __forceinline__ void kv_store(f32x4 (&acc)[8], bf16* out, long gr, long rows, int l16, int g) {
-    const long row = gr * 16 + l16;
+// rows first (D = X W^T: a lane holds rows 4 g + e of column l16 of every tile) with the weight rows permuted so that column n of tile t is feature
+// 64 (n >> 3) + 8 (n & 7) + t: a lane's eight tiles are 8 CONSECUTIVE features of a row, the 16 lanes of a lane group cover the row's 128 features, and one
+// store instruction writes four whole rows = 4 x 256 contiguous bytes (round 5 held one row per lane and traded tile halves between lane groups: 64-byte pieces per row and instruction)
+__device__ __forceinline__ void kv_store(const f32x4 (&acc)[8], bf16* out, long gr, long rows, int l16, int g) {
+    const long row0 = gr * 16 + 4 * g;
 #pragma unroll
-    for (int t = 0; t < 8; t += 2) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {                                          // groups 0 / 1 and 2 / 3 trade halves: group g then holds features 16 t + 16 (g & 1) + 8 (g >> 1) .. + 7
-            const float a0 = acc[t][e], a1 = acc[t + 1][e];                   // (selects on values: a lane-dependent choice of the ELEMENT to overwrite put the array in scratch)
-            const float got = lane_xor16((g & 1) ? a0 : a1);
-            acc[t][e] = (g & 1) ? got : a0;
-            acc[t + 1][e] = (g & 1) ? a1 : got;
-        }
+    for (int e = 0; e < 4; ++e) {
         bf16x8_t c;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { c[e] = (__bf16)acc[t][e]; c[4 + e] = (__bf16)acc[t + 1][e]; }
-        if (row < rows) *reinterpret_cast<bf16x8_t*>(out + (size_t)row * 128 + 16 * t + 16 * (g & 1) + 8 * (g >> 1)) = c;
+        for (int t = 0; t < 8; ++t) c[t] = (__bf16)acc[t][e];
+        if (row0 + e < rows) *reinterpret_cast<bf16x8_t*>(out + (size_t)(row0 + e) * 128 + 8 * l16) = c;
     }
 }
 __global__ __launch_bounds__(64 * KV_WAVES) void kv_proj_kernel(KvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bs = reinterpret_cast<float*>(smem + 2 * 128 * 256 * 2);          // bk [128] | bv [128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
-    // fragment (matrix w, tile t, k-step ks) = one contiguous KiB: lane (m, gg) <- W[16 t + m][32 ks + 8 gg .. + 7]
+    // B fragment (matrix w, tile t, k-step ks) = one contiguous KiB: lane (n, gg) <- W[64 (n >> 3) + 8 (n & 7) + t][32 ks + 8 gg .. + 7]
     for (int c = tid; c < 2 * 8 * 8 * 64; c += 64 * KV_WAVES) {
-        const int w = c >> 12, f = (c >> 6) & 63, ln = c & 63, t = f >> 3, ks = f & 7, m = ln & 15, gg = ln >> 4;
-        *reinterpret_cast<uint4*>(smem + c * 16) = *reinterpret_cast<const uint4*>((w ? p.Wv : p.Wk) + (size_t)(16 * t + m) * 256 + 32 * ks + 8 * gg);
+        const int w = c >> 12, f = (c >> 6) & 63, ln = c & 63, t = f >> 3, ks = f & 7, n = ln & 15, gg = ln >> 4;
+        *reinterpret_cast<uint4*>(smem + c * 16) = *reinterpret_cast<const uint4*>((w ? p.Wv : p.Wk) + (size_t)(64 * (n >> 3) + 8 * (n & 7) + t) * 256 + 32 * ks + 8 * gg);
     }
     if (tid < 128) { bs[tid] = p.bk ? p.bk[tid] : 0.f; bs[128 + tid] = p.bv ? p.bv[tid] : 0.f; }
     __syncthreads();
@@ -795,10 +793,10 @@ __global__ __launch_bounds__(64 * KV_WAVES) void kv_proj_kernel(KvArgs p) {
         const char* wl = smem + lo_;
         const long nxt = min(grp + stride, groups - 1);                       // (the last trip re-requests its own rows: no branch around the loads)
         f32x4 acc[8], acc2[8];
-        kv_product(acc, ak, wl, bs, g);
+        kv_product(acc, ak, wl, bs, l16);
         kv_load(ak, p.xk, nxt, p.rows, l16, g);                               // the next group's k rows pass under the v product
         kv_store(acc, p.K, grp, p.rows, l16, g);
-        kv_product(acc2, av, wl + 8 * 8 * 1024, bs + 128, g);
+        kv_product(acc2, av, wl + 8 * 8 * 1024, bs + 128, l16);
         kv_load(av, p.xv, nxt, p.rows, l16, g);                               // its v rows under the stores and the next k product
         kv_store(acc2, p.V, grp, p.rows, l16, g);
     }
@@ -924,8 +922,11 @@ extern "C" int ullsam_up2_hyper_masks(const void* u1, const void* w1, const floa
 //     u1[row * 4 + tap][c] = bf16(GELU(LayerNorm_c(src[row] . w0[tap * 64 + c] + b0[tap * 64 + c])))
 // src bf16 [rows, 256] (the image side of the two-way transformer), w0 bf16 [256 = (ky, kx, c), 256]; out bf16 [rows * 4, 64] = [rows, 256].
 // The fp32 result of the convolution ([rows, 256] fp32 = 268 MB for 64 prompts) used to be written by the GEMM and read back by the 64-channel
-// LayerNorm; here w0 (128 KiB) sits in LDS with its rows permuted so that lane (row, g) holds the 64 channels of ONE tap (tap = g): mean, variance, the
-// affine, GELU and the rounding are lane-local, the store is 128 contiguous bytes per lane.
+// LayerNorm; here w0 (128 KiB) sits in LDS as B fragments with its rows permuted so that a lane holds, for FOUR rows (4 g + e), 8 consecutive channels
+// 8 (l16 % 8) .. + 7 of tap 2 T + l16 / 8 (tile T * 8 + t = channel offset t): a (row, tap)'s 64 channels sit in 8 neighbouring lanes (mean and variance: an
+// 8-value lane sum + three DPP steps), and ONE store instruction writes 16 lanes x 16 B = 256 contiguous bytes per row -- whole 128-byte lines.  (Round 5's
+// layout kept a (row, tap)'s 64 channels in one lane: lane-local statistics, but eight 16-byte stores per 128-byte line, each a separate instruction:
+// WRITE_SIZE 214 MB for 134 MB of output, lines left the L2 half-written.)
 // ---------------------------------------------------------------------------------------------------------------
 struct Up1Args { const bf16* src; const bf16* w0; const float* b0; const float* lnw; const float* lnb; float eps; bf16* out; long rows; };
 constexpr int UP1_WAVES = 8;       // two per SIMD share the weights (162 registers; twelve waves were measured: 90.9 vs 84.4 us for 64 prompts)
@@ -935,17 +936,21 @@ __global__ __launch_bounds__(64 * UP1_WAVES) void up1_ln_gelu_kernel(Up1Args p) 
     float* lw = bs + 256;
     float* lb = lw + 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
-    // w0 -> LDS in MFMA A-fragment order: fragment (tile t, k-step ks) = one contiguous KiB, lane (m, gg) <- w0[row(t, m)][32 ks + 8 gg .. + 7] with
-    // row(t, m = 4 gq + i) = 64 gq + 4 t + i: the accumulator of tile t gives lane group g (= tap g) its channels 4 t .. 4 t + 3
+    // w0 -> LDS in MFMA B-fragment order: fragment (tile tt, k-step ks) = one contiguous KiB, lane (n, gg) <- w0[row(tt, n)][32 ks + 8 gg .. + 7] with
+    // row(tt, n) = 64 (2 (tt >> 3) + (n >> 3)) + 8 (n & 7) + (tt & 7): column n of tile tt is channel 8 (n & 7) + (tt & 7) of tap 2 (tt >> 3) + (n >> 3)
     for (int c = tid; c < 16 * 8 * 64; c += 64 * UP1_WAVES) {
-        const int f = c >> 6, ln = c & 63, t = f >> 3, ks = f & 7, m = ln & 15, gg = ln >> 4;
-        *reinterpret_cast<uint4*>(smem + c * 16) = *reinterpret_cast<const uint4*>(p.w0 + (size_t)(64 * (m >> 2) + 4 * t + (m & 3)) * 256 + 32 * ks + 8 * gg);
+        const int f = c >> 6, ln = c & 63, tt = f >> 3, ks = f & 7, n = ln & 15, gg = ln >> 4;
+        *reinterpret_cast<uint4*>(smem + c * 16) = *reinterpret_cast<const uint4*>(p.w0 + (size_t)(64 * (2 * (tt >> 3) + (n >> 3)) + 8 * (n & 7) + (tt & 7)) * 256 + 32 * ks + 8 * gg);
     }
     if (tid < 256) bs[tid] = p.b0 ? p.b0[tid] : 0.f;
     if (tid < 64) { lw[tid] = p.lnw ? p.lnw[tid] : 1.f; lb[tid] = p.lnb ? p.lnb[tid] : 0.f; }
     __syncthreads();
     const long groups = (p.rows + 15) / 16;
     const long stride = (long)gridDim.x * UP1_WAVES;
+    const int l8 = l16 & 7, hp = l16 >> 3;                                    // the lane's channel octet and the parity of its taps
+    float lwr[8], lbr[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { lwr[t] = lw[8 * l8 + t]; lbr[t] = lb[8 * l8 + t]; }
     bf16x8_t a[8];
     auto load = [&](long grp) {
         const long row = min(grp * 16 + l16, p.rows - 1);
@@ -958,7 +963,11 @@ __global__ __launch_bounds__(64 * UP1_WAVES) void up1_ln_gelu_kernel(Up1Args p) 
         asm volatile("" : "+v"(lo_));                                         // (opaque per group: the fragment addresses are not loop invariants to hoist into registers)
         const char* wl = smem + lo_;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) u[t] = *reinterpret_cast<const f32x4*>(bs + g * 64 + 4 * t);
+        for (int T = 0; T < 2; ++T) {                                         // the lane's 8 channels of tap 2 T + hp: the same bias for its four rows
+            const f32x4 b0v = *reinterpret_cast<const f32x4*>(bs + (2 * T + hp) * 64 + 8 * l8), b1v = *reinterpret_cast<const f32x4*>(bs + (2 * T + hp) * 64 + 8 * l8 + 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { u[8 * T + t] = f32x4{b0v[t], b0v[t], b0v[t], b0v[t]}; u[8 * T + 4 + t] = f32x4{b1v[t], b1v[t], b1v[t], b1v[t]}; }
+        }
         // batches of four fragment reads run one batch ahead of their MFMAs (two register sets pinned by the scheduling fences)
         bf16x8_t wr[2][4];
 #pragma unroll
@@ -971,35 +980,50 @@ __global__ __launch_bounds__(64 * UP1_WAVES) void up1_ln_gelu_kernel(Up1Args p) 
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) u[4 * (b & 3) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[b & 1][i], a[b >> 2], u[4 * (b & 3) + i], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) u[4 * (b & 3) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[b >> 2], wr[b & 1][i], u[4 * (b & 3) + i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    auto sum8 = [](float v) __attribute__((always_inline)) {                  // over the 8 lanes l16 % 8 = 0 .. 7 of a (row quad, tap): every lane gets the total
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+        return v;
+    };
     auto finish = [&](f32x4 (&u)[16], long grp) {
-        const long row = grp * 16 + l16;
-        if (row >= p.rows) return;
-        float sum = 0.f;
+        const long row0 = grp * 16 + 4 * g;
+        // the eight (tap pair T, row e) statistics of the lane as batches (8 independent DPP chains at a time, not one after the other)
+        float mean[8], rstd[8];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) sum += (u[t][0] + u[t][1]) + (u[t][2] + u[t][3]);
-        const float mean = sum * (1.0f / 64.0f);
-        float ss = 0.f;
+        for (int k = 0; k < 8; ++k) {
+            const int T = k >> 2, e = k & 3;
+            float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const f32x4 d = u[t] - mean;
-            ss += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            for (int t = 0; t < 8; t += 2) sum += u[8 * T + t][e] + u[8 * T + t + 1][e];
+            mean[k] = sum;
         }
-        const float rstd = 1.0f / sqrtf(ss * (1.0f / 64.0f) + p.eps);
-        bf16* op = p.out + (size_t)row * 256 + g * 64;
 #pragma unroll
-        for (int t = 0; t < 16; t += 2) {
+        for (int k = 0; k < 8; ++k) mean[k] = sum8(mean[k]) * (1.0f / 64.0f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int T = k >> 2, e = k & 3;
+            float ss = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; t += 2) {
+                const float d0 = u[8 * T + t][e] - mean[k], d1 = u[8 * T + t + 1][e] - mean[k];
+                ss += d0 * d0 + d1 * d1;
+            }
+            rstd[k] = ss;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rstd[k] = 1.0f / sqrtf(sum8(rstd[k]) * (1.0f / 64.0f) + p.eps);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int T = k >> 2, e = k & 3;
             bf16x8_t c;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                c[e] = (__bf16)gelu_erfc5((u[t][e] - mean) * rstd * lw[4 * t + e] + lb[4 * t + e]);
-                c[4 + e] = (__bf16)gelu_erfc5((u[t + 1][e] - mean) * rstd * lw[4 * t + 4 + e] + lb[4 * t + 4 + e]);
-            }
-            *reinterpret_cast<bf16x8_t*>(op + 4 * t) = c;
-            __builtin_amdgcn_sched_barrier(0);
+            for (int t = 0; t < 8; ++t) c[t] = (__bf16)gelu_erfc5((u[8 * T + t][e] - mean[k]) * rstd[k] * lwr[t] + lbr[t]);
+            if (row0 + e < p.rows) *reinterpret_cast<bf16x8_t*>(p.out + (size_t)(row0 + e) * 256 + T * 128 + l16 * 8) = c;   // 16 lanes: 256 contiguous bytes of the row
         }
     };
     long grp = (long)blockIdx.x * UP1_WAVES + wave;
