@@ -27,7 +27,7 @@ extern "C" {
 
 /* Bumped whenever an entry point is added or a signature changes.  The Python binding refuses a library that reports another
    version (a stale libullsam_hip.so would otherwise receive shifted arguments, e.g. a row count where the stream is expected). */
-#define ULLSAM_ABI_VERSION 10
+#define ULLSAM_ABI_VERSION 11
 
 const char* ullsam_last_error_string(void);
 int ullsam_abi_version(void); /* == ULLSAM_ABI_VERSION of the header the library was built from */
@@ -39,7 +39,9 @@ int ullsam_set_gemm_variant(int variant);
    key 1 = ring tile shapes the automatic dispatch may use (bit 0 256x256, bit 1 256x320, bit 2 272x256; default 7);
    key 2 = how ring launches of MORE than one round of tiles run (csrc/gemm_ring8p.h; every value gives bit-equal outputs except the ablations): 2 (default) = persistent grid,
    identical trips, both wave groups' epilogues together; 0 = one tile per workgroup (the kernel of rounds 2 - 5); 1 / 4 = the first persistent schedule / one barrier per stage;
-   5 - 7 = timing-only ablations of the 272x256 loop (no LDS-DMA requests / no fragment reads / neither: WRONG results) */
+   5 - 7 = timing-only ablations of the 272x256 loop (no LDS-DMA requests / no fragment reads / neither: WRONG results);
+   key 3 = split-K on the ring kernel for launches of <= 128 tiles whose K cuts into ranges of >= 1280 that fill >= 224 workgroups: 1 (default) = where the caller allows it
+   (ullsam_gemm's act | 256), 0 = never, 2 = wherever it fits */
 int ullsam_set_gemm_tuning(int key, int value);
 /* Attention kernel selection for A/B measurements and the kernel tests: 0 = production; 1 / 2 = windowed attention on the tiled kernel (7-wave /
    4-wave workgroups) instead of the whole-window kernel; 3..8 = start stagger of the whole-window kernel's second resident workgroup; 9 = global
@@ -54,8 +56,13 @@ int ullsam_set_attn_debug(void* stamps);
  * modeling_internlm2.py:261-264,359,421,1081; transformer.py:220-227 (image side); mask_decoder.py:53-59.
  * A, W in `dtype`; C float when out_f32 else `dtype`; bias/residual fp32 (nullable); residual row = m %% res_row_mod
  * when res_row_mod > 0 (pos_embed broadcast, image_encoder.py:107-109).  K %% (128/elem_size) == 0.
- * workspace (optional, caller-owned device scratch, >= 32 MiB useful): lets launches whose last wave of tiles is mostly empty
- * split those tiles along K (fp32 partials in the workspace + a reduce kernel); null disables it. */
+ * workspace (optional, caller-owned device scratch, >= 32 MiB useful, 128 MiB for every split-K form): lets launches whose last wave of tiles is mostly empty
+ * split those tiles along K (fp32 partials in the workspace + a reduce kernel), and launches of few tiles (e.g. 1081 x 4096 outputs) run as up to 8 K ranges
+ * side by side (S fp32 planes of the output in the workspace, added in order); null disables both.
+ * act: 0 none, 1 GELU (erf), 2 ReLU, 3 SwiGLU pair; | 256 = ULLSAM_ACT_SPLITK_OK: the caller accepts the K-ranges form just described.  Every one-launch kernel adds the
+ * 32-deep k steps of an output in sequence, so an image gets the same bits alone and inside a batch; K ranges summed apart do not -- the training step's frozen
+ * linears set the flag (one image per step, train_joint_v2.py), the inference modules never do. */
+#define ULLSAM_ACT_SPLITK_OK 256
 int ullsam_gemm(int dtype, const void* A, long lda, const void* W, long ldw, void* C, long ldc, int out_f32,
                 const float* bias, const float* residual, long ldr, int res_row_mod, int act, int M, int N, int K,
                 void* workspace, long ws_bytes, void* stream);

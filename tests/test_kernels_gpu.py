@@ -218,6 +218,53 @@ def test_gemm_272x256_kernel(ops, M, N, K, mode):
     assert float((got - want).abs().max()) < tol * max(1.0, float(want.abs().max()) / 4)
 
 
+@pytest.mark.parametrize("M,N,K,mode", [(1081, 4096, 14336, "res"), (1081, 4096, 5120, "bias"), (1081, 4096, 6144, "plain"), (1081, 4096, 28672, "f32"),
+                                        (4096, 1280, 5120, "res"), (2049, 2048, 8192, "bias"), (1081, 4096, 1024, "plain")])
+def test_gemm_split_k_ring_against_float64_and_the_128_tile_kernel(ops, M, N, K, mode):
+    """Launches of few ring tiles under a long sum (csrc/gemm.hip launch_gemm_ring_splitk: 1081 x 4096 outputs = a batch-1 prefill's wo / w2 and the frozen LLM's products of a
+    training step; the AMG encoder's lin2 at one image) run as up to 8 K ranges of the ring kernel side by side, fp32 planes in the workspace added in order by splitk_finish_kernel
+    (+ bias / residual, bf16 or fp32 out).  Against float64 on the bf16-rounded operands, against the 128x128 kernel that takes these shapes without the caller's ULLSAM_ACT_SPLITK_OK (the default; ullsam_set_gemm_tuning(3, 2) forces the split form),
+    and twice (the sums are ordered: bit-equal).  Odd M, the 256x320 shape, in-place residual; a K without ranges of >= 1280 (the last case) stays on the old path."""
+    from ullsam_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV); g.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g)
+    x0 = torch.randn(M, N, device=DEV, generator=g)
+    ref = (a.double() @ w.double().T)
+
+    def run():
+        if mode == "plain":
+            return ops.gemm(a, w).double(), ref, 2e-2
+        if mode == "bias":
+            return ops.gemm(a, w, bias).double(), ref + bias.double(), 2e-2
+        if mode == "f32":
+            return ops.gemm(a, w, bias, out_f32=True).double(), ref + bias.double(), 1e-4
+        x = x0.clone()
+        ops.gemm(a, w, bias, residual=x, out_f32=True, out=x)
+        return x.double(), ref + bias.double() + x0.double(), 1e-4
+    try:
+        lib.ullsam_set_gemm_tuning(3, 1)          # the default: a plain ops.gemm call does not carry ULLSAM_ACT_SPLITK_OK -> the one-launch kernel
+        old, want, tol = run()
+        lib.ullsam_set_gemm_tuning(3, 2)          # wherever the plan fits
+        got, _, _ = run()
+        again, _, _ = run()
+        torch.cuda.synchronize()
+    finally:
+        lib.ullsam_set_gemm_tuning(3, 1)
+    if mode == "plain" and K != 1024:             # the caller's flag does the same as the forced mode
+        assert torch.equal(ops.gemm(a, w, splitk_ok=True).double(), got) and not torch.equal(got, old)
+    scale = max(1.0, float(want.abs().max()) / 4)
+    assert float((got - want).abs().max()) < tol * scale, float((got - want).abs().max())
+    assert float((got - old).abs().max()) < 2 * tol * scale
+    assert torch.equal(again, got)
+    if K == 1024:
+        assert torch.equal(got, old)     # no cut into ranges of >= 1280 exists: ring_splitk_plan declines, the launch is the old one
+    mean_err_new, mean_err_old = float((got - want).abs().mean()), float((old - want).abs().mean())
+    assert mean_err_new <= 1.05 * mean_err_old + 1e-7, (mean_err_new, mean_err_old)
+
+
 @pytest.mark.parametrize("variant,M,N,K,mode", [(9, 4324, 8192, 384, "swiglu"), (9, 8704, 4096, 512, "res"), (8, 8192, 3840, 384, "bias_gelu"), (8, 8000, 3840, 640, "res_mod"),
                                                 (6, 8192, 4096, 384, "bias"), (6, 6000, 6144, 1024, "plain")])
 @pytest.mark.parametrize("persist", [1, 2, 4])

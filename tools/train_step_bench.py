@@ -14,6 +14,9 @@ llm = sys.argv[2] if len(sys.argv) > 2 else "2b"
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 dt = torch.bfloat16 if (len(sys.argv) > 4 and sys.argv[4] == "bf16") else torch.float32
 dev = "cuda:0"
+if os.environ.get("ULLSAM_GEMM_TUNING3"):    # A/B of the frozen linears' K-range split: 0 = off
+    from ullsam_amd import _lib
+    _lib.load().ullsam_set_gemm_tuning(3, int(os.environ["ULLSAM_GEMM_TUNING3"]))
 m = bench.build_model(vit, llm, dt, dev)
 for n, p in m.named_parameters():
     p.requires_grad_(not n.startswith("language_model."))

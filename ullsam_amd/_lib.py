@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ULLSAM_HIP_LIB") or os.path.join(_HERE, "lib", "libullsam_hip.so")  # env: A/B a side build (developer switch)
 
-ABI_VERSION = 10  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
+ABI_VERSION = 11  # == ULLSAM_ABI_VERSION in include/ullsam_hip.h (tests/test_host_cpu.py checks the three agree)
 
 _lib = None
 

@@ -18,6 +18,8 @@
 //                       from the accumulators (swapped operands, permuted weight rows, lane-pair swap).
 //   gemm_ring8p_kernel  (gemm_ring8p.h, round 6) the ring kernel as a persistent grid -- workgroups walk tiles with the LDS ring kept full across tile borders: launches of more
 //                       than one round of tiles with a direct epilogue (llm.w13, llm.wqkv + RoPE, vit.qkv, vit.lin1 of the bench step); outputs bit-equal to gemm_ring8_kernel.
+//                       Split-K form (EMODE 2, launch_gemm_ring_splitk + splitk_finish_kernel): launches of <= 128 tiles under a long K (1081 x 4096 outputs: a batch-1
+//                       prefill, the frozen LLM of a training step) run up to 8 K ranges side by side into fp32 planes of the workspace, added in order.
 //   gemm256_kernel      256x256 tile, two 64 KiB stages, staggered two-group schedule (L0|C0|L1|C1), split-K tail + gemm256_tail_reduce_kernel,
 //                       LDS-staged epilogue.  fp32 (parity mode), the wqkv GEMM with its RoPE epilogue, and bf16 launches whose 256x256
 //                       tile count leaves a sliver that a split-K tail absorbs.
@@ -747,6 +749,12 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     constexpr int PA = BM / 16, PB = BN / 16;          // DMA pieces (16 rows x 64 B) per stage
     constexpr int ASZ = BM * 64, STG = ASZ + BN * 64;
     static_assert(PA >= 8 && PA <= 24 && PB >= 8 && PB <= 24, "piece assignment below: one to three pieces per wave and operand");
+    if constexpr (EMODE == 2) {   // split-K (launch_gemm_ring_splitk): part blockIdx.y sums its K / gridDim.y range into plane `part` of the fp32 workspace that p.C points at
+        p.K /= (int)gridDim.y;
+        p.A = reinterpret_cast<const char*>(p.A) + (size_t)blockIdx.y * p.K * 2;
+        p.W = reinterpret_cast<const char*>(p.W) + (size_t)blockIdx.y * p.K * 2;
+        p.C = reinterpret_cast<float*>(p.C) + (size_t)blockIdx.y * p.M * p.ldc;
+    }
 
     const int nblk = p.full_tiles;
     const int bid = blockIdx.x;
@@ -1198,6 +1206,70 @@ static int launch_gemm_ring8(GemmArgs a, hipStream_t stream) {
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
+// Split-K on the ring kernel for launches of FEW tiles under a long sum (M = 1081 rows x N = 4096: 4 x 16 tiles of 272 x 256 -- a batch-1 prefill's wo / w2, the
+// frozen LLM's products of a training step; the AMG encoder's lin2 at one image): S = 256 / tiles K-ranges run as S x tiles workgroups of ONE launch, each writing its
+// fp32 sums to a plane of the caller's workspace; splitk_finish_kernel adds the planes in order (deterministic) with bias / residual and writes C.
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, TO* __restrict__ C, long ldc, const float* __restrict__ bias,
+                                                            const float* __restrict__ residual, long ldr, int res_row_mod, int M, int N, int S) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x, nq = N >> 2;
+    if (q >= (long)M * nq) return;
+    const int m = (int)(q / nq), c = (int)(q - (long)m * nq) * 4;
+    const size_t plane = (size_t)M * N;
+    const float* src = ws + (size_t)m * N + c;
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < S) v[k] = *reinterpret_cast<const float4*>(src + k * plane);   // S <= 8 independent loads, then the sum in plane order
+    float4 s = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) if (k < S) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+    if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + c); s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w; }
+    if (residual) {
+        const int rr = res_row_mod > 0 ? m % res_row_mod : m;
+        const float4 r = *reinterpret_cast<const float4*>(residual + (size_t)rr * ldr + c);
+        s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
+    }
+    if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(C + (size_t)m * ldc + c) = s;
+    else *reinterpret_cast<uint2*>(C + (size_t)m * ldc + c) = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
+}
+template <int MI0, int MI1, int NTW>
+static int launch_gemm_ring_splitk(const GemmArgs& a, int S, hipStream_t stream) {
+    constexpr int BM = 16 * (MI0 + MI1), BN = 64 * NTW;
+    constexpr int LDS = (4 * (BM + BN) * 64 > 16 * MI0 * BN * 4) ? 4 * (BM + BN) * 64 : 16 * MI0 * BN * 4;
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring8_kernel<MI0, MI1, NTW, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    GemmArgs b = a;
+    b.C = a.ws; b.ldc = a.N; b.out_f32 = 1; b.bias = nullptr; b.residual = nullptr; b.act = 0; b.vec_ok = 1; b.dbg = nullptr;
+    b.tiles_m = (a.M + BM - 1) / BM;
+    b.tiles_n = (a.N + BN - 1) / BN;
+    b.full_tiles = b.tiles_m * b.tiles_n;
+    b.ksplit = 1;
+    gemm_ring8_kernel<MI0, MI1, NTW, false, 2><<<dim3(b.full_tiles, S), dim3(512), LDS, stream>>>(b);
+    ULLSAM_LAUNCH_CHECK();
+    const long quads = (long)a.M * (a.N >> 2);
+    if (a.out_f32) splitk_finish_kernel<float><<<dim3((unsigned)((quads + 255) / 256)), 256, 0, stream>>>(a.ws, static_cast<float*>(a.C), a.ldc, a.bias, a.residual, a.ldr, a.res_row_mod, a.M, a.N, S);
+    else splitk_finish_kernel<bf16><<<dim3((unsigned)((quads + 255) / 256)), 256, 0, stream>>>(a.ws, static_cast<bf16*>(a.C), a.ldc, a.bias, a.residual, a.ldr, a.res_row_mod, a.M, a.N, S);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+static int g_ring_splitk = 1;  // ullsam_set_gemm_tuning(3, v): 1 (default) = where the caller allows it (act | 256), 0 = never, 2 = wherever the plan below fits (tests, A/B).
+//                                A launch cut into K ranges sums in another order than the one-launch kernels, which all add the 32-deep k steps in sequence: the inference
+//                                modules never ask for it, so a batch of images gives each image the bits it gets alone (tests/test_model_gpu.py: batched == per image)
+// -> the number of K ranges (0: not a split-K launch) and the tile shape (6 / 8 / 9 = 256x256 / 256x320 / 272x256) for a launch the ring would leave mostly idle
+static int ring_splitk_plan(const GemmArgs& a, int* shape) {
+    if (a.act != 0 || !a.vec_ok || !a.ws || (a.N & 7) != 0 || a.M < 1024 || a.N < 256 || a.dbg) return 0;
+    const long t272 = (long)((a.M + 271) / 272) * ((a.N + 255) / 256), t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const long t320 = a.N % 320 == 0 ? (long)((a.M + 255) / 256) * (a.N / 320) : 1l << 40;
+    // the shape that covers the problem with the least padded area (272-row tiles for 1081 = 4 x 272 - 7 rows; 256x320 for the ViT's 1280-wide outputs)
+    const double a272 = 1.0625 * t272, a256 = 1.0 * t256, a320 = 1.25 * t320;
+    long t; if (a320 <= a272 && a320 <= a256) { t = t320; *shape = 8; } else if (a272 < a256) { t = t272; *shape = 9; } else { t = t256; *shape = 6; }
+    if (t > 128) return 0;
+    int S = (int)(256 / t); if (S > 8) S = 8;
+    while (S >= 2 && (a.K % (64 * S) != 0 || a.K / S < 1280 || (size_t)S * a.M * a.N * 4 > a.ws_bytes)) --S;
+    // measured (tools/probes/splitk_ab.py, against the 128x128 kernel): 1081 x 4096 x K 14336 -35 %, K 6144 -17 %, 4096 x 1280 x 5120 -7 %; K 4096 in four ranges of 1024 equal, and
+    // 96 tiles x 2 ranges (1081 x 6144 x 4096: 192 workgroups) +15 % -- hence ranges of >= 1280 and >= 224 workgroups
+    return (S >= 2 && S * t >= 224) ? S : 0;
+}
 #include "gemm_ring8p.h"
 // Persistent form (gemm_ring8p.h) for launches of MORE than one round of tiles whose shape and epilogue it takes; everything else -- one-round
 // launches, ragged N, K not a multiple of 128, the LDS-staged epilogues -- stays on the one-tile-per-workgroup kernel.
@@ -1405,6 +1477,7 @@ extern "C" int ullsam_set_gemm_tuning(int key, int value) {
     if (key == 0 && value >= 1 && value <= 1024) { g_group_m = value; return 0; }
     if (key == 1 && value >= 0 && value <= 7) { g_auto_mask = value; return 0; }
     if (key == 2 && value >= 0 && value <= 7 && value != 3) { g_persist = value; return 0; }
+    if (key == 3 && value >= 0 && value <= 2) { g_ring_splitk = value; return 0; }
     ullsam_set_error("ullsam_set_gemm_tuning: unknown key %d / bad value %d", key, value);
     return -1;
 }
@@ -1973,6 +2046,8 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     ULLSAM_CHECK(K % bk == 0, "ullsam_gemm: K=%d must be a multiple of %d", K, bk);
     ULLSAM_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "ullsam_gemm: A/W must be 16-byte aligned");
     ULLSAM_CHECK((lda * esz) % 16 == 0 && (ldw * esz) % 16 == 0, "ullsam_gemm: lda/ldw rows must be 16-byte multiples");
+    const bool split_ok = (act & 256) != 0;   // the caller accepts K ranges summed apart (ullsam_hip.h): set by the training step's frozen linears, never by the inference modules
+    act &= 255;
     ULLSAM_CHECK(act >= 0 && act <= 4 && (act == 4) == (rope != nullptr), "ullsam_gemm: bad act %d", act);
     if (act == 3) ULLSAM_CHECK(N % 128 == 0 && !bias && !residual, "ullsam_gemm: swiglu needs N%%128==0, no bias/residual");
     GemmArgs a;
@@ -2044,6 +2119,11 @@ static int gemm_impl(int dtype, const void* A, long lda, const void* W, long ldw
     // area in units of 256x256; a split-K tail of the two-buffer kernel counts as half a round).  256x320 needs N % 320 == 0 (ViT-H: 1280,
     // 3840, 5120 -- vit.proj / lin2 become ONE round instead of 1.25, vit.qkv 3 x 1.25 instead of 4); 272x256 makes the bench's 4 x 1081 =
     // 4324 prompt rows 16 tile rows (llm.wo / w2: one round instead of 256 tiles + a tail; llm.w13: 7 whole rounds instead of 7.44).
+    if (ring_ok && variant == 0 && (g_ring_splitk == 2 || (g_ring_splitk == 1 && split_ok))) {   // few tiles under a long sum: K ranges of the ring kernel side by side (launch_gemm_ring_splitk)
+        int shape = 0;
+        const int S = ring_splitk_plan(a, &shape);
+        if (S) return shape == 8 ? launch_gemm_ring_splitk<8, 8, 5>(a, S, s) : shape == 9 ? launch_gemm_ring_splitk<9, 8, 4>(a, S, s) : launch_gemm_ring_splitk<8, 8, 4>(a, S, s);
+    }
     if (ring_ok && M >= 1024 && N >= 256 && K >= 256) {
         const double c256 = v3_split ? (double)(t256 / 256) + 0.5 : (double)((t256 + 255) / 256);   // 256x256 tiles (with the two-buffer kernel's split-K tail)
         const long t320 = (long)((M + 255) / 256) * (N / 320), t272 = (long)((M + 271) / 272) * ((N + 255) / 256);

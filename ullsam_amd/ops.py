@@ -12,6 +12,7 @@ import torch
 from . import _lib
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SWIGLU = 0, 1, 2, 3
+ACT_SPLITK_OK = 256   # ullsam_hip.h ULLSAM_ACT_SPLITK_OK
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
 
@@ -48,18 +49,19 @@ _WS = {}
 
 
 def _gemm_workspace(device) -> torch.Tensor:
-    """Caller-owned scratch for the GEMM's split-K tail (one 64 MiB buffer per device AND stream: launches on different
-    streams may overlap)."""
+    """Caller-owned scratch for the GEMM's split-K forms (one 128 MiB buffer per device AND stream: launches on different
+    streams may overlap; the ring kernel's split-K keeps up to 8 fp32 planes of the output there, e.g. 4 x 1081 x 4096 x 4 B = 71 MB)."""
     key = (str(device), torch.cuda.current_stream().cuda_stream)
     ws = _WS.get(key)
     if ws is None:
-        ws = _WS[key] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+        ws = _WS[key] = torch.empty(128 << 20, dtype=torch.uint8, device=device)
     return ws
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-         act: int = ACT_NONE, out_f32: bool = False, out: Optional[torch.Tensor] = None, res_row_mod: int = 0) -> torch.Tensor:
-    """out[M, N'] = act(a[M,K] @ w[N,K]^T + bias) + residual   (N' = N/2 for ACT_SWIGLU)."""
+         act: int = ACT_NONE, out_f32: bool = False, out: Optional[torch.Tensor] = None, res_row_mod: int = 0, splitk_ok: bool = False) -> torch.Tensor:
+    """out[M, N'] = act(a[M,K] @ w[N,K]^T + bias) + residual   (N' = N/2 for ACT_SWIGLU).  splitk_ok: a launch of few tiles under a long K may run as K ranges
+    summed apart (ULLSAM_ACT_SPLITK_OK, include/ullsam_hip.h): not bit-equal to the one-launch kernels -- the training step's frozen linears only."""
     _chk(a, "a"); _chk(w, "w", a.dtype)
     M, K = a.shape
     N = w.shape[0]
@@ -79,7 +81,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         ldr = residual.shape[-1]
     ws = _gemm_workspace(a.device)
     _lib.call("ullsam_gemm", dt_code(a.dtype), a.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), n_out, int(out_f32),
-              _p(bias), _p(residual), ldr, res_row_mod, act, M, N, K, ws.data_ptr(), ws.numel(), _stream())
+              _p(bias), _p(residual), ldr, res_row_mod, act | (ACT_SPLITK_OK if splitk_ok else 0), M, N, K, ws.data_ptr(), ws.numel(), _stream())
     return out
 
 

@@ -209,17 +209,19 @@ def _transposed_frozen(w: torch.Tensor) -> torch.Tensor:
 class FrozenLinearBf16Fn(Function):
     """y = x W^T (+ b) for a FROZEN bf16 weight (the LLM of a bf16 model, train_joint_v2.py:1599,1676: autocast semantics): activations are
     rounded to bf16 at the GEMM's door, the products run on the inference path's bf16 MFMA GEMM with fp32 accumulation and fp32 results,
-    forward (W as stored) and backward (dX = dY W, with the cached W^T); there is no weight gradient."""
+    forward (W as stored) and backward (dX = dY W, with the cached W^T); there is no weight gradient.  The 1081-row products with N = 4096 (w2 forward, dX of
+    wqkv / w1 / w3) are 64 ring tiles: they may run as four K ranges side by side (`splitk_ok`; 228 -> 148 us at K = 14336, tools/probes/splitk_ab.py).  Only here:
+    a step holds one image, so there is no batch whose images could get other bits than alone."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         x = _c(x)
         ctx.w = w
-        return ops.gemm(ops.cast(x, torch.bfloat16), w.detach(), None if b is None else _c(b), out_f32=True)
+        return ops.gemm(ops.cast(x, torch.bfloat16), w.detach(), None if b is None else _c(b), out_f32=True, splitk_ok=True)
 
     @staticmethod
     def backward(ctx, dy):
-        return ops.gemm(ops.cast(_c(dy), torch.bfloat16), _transposed_frozen(ctx.w), out_f32=True), None, None
+        return ops.gemm(ops.cast(_c(dy), torch.bfloat16), _transposed_frozen(ctx.w), out_f32=True, splitk_ok=True), None, None
 
 
 BF16_LINEAR = True   # a bf16 model's large linears (>= 256 rows, both dimensions % 64) run forward, dX and dW on the bf16 MFMA GEMM -- the trainer's own
