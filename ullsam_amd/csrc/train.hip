@@ -16,15 +16,20 @@ struct MmArgs {
     int accumulate;
     int ksplit, kc;      // blockIdx.z = batch index * ksplit + s: split s sums k in [s kc, min(K, (s + 1) kc)) into C + s c_s (partials, reduced in order afterwards)
     long c_s;
+    // two-level batch index (ullsam_train_matmul_heads): bin > 1 -> entry b = (o, h) = (b / bin, b % bin) of operand X starts at o X_b + (h / X_div) X_h, i.e. the heads of
+    // [rows, heads x hd] activations are read / written in place (h / div: grouped KV heads, modeling_internlm2.py:250-259) instead of from head-major copies
+    int bin, a_div, b_div;
+    long a_h, b_h, c_h;
 };
+__device__ __forceinline__ long mm_boff(int b, int bin, long s_o, long s_h, int div) { return bin > 1 ? (long)(b / bin) * s_o + (long)((b % bin) / div) * s_h : (long)b * s_o; }
 __global__ __launch_bounds__(256) void matmul_f32_kernel(MmArgs p) {
     // 64 x 64 outputs per workgroup, 4 x 4 per thread, K in steps of 16 through LDS.  The element -> thread assignment of the two tile loads
     // follows the operand's unit stride (k-fastest for a row-major operand, m- / n-fastest for a transposed one), so both are coalesced.
     __shared__ float As[16][65], Bs[16][65];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, b = blockIdx.z / p.ksplit, ks = blockIdx.z % p.ksplit;
-    const float* A = p.A + (long)b * p.a_b + (long)ks * p.kc * p.a_k;
-    const float* B = p.B + (long)b * p.b_b + (long)ks * p.kc * p.b_k;
+    const float* A = p.A + mm_boff(b, p.bin, p.a_b, p.a_h, p.a_div) + (long)ks * p.kc * p.a_k;
+    const float* B = p.B + mm_boff(b, p.bin, p.b_b, p.b_h, p.b_div) + (long)ks * p.kc * p.b_k;
     p.K = min(p.kc, p.K - ks * p.kc);
     p.C += (long)ks * p.c_s;
     const bool a_kfast = p.a_k <= p.a_m, b_nfast = p.b_n <= p.b_k;
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(256) void matmul_f32_kernel(MmArgs p) {
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
             if (m < p.M && n < p.N) {
-                float* c = p.C + (long)b * p.c_b + (long)m * p.c_m + (long)n * p.c_n;
+                float* c = p.C + mm_boff(b, p.bin, p.c_b, p.c_h, 1) + (long)m * p.c_m + (long)n * p.c_n;
                 *c = p.accumulate ? *c + acc[i][j] : acc[i][j];
             }
         }
@@ -92,8 +97,8 @@ __global__ __launch_bounds__(256, 2) void matmul_f32_mfma_kernel(MmArgs p) {
     // element i (0..15) of a thread's share of a 128 x 32 tile: the thread index runs along the operand's unit stride
     //   k-fastest:  row (tid >> 5) + 8 i, k = tid & 31          row-fastest:  row tid & 127, k = (tid >> 7) + 2 i
     const int t5 = tid >> 5, k5 = tid & 31, t7 = tid >> 7, r7 = tid & 127;
-    const float* pa = p.A + (long)b * p.a_b + (AK ? (long)(m0 + t5) * p.a_m + (long)k5 * p.a_k : (long)(m0 + r7) * p.a_m + (long)t7 * p.a_k);
-    const float* pb = p.B + (long)b * p.b_b + (BN ? (long)(n0 + r7) * p.b_n + (long)t7 * p.b_k : (long)(n0 + t5) * p.b_n + (long)k5 * p.b_k);
+    const float* pa = p.A + mm_boff(b, p.bin, p.a_b, p.a_h, p.a_div) + (AK ? (long)(m0 + t5) * p.a_m + (long)k5 * p.a_k : (long)(m0 + r7) * p.a_m + (long)t7 * p.a_k);
+    const float* pb = p.B + mm_boff(b, p.bin, p.b_b, p.b_h, p.b_div) + (BN ? (long)(n0 + r7) * p.b_n + (long)t7 * p.b_k : (long)(n0 + t5) * p.b_n + (long)k5 * p.b_k);
     const long a_inc = AK ? 8 * p.a_m : 2 * p.a_k, b_inc = BN ? 2 * p.b_k : 8 * p.b_n, a_step = 32 * p.a_k, b_step = 32 * p.b_k;
     const bool inner = m0 + 128 <= p.M && n0 + 128 <= p.N;
     float ra[16], rb[16];
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void matmul_f32_mfma_kernel(MmArgs p) {
         __syncthreads();
     }
     // accumulator element e of lane l: row 8 (e / 4) + 4 (l / 32) + e % 4, column l % 32 of the 32 x 32 tile
-    float* cb = p.C + (long)b * p.c_b;
+    float* cb = p.C + mm_boff(b, p.bin, p.c_b, p.c_h, 1);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -194,8 +199,8 @@ __global__ __launch_bounds__(256, 2) void matmul_bf16_mfma_kernel(MmArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int t5 = tid >> 5, k5 = tid & 31, t7 = tid >> 7, r7 = tid & 127;
-    const float* pa = p.A + (long)b * p.a_b + (AK ? (long)(m0 + t5) * p.a_m + (long)k5 * p.a_k : (long)(m0 + r7) * p.a_m + (long)t7 * p.a_k);
-    const float* pb = p.B + (long)b * p.b_b + (BN ? (long)(n0 + r7) * p.b_n + (long)t7 * p.b_k : (long)(n0 + t5) * p.b_n + (long)k5 * p.b_k);
+    const float* pa = p.A + mm_boff(b, p.bin, p.a_b, p.a_h, p.a_div) + (AK ? (long)(m0 + t5) * p.a_m + (long)k5 * p.a_k : (long)(m0 + r7) * p.a_m + (long)t7 * p.a_k);
+    const float* pb = p.B + mm_boff(b, p.bin, p.b_b, p.b_h, p.b_div) + (BN ? (long)(n0 + r7) * p.b_n + (long)t7 * p.b_k : (long)(n0 + t5) * p.b_n + (long)k5 * p.b_k);
     const long a_inc = AK ? 8 * p.a_m : 2 * p.a_k, b_inc = BN ? 2 * p.b_k : 8 * p.b_n, a_step = 32 * p.a_k, b_step = 32 * p.b_k;
     const bool inner = m0 + 128 <= p.M && n0 + 128 <= p.N;
     float ra[16], rb[16];
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void matmul_bf16_mfma_kernel(MmArgs p) {
         if (t + 1 < steps) stash((t + 1) & 1);
         __syncthreads();
     }
-    float* cb = p.C + (long)b * p.c_b;
+    float* cb = p.C + mm_boff(b, p.bin, p.c_b, p.c_h, 1);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -299,16 +304,35 @@ static int train_matmul_launch(MmArgs a, hipStream_t st) {
 extern "C" int ullsam_train_matmul(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k,
                                    long b_b, long b_k, long b_n, long c_b, long c_m, long c_n, int accumulate, void* stream) {
     ULLSAM_CHECK(M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "train_matmul: M=%d N=%d K=%d batch=%d", M, N, K, batch);
-    MmArgs a{A, B, C, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n, accumulate, 1, K, 0};
+    MmArgs a{A, B, C, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n, accumulate, 1, K, 0, 1, 1, 1, 0, 0, 0};
     return train_matmul_launch(a, reinterpret_cast<hipStream_t>(stream));
 }
 // fp32 operands rounded to bf16 at the product's door (see matmul_bf16_mfma_kernel); shapes below the MFMA tile fall back to the fp32 product
 extern "C" int ullsam_train_matmul_bf16(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k,
                                         long b_b, long b_k, long b_n, long c_b, long c_m, long c_n, int accumulate, void* stream) {
     ULLSAM_CHECK(M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "train_matmul_bf16: M=%d N=%d K=%d batch=%d", M, N, K, batch);
-    MmArgs a{A, B, C, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n, accumulate, 1, K, 0};
+    MmArgs a{A, B, C, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n, accumulate, 1, K, 0, 1, 1, 1, 0, 0, 0};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (!(M >= 64 && N >= 48 && K >= 16)) return train_matmul_launch(a, st);
+    const bool ak = a_k <= a_m, bn = b_n <= b_k;
+    if (ak && bn) launch_matmul_bf16<true, true>(a, st);
+    else if (ak) launch_matmul_bf16<true, false>(a, st);
+    else if (bn) launch_matmul_bf16<false, true>(a, st);
+    else launch_matmul_bf16<false, false>(a, st);
+    ULLSAM_LAUNCH_CHECK();
+    return 0;
+}
+// The product over (outer, head) pairs whose operands live inside [rows, heads x hd] activations (the matrix-form attention of training.AttentionFn): entry (o, h) of
+// operand X starts at o x_o + (h / x_hdiv) x_h -- q / k / v, dO and the gradients are read and written where they are, no head-major copies, no repeat_kv copies.
+extern "C" int ullsam_train_matmul_heads(const float* A, const float* B, float* C, int M, int N, int K, int outer, int heads, long a_o, long a_h, int a_hdiv, long a_m,
+                                         long a_k, long b_o, long b_h, int b_hdiv, long b_k, long b_n, long c_o, long c_h, long c_m, long c_n, int accumulate, int bf16,
+                                         void* stream) {
+    ULLSAM_CHECK(M > 0 && N > 0 && K > 0 && outer > 0 && heads > 0 && (long)outer * heads < 65536 && a_hdiv >= 1 && b_hdiv >= 1,
+                 "train_matmul_heads: M=%d N=%d K=%d outer=%d heads=%d", M, N, K, outer, heads);
+    MmArgs a{A, B, C, M, N, K, outer * heads, a_o, a_m, a_k, b_o, b_k, b_n, c_o, c_m, c_n, accumulate, 1, K, 0, heads, a_hdiv, b_hdiv, a_h, b_h, c_h};
+    if (heads == 1) { a.bin = 1; }                                            // (single level: entry b at b x_o)
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!bf16 || !(M >= 64 && N >= 48 && K >= 16)) return train_matmul_launch(a, st);
     const bool ak = a_k <= a_m, bn = b_n <= b_k;
     if (ak && bn) launch_matmul_bf16<true, true>(a, st);
     else if (ak) launch_matmul_bf16<true, false>(a, st);
@@ -326,7 +350,7 @@ extern "C" int ullsam_train_matmul_splitk(const float* A, const float* B, float*
     const int kc = ((K + ksplit - 1) / ksplit + 31) / 32 * 32;
     const int ns = (K + kc - 1) / kc;                      // every split owns at least one k
     const long n = (long)batch * M * N;
-    MmArgs a{A, B, partial, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, (long)M * N, (long)N, 1, 0, ns, kc, n};
+    MmArgs a{A, B, partial, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, (long)M * N, (long)N, 1, 0, ns, kc, n, 1, 1, 1, 0, 0, 0};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rc = train_matmul_launch(a, st);
     if (rc) return rc;

@@ -64,6 +64,13 @@ def _mm(A, B, C, M, N, K, sa, sb, sc, batch=1, accumulate=False, bf16=False):
     _lib.call("ullsam_train_matmul", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, batch, *sa, *sb, *sc, int(accumulate), _s())
 
 
+def _mmh(A, B, C, M, N, K, outer, heads, sa, sb, sc, accumulate=False, bf16=False):
+    """The product over (outer, head) pairs on operands that sit inside [rows, heads x hd] activations (ullsam_train_matmul_heads): entry (o, h) of A starts at
+    o sa[0] + (h // sa[2]) sa[1]; sa = (outer, head, head divisor, m, k) element strides, sb = (outer, head, head divisor, k, n), sc = (outer, head, m, n)."""
+    _lib.call("ullsam_train_matmul_heads", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, outer, heads, sa[0], sa[1], sa[2], sa[3], sa[4],
+              sb[0], sb[1], sb[2], sb[3], sb[4], sc[0], sc[1], sc[2], sc[3], int(accumulate), int(bf16), _s())
+
+
 def _colsum(x2d: torch.Tensor) -> torch.Tensor:
     rows, cols = x2d.shape
     out = torch.zeros((cols,), dtype=F32, device=x2d.device)
@@ -397,9 +404,26 @@ class AttentionFn(Function):
             out = torch.empty_like(q)
             ctx.save_for_backward(q, k, v, key_mask, bias_h, bias_w)
             ctx.matrix = False
+            ctx.inplace = False
             AttentionFn._launch(q, k, v, None, out, None, None, None, ctx.dims, key_mask, bias_h, bias_w, None, None)
             return out
-        # Matrix form (csrc/train.hip attn_rows_kernel): head-major copies, batched matmuls around one row pass; P is kept for the backward.
+        ctx.matrix = True
+        ctx.recompute = RECOMPUTE_P
+        ctx.inplace = Sq >= 64 and Sk >= 64 and hd >= 16
+        if ctx.inplace:
+            # Matrix form on the activations where they are (ViT, LLM): the products index (image / window, head) pairs inside the [rows, heads x hd] tensors
+            # (ullsam_train_matmul_heads; grouped KV heads by h // G) -- no head-major copies of q / k / v, no repeat_kv copies, out written as rows.
+            G = H // KVH
+            qs = AttentionFn._scaled(q, 1.0 / math.sqrt(hd))
+            P = torch.empty((B * H, Sq, Sk), dtype=F32, device=q.device)
+            AttentionFn._scores(qs, k, P, ctx.dims, ctx.bf16)
+            _lib.call("ullsam_train_attn_rows", P.data_ptr(), None, ops._p(bias_h), ops._p(bias_w), None, None, ops._p(key_mask), B, H, Sq, Sk, kw,
+                      causal, 0, _s())
+            out = torch.empty_like(q)
+            _mmh(P, v, out, Sq, hd, Sk, B, H, (H * Sq * Sk, Sq * Sk, 1, Sk, 1), (Sk * KVH * hd, hd, G, KVH * hd, 1), (Sq * H * hd, hd, H * hd, 1), bf16=ctx.bf16)   # out = P v
+            ctx.save_for_backward(qs, k, v, key_mask if RECOMPUTE_P else P, bias_h, bias_w)
+            return out
+        # Matrix form (csrc/train.hip attn_rows_kernel) for the decoder's few-token attentions: head-major copies, batched matmuls around one row pass; P is kept for the backward.
         qs, kh, vh = AttentionFn._head_major(q, k, v, ctx.dims)
         BH = B * H
         P = torch.empty((BH, Sq, Sk), dtype=F32, device=q.device)
@@ -412,9 +436,13 @@ class AttentionFn(Function):
             ctx.save_for_backward(qs, kh, vh, key_mask, bias_h, bias_w)
         else:
             ctx.save_for_backward(qs, kh, vh, P, bias_h, bias_w)
-        ctx.recompute = RECOMPUTE_P
-        ctx.matrix = True
         return oh.permute(0, 2, 1, 3).reshape(B * Sq, H * hd).contiguous()
+
+    @staticmethod
+    def _scores(qs, k, P, dims, bf16):
+        """P[(b, h)] = qs_h k_{h // G}^T on the row tensors (qs [B*Sq, H*hd], k [B*Sk, KVH*hd])."""
+        B, H, KVH, hd, Sq, Sk, _, _ = dims
+        _mmh(qs, k, P, Sq, Sk, hd, B, H, (Sq * H * hd, hd, 1, H * hd, 1), (Sk * KVH * hd, hd, H // KVH, 1, KVH * hd), (H * Sq * Sk, Sq * Sk, Sk, 1), bf16=bf16)
 
     @staticmethod
     def _head_major(q, k, v, dims):
@@ -457,6 +485,8 @@ class AttentionFn(Function):
             dq, dk, dv = torch.empty_like(q), torch.zeros_like(k), torch.zeros_like(v)
             AttentionFn._launch(q, k, v, dout, None, dq, dk, dv, ctx.dims, key_mask, bias_h, bias_w, dbh, dbw)
             return (dq, dk, dv) + nones + (dbh, dbw, None, None)
+        if ctx.inplace:
+            return AttentionFn._backward_inplace(ctx, dout)
         qs, kh, vh, P, bias_h, bias_w = ctx.saved_tensors
         G, BH = H // KVH, B * H
         key_mask = None
@@ -480,6 +510,46 @@ class AttentionFn(Function):
             dkh, dvh = red(dkh), red(dvh)
         back = lambda t, S_, Hx: t.permute(0, 2, 1, 3).reshape(B * S_, Hx * hd).contiguous()
         return (back(dqh, Sq, H), back(dkh, Sk, KVH), back(dvh, Sk, KVH)) + nones + (dbh, dbw, None, None)
+
+
+def _attn_backward_inplace(ctx, dout):
+    """The backward of the in-place matrix form: dP = dO v^T, one row pass (dS, bias-gradient rows), dV = P^T dO, dK = dS^T (q scale), d(q scale) = dS k, every product on
+    the row tensors; with grouped KV heads dK / dV are formed per query head and summed over the group in order (repeat_kv's gradient)."""
+    B, H, KVH, hd, Sq, Sk, causal, kw = ctx.dims
+    qs, k, v, P, bias_h, bias_w = ctx.saved_tensors
+    G = H // KVH
+    key_mask = None
+    if ctx.recompute:
+        key_mask, P = P, torch.empty((B * H, Sq, Sk), dtype=F32, device=qs.device)
+        AttentionFn._scores(qs, k, P, ctx.dims, ctx.bf16)
+    dbh = torch.empty_like(bias_h) if bias_h is not None else None
+    dbw = torch.empty_like(bias_w) if bias_w is not None else None
+    sP, sPT = (H * Sq * Sk, Sq * Sk, 1, Sk, 1), (H * Sq * Sk, Sq * Sk, 1, 1, Sk)        # P / dS as [m = q][k = key] and transposed [m = key][k = q]
+    rows_q = (Sq * H * hd, hd, 1, H * hd, 1)                                               # dO / qs as the B operand [k = q][n = d] resp. the A operand [m = q][k = d]
+    dP = torch.empty_like(P)
+    _mmh(dout, v, dP, Sq, Sk, hd, B, H, rows_q, (Sk * KVH * hd, hd, G, 1, KVH * hd), (H * Sq * Sk, Sq * Sk, Sk, 1), bf16=ctx.bf16)            # dP = dO v^T
+    _lib.call("ullsam_train_attn_rows", P.data_ptr(), dP.data_ptr(), ops._p(bias_h), ops._p(bias_w), ops._p(dbh), ops._p(dbw), ops._p(key_mask), B, H,
+              Sq, Sk, kw, causal, 0 if ctx.recompute else 1, _s())                                                          # dP <- dS
+    if G == 1:
+        dk, dv = torch.empty_like(k), torch.empty_like(v)
+        kv_c = (Sk * H * hd, hd, H * hd, 1)
+    else:
+        dk = torch.empty((B, H, Sk, hd), dtype=F32, device=qs.device)
+        dv = torch.empty_like(dk)
+        kv_c = (H * Sk * hd, Sk * hd, hd, 1)
+    _mmh(P, dout, dv, Sk, hd, Sq, B, H, sPT, rows_q, kv_c, bf16=ctx.bf16)                                                    # dV = P^T dO
+    _mmh(dP, qs, dk, Sk, hd, Sq, B, H, sPT, rows_q, kv_c, bf16=ctx.bf16)                                                     # dK = dS^T (q scale)
+    dqs = torch.empty_like(qs)
+    _mmh(dP, k, dqs, Sq, hd, Sk, B, H, sP, (Sk * KVH * hd, hd, G, KVH * hd, 1), (Sq * H * hd, hd, H * hd, 1), bf16=ctx.bf16)    # d(q scale) = dS k
+    dq = AttentionFn._scaled(dqs, 1.0 / math.sqrt(hd))
+    if G > 1:                                                                               # the gradient of repeat_kv: sum over the group, then back to rows
+        red = lambda t: _colsum(t.reshape(B, KVH, G, Sk * hd).permute(2, 0, 1, 3).reshape(G, -1).contiguous()).reshape(B, KVH, Sk, hd)
+        back = lambda t: t.permute(0, 2, 1, 3).reshape(B * Sk, KVH * hd).contiguous()
+        dk, dv = back(red(dk)), back(red(dv))
+    return (dq, dk, dv) + (None,) * 7 + (dbh, dbw, None, None)
+
+
+AttentionFn._backward_inplace = staticmethod(_attn_backward_inplace)
 
 
 class GatherRowsFn(Function):
