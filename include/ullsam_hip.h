@@ -111,10 +111,10 @@ int ullsam_train_matmul_splitk(const float* A, const float* B, float* C, int M, 
 int ullsam_train_set_matmul_mfma(int on);
 /* out[c] += sum_r x[r*ld + c] (bias gradients; gradients of parameters broadcast over the batch) */
 int ullsam_train_colsum(const float* x, float* out, long rows, int cols, long ld, float* partial, void* stream);
-/* (row blocks write partial sums that are added in order -- no atomics; partial: min(64, ceil(rows / 256)) * cols floats, may be NULL for rows <= 256) */
+/* (row blocks write partial sums that are added in order -- no atomics; partial: min(64, ceil(rows / 64)) * cols floats, may be NULL for rows <= 64) */
 /* nn.LayerNorm / LayerNorm2d backward on rows of D (w NULL: no affine, prompt_encoder.py:141-144); dw / db may be NULL */
 int ullsam_train_ln_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, long rows, int D, float eps, float* ws, void* stream);
-/* (ws: 2 * rows + 2 * min(64, ceil(rows / 256)) * D floats when dw or db is given: row statistics and ordered partial sums) */
+/* (ws: 2 * rows + 2 * min(64, ceil(rows / 64)) * D floats when dw or db is given: row statistics and ordered partial sums) */
 /* kind 1 exact GELU, 2 ReLU: dy NULL -> out = act(x), else out = dy * act'(x) */
 int ullsam_train_act(const float* x, const float* dy, float* out, long n, int kind, void* stream);
 /* prompt_encoder.py:148 y = x * llm_scale_factor + llm_bias (dy NULL), else out = dy * s, ds += sum dy x, dt += sum dy */

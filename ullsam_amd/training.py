@@ -82,7 +82,7 @@ def _colsum(x2d: torch.Tensor) -> torch.Tensor:
 
 def _row_blocks(rows: int) -> int:
     """Row blocks of the ordered two-stage column sums (csrc/train.hip colsum_blocks)."""
-    return min(64, -(-rows // 256))
+    return min(64, -(-rows // 64))
 
 
 def _t2d(x: torch.Tensor) -> torch.Tensor:
@@ -552,6 +552,28 @@ def _attn_backward_inplace(ctx, dout):
 AttentionFn._backward_inplace = staticmethod(_attn_backward_inplace)
 
 
+class SplitFn(Function):
+    """x [R, n_0 + n_1 + ..., C] -> contiguous pieces [R, n_i * C] along the middle axis (the q / k / v split of a fused qkv projection: image_encoder.py:232-233,
+    modeling_internlm2.py:361-370); data movement only.  The backward is ONE concatenation of the incoming gradients -- torch's own select / slice backward builds a
+    zero tensor of the whole qkv per piece and adds them up (three zero fills, three copies and two adds of the full tensor per attention)."""
+
+    @staticmethod
+    def forward(ctx, x, sizes):
+        ctx.sizes = tuple(sizes)
+        ctx.shape = x.shape
+        R, _, C = x.shape
+        outs, o = [], 0
+        for n in sizes:
+            outs.append(x[:, o:o + n].reshape(R, n * C).contiguous())
+            o += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        R, _, C = ctx.shape
+        return torch.cat([_c(g).reshape(R, n, C) for g, n in zip(grads, ctx.sizes)], dim=1), None
+
+
 class GatherRowsFn(Function):
     """table[idx] (get_rel_pos, image_encoder.py:303-322, without interpolation); the gradient adds the rows back."""
 
@@ -1005,10 +1027,11 @@ def llm_image_hidden(model, vit_feature_rows: torch.Tensor, input_ids: torch.Ten
     for layer in lm.model.layers:
         at, ff = layer.attention, layer.feed_forward
         xn = RMSNormFn.apply(x, layer.attention_norm.weight, layer.attention_norm.variance_epsilon)
-        qkv = _frozen_linear(xn, at.wqkv.weight, at.wqkv.bias).reshape(B * S, KVH, G + 2, hd)   # 'b q (h gs d) -> b q h gs d' (:361-366)
-        q = RoPEFn.apply(qkv[:, :, :G].reshape(B * S, H * hd), pos, cos, sin, H)
-        k = RoPEFn.apply(qkv[:, :, G].reshape(B * S, KVH * hd), pos, cos, sin, KVH)
-        v = qkv[:, :, G + 1].reshape(B * S, KVH * hd)
+        qkv = _frozen_linear(xn, at.wqkv.weight, at.wqkv.bias).reshape(B * S * KVH, G + 2, hd)   # 'b q (h gs d) -> b q h gs d' (:361-366)
+        q, k, v = SplitFn.apply(qkv, (G, 1, 1))                                                   # per (row, kv head): its G query heads, its key, its value
+        q = RoPEFn.apply(q.reshape(B * S, H * hd), pos, cos, sin, H)
+        k = RoPEFn.apply(k.reshape(B * S, KVH * hd), pos, cos, sin, KVH)
+        v = v.reshape(B * S, KVH * hd)
         a = AttentionFn.apply(q, k, v, B, H, KVH, S, S, 0, key_mask, None, None, 0, BF16_LINEAR and at.wqkv.weight.dtype == torch.bfloat16)
         x = AddFn.apply(x, _frozen_linear(a, at.wo.weight, at.wo.bias))
         xn = RMSNormFn.apply(x, layer.ffn_norm.weight, layer.ffn_norm.variance_epsilon)
@@ -1052,8 +1075,7 @@ def vision_feature_rows(enc, pixel_values: torch.Tensor) -> torch.Tensor:
         else:
             Hh = g
         Bw, T = t.shape[0], Hh * Hh
-        qkv = _apply_linear(t.reshape(Bw * T, D), at.qkv.weight, at.qkv.bias).reshape(Bw, T, 3, heads, hd)
-        q, k, v = (qkv[:, :, i].reshape(Bw * T, heads * hd) for i in range(3))
+        q, k, v = SplitFn.apply(_apply_linear(t.reshape(Bw * T, D), at.qkv.weight, at.qkv.bias).reshape(Bw * T, 3, heads * hd), (1, 1, 1))
         def table(p):                                                                           # get_rel_pos's interpolation (:306-318) of a table of another length:
             if p.shape[0] == 2 * Hh - 1:                                                        # F.interpolate(mode="linear") = the resize kernel on [hd planes] x [1 x L] images;
                 return p                                                                        # its adjoint (ResizeFn.backward) carries the gradient back to the stored rows
