@@ -95,6 +95,7 @@ RECOMPUTE_P = True   # matrix-form attention keeps q, k, v and rebuilds the prob
 #                      backward's row pass) instead of holding it from the forward: -10.8 GB on a ViT-H + 7B-shaped step for ~4 % of its time
 MATRIX_ATTN_FROM = 0         # attention through materialised score matrices from Sq * Sk >= this; below it one workgroup per query, whose backward adds dk / dv by
 #                              atomics (order-dependent sums): 0 keeps every attention on the matrix form, so that two runs of a step are bit-equal
+INPLACE_ATTN = True  # the ViT / LLM attention products read q / k / v / dO and write out / dq / dk / dv inside the row tensors (ullsam_train_matmul_heads); False: head-major copies around plain batched products (tests / A-B)
 MFMA_LINEAR = True   # nn.Linear forward / backward on the fp32 MFMA GEMM of the inference path where its shapes allow (inner dimension % 32 == 0);
 #                     the one-output-per-thread matmul of csrc/train.hip otherwise (and always with MFMA_LINEAR = False: tests compare the two)
 
@@ -409,7 +410,7 @@ class AttentionFn(Function):
             return out
         ctx.matrix = True
         ctx.recompute = RECOMPUTE_P
-        ctx.inplace = Sq >= 64 and Sk >= 64 and hd >= 16
+        ctx.inplace = INPLACE_ATTN and Sq >= 64 and Sk >= 64 and hd >= 16
         if ctx.inplace:
             # Matrix form on the activations where they are (ViT, LLM): the products index (image / window, head) pairs inside the [rows, heads x hd] tensors
             # (ullsam_train_matmul_heads; grouped KV heads by h // G) -- no head-major copies of q / k / v, no repeat_kv copies, out written as rows.
