@@ -109,6 +109,9 @@ int ullsam_train_matmul_splitk(const float* A, const float* B, float* C, int M, 
 /* the product above runs on the matrix pipe (exact fp32 MFMA, 128 x 128 tiles) from M >= 64, N >= 48, K >= 16; 0 keeps every launch on the
  * one-output-per-thread kernel (tests compare the two); returns the previous setting */
 int ullsam_train_set_matmul_mfma(int on);
+/* the bf16 product (ullsam_train_matmul_bf16 / _heads) fetches its k-fastest operands 16 bytes per lane where their strides and alignment allow (1, default) or element by
+ * element as in round 4 (0); the LDS image and the MFMA order are the same: equal bits (tests compare); returns the previous setting */
+int ullsam_train_set_matmul_vec(int on);
 /* out[c] += sum_r x[r*ld + c] (bias gradients; gradients of parameters broadcast over the batch) */
 int ullsam_train_colsum(const float* x, float* out, long rows, int cols, long ld, float* partial, void* stream);
 /* (row blocks write partial sums that are added in order -- no atomics; partial: min(64, ceil(rows / 64)) * cols floats, may be NULL for rows <= 64) */

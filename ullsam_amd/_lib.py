@@ -90,7 +90,7 @@ SIGNATURES = {
 }
 PLAIN = {"ullsam_last_error_string": ([], C.c_char_p), "ullsam_abi_version": ([], i32), "ullsam_device_count": ([], i32),
          "ullsam_set_gemm_variant": ([i32], i32), "ullsam_set_gemm_tuning": ([i32, i32], i32), "ullsam_set_attn_variant": ([i32], i32),
-         "ullsam_set_norm_variant": ([i32], i32), "ullsam_train_set_matmul_mfma": ([i32], i32), "ullsam_train_set_rows_reg": ([i32], i32), "ullsam_set_skinny_linear_mfma": ([i32], i32), "ullsam_set_attn_debug": ([vp], i32)}
+         "ullsam_set_norm_variant": ([i32], i32), "ullsam_train_set_matmul_mfma": ([i32], i32), "ullsam_train_set_matmul_vec": ([i32], i32), "ullsam_train_set_rows_reg": ([i32], i32), "ullsam_set_skinny_linear_mfma": ([i32], i32), "ullsam_set_attn_debug": ([vp], i32)}
 
 
 class UllsamError(RuntimeError):

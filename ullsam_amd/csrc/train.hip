@@ -182,7 +182,7 @@ static void launch_matmul_mfma(const MmArgs& a, hipStream_t stream) {
 // (train_joint_v2.py:1665).  Operands and result stay fp32 in memory, so the kernel is a drop-in for the one above; 16x fewer matrix cycles leave it
 // bound by the operand reads.  LDS image: [row][32 k] bf16 with an 80-byte row stride (a 16-lane group of a ds_read_b128 fragment read covers all 64 banks).
 constexpr int MMB_LD = 40;
-template <bool AK, bool BN>
+template <bool AK, bool BN, bool VEC = false>   // VEC: every k-fastest operand (A if AK, B if !BN) is fetched as float4 along k -- the launcher has checked unit k stride, 16-byte alignment, K % 4 == 0
 __global__ __launch_bounds__(256, 2) void matmul_bf16_mfma_kernel(MmArgs p) {
     extern __shared__ bf16 mmb_lds[];                      // [2 buffers][A | B][128 rows][40]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -199,36 +199,62 @@ __global__ __launch_bounds__(256, 2) void matmul_bf16_mfma_kernel(MmArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int t5 = tid >> 5, k5 = tid & 31, t7 = tid >> 7, r7 = tid & 127;
-    const float* pa = p.A + mm_boff(b, p.bin, p.a_b, p.a_h, p.a_div) + (AK ? (long)(m0 + t5) * p.a_m + (long)k5 * p.a_k : (long)(m0 + r7) * p.a_m + (long)t7 * p.a_k);
-    const float* pb = p.B + mm_boff(b, p.bin, p.b_b, p.b_h, p.b_div) + (BN ? (long)(n0 + r7) * p.b_n + (long)t7 * p.b_k : (long)(n0 + t5) * p.b_n + (long)k5 * p.b_k);
-    const long a_inc = AK ? 8 * p.a_m : 2 * p.a_k, b_inc = BN ? 2 * p.b_k : 8 * p.b_n, a_step = 32 * p.a_k, b_step = 32 * p.b_k;
+    // element i (0..15) of a thread's share of a 128 x 32 tile.  Scalar: k-fastest row (tid >> 5) + 8 i, k = tid & 31; row-fastest row tid & 127, k = (tid >> 7) + 2 i.
+    // VEC (k-fastest operands only): rows (tid >> 3) + 32 j, j = 0..3, the four k 4 (tid & 7) .. + 3 as one 16-byte load -> one 8-byte LDS store (the LDS image is the same)
+    constexpr bool VA = VEC && AK, VB = VEC && !BN;
+    const int tr = tid >> 3, kq = 4 * (tid & 7);
+    const float* pa = p.A + mm_boff(b, p.bin, p.a_b, p.a_h, p.a_div) + (VA ? (long)(m0 + tr) * p.a_m + kq : AK ? (long)(m0 + t5) * p.a_m + (long)k5 * p.a_k : (long)(m0 + r7) * p.a_m + (long)t7 * p.a_k);
+    const float* pb = p.B + mm_boff(b, p.bin, p.b_b, p.b_h, p.b_div) + (VB ? (long)(n0 + tr) * p.b_n + kq : BN ? (long)(n0 + r7) * p.b_n + (long)t7 * p.b_k : (long)(n0 + t5) * p.b_n + (long)k5 * p.b_k);
+    const long a_inc = VA ? 32 * p.a_m : AK ? 8 * p.a_m : 2 * p.a_k, b_inc = VB ? 32 * p.b_n : BN ? 2 * p.b_k : 8 * p.b_n, a_step = 32 * p.a_k, b_step = 32 * p.b_k;
     const bool inner = m0 + 128 <= p.M && n0 + 128 <= p.N;
     float ra[16], rb[16];
     auto fetch = [&](int k0) {
-        if (inner && k0 + 32 <= p.K) {
+        const bool whole = inner && k0 + 32 <= p.K;
+        if constexpr (VA) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { ra[i] = pa[i * a_inc]; rb[i] = pb[i * b_inc]; }
+            for (int j = 0; j < 4; ++j) {
+                const float4 v = (whole || (m0 + tr + 32 * j < p.M && k0 + kq < p.K)) ? *reinterpret_cast<const float4*>(pa + j * a_inc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
+            }
+        }
+        if constexpr (VB) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 v = (whole || (n0 + tr + 32 * j < p.N && k0 + kq < p.K)) ? *reinterpret_cast<const float4*>(pb + j * b_inc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[4 * j] = v.x; rb[4 * j + 1] = v.y; rb[4 * j + 2] = v.z; rb[4 * j + 3] = v.w;
+            }
+        }
+        if (whole) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { if constexpr (!VA) ra[i] = pa[i * a_inc]; if constexpr (!VB) rb[i] = pb[i * b_inc]; }
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const bool va = AK ? (m0 + t5 + 8 * i < p.M && k0 + k5 < p.K) : (m0 + r7 < p.M && k0 + t7 + 2 * i < p.K);
                 const bool vb = BN ? (n0 + r7 < p.N && k0 + t7 + 2 * i < p.K) : (n0 + t5 + 8 * i < p.N && k0 + k5 < p.K);
-                ra[i] = va ? pa[i * a_inc] : 0.f;
-                rb[i] = vb ? pb[i * b_inc] : 0.f;
+                if constexpr (!VA) ra[i] = va ? pa[i * a_inc] : 0.f;
+                if constexpr (!VB) rb[i] = vb ? pb[i * b_inc] : 0.f;
             }
         }
         pa += a_step;
         pb += b_step;
     };
+    auto pack4 = [](const float* r) { bf16x4_t v; v[0] = (__bf16)r[0]; v[1] = (__bf16)r[1]; v[2] = (__bf16)r[2]; v[3] = (__bf16)r[3]; return v; };
     auto stash = [&](int buf) {
         bf16* As = mmb_lds + buf * (2 * 128 * MMB_LD);
         bf16* Bs = As + 128 * MMB_LD;
+        if constexpr (VA) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16x4_t*>(As + (tr + 32 * j) * MMB_LD + kq) = pack4(ra + 4 * j);
+        }
+        if constexpr (VB) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16x4_t*>(Bs + (tr + 32 * j) * MMB_LD + kq) = pack4(rb + 4 * j);
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            if (AK) As[(t5 + 8 * i) * MMB_LD + k5] = (bf16)ra[i];
-            else    As[r7 * MMB_LD + t7 + 2 * i] = (bf16)ra[i];
-            if (BN) Bs[r7 * MMB_LD + t7 + 2 * i] = (bf16)rb[i];
-            else    Bs[(t5 + 8 * i) * MMB_LD + k5] = (bf16)rb[i];
+            if constexpr (!VA) { if (AK) As[(t5 + 8 * i) * MMB_LD + k5] = (bf16)ra[i]; else As[r7 * MMB_LD + t7 + 2 * i] = (bf16)ra[i]; }
+            if constexpr (!VB) { if (BN) Bs[r7 * MMB_LD + t7 + 2 * i] = (bf16)rb[i]; else Bs[(t5 + 8 * i) * MMB_LD + k5] = (bf16)rb[i]; }
         }
     };
     const int steps = (p.K + 31) / 32;
@@ -270,10 +296,23 @@ __global__ __launch_bounds__(256, 2) void matmul_bf16_mfma_kernel(MmArgs p) {
                 }
             }
 }
+static int g_train_matmul_vec = 1;   // ullsam_train_set_matmul_vec: 16-byte fetches of the k-fastest operands of the bf16 product (0: per-element fetches, the round-4 form; same bits)
+extern "C" int ullsam_train_set_matmul_vec(int on) { const int old = g_train_matmul_vec; g_train_matmul_vec = on; return old; }
 template <bool AK, bool BN>
 static void launch_matmul_bf16(const MmArgs& a, hipStream_t stream) {
     constexpr int LDS = 2 * 2 * 128 * MMB_LD * 2;
-    matmul_bf16_mfma_kernel<AK, BN><<<dim3((a.N + 127) / 128, (a.M + 127) / 128, a.batch * a.ksplit), 256, LDS, stream>>>(a);
+    const dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, a.batch * a.ksplit);
+    // the vector form needs, of every k-fastest operand: unit k stride, rows / batch entries / head offsets / the k-split pieces on 16-byte boundaries, K in whole quads
+    auto quad = [](long v) { return (v & 3) == 0; };
+    const bool a_ok = !AK || (a.a_k == 1 && quad(a.a_m) && quad(a.a_b) && quad(a.a_h) && ((uintptr_t)a.A & 15) == 0);
+    const bool b_ok = BN || (a.b_k == 1 && quad(a.b_n) && quad(a.b_b) && quad(a.b_h) && ((uintptr_t)a.B & 15) == 0);
+    if constexpr (AK || !BN) {
+        if (g_train_matmul_vec && a_ok && b_ok && quad(a.K) && quad(a.kc)) {
+            matmul_bf16_mfma_kernel<AK, BN, true><<<grid, 256, LDS, stream>>>(a);
+            return;
+        }
+    }
+    matmul_bf16_mfma_kernel<AK, BN, false><<<grid, 256, LDS, stream>>>(a);
 }
 static int g_train_matmul_mfma = 1;
 extern "C" int ullsam_train_set_matmul_mfma(int on) { const int old = g_train_matmul_mfma; g_train_matmul_mfma = on; return old; }
