@@ -42,10 +42,30 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     """fp32, contiguous.  bf16 parameters / inputs (the trainer's default `--dtype bfloat16` keeps the model in bf16, train_joint_v2.py:1676) are
     widened here: the arithmetic of the step is fp32 throughout, and autograd hands every bf16 parameter its gradient rounded to bf16."""
     if t.dtype == torch.bfloat16:
+        if CACHE_WIDENED and isinstance(t, torch.nn.Parameter) and t.numel() <= (1 << 22):
+            return _widened(t)
         t = t.float()
     elif t.dtype != F32:
         raise TypeError(f"the training step computes in fp32 from fp32 or bf16 tensors (got {t.dtype})")
     return t if t.is_contiguous() else t.contiguous()
+
+
+CACHE_WIDENED = True   # the fp32 copies of a bf16 model's SMALL parameters (norm weights, biases, decoder linears: <= 4 M elements) are kept per parameter object and
+#                        re-made when its `_version` or storage changes: a step made ~1200 such copies, 4 us each, all launch-bound
+_WIDE = None
+
+
+def _widened(p: torch.Tensor) -> torch.Tensor:
+    global _WIDE
+    if _WIDE is None:
+        from torch.utils.weak import WeakIdKeyDictionary   # keyed on identity, dies with the parameter (as _TransposeCache)
+        _WIDE = WeakIdKeyDictionary()
+    e = _WIDE.get(p)
+    if e is not None and e[1] == p._version and e[2] == p.data_ptr() and e[0].shape == p.shape:
+        return e[0]
+    f = p.detach().float().contiguous()
+    _WIDE[p] = (f, p._version, p.data_ptr())
+    return f
 
 
 def _mm(A, B, C, M, N, K, sa, sb, sc, batch=1, accumulate=False, bf16=False):
@@ -207,6 +227,8 @@ def invalidate_transposed_weights():
     """Drop every cached W^T.  Needed only after edits that autograd's version counter cannot see (writes through `.data` that keep the
     storage: `w.data.copy_()`, a LoRA merge, EMA) -- in-place ops on the parameter itself and reallocation are detected."""
     _WT_CACHE.clear()
+    if _WIDE is not None:
+        _WIDE.clear()
 
 
 def _transposed_frozen(w: torch.Tensor) -> torch.Tensor:
