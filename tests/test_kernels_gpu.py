@@ -1093,3 +1093,18 @@ def test_ring_kernel_swiglu_epilogue_to_1e5_of_exact_division(ops):
     e, ulps = _implied_abs_error(got, exact)
     print(f"272x256 ring: SwiGLU epilogue implied |error| {e:.2e}, worst mismatch {ulps} ulp")
     assert e < 1e-5 and ulps <= 1, (e, ulps)
+
+
+@pytest.mark.parametrize("R,C,pad,dt", [(4096, 1280, 64, torch.float32), (1081, 4096, 64, torch.float32), (1000, 257, 1, torch.float32), (1001, 130, 1, torch.bfloat16),
+                                        (70, 3840, 64, torch.bfloat16), (4096, 5120, 4, torch.float32)])
+def test_transpose_to_bf16_against_torch(ops, R, C, pad, dt):
+    """ops.transpose_to_bf16 (csrc/vit_misc.hip: the dW = dY^T X operands of the training step and the W^T of dX): [R, C] fp32 / bf16 -> bf16 [C, R rounded up to pad] with zero
+    columns behind R -- the 8-byte-store form (padded row length % 4 == 0) and the 2-byte form (odd lengths), ragged tiles."""
+    g = torch.Generator(device=DEV); g.manual_seed(R + C)
+    x = torch.randn(R, C, device=DEV, generator=g).to(dt)
+    got = ops.transpose_to_bf16(x, pad)
+    Rp = -(-R // pad) * pad
+    want = torch.zeros(C, Rp, dtype=torch.bfloat16, device=DEV)
+    want[:, :R] = x.t().to(torch.bfloat16)
+    torch.cuda.synchronize()
+    assert got.shape == (C, Rp) and torch.equal(got, want)
