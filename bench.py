@@ -543,6 +543,12 @@ def timed_steps(step, warmup: int, steps: int, world: int, device: str, on_timed
         for _ in range(warmup):
             step()
         step.drain()
+        # The cyclic garbage collector is parked for the K timed steps (collected once before, re-enabled after): a generation-2 pass over a model of thousands of modules
+        # lands in one step or another and showed as single steps of 91 / 105 ms among 76.5 ms ones (`step_ms.max`); nothing the step does is skipped
+        import gc
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
         barrier()
         if on_timed:
             on_timed(True)
@@ -563,6 +569,8 @@ def timed_steps(step, warmup: int, steps: int, world: int, device: str, on_timed
         gathered = step.drain()
         barrier()
         dt = time.perf_counter() - t0
+        if gc_was:
+            gc.enable()
         timed_steps.step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
         if on_timed:
             on_timed(False)
