@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import torch
 from ullsam_amd import training as T
 DEV = "cuda:0"
-KNOB = sys.argv[1] if len(sys.argv) > 1 else "INPLACE_ATTN"      # or "matmul_vec": 16-byte fetches of the bf16 product's k-fastest operands (ullsam_train_set_matmul_vec)
+KNOB = sys.argv[1] if len(sys.argv) > 1 else "INPLACE_ATTN"      # or FUSED_CAUSAL_FWD (the LLM forward on the inference causal kernel), or "matmul_vec": 16-byte fetches of the bf16 product's k-fastest operands (ullsam_train_set_matmul_vec)
 def setk(on):
     if KNOB == "matmul_vec":
         from ullsam_amd import _lib

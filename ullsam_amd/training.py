@@ -115,6 +115,7 @@ RECOMPUTE_P = True   # matrix-form attention keeps q, k, v and rebuilds the prob
 #                      backward's row pass) instead of holding it from the forward: -10.8 GB on a ViT-H + 7B-shaped step for ~4 % of its time
 MATRIX_ATTN_FROM = 0         # attention through materialised score matrices from Sq * Sk >= this; below it one workgroup per query, whose backward adds dk / dv by
 #                              atomics (order-dependent sums): 0 keeps every attention on the matrix form, so that two runs of a step are bit-equal
+FUSED_CAUSAL_FWD = True   # bf16 models: the frozen LLM's attention FORWARD runs on the inference path's causal kernel (no score matrix); the backward stays the matrix form
 INPLACE_ATTN = True  # the ViT / LLM attention products read q / k / v / dO and write out / dq / dk / dv inside the row tensors (ullsam_train_matmul_heads); False: head-major copies around plain batched products (tests / A-B)
 MFMA_LINEAR = True   # nn.Linear forward / backward on the fp32 MFMA GEMM of the inference path where its shapes allow (inner dimension % 32 == 0);
 #                     the one-output-per-thread matmul of csrc/train.hip otherwise (and always with MFMA_LINEAR = False: tests compare the two)
@@ -433,6 +434,17 @@ class AttentionFn(Function):
         ctx.matrix = True
         ctx.recompute = RECOMPUTE_P
         ctx.inplace = INPLACE_ATTN and Sq >= 64 and Sk >= 64 and hd >= 16
+        if (FUSED_CAUSAL_FWD and ctx.inplace and ctx.bf16 and RECOMPUTE_P and causal == 0 and bias_h is None and hd == 128 and Sq == Sk and H % KVH == 0):
+            # The LLM's forward on the inference path's causal kernel (csrc/attention.hip causal128_attn_kernel: bf16 q / k / v, fp32 online softmax, bf16 probabilities and output --
+            # autocast's attention; the reference's additive causal + padding masks): no score matrix in the forward at all.  The backward rebuilds P in matrix form from the
+            # saved q scale / k / v as before (RECOMPUTE_P), so it needs nothing from this launch.
+            qs = AttentionFn._scaled(q, 1.0 / math.sqrt(hd))
+            bf = torch.bfloat16
+            kc = k.reshape(B, Sk, KVH, hd).to(bf).permute(0, 2, 1, 3).contiguous()
+            vc = v.reshape(B, Sk, KVH, hd).to(bf).permute(0, 2, 1, 3).contiguous()
+            out = ops.causal_attention(ops.cast(q, bf), kc, vc, key_mask, B, H, KVH, hd, Sq, Sk, 0).float()
+            ctx.save_for_backward(qs, k, v, key_mask, bias_h, bias_w)
+            return out
         if ctx.inplace:
             # Matrix form on the activations where they are (ViT, LLM): the products index (image / window, head) pairs inside the [rows, heads x hd] tensors
             # (ullsam_train_matmul_heads; grouped KV heads by h // G) -- no head-major copies of q / k / v, no repeat_kv copies, out written as rows.
