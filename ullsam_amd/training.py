@@ -76,8 +76,8 @@ def _mm(A, B, C, M, N, K, sa, sb, sc, batch=1, accumulate=False, bf16=False):
         return
     tile = 128 if (M >= 64 and N >= 48) else 64
     tiles = -(-M // tile) * -(-N // tile) * batch
-    if K >= 2048 and tiles <= 128:          # a few output tiles under a long sum: cut k over workgroups (partials added in order: deterministic)
-        ks = max(2, min(K // 512, 1024 // tiles, 65535 // batch))
+    if K >= 512 and tiles <= 128:           # a few output tiles under a long sum: cut k over workgroups (partials added in order: deterministic)
+        ks = max(2, min(K // 128, 1024 // tiles, 65535 // batch))      # (round 6: pieces of >= 128 instead of >= 512 terms -- the rel-pos table gradient, 14 x 80 outputs over 5600 terms x 14, 129 -> ~45 us)
         part = torch.empty((ks * batch * M * N,), dtype=F32, device=C.device)
         _lib.call("ullsam_train_matmul_splitk", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, batch, *sa, *sb, *sc, int(accumulate), ks, part.data_ptr(), _s())
         return
