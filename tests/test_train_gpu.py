@@ -888,3 +888,23 @@ def test_lm_loss_of_the_composite_is_differentiable_into_mlp1(dtype):
     h3 = h.detach().clone().requires_grad_(True)
     (0 * training.lm_loss(lm, h3, labels)).backward()
     assert float(h3.grad.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,D", [(1081, 4096), (37, 96), (64, 2048), (9, 4), (300, 1284)])
+def test_rmsnorm_backward_against_torch_autograd(rows, D):
+    """training.RMSNormFn (InternLM2RMSNorm, modeling_internlm2.py:75-89): dx and dw against torch's autograd on the same formula in float64 -- the row-in-registers kernel
+    (one workgroup per row, float4 fetches) at the 7B width, at widths that leave most of its threads idle and at one that is not a multiple of the workgroup's stride."""
+    from ullsam_amd import training as T
+    g = torch.Generator(device=DEV); g.manual_seed(rows + D)
+    x = torch.randn(rows, D, device=DEV, generator=g, requires_grad=True)
+    w = (1.0 + 0.1 * torch.randn(D, device=DEV, generator=g)).requires_grad_(True)
+    go = torch.randn(rows, D, device=DEV, generator=g)
+    y = T.RMSNormFn.apply(x, w, 1e-6)
+    y.backward(go)
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    yd = xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-6) * wd
+    yd.backward(go.double())
+    assert float((y.detach().double() - yd.detach()).abs().max()) < 1e-5 * max(1.0, float(yd.abs().max()))
+    assert float((x.grad.double() - xd.grad).abs().max()) < 2e-5 * max(1.0, float(xd.grad.abs().max()))
+    assert float((w.grad.double() - wd.grad).abs().max()) < 2e-5 * max(1.0, float(wd.grad.abs().max()))

@@ -282,7 +282,7 @@ class LinearBf16Fn(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dyb, ops.transpose_to_bf16(w.detach()), out_f32=True)
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm(ops.transpose_to_bf16(dy, 64), ops.transpose_to_bf16(xb, 64), out_f32=True)
+            dw = ops.gemm(ops.transpose_to_bf16(dyb, 64), ops.transpose_to_bf16(xb, 64), out_f32=True)   # (from the bf16 copy: the same values, half the bytes read)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = _colsum(dy)
         return dx, dw, db
