@@ -905,6 +905,6 @@ def test_rmsnorm_backward_against_torch_autograd(rows, D):
     xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
     yd = xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-6) * wd
     yd.backward(go.double())
-    assert float((y.detach().double() - yd.detach()).abs().max()) < 1e-5 * max(1.0, float(yd.abs().max()))
+    assert float((y.detach().double() - yd.detach()).abs().max()) < 1e-5 * max(1.0, float(yd.detach().abs().max()))
     assert float((x.grad.double() - xd.grad).abs().max()) < 2e-5 * max(1.0, float(xd.grad.abs().max()))
     assert float((w.grad.double() - wd.grad).abs().max()) < 2e-5 * max(1.0, float(wd.grad.abs().max()))
