@@ -223,6 +223,10 @@ int ullsam_add_cast(const void* a, int a_dtype, long a_rows, const float* b, lon
 int ullsam_transpose_f32(const float* in, float* out, int B, int R, int C, void* stream);  /* image_encoder.py:114 permute */
 /* in [R, C] (in_dtype: f32 or bf16) -> out bf16 [C, Rp], transposed, columns R..Rp-1 zero (training: the dW / dX GEMM operands, cast + transposed in one pass) */
 int ullsam_transpose_to_bf16(int in_dtype, const void* in, void* out, int R, int C, int Rp, void* stream);
+/* fp32 [R, C] -> bf16 [R, C] (out_rm, may be NULL) and bf16 [C, Rp] (out_t: transposed, zero columns behind R) and the column sums sum_r in[r][c] (colsum_out fp32 [C], may be NULL;
+ * colsum_ws: ceil(Rp / 64) * C floats of scratch, 64-row blocks added in order) in ONE pass: what a bf16 Linear of the training step needs of an activation and of a gradient.
+ * C and Rp multiples of 4. */
+int ullsam_cast_transpose_bf16(const float* in, void* out_rm, void* out_t, float* colsum_out, float* colsum_ws, int R, int C, int Rp, void* stream);
 int ullsam_pixel_shuffle_ln(int dtype, const float* in_nhwc, void* out, const float* w, const float* b, int B, int H, int W,
                             int C, float eps, void* stream);                             /* modeling_internvl_sam.py:226-251,89 */
 int ullsam_pixel_unshuffle(const float* in, float* out_nhwc, int B, int H, int W, int C, void* stream); /* :256-268 */

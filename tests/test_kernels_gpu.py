@@ -1108,3 +1108,21 @@ def test_transpose_to_bf16_against_torch(ops, R, C, pad, dt):
     want[:, :R] = x.t().to(torch.bfloat16)
     torch.cuda.synchronize()
     assert got.shape == (C, Rp) and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("R,C,pad", [(4096, 1280, 64), (1081, 4096, 64), (1000, 260, 4), (70, 3840, 64)])
+def test_cast_transpose_bf16_against_torch(ops, R, C, pad):
+    """ops.cast_transpose_bf16 (csrc/vit_misc.hip: one pass over an fp32 activation or gradient of the training step's bf16 Linear): the bf16 copy, the zero-padded bf16 transpose
+    and the column sums (64-row blocks added in order) against torch; the two bf16 outputs must be exact, the sums within fp32 summation noise of a float64 sum."""
+    g = torch.Generator(device=DEV); g.manual_seed(R + C)
+    x = torch.randn(R, C, device=DEV, generator=g)
+    rm, xt, cs = ops.cast_transpose_bf16(x, pad, row_major=True, colsum=True)
+    Rp = -(-R // pad) * pad
+    want_t = torch.zeros(C, Rp, dtype=torch.bfloat16, device=DEV)
+    want_t[:, :R] = x.t().to(torch.bfloat16)
+    torch.cuda.synchronize()
+    assert torch.equal(rm, x.to(torch.bfloat16)) and torch.equal(xt, want_t) and torch.equal(xt, ops.transpose_to_bf16(x, pad))
+    ref = x.double().sum(0)
+    assert float((cs.double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max())) * (R ** 0.5)
+    rm2, xt2, cs2 = ops.cast_transpose_bf16(x, pad, row_major=False, colsum=False)
+    assert rm2 is None and cs2 is None and torch.equal(xt2, want_t)

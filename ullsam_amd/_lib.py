@@ -55,6 +55,7 @@ SIGNATURES = {
     "ullsam_add_cast": [vp, i32, i64, vp, i64, vp, i32, i64, i32, vp],
     "ullsam_transpose_f32": [vp, vp, i32, i32, i32, vp],
     "ullsam_transpose_to_bf16": [i32, vp, vp, i32, i32, i32, vp],
+    "ullsam_cast_transpose_bf16": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "ullsam_pixel_shuffle_ln": [i32, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "ullsam_pixel_unshuffle": [vp, vp, i32, i32, i32, i32, vp],
     "ullsam_scan_image_tokens": [vp, vp, vp, i32, i32, C.c_longlong, vp],

@@ -170,6 +170,68 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const Tin* __res
         if (c < C && r < Rp) out[(long)c * Rp + r] = from_f32<bf16>(tile[tx][ty + 4 * j]);
     }
 }
+// ---- fp32 [R, C] -> bf16 [R, C] (row-major copy, optional) AND bf16 [C, Rp] (transposed, zero columns behind R) AND per-64-row-block column sums (optional) in ONE pass over the input:
+// what the training step's bf16 Linear needs of an activation (forward: x for the GEMM, x^T for the later dW) and of a gradient (backward: dY for dX, dY^T for dW, sum_rows dY for db),
+// which were a cast, a transpose and a column-sum launch reading the same fp32 tensor three times.  C % 4 == 0, Rp % 4 == 0; colsum: [ceil(R / 64)][C] floats, added in order afterwards.
+__global__ __launch_bounds__(256) void cast_transpose_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out_rm, bf16* __restrict__ out_t, float* __restrict__ colsum,
+                                                                  int R, int C, int Rp) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ry + 16 * j, c = c0 + 4 * cq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R && c < C) {                                // (C % 4 == 0: the quad is inside the row)
+            v = *reinterpret_cast<const float4*>(in + (long)r * C + c);
+            if (out_rm) {
+                bf16x4_t o; o[0] = from_f32<bf16>(v.x); o[1] = from_f32<bf16>(v.y); o[2] = from_f32<bf16>(v.z); o[3] = from_f32<bf16>(v.w);
+                *reinterpret_cast<bf16x4_t*>(out_rm + (long)r * C + c) = o;
+            }
+        }
+        float* t = &tile[ry + 16 * j][4 * cq];
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+    __syncthreads();
+    if (colsum && threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {   // rows r0 .. r0 + 63 of column c0 + t, in row order (rows past R hold zeros)
+        float s = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) s += tile[r][threadIdx.x];
+        colsum[(long)blockIdx.y * C + c0 + threadIdx.x] = s;
+    }
+    const int q = threadIdx.x & 15, cy = threadIdx.x >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + cy + 16 * j, r = r0 + 4 * q;
+        if (c < C && r < Rp) {
+            bf16x4_t v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = from_f32<bf16>(tile[4 * q + e][cy + 16 * j]);
+            *reinterpret_cast<bf16x4_t*>(out_t + (long)c * Rp + r) = v;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void colsum_blocks_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int C, int nb) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += partial[(long)b * C + c];
+    out[c] = s;
+}
+// out_rm bf16 [R, C] | NULL; out_t bf16 [C, Rp]; colsum_out fp32 [C] | NULL with colsum_ws fp32 [ceil(Rp / 64) * C]
+extern "C" int ullsam_cast_transpose_bf16(const float* in, void* out_rm, void* out_t, float* colsum_out, float* colsum_ws, int R, int C, int Rp, void* stream) {
+    ULLSAM_CHECK(R > 0 && C > 0 && Rp >= R && (C & 3) == 0 && (Rp & 3) == 0 && out_t, "cast_transpose_bf16: R=%d C=%d Rp=%d (C, Rp multiples of 4)", R, C, Rp);
+    ULLSAM_CHECK((((uintptr_t)in | (uintptr_t)out_rm | (uintptr_t)out_t) & 15) == 0 && (!colsum_out || colsum_ws), "cast_transpose_bf16: 16-byte aligned operands; column sums need their workspace");
+    const dim3 grid((C + 63) / 64, (Rp + 63) / 64);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    cast_transpose_bf16_kernel<<<grid, 256, 0, st>>>(in, static_cast<bf16*>(out_rm), static_cast<bf16*>(out_t), colsum_out ? colsum_ws : nullptr, R, C, Rp);
+    ULLSAM_LAUNCH_CHECK();
+    if (colsum_out) {
+        colsum_blocks_reduce_kernel<<<dim3((C + 255) / 256), 256, 0, st>>>(colsum_ws, colsum_out, C, (int)grid.y);
+        ULLSAM_LAUNCH_CHECK();
+    }
+    return 0;
+}
 extern "C" int ullsam_transpose_to_bf16(int in_dtype, const void* in, void* out, int R, int C, int Rp, void* stream) {
     ULLSAM_CHECK(R > 0 && C > 0 && Rp >= R, "transpose_to_bf16: R=%d C=%d Rp=%d", R, C, Rp);
     const dim3 grid((C + 63) / 64, (Rp + 63) / 64);

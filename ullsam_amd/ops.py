@@ -396,6 +396,23 @@ def transpose_to_bf16(x: torch.Tensor, pad_to: int = 1) -> torch.Tensor:
     return out
 
 
+def cast_transpose_bf16(x: torch.Tensor, pad_to: int = 64, row_major: bool = True, colsum: bool = False):
+    """fp32 [R, C] -> (bf16 [R, C] | None, bf16 [C, R rounded up to pad_to] zero filled, fp32 [C] column sums | None) in one pass over x (csrc/vit_misc.hip
+    cast_transpose_bf16_kernel); C % 4 == 0 and pad_to % 4 == 0."""
+    _chk(x, "x", torch.float32)
+    R, Cn = x.shape
+    assert Cn % 4 == 0 and pad_to % 4 == 0
+    Rp = -(-R // pad_to) * pad_to
+    rm = torch.empty((R, Cn), dtype=torch.bfloat16, device=x.device) if row_major else None
+    xt = torch.empty((Cn, Rp), dtype=torch.bfloat16, device=x.device)
+    cs = ws = None
+    if colsum:
+        cs = torch.empty((Cn,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((-(-Rp // 64) * Cn,), dtype=torch.float32, device=x.device)
+    _lib.call("ullsam_cast_transpose_bf16", x.data_ptr(), _p(rm), xt.data_ptr(), _p(cs), _p(ws), R, Cn, Rp, _stream())
+    return rm, xt, cs
+
+
 def pixel_shuffle_ln(x_nhwc: torch.Tensor, w, b, B, H, W, C, eps, dtype) -> torch.Tensor:
     _chk(x_nhwc, "x", torch.float32)
     out = torch.empty((B * (H // 2) * (W // 2), 4 * C), dtype=dtype, device=x_nhwc.device)

@@ -116,6 +116,7 @@ RECOMPUTE_P = True   # matrix-form attention keeps q, k, v and rebuilds the prob
 MATRIX_ATTN_FROM = 0         # attention through materialised score matrices from Sq * Sk >= this; below it one workgroup per query, whose backward adds dk / dv by
 #                              atomics (order-dependent sums): 0 keeps every attention on the matrix form, so that two runs of a step are bit-equal
 FUSED_CAUSAL_FWD = True   # bf16 models: the frozen LLM's attention FORWARD runs on the inference path's causal kernel (no score matrix); the backward stays the matrix form
+FUSED_CAST_TRANSPOSE = True   # LinearBf16Fn: x -> (bf16 x, x^T) and dY -> (bf16 dY, dY^T, column sums) each in one pass (ops.cast_transpose_bf16); False: separate cast / transpose / column-sum launches
 INPLACE_ATTN = True  # the ViT / LLM attention products read q / k / v / dO and write out / dq / dk / dv inside the row tensors (ullsam_train_matmul_heads); False: head-major copies around plain batched products (tests / A-B)
 MFMA_LINEAR = True   # nn.Linear forward / backward on the fp32 MFMA GEMM of the inference path where its shapes allow (inner dimension % 32 == 0);
 #                     the one-output-per-thread matmul of csrc/train.hip otherwise (and always with MFMA_LINEAR = False: tests compare the two)
@@ -268,21 +269,35 @@ class LinearBf16Fn(Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
-        xb = ops.cast(_c(x), torch.bfloat16)
-        ctx.save_for_backward(xb, w)
+        x = _c(x)
         ctx.has_b = b is not None
+        ctx.fused = FUSED_CAST_TRANSPOSE and x.shape[1] % 4 == 0 and w.shape[0] % 4 == 0
+        if ctx.fused and ctx.needs_input_grad[1]:      # x leaves its one pass as the GEMM's bf16 operand AND as the x^T the dW product will want (kept instead of x)
+            xb, xt, _ = ops.cast_transpose_bf16(x, 64)
+            ctx.save_for_backward(xt, w)
+        else:
+            ctx.fused = False
+            xb = ops.cast(x, torch.bfloat16)
+            ctx.save_for_backward(xb, w)
         return ops.gemm(xb, w.detach(), None if b is None else _c(b), out_f32=True)
 
     @staticmethod
     def backward(ctx, dy):
-        xb, w = ctx.saved_tensors
+        xs, w = ctx.saved_tensors
         dy = _c(dy)
-        dyb = ops.cast(dy, torch.bfloat16)
         dx = dw = db = None
+        if ctx.fused:              # one pass over dY: its bf16 copy (dX), its transpose (dW) and its column sums (db)
+            want_b = ctx.has_b and ctx.needs_input_grad[2]
+            dyb, dyt, db = ops.cast_transpose_bf16(dy, 64, row_major=ctx.needs_input_grad[0], colsum=want_b)
+            if ctx.needs_input_grad[0]:
+                dx = ops.gemm(dyb, ops.transpose_to_bf16(w.detach()), out_f32=True)
+            dw = ops.gemm(dyt, xs, out_f32=True)
+            return dx, dw, db
+        dyb = ops.cast(dy, torch.bfloat16)
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dyb, ops.transpose_to_bf16(w.detach()), out_f32=True)
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm(ops.transpose_to_bf16(dyb, 64), ops.transpose_to_bf16(xb, 64), out_f32=True)   # (from the bf16 copy: the same values, half the bytes read)
+            dw = ops.gemm(ops.transpose_to_bf16(dyb, 64), ops.transpose_to_bf16(xs, 64), out_f32=True)   # (from the bf16 copy: the same values, half the bytes read)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = _colsum(dy)
         return dx, dw, db
