@@ -115,6 +115,7 @@ RECOMPUTE_P = True   # matrix-form attention keeps q, k, v and rebuilds the prob
 #                      backward's row pass) instead of holding it from the forward: -10.8 GB on a ViT-H + 7B-shaped step for ~4 % of its time
 MATRIX_ATTN_FROM = 0         # attention through materialised score matrices from Sq * Sk >= this; below it one workgroup per query, whose backward adds dk / dv by
 #                              atomics (order-dependent sums): 0 keeps every attention on the matrix form, so that two runs of a step are bit-equal
+FUSED_GLOBAL_FWD = True   # bf16 models: the forward value of the ViT's attention blocks (global and windowed) comes from the inference path's kernels on the packed qkv; the backward stays the matrix form
 FUSED_CAUSAL_FWD = True   # bf16 models: the frozen LLM's attention FORWARD runs on the inference path's causal kernel (no score matrix); the backward stays the matrix form
 FUSED_CAST_TRANSPOSE = True   # LinearBf16Fn: x -> (bf16 x, x^T) and dY -> (bf16 dY, dY^T, column sums) each in one pass (ops.cast_transpose_bf16); False: separate cast / transpose / column-sum launches
 INPLACE_ATTN = True  # the ViT / LLM attention products read q / k / v / dO and write out / dq / dk / dv inside the row tensors (ullsam_train_matmul_heads); False: head-major copies around plain batched products (tests / A-B)
@@ -432,7 +433,7 @@ class AttentionFn(Function):
     ViT's (image_encoder.py:224-240: bias_h [B, H, Sq, Sk/kw] + bias_w [B, H, Sq, kw], the decomposed relative-position terms)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, B, H, KVH, Sq, Sk, causal, key_mask, bias_h, bias_w, kw, bf16=False):
+    def forward(ctx, q, k, v, B, H, KVH, Sq, Sk, causal, key_mask, bias_h, bias_w, kw, bf16=False, fused_out=None):
         q, k, v = _c(q), _c(k), _c(v)
         ctx.bf16 = bool(bf16)     # matrix form only: the score / probability products as autocast(bfloat16) computes them (bf16 models)
         if bias_h is not None:
@@ -449,6 +450,10 @@ class AttentionFn(Function):
         ctx.matrix = True
         ctx.recompute = RECOMPUTE_P
         ctx.inplace = INPLACE_ATTN and Sq >= 64 and Sk >= 64 and hd >= 16
+        if fused_out is not None and ctx.inplace and RECOMPUTE_P:
+            # the caller has the forward value from an inference kernel (the ViT's global blocks: ullsam_vit_attention on the packed qkv); the backward rebuilds P from q / k / v
+            ctx.save_for_backward(AttentionFn._scaled(q, 1.0 / math.sqrt(hd)), k, v, key_mask, bias_h, bias_w)
+            return _c(fused_out)
         if (FUSED_CAUSAL_FWD and ctx.inplace and ctx.bf16 and RECOMPUTE_P and causal == 0 and bias_h is None and hd == 128 and Sq == Sk and H % KVH == 0):
             # The LLM's forward on the inference path's causal kernel (csrc/attention.hip causal128_attn_kernel: bf16 q / k / v, fp32 online softmax, bf16 probabilities and output --
             # autocast's attention; the reference's additive causal + padding masks): no score matrix in the forward at all.  The backward rebuilds P in matrix form from the
@@ -534,7 +539,7 @@ class AttentionFn(Function):
             dbw = torch.empty_like(bias_w) if bias_w is not None else None
             dq, dk, dv = torch.empty_like(q), torch.zeros_like(k), torch.zeros_like(v)
             AttentionFn._launch(q, k, v, dout, None, dq, dk, dv, ctx.dims, key_mask, bias_h, bias_w, dbh, dbw)
-            return (dq, dk, dv) + nones + (dbh, dbw, None, None)
+            return (dq, dk, dv) + nones + (dbh, dbw, None, None, None)
         if ctx.inplace:
             return AttentionFn._backward_inplace(ctx, dout)
         qs, kh, vh, P, bias_h, bias_w = ctx.saved_tensors
@@ -559,7 +564,7 @@ class AttentionFn(Function):
             red = lambda t: _colsum(t.reshape(B, KVH, G, Sk * hd).permute(2, 0, 1, 3).reshape(G, -1).contiguous()).reshape(B, KVH, Sk, hd)
             dkh, dvh = red(dkh), red(dvh)
         back = lambda t, S_, Hx: t.permute(0, 2, 1, 3).reshape(B * S_, Hx * hd).contiguous()
-        return (back(dqh, Sq, H), back(dkh, Sk, KVH), back(dvh, Sk, KVH)) + nones + (dbh, dbw, None, None)
+        return (back(dqh, Sq, H), back(dkh, Sk, KVH), back(dvh, Sk, KVH)) + nones + (dbh, dbw, None, None, None)
 
 
 def _attn_backward_inplace(ctx, dout):
@@ -596,7 +601,7 @@ def _attn_backward_inplace(ctx, dout):
         red = lambda t: _colsum(t.reshape(B, KVH, G, Sk * hd).permute(2, 0, 1, 3).reshape(G, -1).contiguous()).reshape(B, KVH, Sk, hd)
         back = lambda t: t.permute(0, 2, 1, 3).reshape(B * Sk, KVH * hd).contiguous()
         dk, dv = back(red(dk)), back(red(dv))
-    return (dq, dk, dv) + (None,) * 7 + (dbh, dbw, None, None)
+    return (dq, dk, dv) + (None,) * 7 + (dbh, dbw, None, None, None)
 
 
 AttentionFn._backward_inplace = staticmethod(_attn_backward_inplace)
@@ -1125,7 +1130,28 @@ def vision_feature_rows(enc, pixel_values: torch.Tensor) -> torch.Tensor:
         else:
             Hh = g
         Bw, T = t.shape[0], Hh * Hh
-        q, k, v = SplitFn.apply(_apply_linear(t.reshape(Bw * T, D), at.qkv.weight, at.qkv.bias).reshape(Bw * T, 3, heads * hd), (1, 1, 1))
+        qkv = _apply_linear(t.reshape(Bw * T, D), at.qkv.weight, at.qkv.bias)
+        bf_mode = BF16_LINEAR and at.qkv.weight.dtype == torch.bfloat16
+        fused = None
+        if FUSED_GLOBAL_FWD and bf_mode and RECOMPUTE_P and INPLACE_ATTN:
+            # a block of a bf16 model: the forward VALUE from the inference path's kernels on the packed qkv (csrc/attention.hip vitglob_attn_kernel / win14r_attn_kernel / the tiled
+            # kernel: bf16 operands, the decomposed rel-pos terms formed inside, fp32 softmax, bf16 probabilities and output) -- no score matrices in the forward.  Windowed blocks: the
+            # kernel takes the UNpartitioned tokens (it gathers the windows and makes the pad tokens' k / v from the qkv bias itself); its output goes back into the padded-window
+            # layout with zeros on the pad rows, whose outputs window_unpartition drops (and whose gradients are therefore zero) anyway
+            with torch.no_grad():
+                bf = torch.bfloat16
+                qb = at.qkv.bias if at.qkv.bias is not None else torch.zeros(3 * D, device=x.device)
+                qd = qkv.detach()
+                if ws > 0:
+                    qd = qd.reshape(B, gp // ws, gp // ws, ws, ws, 3 * D).permute(0, 1, 3, 2, 4, 5).reshape(B, gp, gp, 3 * D)[:, :g, :g]
+                fused = ops.vit_attention(qd.to(bf).contiguous().reshape(B * N, 3 * D), at.rel_table("rh", at.rel_pos_h, Hh, bf), at.rel_table("rw", at.rel_pos_w, Hh, bf), at.cdt("qb", qb, bf),
+                                          B, heads, hd, g, g, ws).float()
+                if ws > 0:
+                    fused = fused.reshape(B, g, g, D)
+                    if gp > g:
+                        fused = TF.pad(fused, (0, 0, 0, gp - g, 0, gp - g))
+                    fused = fused.reshape(B, gp // ws, ws, gp // ws, ws, D).permute(0, 1, 3, 2, 4, 5).reshape(Bw * T, D).contiguous()
+        q, k, v = SplitFn.apply(qkv.reshape(Bw * T, 3, heads * hd), (1, 1, 1))
         def table(p):                                                                           # get_rel_pos's interpolation (:306-318) of a table of another length:
             if p.shape[0] == 2 * Hh - 1:                                                        # F.interpolate(mode="linear") = the resize kernel on [hd planes] x [1 x L] images;
                 return p                                                                        # its adjoint (ResizeFn.backward) carries the gradient back to the stored rows
@@ -1139,7 +1165,7 @@ def vision_feature_rows(enc, pixel_values: torch.Tensor) -> torch.Tensor:
         rel_h = rel_h.reshape(Hh, Bw, Hh, heads, Hh).permute(1, 3, 0, 2, 4).reshape(Bw, heads, T, Hh)
         rel_w = BmmNTFn.apply(q5.permute(2, 0, 1, 3, 4).reshape(Hh, Bw * Hh * heads, hd), Rw)   # [qw, (b, qh, head), kw]
         rel_w = rel_w.reshape(Hh, Bw, Hh, heads, Hh).permute(1, 3, 2, 0, 4).reshape(Bw, heads, T, Hh)
-        a = AttentionFn.apply(q, k, v, Bw, heads, heads, T, T, -1, None, rel_h, rel_w, Hh, BF16_LINEAR and at.qkv.weight.dtype == torch.bfloat16)
+        a = AttentionFn.apply(q, k, v, Bw, heads, heads, T, T, -1, None, rel_h, rel_w, Hh, bf_mode, fused)
         a = _apply_linear(a, at.proj.weight, at.proj.bias)
         if ws > 0:                                                                             # window_unpartition :267-290
             a = a.reshape(B, gp // ws, gp // ws, ws, ws, D).permute(0, 1, 3, 2, 4, 5).contiguous().reshape(B, gp, gp, D)
