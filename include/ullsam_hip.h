@@ -99,9 +99,11 @@ int ullsam_train_matmul_bf16(const float* A, const float* B, float* C, int M, in
                              long b_k, long b_n, long c_b, long c_m, long c_n, int accumulate, void* stream);
 /* the product over (outer, head) pairs whose operands sit inside [rows, heads x hd] activations: entry (o, h) of operand X starts at o x_o + (h / x_hdiv) x_h elements
  * (x_hdiv = query heads per KV head for k / v, modeling_internlm2.py:250-259 repeat_kv); bf16 != 0: operands rounded to bf16 as ullsam_train_matmul_bf16.  The attention
- * products of a training step read q / k / v / dO and write out / dq / dk / dv in place instead of through head-major copies */
+ * products of a training step read q / k / v / dO and write out / dq / dk / dv in place instead of through head-major copies.  tri: the causal structure of a square
+ * attention (0 none): 1 = C[query][key], 128 x 128 tiles wholly behind the diagonal are not formed (ullsam_train_attn_rows does not read masked entries and writes zeros there);
+ * 2 = the sum runs over queries, m is the key: it starts at the tile's first key; 3 = the sum runs over keys, m is the query: it stops after the tile's last query */
 int ullsam_train_matmul_heads(const float* A, const float* B, float* C, int M, int N, int K, int outer, int heads, long a_o, long a_h, int a_hdiv, long a_m, long a_k,
-                              long b_o, long b_h, int b_hdiv, long b_k, long b_n, long c_o, long c_h, long c_m, long c_n, int accumulate, int bf16, void* stream);
+                              long b_o, long b_h, int b_hdiv, long b_k, long b_n, long c_o, long c_h, long c_m, long c_n, int accumulate, int bf16, int tri, void* stream);
 /* the same product with its k range cut into `ksplit` pieces run by separate workgroups and added IN ORDER by a second kernel (few output tiles,
  * long sums: rel-pos table gradients, the hypernetwork gradient over 65536 pixels); partial: ksplit * batch * M * N floats of scratch */
 int ullsam_train_matmul_splitk(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k, long b_b,

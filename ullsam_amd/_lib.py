@@ -25,7 +25,7 @@ SIGNATURES = {
     "ullsam_train_matmul": [vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [i32, vp],
     "ullsam_train_matmul_bf16": [vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [i32, vp],
     "ullsam_train_matmul_splitk": [vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [i32, i32, vp, vp],
-    "ullsam_train_matmul_heads": [vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i32, i64, i64, i64, i64, i32, i64, i64, i64, i64, i64, i64, i32, i32, vp],
+    "ullsam_train_matmul_heads": [vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i32, i64, i64, i64, i64, i32, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp],
     "ullsam_train_colsum": [vp, vp, i64, i32, i64, vp, vp],
     "ullsam_train_ln_bwd": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp, vp],
     "ullsam_train_act": [vp, vp, vp, i64, i32, vp],

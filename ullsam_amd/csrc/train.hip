@@ -20,7 +20,17 @@ struct MmArgs {
     // [rows, heads x hd] activations are read / written in place (h / div: grouped KV heads, modeling_internlm2.py:250-259) instead of from head-major copies
     int bin, a_div, b_div;
     long a_h, b_h, c_h;
+    // causal structure of a square attention (Sq == Sk, key j visible to query i iff j <= i), MFMA kernels only: 1 = C[m = query][n = key]: tiles with every key behind every query are
+    // not formed (the row pass does not read masked entries and writes zeros there); 2 = the sum runs over queries and m is the key: queries before the tile's first key meet zeros,
+    // start at it; 3 = the sum runs over keys and m is the query: keys behind the tile's last query meet zeros, stop after it.  0 elsewhere.
+    int tri;
 };
+__device__ __forceinline__ bool mm_tri_clip(MmArgs& p, int m0, int n0) {   // -> true: nothing to do for this tile
+    if (p.tri == 1) return n0 >= m0 + 128;
+    if (p.tri == 2) { const int kb = min(m0 & ~31, p.K); p.A += (long)kb * p.a_k; p.B += (long)kb * p.b_k; p.K -= kb; }
+    if (p.tri == 3) p.K = min(p.K, m0 + 128);
+    return false;
+}
 __device__ __forceinline__ long mm_boff(int b, int bin, long s_o, long s_h, int div) { return bin > 1 ? (long)(b / bin) * s_o + (long)((b % bin) / div) * s_h : (long)b * s_o; }
 __global__ __launch_bounds__(256) void matmul_f32_kernel(MmArgs p) {
     // 64 x 64 outputs per workgroup, 4 x 4 per thread, K in steps of 16 through LDS.  The element -> thread assignment of the two tile loads
@@ -87,6 +97,7 @@ __global__ __launch_bounds__(256, 2) void matmul_f32_mfma_kernel(MmArgs p) {
     p.B += (long)ks * p.kc * p.b_k;
     p.K = min(p.kc, p.K - ks * p.kc);
     p.C += (long)ks * p.c_s;
+    if (mm_tri_clip(p, m0, n0)) return;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -191,6 +202,7 @@ __global__ __launch_bounds__(256, 2) void matmul_bf16_mfma_kernel(MmArgs p) {
     p.B += (long)ks * p.kc * p.b_k;
     p.K = min(p.kc, p.K - ks * p.kc);
     p.C += (long)ks * p.c_s;
+    if (mm_tri_clip(p, m0, n0)) return;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -343,14 +355,14 @@ static int train_matmul_launch(MmArgs a, hipStream_t st) {
 extern "C" int ullsam_train_matmul(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k,
                                    long b_b, long b_k, long b_n, long c_b, long c_m, long c_n, int accumulate, void* stream) {
     ULLSAM_CHECK(M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "train_matmul: M=%d N=%d K=%d batch=%d", M, N, K, batch);
-    MmArgs a{A, B, C, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n, accumulate, 1, K, 0, 1, 1, 1, 0, 0, 0};
+    MmArgs a{A, B, C, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n, accumulate, 1, K, 0, 1, 1, 1, 0, 0, 0, 0};
     return train_matmul_launch(a, reinterpret_cast<hipStream_t>(stream));
 }
 // fp32 operands rounded to bf16 at the product's door (see matmul_bf16_mfma_kernel); shapes below the MFMA tile fall back to the fp32 product
 extern "C" int ullsam_train_matmul_bf16(const float* A, const float* B, float* C, int M, int N, int K, int batch, long a_b, long a_m, long a_k,
                                         long b_b, long b_k, long b_n, long c_b, long c_m, long c_n, int accumulate, void* stream) {
     ULLSAM_CHECK(M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "train_matmul_bf16: M=%d N=%d K=%d batch=%d", M, N, K, batch);
-    MmArgs a{A, B, C, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n, accumulate, 1, K, 0, 1, 1, 1, 0, 0, 0};
+    MmArgs a{A, B, C, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, c_b, c_m, c_n, accumulate, 1, K, 0, 1, 1, 1, 0, 0, 0, 0};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (!(M >= 64 && N >= 48 && K >= 16)) return train_matmul_launch(a, st);
     const bool ak = a_k <= a_m, bn = b_n <= b_k;
@@ -365,10 +377,11 @@ extern "C" int ullsam_train_matmul_bf16(const float* A, const float* B, float* C
 // operand X starts at o x_o + (h / x_hdiv) x_h -- q / k / v, dO and the gradients are read and written where they are, no head-major copies, no repeat_kv copies.
 extern "C" int ullsam_train_matmul_heads(const float* A, const float* B, float* C, int M, int N, int K, int outer, int heads, long a_o, long a_h, int a_hdiv, long a_m,
                                          long a_k, long b_o, long b_h, int b_hdiv, long b_k, long b_n, long c_o, long c_h, long c_m, long c_n, int accumulate, int bf16,
-                                         void* stream) {
+                                         int tri, void* stream) {
     ULLSAM_CHECK(M > 0 && N > 0 && K > 0 && outer > 0 && heads > 0 && (long)outer * heads < 65536 && a_hdiv >= 1 && b_hdiv >= 1,
                  "train_matmul_heads: M=%d N=%d K=%d outer=%d heads=%d", M, N, K, outer, heads);
-    MmArgs a{A, B, C, M, N, K, outer * heads, a_o, a_m, a_k, b_o, b_k, b_n, c_o, c_m, c_n, accumulate, 1, K, 0, heads, a_hdiv, b_hdiv, a_h, b_h, c_h};
+    ULLSAM_CHECK(tri >= 0 && tri <= 3 && (tri == 0 || M == N || M == K), "train_matmul_heads: tri=%d (a square attention: Sq == Sk)", tri);   // (the one-output-per-thread kernel ignores it: the clipped parts are zeros)
+    MmArgs a{A, B, C, M, N, K, outer * heads, a_o, a_m, a_k, b_o, b_k, b_n, c_o, c_m, c_n, accumulate, 1, K, 0, heads, a_hdiv, b_hdiv, a_h, b_h, c_h, tri};
     if (heads == 1) { a.bin = 1; }                                            // (single level: entry b at b x_o)
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (!bf16 || !(M >= 64 && N >= 48 && K >= 16)) return train_matmul_launch(a, st);
@@ -389,7 +402,7 @@ extern "C" int ullsam_train_matmul_splitk(const float* A, const float* B, float*
     const int kc = ((K + ksplit - 1) / ksplit + 31) / 32 * 32;
     const int ns = (K + kc - 1) / kc;                      // every split owns at least one k
     const long n = (long)batch * M * N;
-    MmArgs a{A, B, partial, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, (long)M * N, (long)N, 1, 0, ns, kc, n, 1, 1, 1, 0, 0, 0};
+    MmArgs a{A, B, partial, M, N, K, batch, a_b, a_m, a_k, b_b, b_k, b_n, (long)M * N, (long)N, 1, 0, ns, kc, n, 1, 1, 1, 0, 0, 0, 0};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rc = train_matmul_launch(a, st);
     if (rc) return rc;
@@ -754,9 +767,9 @@ __global__ __launch_bounds__(256) void attn_rows_bwd_kernel(float* __restrict__ 
     if (!have_p) {   // S holds (q * scale) k^T: add bias and masks, softmax in place
         float mx = -INFINITY;
         for (int kt = tid; kt < Sk; kt += 256) {
-            float v = s[kt];
+            const bool behind = causal >= 0 && kt > qi + causal;   // (not read: the products do not form the tiles that hold only such entries; s + FMIN is FMIN for every finite score)
+            float v = behind ? FMIN : s[kt];
             if (bhp) v += bhp[kt / kw] + bwp[kt % kw];
-            if (causal >= 0 && kt > qi + causal) v += FMIN;
             if (key_mask && key_mask[(long)b * Sk + kt] == 0) v += FMIN;
             s[kt] = v;
             mx = fmaxf(mx, v);
@@ -772,7 +785,12 @@ __global__ __launch_bounds__(256) void attn_rows_bwd_kernel(float* __restrict__ 
         return;
     }
     float ds = 0.f;
-    for (int kt = tid; kt < Sk; kt += 256) { const float pj = s[kt] * inv; s[kt] = pj; ds += pj * g[kt]; }
+    for (int kt = tid; kt < Sk; kt += 256) {
+        const float pj = s[kt] * inv;
+        s[kt] = pj;
+        if (causal >= 0 && kt > qi + causal) g[kt] = 0.f;        // (dP behind the diagonal may never have been written)
+        ds += pj * g[kt];
+    }
     const float D = block_reduce(ds, false);
     if (bhp) dbs[tid] = 0.f;
     __syncthreads();
@@ -826,9 +844,8 @@ __global__ __launch_bounds__(256) void attn_rows_reg_kernel(float* __restrict__ 
             const int kt = tix + T * i;
             float v = -INFINITY;
             if (live && kt < Sk) {
-                v = s[kt];
+                v = (causal >= 0 && kt > qi + causal) ? FMIN : s[kt];   // (entries behind the diagonal are not read: their tiles may never have been formed; s + FMIN is FMIN for every finite score)
                 if (bhp) v += bhp[kt / kw] + bwp[kt % kw];
-                if (causal >= 0 && kt > qi + causal) v += FMIN;
                 if (key_mask && key_mask[(long)b * Sk + kt] == 0) v += FMIN;
             }
             p[i] = v;
@@ -853,7 +870,7 @@ __global__ __launch_bounds__(256) void attn_rows_reg_kernel(float* __restrict__ 
     if (!dP) return;
     float gr[VPT], ds = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) { const int kt = tix + T * i; gr[i] = (live && kt < Sk) ? g[kt] : 0.f; ds += p[i] * gr[i]; }
+    for (int i = 0; i < VPT; ++i) { const int kt = tix + T * i; gr[i] = (live && kt < Sk && !(causal >= 0 && kt > qi + causal)) ? g[kt] : 0.f; ds += p[i] * gr[i]; }
     const float D = row_reduce(ds, false);
     float* mine = rows_lds + rib * (T * VPT);
 #pragma unroll

@@ -84,11 +84,20 @@ def _mm(A, B, C, M, N, K, sa, sb, sc, batch=1, accumulate=False, bf16=False):
     _lib.call("ullsam_train_matmul", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, batch, *sa, *sb, *sc, int(accumulate), _s())
 
 
-def _mmh(A, B, C, M, N, K, outer, heads, sa, sb, sc, accumulate=False, bf16=False):
+def _mmh(A, B, C, M, N, K, outer, heads, sa, sb, sc, accumulate=False, bf16=False, tri=0):
     """The product over (outer, head) pairs on operands that sit inside [rows, heads x hd] activations (ullsam_train_matmul_heads): entry (o, h) of A starts at
     o sa[0] + (h // sa[2]) sa[1]; sa = (outer, head, head divisor, m, k) element strides, sb = (outer, head, head divisor, k, n), sc = (outer, head, m, n)."""
     _lib.call("ullsam_train_matmul_heads", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, outer, heads, sa[0], sa[1], sa[2], sa[3], sa[4],
-              sb[0], sb[1], sb[2], sb[3], sb[4], sc[0], sc[1], sc[2], sc[3], int(accumulate), int(bf16), _s())
+              sb[0], sb[1], sb[2], sb[3], sb[4], sc[0], sc[1], sc[2], sc[3], int(accumulate), int(bf16), int(tri), _s())
+
+
+TRI_CAUSAL = True   # a causal square attention (the LLM's): the matrix-form products skip the 128 x 128 tiles wholly behind the diagonal and clip their sums to the visible part
+#                     (ullsam_train_matmul_heads `tri`); the row pass writes zeros there without reading.  False: whole matrices (tests / A-B: same bits)
+
+
+def _tri(dims) -> bool:
+    B, H, KVH, hd, Sq, Sk, causal, kw = dims
+    return bool(TRI_CAUSAL and causal == 0 and Sq == Sk)
 
 
 def _colsum(x2d: torch.Tensor) -> torch.Tensor:
@@ -475,7 +484,8 @@ class AttentionFn(Function):
             _lib.call("ullsam_train_attn_rows", P.data_ptr(), None, ops._p(bias_h), ops._p(bias_w), None, None, ops._p(key_mask), B, H, Sq, Sk, kw,
                       causal, 0, _s())
             out = torch.empty_like(q)
-            _mmh(P, v, out, Sq, hd, Sk, B, H, (H * Sq * Sk, Sq * Sk, 1, Sk, 1), (Sk * KVH * hd, hd, G, KVH * hd, 1), (Sq * H * hd, hd, H * hd, 1), bf16=ctx.bf16)   # out = P v
+            _mmh(P, v, out, Sq, hd, Sk, B, H, (H * Sq * Sk, Sq * Sk, 1, Sk, 1), (Sk * KVH * hd, hd, G, KVH * hd, 1), (Sq * H * hd, hd, H * hd, 1), bf16=ctx.bf16,
+                 tri=3 if _tri(ctx.dims) else 0)   # out = P v
             ctx.save_for_backward(qs, k, v, key_mask if RECOMPUTE_P else P, bias_h, bias_w)
             return out
         # Matrix form (csrc/train.hip attn_rows_kernel) for the decoder's few-token attentions: head-major copies, batched matmuls around one row pass; P is kept for the backward.
@@ -497,7 +507,8 @@ class AttentionFn(Function):
     def _scores(qs, k, P, dims, bf16):
         """P[(b, h)] = qs_h k_{h // G}^T on the row tensors (qs [B*Sq, H*hd], k [B*Sk, KVH*hd])."""
         B, H, KVH, hd, Sq, Sk, _, _ = dims
-        _mmh(qs, k, P, Sq, Sk, hd, B, H, (Sq * H * hd, hd, 1, H * hd, 1), (Sk * KVH * hd, hd, H // KVH, 1, KVH * hd), (H * Sq * Sk, Sq * Sk, Sk, 1), bf16=bf16)
+        _mmh(qs, k, P, Sq, Sk, hd, B, H, (Sq * H * hd, hd, 1, H * hd, 1), (Sk * KVH * hd, hd, H // KVH, 1, KVH * hd), (H * Sq * Sk, Sq * Sk, Sk, 1), bf16=bf16,
+             tri=1 if _tri(dims) else 0)
 
     @staticmethod
     def _head_major(q, k, v, dims):
@@ -582,7 +593,8 @@ def _attn_backward_inplace(ctx, dout):
     sP, sPT = (H * Sq * Sk, Sq * Sk, 1, Sk, 1), (H * Sq * Sk, Sq * Sk, 1, 1, Sk)        # P / dS as [m = q][k = key] and transposed [m = key][k = q]
     rows_q = (Sq * H * hd, hd, 1, H * hd, 1)                                               # dO / qs as the B operand [k = q][n = d] resp. the A operand [m = q][k = d]
     dP = torch.empty_like(P)
-    _mmh(dout, v, dP, Sq, Sk, hd, B, H, rows_q, (Sk * KVH * hd, hd, G, 1, KVH * hd), (H * Sq * Sk, Sq * Sk, Sk, 1), bf16=ctx.bf16)            # dP = dO v^T
+    tri = _tri(ctx.dims)
+    _mmh(dout, v, dP, Sq, Sk, hd, B, H, rows_q, (Sk * KVH * hd, hd, G, 1, KVH * hd), (H * Sq * Sk, Sq * Sk, Sk, 1), bf16=ctx.bf16, tri=1 if tri else 0)   # dP = dO v^T
     _lib.call("ullsam_train_attn_rows", P.data_ptr(), dP.data_ptr(), ops._p(bias_h), ops._p(bias_w), ops._p(dbh), ops._p(dbw), ops._p(key_mask), B, H,
               Sq, Sk, kw, causal, 0 if ctx.recompute else 1, _s())                                                          # dP <- dS
     if G == 1:
@@ -592,10 +604,10 @@ def _attn_backward_inplace(ctx, dout):
         dk = torch.empty((B, H, Sk, hd), dtype=F32, device=qs.device)
         dv = torch.empty_like(dk)
         kv_c = (H * Sk * hd, Sk * hd, hd, 1)
-    _mmh(P, dout, dv, Sk, hd, Sq, B, H, sPT, rows_q, kv_c, bf16=ctx.bf16)                                                    # dV = P^T dO
-    _mmh(dP, qs, dk, Sk, hd, Sq, B, H, sPT, rows_q, kv_c, bf16=ctx.bf16)                                                     # dK = dS^T (q scale)
+    _mmh(P, dout, dv, Sk, hd, Sq, B, H, sPT, rows_q, kv_c, bf16=ctx.bf16, tri=2 if tri else 0)                                # dV = P^T dO
+    _mmh(dP, qs, dk, Sk, hd, Sq, B, H, sPT, rows_q, kv_c, bf16=ctx.bf16, tri=2 if tri else 0)                                 # dK = dS^T (q scale)
     dqs = torch.empty_like(qs)
-    _mmh(dP, k, dqs, Sq, hd, Sk, B, H, sP, (Sk * KVH * hd, hd, G, KVH * hd, 1), (Sq * H * hd, hd, H * hd, 1), bf16=ctx.bf16)    # d(q scale) = dS k
+    _mmh(dP, k, dqs, Sq, hd, Sk, B, H, sP, (Sk * KVH * hd, hd, G, KVH * hd, 1), (Sq * H * hd, hd, H * hd, 1), bf16=ctx.bf16, tri=3 if tri else 0)    # d(q scale) = dS k
     dq = AttentionFn._scaled(dqs, 1.0 / math.sqrt(hd))
     if G > 1:                                                                               # the gradient of repeat_kv: sum over the group, then back to rows
         red = lambda t: _colsum(t.reshape(B, KVH, G, Sk * hd).permute(2, 0, 1, 3).reshape(G, -1).contiguous()).reshape(B, KVH, Sk, hd)
