@@ -497,12 +497,60 @@ __global__ __launch_bounds__(256) void ln_bwd_params_reduce_kernel(const float* 
     if (dw) dw[c] += a;
     if (db) db[c] += b;
 }
+// The same row backward with the row in registers (D % 4 == 0, D <= 256 VPT: one wave per row, x and dy w fetched once as float4; the kernel above walks the row four times with
+// 4-byte loads).  Same formulas; the row sums add a lane's VPT quads first.
+template <int VPT>
+__global__ __launch_bounds__(256) void ln_bwd_row_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
+                                                         float* __restrict__ dx, float* __restrict__ stats, long rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    const float* gr = dy + row * D;
+    float4 xv[VPT], gv[VPT];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int i = 4 * (lane + 64 * j);
+        if (i < D) {
+            xv[j] = *reinterpret_cast<const float4*>(xr + i);
+            const float4 g = *reinterpret_cast<const float4*>(gr + i);
+            if (w) { const float4 ww = *reinterpret_cast<const float4*>(w + i); gv[j] = make_float4(g.x * ww.x, g.y * ww.y, g.z * ww.z, g.w * ww.w); } else gv[j] = g;
+            s += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+        } else { xv[j] = gv[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j)
+        if (4 * (lane + 64 * j) < D) { const float a = xv[j].x - mean, b = xv[j].y - mean, c = xv[j].z - mean, d = xv[j].w - mean; ss += (a * a + b * b) + (c * c + d * d); }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j)
+        if (4 * (lane + 64 * j) < D) {
+            xv[j] = make_float4((xv[j].x - mean) * rstd, (xv[j].y - mean) * rstd, (xv[j].z - mean) * rstd, (xv[j].w - mean) * rstd);   // xhat
+            sg += (gv[j].x + gv[j].y) + (gv[j].z + gv[j].w);
+            sgx += (gv[j].x * xv[j].x + gv[j].y * xv[j].y) + (gv[j].z * xv[j].z + gv[j].w * xv[j].w);
+        }
+    const float mg = wave_sum(sg) / (float)D, mgx = wave_sum(sgx) / (float)D;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int i = 4 * (lane + 64 * j);
+        if (i < D) *reinterpret_cast<float4*>(dx + row * D + i) = make_float4(rstd * (gv[j].x - mg - xv[j].x * mgx), rstd * (gv[j].y - mg - xv[j].y * mgx),
+                                                                               rstd * (gv[j].z - mg - xv[j].z * mgx), rstd * (gv[j].w - mg - xv[j].w * mgx));
+    }
+    if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
 extern "C" int ullsam_train_ln_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, long rows, int D, float eps,
                                    float* ws, void* stream) {
     ULLSAM_CHECK(rows > 0 && D > 0, "train_ln_bwd: rows=%ld D=%d", rows, D);
     ULLSAM_CHECK(!(dw || db) || ws, "train_ln_bwd: parameter gradients need the workspace (2 rows + 2 * %d * D floats)", colsum_blocks(rows));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    ln_bwd_kernel<<<dim3((unsigned)((rows + 3) / 4)), 256, 0, st>>>(x, w, dy, dx, (dw || db) ? ws : nullptr, rows, D, eps);
+    const bool vec = D % 4 == 0 && D <= 2048 && ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)w)) & 15) == 0;
+    if (vec && D <= 512) ln_bwd_row_kernel<2><<<dim3((unsigned)((rows + 3) / 4)), 256, 0, st>>>(x, w, dy, dx, (dw || db) ? ws : nullptr, rows, D, eps);
+    else if (vec) ln_bwd_row_kernel<8><<<dim3((unsigned)((rows + 3) / 4)), 256, 0, st>>>(x, w, dy, dx, (dw || db) ? ws : nullptr, rows, D, eps);
+    else ln_bwd_kernel<<<dim3((unsigned)((rows + 3) / 4)), 256, 0, st>>>(x, w, dy, dx, (dw || db) ? ws : nullptr, rows, D, eps);
     ULLSAM_LAUNCH_CHECK();
     if (dw || db) {
         const int nb = colsum_blocks(rows);
@@ -1143,13 +1191,22 @@ extern "C" int ullsam_train_seg_loss_bwd(const float* x, const float* t, const f
 // tables (image_encoder.py:303-322).  Gather form: one thread per destination element walks the index list in order (tables of 5 ... 127 rows,
 // lists of a few thousand entries): no atomics, bit-reproducible ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void index_add_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, long rows, int C, int nrows_dst) {
+    // (the index list goes through LDS a KiB-entry chunk at a time: walked straight from memory, every step of the loop was a dependent global load -- 50 us for a 196-entry list)
+    __shared__ int sidx[1024];
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)nrows_dst * C) return;
-    const int k = (int)(i / C), c = (int)(i - (long)k * C);
+    const bool live = i < (long)nrows_dst * C;
+    const int k = live ? (int)(i / C) : -1, c = live ? (int)(i - (long)k * C) : 0;
     float a = 0.f;
-    for (long r = 0; r < rows; ++r)
-        if (idx[r] == k) a += src[r * C + c];
-    dst[i] += a;
+    for (long r0 = 0; r0 < rows; r0 += 1024) {
+        const int n = (int)min(1024l, rows - r0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += 256) sidx[j] = idx[r0 + j];
+        __syncthreads();
+        if (live)
+            for (int j = 0; j < n; ++j)
+                if (sidx[j] == k) a += src[(r0 + j) * C + c];
+    }
+    if (live) dst[i] += a;
 }
 extern "C" int ullsam_train_index_add_rows(const float* src, const int* idx, float* dst, long rows, int C, int nrows_dst, void* stream) {
     ULLSAM_CHECK(rows > 0 && C > 0 && nrows_dst > 0, "train_index_add_rows: bad dims");
