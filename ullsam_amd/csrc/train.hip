@@ -1189,11 +1189,14 @@ extern "C" int ullsam_train_seg_loss_bwd(const float* x, const float* t, const f
 
 // ---- dst[idx[r]] += src[r] (rows of C floats): gradients of the point-label embedding table (prompt_encoder.py:76-96) and of the relative-position
 // tables (image_encoder.py:303-322).  Gather form: one thread per destination element walks the index list in order (tables of 5 ... 127 rows,
-// lists of a few thousand entries): no atomics, bit-reproducible ---------------------------------------------------------------------------------
+// lists of a few thousand entries): no atomics, bit-reproducible (sixteen lanes per element, fixed tree) ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void index_add_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, long rows, int C, int nrows_dst) {
     // (the index list goes through LDS a KiB-entry chunk at a time: walked straight from memory, every step of the loop was a dependent global load -- 50 us for a 196-entry list)
+    // SIXTEEN lanes per destination element, lane s taking the list entries j = s (mod 16) in order, their sums added in a fixed tree (bit-reproducible): the 4096-entry lists of the
+    // global blocks took 227 us with one thread per element
     __shared__ int sidx[1024];
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
     const bool live = i < (long)nrows_dst * C;
     const int k = live ? (int)(i / C) : -1, c = live ? (int)(i - (long)k * C) : 0;
     float a = 0.f;
@@ -1203,14 +1206,15 @@ __global__ __launch_bounds__(256) void index_add_rows_kernel(const float* __rest
         for (int j = threadIdx.x; j < n; j += 256) sidx[j] = idx[r0 + j];
         __syncthreads();
         if (live)
-            for (int j = 0; j < n; ++j)
+            for (int j = sub; j < n; j += 16)
                 if (sidx[j] == k) a += src[(r0 + j) * C + c];
     }
-    if (live) dst[i] += a;
+    a += __shfl_xor(a, 8, 16); a += __shfl_xor(a, 4, 16); a += __shfl_xor(a, 2, 16); a += __shfl_xor(a, 1, 16);
+    if (live && sub == 0) dst[i] += a;
 }
 extern "C" int ullsam_train_index_add_rows(const float* src, const int* idx, float* dst, long rows, int C, int nrows_dst, void* stream) {
     ULLSAM_CHECK(rows > 0 && C > 0 && nrows_dst > 0, "train_index_add_rows: bad dims");
-    index_add_rows_kernel<<<dim3((unsigned)(((long)nrows_dst * C + 255) / 256)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(src, idx, dst, rows, C, nrows_dst);
+    index_add_rows_kernel<<<dim3((unsigned)(((long)nrows_dst * C * 16 + 255) / 256)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(src, idx, dst, rows, C, nrows_dst);
     ULLSAM_LAUNCH_CHECK();
     return 0;
 }
